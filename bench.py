@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- TSDF fusion + depth preprocessing on MI355X.
+
+A step is one pass of the hot path over one synthetic frame set already resident
+in HBM: NetKinectArray::update (device->device copy of the resident frames),
+clearOccupiedBricks, processTextures (morph/bilateral/boundary/normal/quality),
+updateOccupiedBricks and a FULL-SWEEP integrate() of every voxel
+(source/kinect_client.cpp:572-602).  The brick-skipping mode the reference
+defaults to is timed separately and reported under "bricked".
+
+N = 1: BASELINE.json config "4 sensors, 512^3 TSDF, full pre_* chain".
+N > 1: one process per GPU, the volume is split into Z slabs of storage-tile
+layers (no data-path collective for integration; the one exchange per step is the
+one-tile-layer halo to the Z neighbours over RCCL), weak scaling: cubic grids
+512^3 / 640^3 / 800^3 / 1024^3 over the same 2 m box for 1 / 2 / 4 / 8 GPUs, i.e.
+~134 M voxels per GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+GRID_FOR_GPUS = {1: 512, 2: 640, 4: 800, 8: 1024}
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--grid", type=int, default=0, help="override the cubic grid size")
+    ap.add_argument("--sensors", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=32, help="z rows of the volume the CPU baseline integrates")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    N = args.sensors
+    W, H = 512, 424
+    G = args.grid or GRID_FOR_GPUS.get(world, 512)
+    scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
+    cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=capi.FLAGS_DEFAULT,
+                           slab_rank=rank, slab_count=world)
+    ctx = capi.Context(cfg, local_rank)
+    g = ctx.geo
+    for i in range(N):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.synth_inverse_calibration(i, scene.pinhole(i))
+    d_depth = torch.from_numpy(scene.depth).to(dev)
+    d_color = torch.from_numpy(scene.color).to(dev)
+    torch.cuda.synchronize()
+
+    halo = None
+    if world > 1:
+        halo = rdist.halo_views(ctx.device_tsdf(), dev)
+
+    def step(bricks):
+        ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        if halo is not None:
+            ctx.sync()                       # library stream -> RCCL stream hand-off
+            rdist.exchange_halo(*halo, rank=rank, world=world)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(bricks, steps, warmup):
+        ctx.set_use_bricks(bricks)
+        for _ in range(warmup):
+            step(bricks)
+        barrier()
+        ctx.enable_timer_accumulation(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(bricks)
+        barrier()
+        dt = time.perf_counter() - t0
+        stats = {n: ctx.timer_stats(n) for n in ("2integrate", "1preprocess", "morph", "bilateral", "boundary",
+                                                 "normal", "quality", "bricks")}
+        ctx.enable_timer_accumulation(False)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, stats
+
+    # ---- headline: full sweep ------------------------------------------------
+    dt, stats = timed(False, args.steps, args.warmup)
+    V_local = g.res_volume[0] * g.res_volume[1] * (g.slab_voxel_z1 - g.slab_voxel_z0)
+    V_total = g.res_volume[0] * g.res_volume[1] * g.res_volume[2]
+    ms_per_step = dt / args.steps * 1e3
+    value = V_total / (dt / args.steps) / 1e6
+    int_ns, int_n = stats["2integrate"]
+    int_s = int_ns / max(int_n, 1) * 1e-9
+    # algorithmic bytes of one integrate launch on this rank (DESIGN.md "Algorithmic bytes"):
+    # one f32 store per voxel + the three f32 LUT planes per voxel and sensor (the
+    # repacked, xyz-only 1:1 LUT) + the packed 16-B frame texels read once
+    bytes_launch = V_local * (4 + 12 * N) + N * W * H * 16
+    achieved = bytes_launch / int_s if int_s > 0 else 0.0
+    tsdf_full = None
+
+    # ---- brick-skipping mode (reference default) -------------------------------
+    dtb, stats_b = timed(True, max(args.steps // 2, 1), 2)
+    bsteps = max(args.steps // 2, 1)
+    occ = ctx.occupied_ratio()
+    bint_ns, bint_n = stats_b["2integrate"]
+
+    out = {
+        "metric": "Mvoxels/s TSDF integration (4 sensors, 512^3 grid) + frames/s",
+        "value": round(value, 1),
+        "unit": "Mvoxels/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "frames_per_s": round(args.steps / dt, 2),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%d sensors 512x424 -> %d^3 TSDF, full pre_* chain + full-sweep integrate, 1:1 inverse LUT"
+                               % (N, G),
+                   "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
+                   "parallelism": "zslab%d" % world if world > 1 else "single"},
+        "roofline": {"bound": "hbm", "kernel": "k_integrate_tiled<%d,false>" % N,
+                     "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
+                     "launches_timed": int_n},
+        "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
+        "bricked": {"ms_per_step": round(dtb / bsteps * 1e3, 4),
+                    "value": round(V_total / (dtb / bsteps) / 1e6, 1),
+                    "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
+                    "occupied_ratio": round(occ, 4)},
+    }
+    traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(traffic_file):
+        try:
+            t = json.load(open(traffic_file))
+            key = "%dx%d" % (N, G)
+            if key in t:
+                out["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+
+    # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)
+
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
+    """Times the CPU oracle ("port") on this box's host cores: the whole pre_*
+    chain for the frame set, plus integrate() on a slab of `rows` z rows of the
+    same volume (1:1 LUT rows read back from the device), extrapolated to the
+    whole grid.  The slab result is also compared with the HIP TSDF (parity at
+    the benchmark's full size)."""
+    orc = load_oracle()
+    cores = os.cpu_count() or 1
+    threads = orc.set_threads(cores)
+    g = ctx.geo
+    ctx.set_use_bricks(False)
+    ctx.integrate()
+    z0 = (G // 2 // 8) * 8
+    rows = max(8, min(rows, G - z0))
+    hip_rows = ctx.readback_tsdf()[z0:z0 + rows]
+    inv = [ctx.readback_inverse_calibration(i, z0, z0 + rows) for i in range(N)]
+    sil = [ctx.readback_image(capi.IMG_SILHOUETTE, i) for i in range(N)]
+    db = [ctx.readback_image(capi.IMG_DEPTH_B_RG, i) for i in range(N)]
+    q = [ctx.readback_image(capi.IMG_QUALITY, i) for i in range(N)]
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref = orc.integrate(inv, sil, db, q, (G, G, rows), 0.01)
+        times.append(time.perf_counter() - t0)
+    t_int = sorted(times)[1]
+    parity = bool(np.all((ref == hip_rows) | (np.isnan(ref) & np.isnan(hip_rows))))
+    t0 = time.perf_counter()
+    orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), None, brick_size=g.brick_size,
+                     bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
+    t_pre = time.perf_counter() - t0
+    t_full = t_pre + t_int * (G / rows)
+    return {"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+            "sample": "oracle (OpenMP, %d threads): full pre_* chain of the %d-sensor frame (%.2f s) + integrate of %d of %d "
+                      "z rows of the same volume (median of 3: %.2f s), extrapolated to the grid"
+                      % (threads, N, t_pre, rows, G, t_int),
+            "integrate_mvoxels_per_s": round(G * G * rows / t_int / 1e6, 2),
+            "parity_rows_bit_exact": parity}
+
+
+if __name__ == "__main__":
+    main()

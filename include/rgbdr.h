@@ -1,0 +1,245 @@
+/*
+ * rgbdr.h -- C ABI of the MI355X-native TSDF-fusion + depth-preprocessing backend
+ * for steppobeck/rgbd-recon.
+ *
+ * The reference has no FFI layer: the path sits behind the in-process C++ classes
+ * kinect::NetKinectArray, kinect::CalibVolumes and kinect::ReconIntegration and
+ * shares state through OpenGL texture-unit numbers.
+ * This header turns every implicit binding into an explicit argument.  Each entry
+ * point cites the reference interface it replaces (paths relative to the
+ * reference checkout).  The library is librgbdr_hip.so; nothing here uses C++,
+ * torch or HIP types.  A context is single-caller (like the GL thread that owns
+ * the reference's context); all calls are asynchronous on the context's HIP
+ * stream except the readbacks / getters, which synchronise it.
+ *
+ * Every function returns RGBDR_OK (0) or a negative rgbdr_status; nothing throws
+ * across the ABI.  rgbdr_last_error() returns the message of the last failure.
+ */
+#ifndef RGBDR_H
+#define RGBDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBDR_MAX_SENSORS 8 /* reference: 5 (sampler3D[5], glsl/tsdf_integration.vs:13) */
+#define RGBDR_TILE 8        /* storage tile edge in voxels (tile-linear TSDF / LUT layout) */
+
+typedef struct rgbdr_ctx rgbdr_ctx;
+
+typedef enum {
+  RGBDR_OK = 0,
+  RGBDR_ERR_INVALID_ARGUMENT = -1, /* reference: std::invalid_argument, source/kinect_client.cpp:202,289 */
+  RGBDR_ERR_OUT_OF_RANGE = -2,     /* reference: std::out_of_range, framework/NetKinectArray.cpp:248 */
+  RGBDR_ERR_NO_DEVICE = -3,        /* no HIP device / HIP runtime failure at create: the product never falls back to a CPU path */
+  RGBDR_ERR_HIP = -4,              /* reference: exception thrown from the GL-error callback, source/kinect_client.cpp:1051 */
+  RGBDR_ERR_IO = -5,               /* reference: exit(1) on missing stream (NetKinectArray.cpp:735-738), NULL deref on missing LUT */
+  RGBDR_ERR_STATE = -6             /* call order violated (e.g. integrate before calibration was set) */
+} rgbdr_status;
+
+/* flags: NetKinectArray::m_filter_textures / m_use_processed_depth / m_refine_bound
+ * (framework/NetKinectArray.cpp:62-63,69, all default true) and
+ * ReconIntegration::m_use_bricks (recon_integration.cpp:58, default true) */
+enum {
+  RGBDR_FLAG_FILTER = 1u,
+  RGBDR_FLAG_PROCESSED = 2u,
+  RGBDR_FLAG_REFINE = 4u,
+  RGBDR_FLAG_USE_BRICKS = 8u,
+  RGBDR_FLAGS_DEFAULT = 15u
+};
+
+/* Replaces the constructor arguments of NetKinectArray (NetKinectArray.cpp:42),
+ * ReconIntegration (recon_integration.cpp:30) and the CalibrationFiles scalars
+ * they read (calibration_files.cpp:26-33: element [0] decides sizes / compression
+ * for all sensors). */
+typedef struct {
+  uint32_t struct_size;          /* sizeof(rgbdr_config), for ABI evolution */
+  int32_t num_sensors;           /* CalibrationFiles::num() */
+  int32_t depth_w, depth_h;      /* yml depth_size: */
+  int32_t color_w, color_h;      /* yml rgb_size: */
+  float bbox_min[3], bbox_max[3];/* .ks `bbx` (kinect_client.cpp:206-234), gloost::BoundingBox */
+  float voxel_size;              /* ReconIntegration ctor `size` (default 0.01, kinect_client.cpp:87) */
+  float brick_size;              /* setBrickSize (default 0.1) */
+  float tsdf_limit;              /* ctor `limit` (default 0.01) */
+  uint32_t min_voxels_per_brick; /* default 10 */
+  uint32_t flags;                /* RGBDR_FLAG_* */
+  int32_t compress_depth;        /* yml compress_depth: 0 = f32 metres, 1 = u8 */
+  int32_t compress_rgb;          /* yml compress_rgb: 0 = RGB8; 1 (DXT1) / 5 (DXT5) are not supported yet */
+  float near_[RGBDR_MAX_SENSORS];/* yml near_far: per sensor (NetKinectArray.cpp:346-347) */
+  float far_[RGBDR_MAX_SENSORS];
+  int32_t res_override[3];       /* 0,0,0 = ceil(extent / voxel_size) as setVoxelSize does */
+  int32_t slab_rank, slab_count; /* Z-slab of storage tiles owned by this context; 0,1 (or 0,0) = whole volume */
+} rgbdr_config;
+
+/* One calibration volume as CalibrationVolume<T> holds it
+ * (framework/calibration/calibration_volume.hpp:13-84): x-fastest records. */
+typedef struct {
+  uint32_t res[3];
+  float depth_limits[2];
+  const void* data; /* host pointer: res[0]*res[1]*res[2] records of 12 B (xyz), 8 B (uv) or 16 B (xyz_inv) */
+} rgbdr_lut;
+
+/* Grid geometry derived from a config; pure host arithmetic, no device needed.
+ * Restates setVoxelSize / setBrickSize / divideBox (recon_integration.cpp:341-388,
+ * :474-484). */
+typedef struct {
+  int32_t res_volume[3];   /* m_res_volume */
+  int32_t res_bricks[3];   /* m_res_bricks */
+  float brick_size;        /* adjusted: voxel * round(size / voxel) */
+  int32_t brick_voxels;    /* voxels per brick edge: round(brick_size / voxel_size) */
+  int32_t num_bricks;
+  int32_t tiles[3];        /* storage tiles per axis = ceil(res / RGBDR_TILE) */
+  int32_t slab_tile_z0, slab_tile_z1; /* tile layers [z0, z1) owned by this slab */
+  int32_t slab_voxel_z0, slab_voxel_z1; /* voxel layers [z0, z1) owned (clipped to res_volume[2]) */
+} rgbdr_geometry;
+
+/* Which per-sensor image rgbdr_readback_image returns (the textures of
+ * framework/NetKinectArray.h:76-88, units in SURVEY.md A.4). Channels in (). */
+typedef enum {
+  RGBDR_IMG_DEPTH_RAW = 0,   /* m_depthArray_raw as sampled: metres, or u8/255 (1) */
+  RGBDR_IMG_DEPTH_MORPH = 1, /* m_textures_depth2.front (1) */
+  RGBDR_IMG_DEPTH_RG = 2,    /* m_textures_depth (2) */
+  RGBDR_IMG_LAB = 3,         /* m_textures_color (3) */
+  RGBDR_IMG_DEPTH_B_RG = 4,  /* m_textures_depth_b (2) */
+  RGBDR_IMG_SILHOUETTE = 5,  /* m_textures_silhouette (1) */
+  RGBDR_IMG_NORMAL = 6,      /* m_textures_normal (3) */
+  RGBDR_IMG_QUALITY = 7      /* m_textures_quality (1) */
+} rgbdr_image;
+
+/* Pinhole description for the device-side synthetic inverse-LUT generator
+ * (benchmark support, SURVEY.md section 8d: LUT generation for 512^3 x N must be
+ * on device).  Not part of the reference surface. */
+typedef struct {
+  float cam_pos[3];
+  float right[3], up[3], forward[3]; /* orthonormal camera axes in world space */
+  float fx, fy, cx, cy;              /* pixels */
+  float depth_min, depth_max;        /* metres, normalisation of the third LUT channel */
+  int32_t lut_res[3];                /* forward-LUT resolution the (idx+0.5)/dims payload refers to */
+} rgbdr_pinhole;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* NetKinectArray ctor + init() (NetKinectArray.cpp:42-219) and ReconIntegration
+ * ctor (recon_integration.cpp:30-149): allocates every image, the TSDF volume
+ * and the brick table on HIP device `device_id`. */
+int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out);
+void rgbdr_destroy(rgbdr_ctx* ctx);
+const char* rgbdr_last_error(const rgbdr_ctx* ctx); /* ctx may be NULL: last create failure */
+const char* rgbdr_status_string(int status);
+const char* rgbdr_version(void);
+
+/* host-only: geometry of a config (no device touched) */
+int rgbdr_compute_geometry(const rgbdr_config* cfg, rgbdr_geometry* out);
+/* host-only: tile layers [t0,t1) of slab `rank` out of `count` over `tiles_z` layers */
+int rgbdr_slab_range(int tiles_z, int count, int rank, int* t0, int* t1);
+/* host-only: Frustum::getCameraPos of a cv_xyz volume (frustum.cpp:21-33, CalibVolumes.cpp:98-113) */
+int rgbdr_camera_position(const rgbdr_lut* cv_xyz, float out[3]);
+
+/* ---- calibration ---------------------------------------------------------- */
+
+/* CalibVolumes::addVolume + createVolumeTextures (CalibVolumes.cpp:115-144):
+ * uploads cv_xyz (12 B records) and cv_uv (8 B records) of one sensor; derives
+ * the camera position and takes depth_limits of cv_xyz as cv_min_ds / cv_max_ds
+ * (NetKinectArray.cpp:339-340). */
+int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* cv_xyz, const rgbdr_lut* cv_uv);
+/* CalibVolumes::loadInverseCalibs (CalibVolumes.cpp:64-80): cv_xyz_inv, 16 B records. */
+int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* cv_xyz_inv);
+/* Same, from files in the reference's on-disk format (calibration_volume.hpp:62-79);
+ * any path may be NULL to skip it. */
+int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv_xyz,
+                                 const char* path_cv_uv, const char* path_cv_xyz_inv);
+/* benchmark support: fill sensor's inverse LUT on the device at 1:1 TSDF resolution */
+int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam);
+
+/* ---- per-frame calls (order is the contract, kinect_client.cpp:572-602) -- */
+
+/* NetKinectArray::update (NetKinectArray.cpp:226-238): depth = N*H*W f32 (or u8
+ * when compress_depth), color = N*Hc*Wc*3 u8; host pointers, copied. */
+int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color);
+/* same for buffers already resident on this context's device */
+int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth_dev, const void* color_dev);
+/* ReconIntegration::clearOccupiedBricks (recon_integration.cpp:272-278) */
+int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx);
+/* NetKinectArray::processTextures (NetKinectArray.cpp:311-428) */
+int rgbdr_process_textures(rgbdr_ctx* ctx);
+/* ReconIntegration::updateOccupiedBricks (recon_integration.cpp:431-446), device side, no readback */
+int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx);
+/* ReconIntegration::integrate (recon_integration.cpp:243-270) */
+int rgbdr_integrate(rgbdr_ctx* ctx);
+/* process_textures() + integrate() of kinect_client.cpp:572-602 in one call */
+int rgbdr_step(rgbdr_ctx* ctx, const void* depth, const void* color);
+int rgbdr_sync(rgbdr_ctx* ctx);
+
+/* ---- setters / getters (recon_integration.hpp:43-57, NetKinectArray.h:56-58) */
+
+int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size);      /* reallocates volume + brick table */
+int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit);
+int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size);
+int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int active);
+int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n);
+int rgbdr_filter_textures(rgbdr_ctx* ctx, int on);         /* unlike the reference these three do not re-run */
+int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on);    /* processTextures() themselves (SURVEY.md A.5:   */
+int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on);         /* that double-counts bricks); call it afterwards */
+float rgbdr_get_brick_size(const rgbdr_ctx* ctx);
+float rgbdr_occupied_ratio(rgbdr_ctx* ctx);
+uint32_t rgbdr_num_bricks(const rgbdr_ctx* ctx);           /* declared but never defined in the reference (recon_integration.hpp:51) */
+int rgbdr_get_geometry(const rgbdr_ctx* ctx, rgbdr_geometry* out);
+int rgbdr_get_camera_position(const rgbdr_ctx* ctx, int sensor, float out[3]);
+
+/* ---- outputs --------------------------------------------------------------- */
+
+/* The reference has no host-side TSDF accessor (consumers sample texture unit 29).
+ * Writes this context's voxel layers [slab_voxel_z0, slab_voxel_z1) as an
+ * x-fastest (z*Y*X + y*X + x) f32 array (volume_sampler.cpp:57). */
+int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst);
+/* one per-sensor image, H*W*channels f32, row-major */
+int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst);
+/* Inspection of the resident inverse LUT of one sensor: voxel-grid z rows [z0, z1)
+ * (1:1 LUT) or texel z rows (other resolutions) as x-fastest RGBA32F records.
+ * The .w channel is returned as 0 for a 1:1 LUT: it is dropped at upload because
+ * the shader never reads it (tsdf_integration.vs:31). */
+int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst);
+/* SSBO binding 3 payload after the 8-uint header: one u32 counter per brick */
+int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst);
+/* m_bricks_occupied (ascending ids) and m_ratio_occupied */
+int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* count, float* ratio);
+
+/* Zero-copy consumers: device pointer of the tile-linear TSDF slab.
+ * Layout: tile (tx,ty,tz_local) at ((tz_local*tiles[1] + ty)*tiles[0] + tx)*512 floats,
+ * voxel (x,y,z) inside it at (z&7)*64 + (y&7)*8 + (x&7).  `halo_layers` tile layers
+ * precede and follow the owned layers when slab_count > 1. */
+typedef struct {
+  void* base;             /* first float of the allocation (lower halo layer if any) */
+  void* owned;            /* first float of the first owned tile layer */
+  size_t layer_bytes;     /* bytes of one tile layer = tiles[0]*tiles[1]*512*4 */
+  int32_t owned_layers;
+  int32_t halo_layers;    /* 0 or 1 on each side */
+} rgbdr_tsdf_device_view;
+int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
+/* device pointer of the packed per-sensor frame the integration kernel gathers
+ * from: H*W float4 {depth_b.r, quality, silhouette, depth_b.g} */
+int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);
+/* the context's HIP stream (hipStream_t) for callers that enqueue dependent work */
+void* rgbdr_stream(rgbdr_ctx* ctx);
+
+/* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
+
+/* names: "morph","bilateral","boundary","normal","quality","1preprocess",
+ * "2integrate","bricks".  Last completed interval, nanoseconds. */
+int rgbdr_enable_timers(rgbdr_ctx* ctx, int on);
+int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns);
+/* Accumulating mode: every interval of a timed region keeps its own HIP event
+ * pair (recorded on the context's stream, no host sync inside the region);
+ * rgbdr_timer_stats synchronises once, returns the summed duration and the
+ * number of intervals since the previous call, and resets them
+ * (TimerDatabase running mean, timer_database.cpp:59-121). */
+int rgbdr_enable_timer_accumulation(rgbdr_ctx* ctx, int on);
+int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint32_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBDR_H */

@@ -1,0 +1,785 @@
+/*
+ * rgbdr_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement of the rgbd-recon depth-preprocessing + TSDF-integration
+ * hot path (the GLSL programs the reference runs on an OpenGL 4.4 device).  It is
+ * the checker for the HIP kernels: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this file's library.  The product library
+ * (rgbd-recon_amd/csrc) never links, loads or calls anything in oracle/.
+ *
+ * PARITY PINNING.  The reference ships no tests, golden vectors or recordings
+ *  and its arithmetic runs inside a GL driver that is not
+ * available here, so the pass arithmetic below is pinned only by reading the
+ * shader source ("parity unpinned" for those functions).  What IS
+ * pinned against reference code compiled from /root/reference (oracle/_ref, see
+ * oracle/Makefile and oracle/ref_shim.cpp):
+ *   - the calibration-volume file format (orc_lut_write / orc_lut_read versus
+ *     framework/calibration/calibration_volume.hpp:30-79),
+ *   - the record layouts (kinect::xyz 12 B, kinect::uv 8 B, framework/DataTypes.h:12-35),
+ *   - trilinear interpolation versus kinect::getTrilinear
+ *     (framework/DataTypes.cpp:115-163) to a few ulp (different but equivalent
+ *     association of the lerps).
+ *
+ * NUMERIC CONVENTIONS (decisions where GLSL / GL leave the result to the driver):
+ *   - all arithmetic is IEEE-754 binary32, no FMA contraction (-ffp-contract=off),
+ *     division and sqrt correctly rounded;
+ *   - LINEAR filtering follows GL 4.4 section 8.14: t = s*n - 0.5, i0 = floor(t),
+ *     a = t - i0, i1 = i0 + 1, both clamped to [0, n-1] (CLAMP_TO_EDGE), and the
+ *     blend is lerp(T0, T1, a) = T0 + a*(T1 - T0), x first, then y, then z.  That
+ *     form returns T0 exactly when T0 == T1 (as fixed-point texture hardware
+ *     does), which matters for `silhouette < 1.0` in tsdf_integration.vs:33;
+ *   - NEAREST: i = clamp(floor(s*n), 0, n-1);
+ *   - a NaN coordinate selects texel 0 and yields a NaN blend weight;
+ *   - fragment (px,py) of a WxH target has texcoord ((px+.5)/W, (py+.5)/H)
+ *     (framework/rendering/screen_quad.cpp:7-35, glsl/texture_passthrough.vs:1-12);
+ *     tap offsets k*texSizeInv on NEAREST textures and LINEAR textures sampled at
+ *     texel centres are integer stencils with index clamping;
+ *   - GLSL pow(x, 6.0) and pow(x, 2.0) (glsl/pre_quality.fs:109-114) are evaluated
+ *     as products (x2 = x*x, x4 = x2*x2, x6 = x4*x2): IEEE-like behaviour for
+ *     negative x (GLSL leaves it undefined);
+ *   - normalize(v) = v / sqrt(dot(v,v)), dot and cross in the glm association.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* cpu_baseline threading: rows / z-slices are independent, so the loops below
+ * carry `omp parallel for`; results do not depend on the thread count. */
+ORC_API int orc_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* sampling (GL 4.4 section 8.14; sampler state table in SURVEY.md section 8a) */
+
+static inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* float floor value -> int index without undefined behaviour for NaN / huge */
+static inline int idx_from_floor(float f, int n)
+{
+  float fc = fminf(fmaxf(f, -1.0f), (float)n); /* NaN -> -1 */
+  return (int)fc;
+}
+
+static inline void axis_linear(float s, int n, int* i0, int* i1, float* a)
+{
+  float t = s * (float)n - 0.5f;
+  float f = floorf(t);
+  int j = idx_from_floor(f, n);
+  *a = t - f;
+  *i0 = clampi(j, 0, n - 1);
+  *i1 = clampi(j + 1, 0, n - 1);
+}
+
+static inline int axis_nearest(float s, int n)
+{
+  float f = floorf(s * (float)n);
+  return clampi(idx_from_floor(f, n), 0, n - 1);
+}
+
+/* 3-D LINEAR / CLAMP_TO_EDGE lookup of a `ch`-channel record volume, x fastest
+ * (framework/calibration/calibration_volume.hpp:57-59; texture state
+ * framework/calibration/CalibVolumes.cpp:76,135,140) */
+static void tex3d_linear(const float* vol, int ch, int nch, int rx, int ry, int rz,
+                         float u, float v, float w, float* out)
+{
+  int x0, x1, y0, y1, z0, z1;
+  float ax, ay, az;
+  axis_linear(u, rx, &x0, &x1, &ax);
+  axis_linear(v, ry, &y0, &y1, &ay);
+  axis_linear(w, rz, &z0, &z1, &az);
+  const size_t sx = (size_t)ch, sy = (size_t)rx * ch, sz = (size_t)rx * ry * ch;
+  for (int c = 0; c < nch; ++c) {
+    float t000 = vol[z0 * sz + y0 * sy + x0 * sx + c];
+    float t100 = vol[z0 * sz + y0 * sy + x1 * sx + c];
+    float t010 = vol[z0 * sz + y1 * sy + x0 * sx + c];
+    float t110 = vol[z0 * sz + y1 * sy + x1 * sx + c];
+    float t001 = vol[z1 * sz + y0 * sy + x0 * sx + c];
+    float t101 = vol[z1 * sz + y0 * sy + x1 * sx + c];
+    float t011 = vol[z1 * sz + y1 * sy + x0 * sx + c];
+    float t111 = vol[z1 * sz + y1 * sy + x1 * sx + c];
+    float c00 = lerpf(t000, t100, ax);
+    float c10 = lerpf(t010, t110, ax);
+    float c01 = lerpf(t001, t101, ax);
+    float c11 = lerpf(t011, t111, ax);
+    float c0 = lerpf(c00, c10, ay);
+    float c1 = lerpf(c01, c11, ay);
+    out[c] = lerpf(c0, c1, az);
+  }
+}
+
+/* 2-D LINEAR lookup, `ch` interleaved float channels */
+static void tex2d_linear(const float* img, int ch, int nch, int W, int H, float u, float v, float* out)
+{
+  int x0, x1, y0, y1;
+  float ax, ay;
+  axis_linear(u, W, &x0, &x1, &ax);
+  axis_linear(v, H, &y0, &y1, &ay);
+  for (int c = 0; c < nch; ++c) {
+    float t00 = img[((size_t)y0 * W + x0) * ch + c];
+    float t10 = img[((size_t)y0 * W + x1) * ch + c];
+    float t01 = img[((size_t)y1 * W + x0) * ch + c];
+    float t11 = img[((size_t)y1 * W + x1) * ch + c];
+    out[c] = lerpf(lerpf(t00, t10, ax), lerpf(t01, t11, ax), ay);
+  }
+}
+
+/* colour array: GL_RGB / GL_UNSIGNED_BYTE -> normalised [0,1], LINEAR
+ * (framework/NetKinectArray.cpp:157-160, framework/rendering/TextureArray.cpp:27) */
+static void tex2d_linear_rgb8(const uint8_t* img, int W, int H, float u, float v, float* out)
+{
+  int x0, x1, y0, y1;
+  float ax, ay;
+  axis_linear(u, W, &x0, &x1, &ax);
+  axis_linear(v, H, &y0, &y1, &ay);
+  for (int c = 0; c < 3; ++c) {
+    float t00 = (float)img[((size_t)y0 * W + x0) * 3 + c] / 255.0f;
+    float t10 = (float)img[((size_t)y0 * W + x1) * 3 + c] / 255.0f;
+    float t01 = (float)img[((size_t)y1 * W + x0) * 3 + c] / 255.0f;
+    float t11 = (float)img[((size_t)y1 * W + x1) * 3 + c] / 255.0f;
+    out[c] = lerpf(lerpf(t00, t10, ax), lerpf(t01, t11, ax), ay);
+  }
+}
+
+ORC_API void orc_tex3d_linear(const float* vol, int ch, int rx, int ry, int rz,
+                              float u, float v, float w, float* out)
+{
+  tex3d_linear(vol, ch, ch, rx, ry, rz, u, v, w, out);
+}
+
+ORC_API void orc_tex2d_linear(const float* img, int ch, int W, int H, float u, float v, float* out)
+{
+  tex2d_linear(img, ch, ch, W, H, u, v, out);
+}
+
+ORC_API int orc_axis_nearest(float s, int n) { return axis_nearest(s, n); }
+
+/* ------------------------------------------------------------------------- */
+/* small vector helpers in the glm association (external/glm-0.9.5.3)         */
+
+static inline float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static inline void cross3(const float* x, const float* y, float* o)
+{
+  o[0] = x[1] * y[2] - y[1] * x[2];
+  o[1] = x[2] * y[0] - y[2] * x[0];
+  o[2] = x[0] * y[1] - y[0] * x[1];
+}
+
+static inline void normalize3(const float* v, float* o)
+{
+  float l = sqrtf(dot3(v, v));
+  o[0] = v[0] / l;
+  o[1] = v[1] / l;
+  o[2] = v[2] / l;
+}
+
+static inline float distance3(const float* a, const float* b)
+{
+  float d[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+  return sqrtf(dot3(d, d));
+}
+
+/* GLSL pow with the constant exponents the path uses (header note) */
+ORC_API float orc_pow6(float x)
+{
+  float x2 = x * x;
+  float x4 = x2 * x2;
+  return x4 * x2;
+}
+ORC_API float orc_pow2(float x) { return x * x; }
+
+/* ------------------------------------------------------------------------- */
+/* pre_morph.fs (a2): pass mode 0 = dilate(), mode 1 = copy                   */
+/* glsl/pre_morph.fs:73-112 (dilate), :114-140 (main); host                   */
+/* framework/NetKinectArray.cpp:251-290.  in_bbox(texcoord, depth) always     */
+/* returns true (:44-50), so the cv_xyz fetch there is dead.                  */
+
+static inline int morph_valid(float d) { return d > 0.5f && d < 4.5f; } /* :36-39 */
+
+ORC_API void orc_morph(const float* in, int W, int H, unsigned mode, float* out)
+{
+#pragma omp parallel for schedule(static)
+  for (int py = 0; py < H; ++py) {
+    for (int px = 0; px < W; ++px) {
+      float depth = in[(size_t)py * W + px];
+      float res;
+      if (mode == 1u) {
+        res = depth;
+      } else if (mode != 0u) {
+        res = 0.25f;
+      } else if (morph_valid(depth)) {
+        res = depth;
+      } else {
+        float average_depth = 0.0f;
+        int valid = 0;
+        float num_samples = 0.0f;
+        for (int y = -1; y < 2; ++y) {
+          for (int x = -1; x < 2; ++x) {
+            float ds = in[(size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)];
+            if (morph_valid(ds)) {
+              valid = 1;
+              average_depth += ds;
+              num_samples += 1.0f;
+            }
+          }
+        }
+        if (!valid) {
+          res = 0.0f;
+        } else {
+          average_depth /= num_samples;
+          float new_depth = 0.0f;
+          num_samples = 0.0f;
+          valid = 0;
+          for (int y = -1; y < 2; ++y) {
+            for (int x = -1; x < 2; ++x) {
+              float ds = in[(size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)];
+              if (morph_valid(ds) && fabsf(average_depth - ds) < 0.2f) {
+                valid = 1;
+                new_depth += ds;
+                num_samples += 1.0f;
+              }
+            }
+          }
+          res = valid ? new_depth / num_samples : 0.0f;
+        }
+      }
+      out[(size_t)py * W + px] = res;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* inc_color.glsl (Lab conversion incl. the extra /255, :14-16)               */
+
+static inline float pivot_rgb(float n)
+{
+  return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : n / 12.92f) * 100.0f;
+}
+static inline float pivot_xyz(float n)
+{
+  return n > 0.008856f ? powf(n, 1.0f / 3.0f) : (903.3f * n + 16.0f) / 116.0f;
+}
+ORC_API void orc_rgb_to_lab(const float* rgb, float* lab)
+{
+  float r = pivot_rgb(rgb[0] / 255.0f);
+  float g = pivot_rgb(rgb[1] / 255.0f);
+  float b = pivot_rgb(rgb[2] / 255.0f);
+  float X = r * 0.4124f + g * 0.3576f + b * 0.1805f;
+  float Y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  float Z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
+  float x = pivot_xyz(X / 95.047f);
+  float y = pivot_xyz(Y / 100.000f);
+  float z = pivot_xyz(Z / 108.883f);
+  lab[0] = fmaxf(0.0f, 116.0f * y - 16.0f);
+  lab[1] = 500.0f * (x - y);
+  lab[2] = 200.0f * (y - z);
+}
+
+/* ------------------------------------------------------------------------- */
+/* pre_depth.fs (a3): bilateral filter + Lab colour                           */
+
+typedef struct {
+  int W, H;             /* depth resolution */
+  int Wc, Hc;           /* colour resolution */
+  int xyz_res[3];       /* cv_xyz / cv_uv resolution (same header, CalibVolumes.cpp:115-130) */
+  int uv_res[3];
+  float cv_min_ds, cv_max_ds; /* depthLimits() of cv_xyz (NetKinectArray.cpp:339-340) */
+  float bbox_min[3], bbox_max[3];
+  int filter_textures;  /* m_filter_textures */
+  int compress;         /* compress_depth: input is the u8 texture normalised to [0,1] */
+  float near_, far_;    /* yml near_far (NetKinectArray.cpp:346-351) */
+} orc_depth_params;
+
+static inline float pd_sample(const float* depth, int W, int H, int px, int py, const orc_depth_params* p)
+{
+  float d = depth[(size_t)clampi(py, 0, H - 1) * W + clampi(px, 0, W - 1)];
+  if (p->compress) { /* pre_depth.fs:51-61 */
+    float scale = p->far_ - p->near_;
+    float scaled_near = scale / 255.0f;
+    if (d < scaled_near) return 0.0f;
+    return (d * d + 0.15f * scaled_near) * scale + p->near_;
+  }
+  return d;
+}
+
+ORC_API void orc_pre_depth(const float* depth, const uint8_t* color_rgb8, const float* cv_xyz,
+                           const float* cv_uv, const orc_depth_params* p, float* out_depth_rg,
+                           float* out_lab)
+{
+  const int W = p->W, H = p->H;
+  const float inv_k = 1.0f / 6.0f; /* dist_space_max_inv, pre_depth.fs:37 */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < H; ++py) {
+    for (int px = 0; px < W; ++px) {
+      const size_t o = (size_t)py * W + px;
+      const float u = ((float)px + 0.5f) / (float)W;
+      const float v = ((float)py + 0.5f) / (float)H;
+      float depth0 = pd_sample(depth, W, H, px, py, p);
+      float range = p->cv_max_ds - p->cv_min_ds;
+      float depth_norm = (depth0 - p->cv_min_ds) / range;
+      float pos_world[3];
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], u, v, depth_norm, pos_world);
+      int in_box = pos_world[0] >= p->bbox_min[0] && pos_world[1] >= p->bbox_min[1] &&
+                   pos_world[2] >= p->bbox_min[2] && pos_world[0] <= p->bbox_max[0] &&
+                   pos_world[1] <= p->bbox_max[1] && pos_world[2] <= p->bbox_max[2];
+      /* pre_depth.fs:136 */
+      float dn_c = (depth_norm <= 0.0f || depth_norm >= 1.0f) ? 1.0f : depth_norm;
+      float cc[2], rgb[3];
+      tex3d_linear(cv_uv, 2, 2, p->uv_res[0], p->uv_res[1], p->uv_res[2], u, v, dn_c, cc);
+      tex2d_linear_rgb8(color_rgb8, p->Wc, p->Hc, cc[0], cc[1], rgb);
+      orc_rgb_to_lab(rgb, out_lab + o * 3);
+      if (!in_box) {
+        out_depth_rg[o * 2 + 0] = 0.0f;
+        out_depth_rg[o * 2 + 1] = 0.0f;
+        continue;
+      }
+      if (!p->filter_textures) {
+        out_depth_rg[o * 2 + 0] = depth_norm;
+        out_depth_rg[o * 2 + 1] = 1.0f;
+        continue;
+      }
+      /* bilateral_filter, pre_depth.fs:85-127 */
+      float d_dmax = depth0 / 4.5f;
+      float dist_range_max = 0.35f * d_dmax;
+      float dist_range_max_inv = 1.0f / dist_range_max;
+      float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f, num_samples = 0.0f;
+      for (int y = -6; y < 7; ++y) {
+        for (int x = -6; x < 7; ++x) {
+          num_samples += 1.0f;
+          float depth_s = pd_sample(depth, W, H, px + x, py + y, p);
+          float depth_range = fabsf(depth_s - depth0);
+          if ((depth_s < p->cv_min_ds) || (depth_s > p->cv_max_ds) || (depth_range > dist_range_max)) continue;
+          float len = sqrtf((float)x * (float)x + (float)y * (float)y);
+          float gauss_space = 1.0f - len * inv_k;
+          float gauss_range = 1.0f - fminf(depth_range, dist_range_max) * dist_range_max_inv;
+          float w_s = gauss_space * gauss_range;
+          depth_bf += w_s * depth_s;
+          w += w_s;
+          w_range += gauss_range;
+        }
+      }
+      float filtered = depth_bf / w;
+      out_depth_rg[o * 2 + 0] = (filtered - p->cv_min_ds) / range;
+      out_depth_rg[o * 2 + 1] = w_range / num_samples;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* pre_boundary.fs (a4)                                                        */
+
+ORC_API void orc_boundary(const float* depth_rg, const float* lab, int W, int H, int refine,
+                          float* out_depth_b_rg, float* out_sil)
+{
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < H; ++py) {
+    for (int px = 0; px < W; ++px) {
+      const size_t o = (size_t)py * W + px;
+      float dx = depth_rg[o * 2 + 0], dy = depth_rg[o * 2 + 1];
+      float sil = 1.0f;
+      if (dx <= 0.0f) { /* :90-100 */
+        dy = 0.0f;
+        sil = 0.0f;
+      } else if (!(dy > 0.65f)) { /* :102-113 */
+        sil = 0.0f;
+        /* get_color_diff, :37-55 */
+        const float* color = lab + o * 3;
+        float total_dist = 0.0f, num_samples = 0.0f;
+        for (int y = -2; y < 3; ++y) {
+          for (int x = -2; x < 3; ++x) {
+            size_t os = (size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1);
+            if (depth_rg[os * 2 + 0] > 0.0f && depth_rg[os * 2 + 1] > 0.65f) {
+              num_samples += 1.0f;
+              total_dist += distance3(color, lab + os * 3);
+            }
+          }
+        }
+        float color_dist = (num_samples < 16.0f * 0.5f) ? 1.0f : total_dist / num_samples;
+        if (color_dist > 0.5f || !refine) {
+          dx = -1.0f;
+          dy = 0.1f;
+        } else {
+          dy = 1.0f;
+        }
+      } else {
+        dy = 0.0f;
+      }
+      out_depth_b_rg[o * 2 + 0] = dx;
+      out_depth_b_rg[o * 2 + 1] = dy;
+      out_sil[o] = sil;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* inc_bricks.glsl mark_brick (:40-58) + pre_normal.fs (a5)                   */
+
+typedef struct {
+  int W, H;
+  int xyz_res[3];
+  float bbox_min[3], bbox_max[3];
+  float brick_size;    /* metres, ReconIntegration::setBrickSize */
+  int res_bricks[3];   /* m_res_bricks from divideBox */
+} orc_normal_params;
+
+static inline float signf_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+/* Returns 0 if the home brick index is outside the brick grid: the reference
+ * converts a possibly negative float to uvec3 there (undefined in GLSL) and
+ * indexes out of range; this build SKIPS such positions. */
+static int mark_brick(const float* pos, const orc_normal_params* p, uint32_t* bricks)
+{
+  int idx[3];
+  float diff[3], dabs[3];
+  for (int a = 0; a < 3; ++a) {
+    float f = floorf((pos[a] - p->bbox_min[a]) / p->brick_size);
+    if (!(f >= 0.0f) || !(f < (float)p->res_bricks[a])) return 0;
+    idx[a] = (int)f;
+  }
+  for (int a = 0; a < 3; ++a) {
+    /* to_world(vec3(0.5), index) = vec3(index)*brick_size + bbox_min + 0.5*brick_size */
+    float center = (float)idx[a] * p->brick_size + p->bbox_min[a] + 0.5f * p->brick_size;
+    diff[a] = pos[a] - center;
+    dabs[a] = fabsf(diff[a]);
+  }
+  float min_v = fmaxf(dabs[0], fmaxf(dabs[1], dabs[2]));
+  int nb[3];
+  for (int a = 0; a < 3; ++a) {
+    float mc = (dabs[a] < min_v) ? 0.0f : 1.0f;
+    int off = (int)signf_(diff[a] * mc);
+    nb[a] = clampi(idx[a] + off, 0, p->res_bricks[a] - 1);
+  }
+  const int rx = p->res_bricks[0], ry = p->res_bricks[1];
+  const uint32_t inc = (dabs[0] > p->brick_size * 0.1f) ? 1u : 0u;
+#pragma omp atomic
+  bricks[(size_t)nb[2] * ry * rx + (size_t)nb[1] * rx + nb[0]] += inc;
+#pragma omp atomic
+  bricks[(size_t)idx[2] * ry * rx + (size_t)idx[1] * rx + idx[0]] += 1u;
+  return 1;
+}
+
+static inline int unit_outside(float d) { return (d <= 0.0f) || (d >= 1.0f); }
+
+ORC_API void orc_normal(const float* depth_b_rg, const float* cv_xyz, const orc_normal_params* p,
+                        float* out_normal, uint32_t* bricks /* may be NULL */)
+{
+  const int W = p->W, H = p->H;
+  const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H; /* texSizeInv NetKinectArray.cpp:197 */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < H; ++py) {
+    for (int px = 0; px < W; ++px) {
+      const size_t o = (size_t)py * W + px;
+      float* n = out_normal + o * 3;
+      float depth = depth_b_rg[o * 2];
+      if (unit_outside(depth)) {
+        n[0] = n[1] = n[2] = 0.0f;
+        continue;
+      }
+      const float u = ((float)px + 0.5f) / (float)W;
+      const float v = ((float)py + 0.5f) / (float)H;
+      float world[3];
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], u, v, depth, world);
+      if (bricks) mark_brick(world, p, bricks);
+      /* pre_normal.fs:35-55; "t" is +y, "b" is -y */
+      float vt = v + tsy, vb = v - tsy, ul = u - tsx, ur = u + tsx;
+      float dt = depth_b_rg[((size_t)clampi(py + 1, 0, H - 1) * W + px) * 2];
+      float db = depth_b_rg[((size_t)clampi(py - 1, 0, H - 1) * W + px) * 2];
+      float dl = depth_b_rg[((size_t)py * W + clampi(px - 1, 0, W - 1)) * 2];
+      float dr = depth_b_rg[((size_t)py * W + clampi(px + 1, 0, W - 1)) * 2];
+      dt = unit_outside(dt) ? depth : dt;
+      db = unit_outside(db) ? depth : db;
+      dl = unit_outside(dl) ? depth : dl;
+      dr = unit_outside(dr) ? depth : dr;
+      float wt[3], wb[3], wl[3], wr[3];
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], u, vt, dt, wt);
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], u, vb, db, wb);
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], ul, v, dl, wl);
+      tex3d_linear(cv_xyz, 3, 3, p->xyz_res[0], p->xyz_res[1], p->xyz_res[2], ur, v, dr, wr);
+      float a[3] = {wb[0] - wt[0], wb[1] - wt[1], wb[2] - wt[2]};
+      float b[3] = {wl[0] - wr[0], wl[1] - wr[1], wl[2] - wr[2]};
+      float c[3];
+      cross3(a, b, c);
+      normalize3(c, n);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* pre_quality.fs (a6)                                                         */
+
+ORC_API void orc_quality(const float* depth_b_rg, const float* normals, const float* cv_xyz,
+                         const int* xyz_res, const float* cam_pos, int W, int H, float* out_quality)
+{
+  const float inv_k = 1.0f / 6.0f;
+  (void)inv_k; /* gauss_space feeds only depth_bf / w, which the shader discards */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < H; ++py) {
+    for (int px = 0; px < W; ++px) {
+      const size_t o = (size_t)py * W + px;
+      float depth = depth_b_rg[o * 2];
+      if (unit_outside(depth)) {
+        out_quality[o] = 0.0f;
+        continue;
+      }
+      float dist_range_max = 0.35f * (depth / 1.0f);
+      float dist_range_max_inv = 1.0f / dist_range_max;
+      float w_range = 0.0f, border_samples = 0.0f, num_samples = 0.0f;
+      for (int y = -6; y < 7; ++y) {
+        for (int x = -6; x < 7; ++x) {
+          num_samples += 1.0f;
+          float ds = depth_b_rg[((size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)) * 2];
+          float depth_range = fabsf(ds - depth);
+          if (unit_outside(ds) || (depth_range > dist_range_max)) {
+            border_samples += 1.0f;
+            continue;
+          }
+          float gauss_range = 1.0f - fminf(depth_range, dist_range_max) * dist_range_max_inv;
+          w_range += gauss_range;
+        }
+      }
+      float lateral_quality = 1.0f - border_samples / num_samples;
+      float q = orc_pow6(lateral_quality);
+      q *= orc_pow6(w_range / num_samples);
+      q /= depth * 6.5f;
+      /* normal_angle, :43-48 */
+      const float u = ((float)px + 0.5f) / (float)W;
+      const float v = ((float)py + 0.5f) / (float)H;
+      float wp[3], d[3], dn[3];
+      tex3d_linear(cv_xyz, 3, 3, xyz_res[0], xyz_res[1], xyz_res[2], u, v, depth, wp);
+      d[0] = cam_pos[0] - wp[0];
+      d[1] = cam_pos[1] - wp[1];
+      d[2] = cam_pos[2] - wp[2];
+      normalize3(d, dn);
+      float angle = dot3(dn, normals + o * 3);
+      q *= orc_pow2(angle);
+      out_quality[o] = q;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* tsdf_integration.vs (a9) + VolumeSampler voxel positions (a8)              */
+/* Writes voxels z in [z0, z1) of an X*Y*Z x-fastest volume (whole-volume     */
+/* pointer).  `occupied_voxel_mask`, if not NULL, is one byte per brick       */
+/* (brick = bv voxels per axis, bricks x-fastest, res_bricks given): voxels    */
+/* of unoccupied bricks keep the clear value -limit                           */
+/* (framework/reconstruction/recon_integration.cpp:243-270).                  */
+
+typedef struct {
+  int num_sensors;
+  int W, H;
+  int res[3];          /* TSDF resolution m_res_volume */
+  float limit;
+  int bv;              /* voxels per brick edge */
+  int res_bricks[3];
+} orc_integrate_params;
+
+ORC_API void orc_integrate(const orc_integrate_params* p, const float* const* cv_xyz_inv /* RGBA */,
+                           const int* inv_res /* 3 per sensor */, const float* const* silhouette,
+                           const float* const* depth_b_rg, const float* const* quality,
+                           const uint8_t* occupied_brick_mask, int z0, int z1, float* tsdf)
+{
+  const int X = p->res[0], Y = p->res[1], Z = p->res[2];
+  const float stepX = 1.0f / (float)X, stepY = 1.0f / (float)Y, stepZ = 1.0f / (float)Z;
+  const float limit = p->limit;
+  (void)Z;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int z = z0; z < z1; ++z) {
+    for (int y = 0; y < Y; ++y) {
+      for (int x = 0; x < X; ++x) {
+        const size_t o = (size_t)z * X * Y + (size_t)y * X + x;
+        if (occupied_brick_mask) {
+          size_t b = ((size_t)(z / p->bv) * p->res_bricks[1] + (size_t)(y / p->bv)) * p->res_bricks[0] + (size_t)(x / p->bv);
+          if (!occupied_brick_mask[b]) {
+            tsdf[o] = -limit;
+            continue;
+          }
+        }
+        /* framework/rendering/volume_sampler.cpp:36-42 */
+        const float pos[3] = {((float)x + 0.5f) * stepX, ((float)y + 0.5f) * stepY, ((float)z + 0.5f) * stepZ};
+        float weighted_tsd = limit;
+        float total_weight = 0.0f;
+        for (int i = 0; i < p->num_sensors; ++i) {
+          float pc[3];
+          tex3d_linear(cv_xyz_inv[i], 4, 3, inv_res[3 * i], inv_res[3 * i + 1], inv_res[3 * i + 2],
+                       pos[0], pos[1], pos[2], pc);
+          float sil;
+          tex2d_linear(silhouette[i], 1, 1, p->W, p->H, pc[0], pc[1], &sil);
+          if (sil < 1.0f) {
+            if (weighted_tsd >= limit) {
+              weighted_tsd = -limit;
+              continue;
+            }
+          }
+          int ix = axis_nearest(pc[0], p->W), iy = axis_nearest(pc[1], p->H);
+          float depth = depth_b_rg[i][((size_t)iy * p->W + ix) * 2];
+          float sdist = pc[2] - depth;
+          if (sdist <= -limit) {
+            weighted_tsd = -limit;
+          } else if (sdist >= limit) {
+          } else {
+            float weight;
+            tex2d_linear(quality[i], 1, 1, p->W, p->H, pc[0], pc[1], &weight);
+            weighted_tsd = (weighted_tsd * total_weight + weight * sdist) / (total_weight + weight);
+            total_weight += weight;
+          }
+        }
+        tsdf[o] = weighted_tsd;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Frustum::getCameraPos (framework/calibration/frustum.cpp:21-33, :97-111)   */
+/* corners from getCornerPoints (framework/calibration/CalibVolumes.cpp:98-113) */
+
+static void closest_point(const float* p, const float* u, const float* q, const float* v, float* o)
+{
+  float w0[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+  float a = dot3(u, u), b = dot3(u, v), c = dot3(v, v), d = dot3(u, w0), e = dot3(v, w0);
+  float sc = (b * e - c * d) / (a * c - b * b);
+  float tc = (a * e - b * d) / (a * c - b * b);
+  for (int k = 0; k < 3; ++k) {
+    float pc = p[k] + u[k] * sc;
+    float qc = q[k] + v[k] * tc;
+    o[k] = (pc + qc) * 0.5f;
+  }
+}
+
+ORC_API void orc_camera_pos(const float* cv_xyz, const int* res, float* out)
+{
+  const int ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;
+  const int cx[8] = {0, 0, ex, ex, 0, 0, ex, ex};
+  const int cy[8] = {0, ey, ey, 0, 0, ey, ey, 0};
+  const int cz[8] = {0, 0, 0, 0, ez, ez, ez, ez};
+  float c[8][3];
+  for (int i = 0; i < 8; ++i)
+    for (int k = 0; k < 3; ++k)
+      c[i][k] = cv_xyz[(((size_t)cz[i] * res[1] + cy[i]) * res[0] + cx[i]) * 3 + k];
+  float cn[3], cf[3], vd[3];
+  for (int k = 0; k < 3; ++k) {
+    cn[k] = (c[0][k] + c[1][k] + c[2][k] + c[3][k]) / 4.0f;
+    cf[k] = (c[4][k] + c[5][k] + c[6][k] + c[7][k]) / 4.0f;
+    vd[k] = cf[k] - cn[k];
+  }
+  float pts[4][3];
+  for (int i = 0; i < 4; ++i) {
+    float u[3] = {c[i][0] - c[i + 4][0], c[i][1] - c[i + 4][1], c[i][2] - c[i + 4][2]};
+    closest_point(c[i], u, cn, vd, pts[i]);
+  }
+  for (int k = 0; k < 3; ++k) out[k] = (pts[0][k] + pts[1][k] + pts[2][k] + pts[3][k]) / 4.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Grid geometry (a8): setVoxelSize / setBrickSize / divideBox                */
+/* framework/reconstruction/recon_integration.cpp:341-354, :474-484, :361-388 */
+
+ORC_API void orc_volume_res(const float* bbox_min, const float* bbox_max, float voxel_size, int* res)
+{
+  for (int a = 0; a < 3; ++a) res[a] = (int)ceilf((bbox_max[a] - bbox_min[a]) / voxel_size);
+}
+
+ORC_API float orc_adjust_brick_size(float size, float voxel_size)
+{
+  return voxel_size * roundf(size / voxel_size);
+}
+
+/* the three nested while loops of divideBox, float accumulation included */
+ORC_API void orc_divide_box(const float* bbox_min, const float* bbox_max, float brick_size, int* res_bricks)
+{
+  for (int a = 0; a < 3; ++a) {
+    float min = bbox_min[a];
+    float size = bbox_max[a] - min;
+    float start = min;
+    int n = 0;
+    while (size - start + min > 0.0f) {
+      start += brick_size;
+      ++n;
+    }
+    res_bricks[a] = n;
+  }
+}
+
+/* updateOccupiedBricks CPU filter loop (recon_integration.cpp:436-441) */
+ORC_API uint32_t orc_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels,
+                                     uint32_t* ids, float* ratio)
+{
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; ++i)
+    if (counters[i] >= min_voxels) ids[k++] = i;
+  *ratio = (float)k / (float)n;
+  return k;
+}
+
+/* Reference's genuinely-CPU work per resize:
+ * VolumeSampler::resize position fill (volume_sampler.cpp:33-46).  Used by
+ * bench.py only to time that loop; returns a checksum so it is not elided. */
+ORC_API double orc_volume_sampler_resize(int X, int Y, int Z, float* pos /* X*Y*Z*3 */)
+{
+  float sx = 1.0f / X, sy = 1.0f / Y, sz = 1.0f / Z;
+  size_t k = 0;
+  double acc = 0.0;
+  for (int z = 0; z < Z; ++z)
+    for (int y = 0; y < Y; ++y)
+      for (int x = 0; x < X; ++x) {
+        pos[k++] = (x + 0.5f) * sx;
+        pos[k++] = (y + 0.5f) * sy;
+        pos[k++] = (z + 0.5f) * sz;
+      }
+  acc = pos[0] + pos[k - 1];
+  return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Calibration-volume file format (framework/calibration/calibration_volume.hpp:30-79) */
+
+ORC_API int orc_lut_write(const char* path, const uint32_t* res, const float* limits,
+                          const float* data, int floats_per_record)
+{
+  FILE* f = fopen(path, "wb");
+  if (!f) return -1;
+  size_t n = (size_t)res[0] * res[1] * res[2] * floats_per_record;
+  int ok = fwrite(res, 4, 3, f) == 3 && fwrite(limits, 4, 2, f) == 2 && fwrite(data, 4, n, f) == n;
+  fclose(f);
+  return ok ? 0 : -2;
+}
+
+ORC_API int orc_lut_read_header(const char* path, uint32_t* res, float* limits)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  int ok = fread(res, 4, 3, f) == 3 && fread(limits, 4, 2, f) == 2;
+  fclose(f);
+  return ok ? 0 : -2;
+}
+
+ORC_API int orc_lut_read(const char* path, float* data, int floats_per_record)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  uint32_t res[3];
+  float lim[2];
+  int ok = fread(res, 4, 3, f) == 3 && fread(lim, 4, 2, f) == 2;
+  size_t n = ok ? (size_t)res[0] * res[1] * res[2] * floats_per_record : 0;
+  ok = ok && fread(data, 4, n, f) == n;
+  fclose(f);
+  return ok ? 0 : -2;
+}

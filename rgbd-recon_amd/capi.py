@@ -1,0 +1,360 @@
+"""ctypes bindings of include/rgbdr.h (one-to-one; see that header for the
+reference interface each entry point replaces)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_SENSORS = 8
+TILE = 8
+
+OK = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_OUT_OF_RANGE = -2
+ERR_NO_DEVICE = -3
+ERR_HIP = -4
+ERR_IO = -5
+ERR_STATE = -6
+
+FLAG_FILTER, FLAG_PROCESSED, FLAG_REFINE, FLAG_USE_BRICKS = 1, 2, 4, 8
+FLAGS_DEFAULT = 15
+
+IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
+IMG_CHANNELS = {IMG_DEPTH_RAW: 1, IMG_DEPTH_MORPH: 1, IMG_DEPTH_RG: 2, IMG_LAB: 3, IMG_DEPTH_B_RG: 2,
+                IMG_SILHOUETTE: 1, IMG_NORMAL: 3, IMG_QUALITY: 1}
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("num_sensors", C.c_int32),
+        ("depth_w", C.c_int32), ("depth_h", C.c_int32),
+        ("color_w", C.c_int32), ("color_h", C.c_int32),
+        ("bbox_min", C.c_float * 3), ("bbox_max", C.c_float * 3),
+        ("voxel_size", C.c_float), ("brick_size", C.c_float), ("tsdf_limit", C.c_float),
+        ("min_voxels_per_brick", C.c_uint32),
+        ("flags", C.c_uint32),
+        ("compress_depth", C.c_int32), ("compress_rgb", C.c_int32),
+        ("near_", C.c_float * MAX_SENSORS), ("far_", C.c_float * MAX_SENSORS),
+        ("res_override", C.c_int32 * 3),
+        ("slab_rank", C.c_int32), ("slab_count", C.c_int32),
+    ]
+
+
+class Lut(C.Structure):
+    _fields_ = [("res", C.c_uint32 * 3), ("depth_limits", C.c_float * 2), ("data", C.c_void_p)]
+
+
+class Geometry(C.Structure):
+    _fields_ = [
+        ("res_volume", C.c_int32 * 3), ("res_bricks", C.c_int32 * 3),
+        ("brick_size", C.c_float), ("brick_voxels", C.c_int32), ("num_bricks", C.c_int32),
+        ("tiles", C.c_int32 * 3),
+        ("slab_tile_z0", C.c_int32), ("slab_tile_z1", C.c_int32),
+        ("slab_voxel_z0", C.c_int32), ("slab_voxel_z1", C.c_int32),
+    ]
+
+
+class Pinhole(C.Structure):
+    _fields_ = [
+        ("cam_pos", C.c_float * 3),
+        ("right", C.c_float * 3), ("up", C.c_float * 3), ("forward", C.c_float * 3),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("depth_min", C.c_float), ("depth_max", C.c_float),
+        ("lut_res", C.c_int32 * 3),
+    ]
+
+
+class TsdfDeviceView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("owned", C.c_void_p), ("layer_bytes", C.c_size_t),
+                ("owned_layers", C.c_int32), ("halo_layers", C.c_int32)]
+
+
+# every symbol include/rgbdr.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_CFG, _GEO, _LUT = C.POINTER(Config), C.POINTER(Geometry), C.POINTER(Lut)
+_F, _U32 = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+SYMBOLS = {
+    "rgbdr_create": (C.c_int, [_CFG, C.c_int, C.POINTER(_P)]),
+    "rgbdr_destroy": (None, [_P]),
+    "rgbdr_last_error": (C.c_char_p, [_P]),
+    "rgbdr_status_string": (C.c_char_p, [C.c_int]),
+    "rgbdr_version": (C.c_char_p, []),
+    "rgbdr_compute_geometry": (C.c_int, [_CFG, _GEO]),
+    "rgbdr_slab_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rgbdr_camera_position": (C.c_int, [_LUT, _F]),
+    "rgbdr_set_calibration": (C.c_int, [_P, C.c_int, _LUT, _LUT]),
+    "rgbdr_set_inverse_calibration": (C.c_int, [_P, C.c_int, _LUT]),
+    "rgbdr_load_calibration_files": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "rgbdr_synth_inverse_calibration": (C.c_int, [_P, C.c_int, C.POINTER(Pinhole)]),
+    "rgbdr_upload_frame": (C.c_int, [_P, _P, _P]),
+    "rgbdr_upload_frame_device": (C.c_int, [_P, _P, _P]),
+    "rgbdr_clear_occupied_bricks": (C.c_int, [_P]),
+    "rgbdr_process_textures": (C.c_int, [_P]),
+    "rgbdr_update_occupied_bricks": (C.c_int, [_P]),
+    "rgbdr_integrate": (C.c_int, [_P]),
+    "rgbdr_step": (C.c_int, [_P, _P, _P]),
+    "rgbdr_sync": (C.c_int, [_P]),
+    "rgbdr_set_voxel_size": (C.c_int, [_P, C.c_float]),
+    "rgbdr_set_tsdf_limit": (C.c_int, [_P, C.c_float]),
+    "rgbdr_set_brick_size": (C.c_int, [_P, C.c_float]),
+    "rgbdr_set_use_bricks": (C.c_int, [_P, C.c_int]),
+    "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
+    "rgbdr_filter_textures": (C.c_int, [_P, C.c_int]),
+    "rgbdr_use_processed_depths": (C.c_int, [_P, C.c_int]),
+    "rgbdr_refine_boundary": (C.c_int, [_P, C.c_int]),
+    "rgbdr_get_brick_size": (C.c_float, [_P]),
+    "rgbdr_occupied_ratio": (C.c_float, [_P]),
+    "rgbdr_num_bricks": (C.c_uint32, [_P]),
+    "rgbdr_get_geometry": (C.c_int, [_P, _GEO]),
+    "rgbdr_get_camera_position": (C.c_int, [_P, C.c_int, _F]),
+    "rgbdr_readback_tsdf": (C.c_int, [_P, _F]),
+    "rgbdr_readback_image": (C.c_int, [_P, C.c_int, C.c_int, _F]),
+    "rgbdr_readback_inverse_calibration": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _F]),
+    "rgbdr_readback_brick_counters": (C.c_int, [_P, _U32]),
+    "rgbdr_get_occupied": (C.c_int, [_P, _U32, C.c_size_t, C.POINTER(C.c_size_t), _F]),
+    "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
+    "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "rgbdr_stream": (_P, [_P]),
+    "rgbdr_enable_timers": (C.c_int, [_P, C.c_int]),
+    "rgbdr_timer_ns": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
+    "rgbdr_enable_timer_accumulation": (C.c_int, [_P, C.c_int]),
+    "rgbdr_timer_stats": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+}
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgbdr_hip.so")
+_lib = None
+
+
+class RgbdrError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("rgbdr status %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    """Load librgbdr_hip.so; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run __graft_entry__.build() (make -C rgbd-recon_amd/csrc)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def make_config(num_sensors, depth_wh, color_wh=None, bbox_min=(-1.0, 0.0, -1.0), bbox_max=(1.0, 2.0, 1.0),
+                voxel_size=0.01, brick_size=None, tsdf_limit=0.01, min_voxels=10, flags=FLAGS_DEFAULT,
+                compress_depth=0, near=0.5, far=4.5, res_override=(0, 0, 0), slab_rank=0, slab_count=1):
+    c = Config()
+    c.struct_size = C.sizeof(Config)
+    c.num_sensors = num_sensors
+    c.depth_w, c.depth_h = depth_wh
+    c.color_w, c.color_h = color_wh if color_wh else depth_wh
+    c.bbox_min[:] = bbox_min
+    c.bbox_max[:] = bbox_max
+    c.voxel_size = voxel_size
+    c.brick_size = brick_size if brick_size is not None else 8 * voxel_size
+    c.tsdf_limit = tsdf_limit
+    c.min_voxels_per_brick = min_voxels
+    c.flags = flags
+    c.compress_depth = compress_depth
+    c.compress_rgb = 0
+    for i in range(MAX_SENSORS):
+        c.near_[i] = near
+        c.far_[i] = far
+    c.res_override[:] = res_override
+    c.slab_rank, c.slab_count = slab_rank, slab_count
+    return c
+
+
+def make_lut(data, res, limits=(0.5, 4.5)):
+    """rgbdr_lut over a contiguous float32 array; keeps the array alive."""
+    arr = np.ascontiguousarray(data, dtype=np.float32)
+    l = Lut()
+    l.res[:] = [int(r) for r in res]
+    l.depth_limits[:] = [float(limits[0]), float(limits[1])]
+    l.data = arr.ctypes.data
+    l._keep = arr
+    return l
+
+
+def compute_geometry(cfg):
+    g = Geometry()
+    rc = lib().rgbdr_compute_geometry(C.byref(cfg), C.byref(g))
+    if rc != OK:
+        raise RgbdrError(rc, lib().rgbdr_last_error(None).decode())
+    return g
+
+
+class Context:
+    """Thin RAII wrapper; method names follow the reference's
+    (NetKinectArray::update/processTextures, ReconIntegration::integrate ...)."""
+
+    def __init__(self, cfg, device=0):
+        self._h = _P()
+        self.cfg = cfg
+        rc = lib().rgbdr_create(C.byref(cfg), device, C.byref(self._h))
+        if rc != OK:
+            raise RgbdrError(rc, lib().rgbdr_last_error(None).decode())
+        self.geo = self.geometry()
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise RgbdrError(rc, lib().rgbdr_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            lib().rgbdr_destroy(self._h)
+            self._h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def geometry(self):
+        g = Geometry()
+        self._chk(lib().rgbdr_get_geometry(self._h, C.byref(g)))
+        return g
+
+    # calibration
+    def set_calibration(self, sensor, xyz, xyz_res, uv, uv_res, limits):
+        a, b = make_lut(xyz, xyz_res, limits), make_lut(uv, uv_res, limits)
+        self._chk(lib().rgbdr_set_calibration(self._h, sensor, C.byref(a), C.byref(b)))
+
+    def set_inverse_calibration(self, sensor, inv, res):
+        a = make_lut(inv, res, (0.5, 4.5))
+        self._chk(lib().rgbdr_set_inverse_calibration(self._h, sensor, C.byref(a)))
+
+    def load_calibration_files(self, sensor, xyz=None, uv=None, inv=None):
+        enc = lambda s: s.encode() if s else None
+        self._chk(lib().rgbdr_load_calibration_files(self._h, sensor, enc(xyz), enc(uv), enc(inv)))
+
+    def synth_inverse_calibration(self, sensor, pinhole):
+        self._chk(lib().rgbdr_synth_inverse_calibration(self._h, sensor, C.byref(pinhole)))
+
+    def camera_position(self, sensor):
+        out = (C.c_float * 3)()
+        self._chk(lib().rgbdr_get_camera_position(self._h, sensor, out))
+        return np.array(out[:], dtype=np.float32)
+
+    # per frame
+    def update(self, depth, color):
+        d = np.ascontiguousarray(depth)
+        c = np.ascontiguousarray(color, dtype=np.uint8)
+        self._chk(lib().rgbdr_upload_frame(self._h, d.ctypes.data, c.ctypes.data))
+
+    def update_device(self, depth_ptr, color_ptr):
+        self._chk(lib().rgbdr_upload_frame_device(self._h, depth_ptr, color_ptr))
+
+    def clear_occupied_bricks(self):
+        self._chk(lib().rgbdr_clear_occupied_bricks(self._h))
+
+    def process_textures(self):
+        self._chk(lib().rgbdr_process_textures(self._h))
+
+    def update_occupied_bricks(self):
+        self._chk(lib().rgbdr_update_occupied_bricks(self._h))
+
+    def integrate(self):
+        self._chk(lib().rgbdr_integrate(self._h))
+
+    def step(self, depth, color):
+        d = np.ascontiguousarray(depth)
+        c = np.ascontiguousarray(color, dtype=np.uint8)
+        self._chk(lib().rgbdr_step(self._h, d.ctypes.data, c.ctypes.data))
+
+    def sync(self):
+        self._chk(lib().rgbdr_sync(self._h))
+
+    # setters
+    def set_voxel_size(self, v):
+        self._chk(lib().rgbdr_set_voxel_size(self._h, v))
+        self.geo = self.geometry()
+
+    def set_brick_size(self, v):
+        self._chk(lib().rgbdr_set_brick_size(self._h, v))
+        self.geo = self.geometry()
+
+    def set_tsdf_limit(self, v):
+        self._chk(lib().rgbdr_set_tsdf_limit(self._h, v))
+
+    def set_use_bricks(self, on):
+        self._chk(lib().rgbdr_set_use_bricks(self._h, int(on)))
+
+    def set_min_voxels_per_brick(self, n):
+        self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))
+
+    def filter_textures(self, on):
+        self._chk(lib().rgbdr_filter_textures(self._h, int(on)))
+
+    def use_processed_depths(self, on):
+        self._chk(lib().rgbdr_use_processed_depths(self._h, int(on)))
+
+    def refine_boundary(self, on):
+        self._chk(lib().rgbdr_refine_boundary(self._h, int(on)))
+
+    def occupied_ratio(self):
+        return float(lib().rgbdr_occupied_ratio(self._h))
+
+    # outputs
+    def readback_tsdf(self):
+        g = self.geo
+        out = np.empty((g.slab_voxel_z1 - g.slab_voxel_z0, g.res_volume[1], g.res_volume[0]), dtype=np.float32)
+        self._chk(lib().rgbdr_readback_tsdf(self._h, out.ctypes.data_as(_F)))
+        return out
+
+    def readback_image(self, which, sensor):
+        ch = IMG_CHANNELS[which]
+        out = np.empty((self.cfg.depth_h, self.cfg.depth_w, ch), dtype=np.float32)
+        self._chk(lib().rgbdr_readback_image(self._h, which, sensor, out.ctypes.data_as(_F)))
+        return out[..., 0] if ch == 1 else out
+
+    def readback_inverse_calibration(self, sensor, z0, z1, res_xy=None):
+        x, y = res_xy if res_xy else (self.geo.res_volume[0], self.geo.res_volume[1])
+        out = np.empty((z1 - z0, y, x, 4), dtype=np.float32)
+        self._chk(lib().rgbdr_readback_inverse_calibration(self._h, sensor, z0, z1, out.ctypes.data_as(_F)))
+        return out
+
+    def readback_brick_counters(self):
+        out = np.empty(self.geo.num_bricks, dtype=np.uint32)
+        self._chk(lib().rgbdr_readback_brick_counters(self._h, out.ctypes.data_as(_U32)))
+        return out
+
+    def get_occupied(self):
+        ids = np.empty(self.geo.num_bricks, dtype=np.uint32)
+        n = C.c_size_t()
+        ratio = C.c_float()
+        self._chk(lib().rgbdr_get_occupied(self._h, ids.ctypes.data_as(_U32), ids.size, C.byref(n), C.byref(ratio)))
+        return ids[: n.value].copy(), ratio.value
+
+    def device_tsdf(self):
+        v = TsdfDeviceView()
+        self._chk(lib().rgbdr_device_tsdf(self._h, C.byref(v)))
+        return v
+
+    def stream(self):
+        return lib().rgbdr_stream(self._h)
+
+    def enable_timers(self, on=True):
+        self._chk(lib().rgbdr_enable_timers(self._h, int(on)))
+
+    def enable_timer_accumulation(self, on=True):
+        self._chk(lib().rgbdr_enable_timer_accumulation(self._h, int(on)))
+
+    def timer_stats(self, name):
+        """(total_ns, count) over the intervals since the last call; resets them"""
+        ns, n = C.c_uint64(), C.c_uint32()
+        self._chk(lib().rgbdr_timer_stats(self._h, name.encode(), C.byref(ns), C.byref(n)))
+        return ns.value, n.value
+
+    def timer_ns(self, name):
+        ns = C.c_uint64()
+        self._chk(lib().rgbdr_timer_ns(self._h, name.encode(), C.byref(ns)))
+        return ns.value

@@ -1,0 +1,981 @@
+// api.cpp -- the C ABI of include/rgbdr.h: context, device memory, call order.
+// Host-side mirror of NetKinectArray / CalibVolumes / ReconIntegration state;
+// every GL texture unit / SSBO binding of the reference is a
+// device pointer owned by the context here.  There is no CPU fallback: without a
+// HIP device rgbdr_create fails with RGBDR_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rgbdr_internal.hpp"
+
+using namespace rgbdr;
+
+namespace {
+thread_local std::string g_create_error;
+
+// One named interval.  In accumulate mode every begin/end takes a fresh event
+// pair so a whole timed region can be resolved afterwards without a host sync
+// inside it (bench.py reads the kernel's average launch duration that way).
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool recorded = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+};
+}  // namespace
+
+struct rgbdr_ctx {
+  rgbdr_config cfg{};
+  rgbdr_geometry geo{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // images ([N][H][W][c])
+  float *d_depth_raw = nullptr, *d_depth_morph = nullptr, *d_depth_rg = nullptr, *d_lab = nullptr;
+  float *d_depth_b = nullptr, *d_sil = nullptr, *d_normal = nullptr, *d_quality = nullptr;
+  float4* d_frame = nullptr;
+  uint8_t *d_color = nullptr, *d_depth_u8 = nullptr;
+  bool frame_uploaded = false, textures_processed = false;
+
+  // forward calibration
+  float4* d_cv_xyz[kMaxSensors] = {};
+  float2* d_cv_uv[kMaxSensors] = {};
+  uint32_t xyz_res[kMaxSensors][3] = {}, uv_res[kMaxSensors][3] = {};
+  float min_ds[kMaxSensors] = {}, max_ds[kMaxSensors] = {};
+  float cam_pos[kMaxSensors][3] = {};
+  bool have_calib[kMaxSensors] = {};
+
+  // inverse calibration
+  bool inv_set[kMaxSensors] = {};
+  bool inv_tiled[kMaxSensors] = {};
+  uint32_t inv_res[kMaxSensors][3] = {};
+  float* d_lut_tiled = nullptr;
+  float4* d_lut_generic[kMaxSensors] = {};
+  int zoff[kMaxSensors] = {};
+
+  // volume
+  float *d_tsdf_base = nullptr, *d_tsdf_owned = nullptr;
+  size_t layer_floats = 0;
+  int halo = 0;
+  float* d_linear = nullptr;  // readback scratch
+  size_t linear_floats = 0;
+
+  // bricks
+  uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
+  uint8_t* d_mask = nullptr;
+  bool mask_valid = false;
+
+  bool timers = false, accumulate = false;
+  std::map<std::string, Timer> tm;
+
+  int fail(int code, const std::string& m)
+  {
+    err = m;
+    return code;
+  }
+};
+
+#define HIPCHK(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return ctx->fail(RGBDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+#define LAUNCHCHK(what)                                                                                    \
+  do {                                                                                                     \
+    hipError_t e_ = hipGetLastError();                                                                     \
+    if (e_ != hipSuccess) return ctx->fail(RGBDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+static int nsens(const rgbdr_ctx* c) { return c->cfg.num_sensors; }
+static size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->cfg.depth_w * c->cfg.depth_h; }
+
+static void tbegin(rgbdr_ctx* c, const char* name)
+{
+  if (!c->timers) return;
+  Timer& t = c->tm[name];
+  if (c->accumulate) {
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (!t.pool.empty()) {
+      ev = t.pool.back();
+      t.pool.pop_back();
+    } else {
+      (void)hipEventCreate(&ev.first);
+      (void)hipEventCreate(&ev.second);
+    }
+    t.pending.push_back(ev);
+    (void)hipEventRecord(ev.first, c->stream);
+    return;
+  }
+  if (!t.a) {
+    (void)hipEventCreate(&t.a);
+    (void)hipEventCreate(&t.b);
+  }
+  (void)hipEventRecord(t.a, c->stream);
+}
+static void tend(rgbdr_ctx* c, const char* name)
+{
+  if (!c->timers) return;
+  Timer& t = c->tm[name];
+  if (c->accumulate) {
+    if (!t.pending.empty()) (void)hipEventRecord(t.pending.back().second, c->stream);
+    return;
+  }
+  (void)hipEventRecord(t.b, c->stream);
+  t.recorded = true;
+}
+
+static void free_volume(rgbdr_ctx* c)
+{
+  (void)hipFree(c->d_tsdf_base);
+  (void)hipFree(c->d_linear);
+  (void)hipFree(c->d_counters);
+  (void)hipFree(c->d_ids);
+  (void)hipFree(c->d_mask);
+  (void)hipFree(c->d_lut_tiled);
+  c->d_tsdf_base = c->d_tsdf_owned = c->d_linear = nullptr;
+  c->d_counters = c->d_ids = nullptr;
+  c->d_mask = nullptr;
+  c->d_lut_tiled = nullptr;
+  c->linear_floats = 0;
+  for (int i = 0; i < kMaxSensors; ++i) {
+    (void)hipFree(c->d_lut_generic[i]);
+    c->d_lut_generic[i] = nullptr;
+    c->inv_set[i] = c->inv_tiled[i] = false;
+  }
+}
+
+// setVoxelSize / setBrickSize: (re)allocate TSDF slab + brick table
+static int alloc_volume(rgbdr_ctx* ctx)
+{
+  std::string e;
+  int rc = compute_geometry(ctx->cfg, &ctx->geo, &e);
+  if (rc != RGBDR_OK) return ctx->fail(rc, e);
+  free_volume(ctx);
+  const rgbdr_geometry& g = ctx->geo;
+  ctx->layer_floats = (size_t)g.tiles[0] * g.tiles[1] * kTileVoxels;
+  const int owned = g.slab_tile_z1 - g.slab_tile_z0;
+  ctx->halo = (ctx->cfg.slab_count > 1) ? 1 : 0;
+  const size_t total = ctx->layer_floats * (size_t)(owned + 2 * ctx->halo);
+  HIPCHK(hipMalloc((void**)&ctx->d_tsdf_base, total * sizeof(float)));
+  ctx->d_tsdf_owned = ctx->d_tsdf_base + ctx->layer_floats * ctx->halo;
+  HIPCHK(hipMemsetAsync(ctx->d_tsdf_base, 0, total * sizeof(float), ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks));
+  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks, ctx->stream));
+  ctx->mask_valid = false;
+  return RGBDR_OK;
+}
+
+extern "C" {
+
+const char* rgbdr_version(void) { return "rgbdr-hip 0.1 (gfx950)"; }
+
+const char* rgbdr_status_string(int s)
+{
+  switch (s) {
+    case RGBDR_OK: return "ok";
+    case RGBDR_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RGBDR_ERR_OUT_OF_RANGE: return "out of range";
+    case RGBDR_ERR_NO_DEVICE: return "no HIP device";
+    case RGBDR_ERR_HIP: return "HIP runtime error";
+    case RGBDR_ERR_IO: return "I/O error";
+    case RGBDR_ERR_STATE: return "call order violated";
+    default: return "unknown status";
+  }
+}
+
+const char* rgbdr_last_error(const rgbdr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rgbdr_compute_geometry(const rgbdr_config* cfg, rgbdr_geometry* out)
+{
+  if (!cfg || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  return compute_geometry(*cfg, out, &g_create_error);
+}
+
+int rgbdr_slab_range(int tiles_z, int count, int rank, int* t0, int* t1)
+{
+  if (!t0 || !t1) return RGBDR_ERR_INVALID_ARGUMENT;
+  return slab_range(tiles_z, count, rank, t0, t1);
+}
+
+int rgbdr_camera_position(const rgbdr_lut* cv_xyz, float out[3])
+{
+  if (!cv_xyz || !cv_xyz->data || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (cv_xyz->res[0] < 1 || cv_xyz->res[1] < 1 || cv_xyz->res[2] < 1) return RGBDR_ERR_INVALID_ARGUMENT;
+  camera_position((const float*)cv_xyz->data, cv_xyz->res, out);
+  return RGBDR_OK;
+}
+
+int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
+{
+  auto bad = [&](int code, const std::string& m) {
+    g_create_error = m;
+    return code;
+  };
+  if (!cfg || !out) return bad(RGBDR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(rgbdr_config)) return bad(RGBDR_ERR_INVALID_ARGUMENT, "rgbdr_config.struct_size mismatch");
+  if (cfg->num_sensors < 1 || cfg->num_sensors > kMaxSensors)
+    return bad(RGBDR_ERR_INVALID_ARGUMENT, "num_sensors must be in [1, 8]");
+  if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1)
+    return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must be positive");
+  if (!(cfg->tsdf_limit > 0.0f)) return bad(RGBDR_ERR_INVALID_ARGUMENT, "tsdf_limit must be > 0");
+  if (cfg->compress_rgb != 0) return bad(RGBDR_ERR_INVALID_ARGUMENT, "compress_rgb (DXT) frames are not supported yet");
+  rgbdr_geometry g;
+  std::string e;
+  int rc = compute_geometry(*cfg, &g, &e);
+  if (rc != RGBDR_OK) return bad(rc, e);
+
+  int ndev = 0;
+  hipError_t he = hipGetDeviceCount(&ndev);
+  if (he != hipSuccess || ndev < 1)
+    return bad(RGBDR_ERR_NO_DEVICE, std::string("no HIP device available (") + hipGetErrorString(he) +
+                                        "); this backend has no CPU fallback");
+  if (device_id < 0 || device_id >= ndev) return bad(RGBDR_ERR_OUT_OF_RANGE, "device_id out of range");
+  if (hipSetDevice(device_id) != hipSuccess) return bad(RGBDR_ERR_NO_DEVICE, "hipSetDevice failed");
+
+  rgbdr_ctx* ctx = new rgbdr_ctx();
+  ctx->cfg = *cfg;
+  if (ctx->cfg.slab_count <= 0) {
+    ctx->cfg.slab_count = 1;
+    ctx->cfg.slab_rank = 0;
+  }
+  ctx->device = device_id;
+  auto cleanup = [&](int code) {
+    g_create_error = ctx->err;
+    rgbdr_destroy(ctx);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    ctx->err = "hipStreamCreate failed";
+    return cleanup(RGBDR_ERR_HIP);
+  }
+  const size_t n = npx(ctx);
+  const size_t ncol = (size_t)cfg->num_sensors * cfg->color_w * cfg->color_h * 3;
+  struct {
+    void** p;
+    size_t bytes;
+  } allocs[] = {{(void**)&ctx->d_depth_raw, n * 4},   {(void**)&ctx->d_depth_morph, n * 4},
+                {(void**)&ctx->d_depth_rg, n * 8},    {(void**)&ctx->d_lab, n * 12},
+                {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
+                {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
+                {(void**)&ctx->d_frame, n * 16},      {(void**)&ctx->d_color, ncol},
+                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 16}};
+  for (auto& a : allocs) {
+    if (hipMalloc(a.p, a.bytes) != hipSuccess) {
+      ctx->err = "hipMalloc of image buffers failed";
+      return cleanup(RGBDR_ERR_HIP);
+    }
+    (void)hipMemsetAsync(*a.p, 0, a.bytes, ctx->stream);
+  }
+  // 13x13 spatial kernel of the bilateral filter, pre_depth.fs:37-41,115
+  float gauss[169];
+  const float inv_k = 1.0f / 6.0f;
+  for (int y = -6; y < 7; ++y)
+    for (int x = -6; x < 7; ++x) {
+      const float len = std::sqrt((float)x * (float)x + (float)y * (float)y);
+      gauss[(y + 6) * 13 + (x + 6)] = 1.0f - len * inv_k;
+    }
+  set_gauss_table(gauss);
+  rc = alloc_volume(ctx);
+  if (rc != RGBDR_OK) return cleanup(rc);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    ctx->err = "device initialisation failed";
+    return cleanup(RGBDR_ERR_HIP);
+  }
+  *out = ctx;
+  return RGBDR_OK;
+}
+
+void rgbdr_destroy(rgbdr_ctx* ctx)
+{
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_volume(ctx);
+  void* ptrs[] = {ctx->d_depth_raw, ctx->d_depth_morph, ctx->d_depth_rg, ctx->d_lab,   ctx->d_depth_b, ctx->d_sil,
+                  ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count};
+  for (void* p : ptrs) (void)hipFree(p);
+  for (int i = 0; i < kMaxSensors; ++i) {
+    (void)hipFree(ctx->d_cv_xyz[i]);
+    (void)hipFree(ctx->d_cv_uv[i]);
+  }
+  for (auto& kv : ctx->tm) {
+    if (kv.second.a) (void)hipEventDestroy(kv.second.a);
+    if (kv.second.b) (void)hipEventDestroy(kv.second.b);
+    for (auto* v : {&kv.second.pending, &kv.second.pool})
+      for (auto& ev : *v) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+      }
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+// ---------------------------------------------------------------------------
+int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, const rgbdr_lut* uv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!xyz || !uv || !xyz->data || !uv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null calibration volume");
+  for (int a = 0; a < 3; ++a)
+    if (xyz->res[a] < 1 || uv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty calibration volume");
+  if (!(xyz->depth_limits[1] > xyz->depth_limits[0]))
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz depth limits must satisfy max > min");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nx = (size_t)xyz->res[0] * xyz->res[1] * xyz->res[2];
+  const size_t nu = (size_t)uv->res[0] * uv->res[1] * uv->res[2];
+  (void)hipFree(ctx->d_cv_xyz[sensor]);
+  (void)hipFree(ctx->d_cv_uv[sensor]);
+  ctx->d_cv_xyz[sensor] = nullptr;
+  ctx->d_cv_uv[sensor] = nullptr;
+  float* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, nx * 12));
+  HIPCHK(hipMalloc((void**)&ctx->d_cv_xyz[sensor], nx * 16));
+  HIPCHK(hipMalloc((void**)&ctx->d_cv_uv[sensor], nu * 8));
+  HIPCHK(hipMemcpyAsync(tmp, xyz->data, nx * 12, hipMemcpyHostToDevice, ctx->stream));
+  launch_repack_xyz(tmp, ctx->d_cv_xyz[sensor], nx, ctx->stream);
+  LAUNCHCHK("repack_xyz");
+  HIPCHK(hipMemcpyAsync(ctx->d_cv_uv[sensor], uv->data, nu * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipFree(tmp));
+  for (int a = 0; a < 3; ++a) {
+    ctx->xyz_res[sensor][a] = xyz->res[a];
+    ctx->uv_res[sensor][a] = uv->res[a];
+  }
+  ctx->min_ds[sensor] = xyz->depth_limits[0];
+  ctx->max_ds[sensor] = xyz->depth_limits[1];
+  camera_position((const float*)xyz->data, xyz->res, ctx->cam_pos[sensor]);
+  ctx->have_calib[sensor] = true;
+  return RGBDR_OK;
+}
+
+static int ensure_tiled_lut(rgbdr_ctx* ctx)
+{
+  if (ctx->d_lut_tiled) return RGBDR_OK;
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
+  const size_t bytes = ntiles * nsens(ctx) * 3 * kTileVoxels * sizeof(float);
+  HIPCHK(hipMalloc((void**)&ctx->d_lut_tiled, bytes));
+  return RGBDR_OK;
+}
+
+int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* inv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!inv || !inv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null inverse calibration volume");
+  for (int a = 0; a < 3; ++a)
+    if (inv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty inverse calibration volume");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const int X = inv->res[0], Y = inv->res[1], Z = inv->res[2];
+  const float4* host = (const float4*)inv->data;
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  ctx->inv_set[sensor] = false;
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = inv->res[a];
+  if (lut_is_one_to_one(inv->res, g.res_volume)) {
+    int rc = ensure_tiled_lut(ctx);
+    if (rc != RGBDR_OK) return rc;
+    // stage whole tile layers through a bounded scratch buffer
+    const int chunk_layers = 8;
+    float4* tmp = nullptr;
+    const size_t row = (size_t)X * Y;
+    HIPCHK(hipMalloc((void**)&tmp, row * kTile * chunk_layers * sizeof(float4)));
+    for (int tz = g.slab_tile_z0; tz < g.slab_tile_z1; tz += chunk_layers) {
+      const int tz_end = tz + chunk_layers < g.slab_tile_z1 ? tz + chunk_layers : g.slab_tile_z1;
+      const int vz0 = tz * kTile;
+      int vz1 = tz_end * kTile;
+      if (vz1 > Z) vz1 = Z;
+      HIPCHK(hipMemcpyAsync(tmp, host + row * vz0, row * (size_t)(vz1 - vz0) * sizeof(float4), hipMemcpyHostToDevice,
+                            ctx->stream));
+      float* dst = ctx->d_lut_tiled +
+                   (size_t)(tz - g.slab_tile_z0) * g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
+      launch_tile_lut(tmp, X, Y, Z, vz0, g.tiles[0], g.tiles[1], tz, tz_end - tz, sensor, nsens(ctx), dst,
+                      ctx->stream);
+      LAUNCHCHK("tile_lut");
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    HIPCHK(hipFree(tmp));
+    ctx->inv_tiled[sensor] = true;
+  } else {
+    int lo, hi;
+    lut_z_range(Z, g.res_volume[2], g.slab_voxel_z0, g.slab_voxel_z1, &lo, &hi);
+    const size_t row = (size_t)X * Y;
+    const size_t cnt = row * (size_t)(hi - lo + 1);
+    HIPCHK(hipMalloc((void**)&ctx->d_lut_generic[sensor], cnt * sizeof(float4)));
+    HIPCHK(hipMemcpyAsync(ctx->d_lut_generic[sensor], host + row * lo, cnt * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->zoff[sensor] = lo;
+    ctx->inv_tiled[sensor] = false;
+  }
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+static int read_lut_file(rgbdr_ctx* ctx, const char* path, size_t rec_bytes, rgbdr_lut* lut, std::vector<char>* buf)
+{
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return ctx->fail(RGBDR_ERR_IO, std::string("cannot open ") + path);
+  bool ok = std::fread(lut->res, 4, 3, f) == 3 && std::fread(lut->depth_limits, 4, 2, f) == 2;
+  size_t n = 0;
+  if (ok) {
+    n = (size_t)lut->res[0] * lut->res[1] * lut->res[2] * rec_bytes;
+    buf->resize(n);
+    ok = std::fread(buf->data(), 1, n, f) == n;
+  }
+  std::fclose(f);
+  if (!ok) return ctx->fail(RGBDR_ERR_IO, std::string("short read from ") + path);
+  lut->data = buf->data();
+  return RGBDR_OK;
+}
+
+int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* pxyz, const char* puv, const char* pinv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if ((pxyz == nullptr) != (puv == nullptr))
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz and cv_uv must be given together");
+  if (pxyz) {
+    rgbdr_lut a{}, b{};
+    std::vector<char> ba, bb;
+    int rc = read_lut_file(ctx, pxyz, 12, &a, &ba);
+    if (rc != RGBDR_OK) return rc;
+    rc = read_lut_file(ctx, puv, 8, &b, &bb);
+    if (rc != RGBDR_OK) return rc;
+    rc = rgbdr_set_calibration(ctx, sensor, &a, &b);
+    if (rc != RGBDR_OK) return rc;
+  }
+  if (pinv) {
+    rgbdr_lut c{};
+    std::vector<char> bc;
+    int rc = read_lut_file(ctx, pinv, 16, &c, &bc);
+    if (rc != RGBDR_OK) return rc;
+    rc = rgbdr_set_inverse_calibration(ctx, sensor, &c);
+    if (rc != RGBDR_OK) return rc;
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!cam) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null pinhole");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const uint32_t r[3] = {(uint32_t)g.res_volume[0], (uint32_t)g.res_volume[1], (uint32_t)g.res_volume[2]};
+  if (!lut_is_one_to_one(r, g.res_volume))
+    return ctx->fail(RGBDR_ERR_STATE, "synthetic inverse LUT needs a grid whose voxel centres hit texel centres exactly");
+  int rc = ensure_tiled_lut(ctx);
+  if (rc != RGBDR_OK) return rc;
+  launch_synth_inverse(*cam, ctx->cfg.depth_w, ctx->cfg.depth_h, ctx->cfg.bbox_min, ctx->cfg.bbox_max, g.res_volume[0],
+                       g.res_volume[1], g.res_volume[2], g.tiles[0], g.tiles[1], g.slab_tile_z0,
+                       g.slab_tile_z1 - g.slab_tile_z0, sensor, nsens(ctx), ctx->d_lut_tiled, ctx->stream);
+  LAUNCHCHK("synth_inverse");
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = r[a];
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  ctx->inv_tiled[sensor] = true;
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, hipMemcpyKind kind)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = npx(ctx);
+  const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
+  if (ctx->cfg.compress_depth) {
+    HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ctx->stream));
+    launch_u8_to_unit(ctx->d_depth_u8, ctx->d_depth_raw, n, ctx->stream);
+    LAUNCHCHK("u8_to_unit");
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ctx->stream));
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ctx->stream));
+  ctx->frame_uploaded = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color)
+{
+  return upload_common(ctx, depth, color, hipMemcpyHostToDevice);
+}
+int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth, const void* color)
+{
+  return upload_common(ctx, depth, color, hipMemcpyDeviceToDevice);
+}
+
+int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_process_textures(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->frame_uploaded) return ctx->fail(RGBDR_ERR_STATE, "process_textures before any frame was uploaded");
+  for (int i = 0; i < nsens(ctx); ++i)
+    if (!ctx->have_calib[i]) return ctx->fail(RGBDR_ERR_STATE, "process_textures before set_calibration of every sensor");
+  HIPCHK(hipSetDevice(ctx->device));
+  PreParams p{};
+  p.N = nsens(ctx);
+  p.W = ctx->cfg.depth_w;
+  p.H = ctx->cfg.depth_h;
+  p.Wc = ctx->cfg.color_w;
+  p.Hc = ctx->cfg.color_h;
+  for (int a = 0; a < 3; ++a) {
+    p.bbox_min[a] = ctx->cfg.bbox_min[a];
+    p.bbox_max[a] = ctx->cfg.bbox_max[a];
+    p.res_bricks[a] = ctx->geo.res_bricks[a];
+  }
+  p.filter = (ctx->cfg.flags & RGBDR_FLAG_FILTER) ? 1 : 0;
+  p.refine = (ctx->cfg.flags & RGBDR_FLAG_REFINE) ? 1 : 0;
+  p.compress = ctx->cfg.compress_depth ? 1 : 0;
+  for (int i = 0; i < p.N; ++i) {
+    p.cv_xyz[i] = ctx->d_cv_xyz[i];
+    p.cv_uv[i] = ctx->d_cv_uv[i];
+    for (int a = 0; a < 3; ++a) {
+      p.xyz_res[i][a] = (int)ctx->xyz_res[i][a];
+      p.uv_res[i][a] = (int)ctx->uv_res[i][a];
+      p.cam_pos[i][a] = ctx->cam_pos[i][a];
+    }
+    p.cv_min_ds[i] = ctx->min_ds[i];
+    p.cv_max_ds[i] = ctx->max_ds[i];
+    p.near_[i] = ctx->cfg.near_[i];
+    p.far_[i] = ctx->cfg.far_[i];
+  }
+  p.brick_size = ctx->geo.brick_size;
+  p.brick_counters = ctx->d_counters;
+  p.color = ctx->d_color;
+  p.depth_morph = ctx->d_depth_morph;
+  p.depth_rg = ctx->d_depth_rg;
+  p.lab = ctx->d_lab;
+  p.depth_b_rg = ctx->d_depth_b;
+  p.silhouette = ctx->d_sil;
+  p.normal = ctx->d_normal;
+  p.quality = ctx->d_quality;
+  p.frame = ctx->d_frame;
+  // m_use_processed_depth: the filter pass reads the morph output instead of the
+  // raw depth (NetKinectArray.cpp:287-289)
+  p.depth_in = (ctx->cfg.flags & RGBDR_FLAG_PROCESSED) ? ctx->d_depth_morph : ctx->d_depth_raw;
+
+  tbegin(ctx, "1preprocess");
+  tbegin(ctx, "morph");
+  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->stream);
+  tend(ctx, "morph");
+  tbegin(ctx, "bilateral");
+  launch_pre_depth(p, ctx->stream);
+  tend(ctx, "bilateral");
+  tbegin(ctx, "boundary");
+  launch_boundary(p, ctx->stream);
+  tend(ctx, "boundary");
+  tbegin(ctx, "normal");
+  launch_normal(p, ctx->stream);
+  tend(ctx, "normal");
+  tbegin(ctx, "quality");
+  launch_quality(p, ctx->stream);
+  tend(ctx, "quality");
+  tend(ctx, "1preprocess");
+  LAUNCHCHK("process_textures");
+  ctx->textures_processed = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(ctx->device));
+  tbegin(ctx, "bricks");
+  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick, ctx->d_mask,
+                         ctx->d_count, ctx->stream);
+  tend(ctx, "bricks");
+  LAUNCHCHK("update_occupied");
+  ctx->mask_valid = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_integrate(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "integrate before process_textures");
+  const int N = nsens(ctx);
+  bool all_tiled = true, any_tiled = false;
+  for (int i = 0; i < N; ++i) {
+    if (!ctx->inv_set[i])
+      return ctx->fail(RGBDR_ERR_STATE, "integrate before set_inverse_calibration of every sensor (it must be repeated "
+                                        "after the grid was resized)");
+    all_tiled = all_tiled && ctx->inv_tiled[i];
+    any_tiled = any_tiled || ctx->inv_tiled[i];
+  }
+  if (any_tiled && !all_tiled)
+    return ctx->fail(RGBDR_ERR_STATE, "inverse LUTs at 1:1 and at other resolutions cannot be mixed in one context yet");
+  const bool bricks = (ctx->cfg.flags & RGBDR_FLAG_USE_BRICKS) != 0;
+  if (bricks && !ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "integrate with bricks before update_occupied_bricks");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  IntegrateParams p{};
+  p.N = N;
+  p.W = ctx->cfg.depth_w;
+  p.H = ctx->cfg.depth_h;
+  p.X = g.res_volume[0];
+  p.Y = g.res_volume[1];
+  p.Z = g.res_volume[2];
+  p.TX = g.tiles[0];
+  p.TY = g.tiles[1];
+  p.tz0 = g.slab_tile_z0;
+  p.ntz = g.slab_tile_z1 - g.slab_tile_z0;
+  p.limit = ctx->cfg.tsdf_limit;
+  p.stepX = 1.0f / (float)p.X;
+  p.stepY = 1.0f / (float)p.Y;
+  p.stepZ = 1.0f / (float)p.Z;
+  const size_t img = (size_t)p.W * p.H;
+  for (int i = 0; i < N; ++i) {
+    p.frame[i] = ctx->d_frame + img * i;
+    p.lut[i] = ctx->d_lut_generic[i];
+    p.rx[i] = (int)ctx->inv_res[i][0];
+    p.ry[i] = (int)ctx->inv_res[i][1];
+    p.rz[i] = (int)ctx->inv_res[i][2];
+    p.zoff[i] = ctx->zoff[i];
+  }
+  p.lut_tiled = ctx->d_lut_tiled;
+  p.use_bricks = bricks ? 1 : 0;
+  p.brick_mask = ctx->d_mask;
+  p.bv = g.brick_voxels;
+  p.bx = g.res_bricks[0];
+  p.by = g.res_bricks[1];
+  p.bz = g.res_bricks[2];
+  p.tsdf = ctx->d_tsdf_owned;
+  tbegin(ctx, "2integrate");
+  launch_integrate(p, all_tiled, ctx->stream);
+  tend(ctx, "2integrate");
+  LAUNCHCHK("integrate");
+  return RGBDR_OK;
+}
+
+int rgbdr_step(rgbdr_ctx* ctx, const void* depth, const void* color)
+{
+  int rc = rgbdr_upload_frame(ctx, depth, color);
+  if (rc == RGBDR_OK) rc = rgbdr_clear_occupied_bricks(ctx);
+  if (rc == RGBDR_OK) rc = rgbdr_process_textures(ctx);
+  if (rc == RGBDR_OK) rc = rgbdr_update_occupied_bricks(ctx);
+  if (rc == RGBDR_OK) rc = rgbdr_integrate(ctx);
+  return rc;
+}
+
+int rgbdr_sync(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "voxel size must be > 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rgbdr_config old = ctx->cfg;
+  ctx->cfg.voxel_size = size;
+  ctx->cfg.res_override[0] = ctx->cfg.res_override[1] = ctx->cfg.res_override[2] = 0;
+  rgbdr_geometry g;
+  std::string e;
+  int rc = compute_geometry(ctx->cfg, &g, &e);
+  if (rc != RGBDR_OK) {
+    ctx->cfg = old;
+    return ctx->fail(rc, e);
+  }
+  return alloc_volume(ctx);
+}
+
+int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "brick size must be > 0");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  rgbdr_config trial = ctx->cfg;
+  trial.brick_size = size;
+  rgbdr_geometry g;
+  std::string e;
+  int rc = compute_geometry(trial, &g, &e);
+  if (rc != RGBDR_OK) return ctx->fail(rc, e);
+  ctx->cfg = trial;
+  ctx->geo = g;
+  // only the brick table changes; the volume and the LUTs stay
+  (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_ids);
+  (void)hipFree(ctx->d_mask);
+  ctx->d_counters = ctx->d_ids = nullptr;
+  ctx->d_mask = nullptr;
+  HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks));
+  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks, ctx->stream));
+  ctx->mask_valid = false;
+  return RGBDR_OK;
+}
+
+int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!(limit > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be > 0");
+  ctx->cfg.tsdf_limit = limit;
+  return RGBDR_OK;
+}
+
+static int set_flag(rgbdr_ctx* ctx, uint32_t flag, int on)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (on)
+    ctx->cfg.flags |= flag;
+  else
+    ctx->cfg.flags &= ~flag;
+  return RGBDR_OK;
+}
+int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_USE_BRICKS, on); }
+int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
+int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_PROCESSED, on); }
+int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }
+
+int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  ctx->cfg.min_voxels_per_brick = n;
+  return RGBDR_OK;
+}
+
+float rgbdr_get_brick_size(const rgbdr_ctx* ctx) { return ctx ? ctx->geo.brick_size : 0.0f; }
+uint32_t rgbdr_num_bricks(const rgbdr_ctx* ctx) { return ctx ? (uint32_t)ctx->geo.num_bricks : 0u; }
+
+float rgbdr_occupied_ratio(rgbdr_ctx* ctx)
+{
+  if (!ctx || !ctx->mask_valid) return 0.0f;
+  (void)hipSetDevice(ctx->device);
+  uint32_t c = 0;
+  if (hipMemcpyAsync(&c, ctx->d_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0.0f;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0.0f;
+  return (float)c / (float)ctx->geo.num_bricks;
+}
+
+int rgbdr_get_geometry(const rgbdr_ctx* ctx, rgbdr_geometry* out)
+{
+  if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  *out = ctx->geo;
+  return RGBDR_OK;
+}
+
+int rgbdr_get_camera_position(const rgbdr_ctx* ctx, int sensor, float out[3])
+{
+  if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= ctx->cfg.num_sensors || !ctx->have_calib[sensor]) return RGBDR_ERR_OUT_OF_RANGE;
+  std::memcpy(out, ctx->cam_pos[sensor], 12);
+  return RGBDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t n = (size_t)g.res_volume[0] * g.res_volume[1] * (size_t)(g.slab_voxel_z1 - g.slab_voxel_z0);
+  if (ctx->linear_floats < n) {
+    (void)hipFree(ctx->d_linear);
+    ctx->d_linear = nullptr;
+    ctx->linear_floats = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_linear, n * sizeof(float)));
+    ctx->linear_floats = n;
+  }
+  launch_detile(ctx->d_tsdf_owned, ctx->d_linear, g.res_volume[0], g.res_volume[1], g.tiles[0], g.tiles[1],
+                g.slab_tile_z0, g.slab_voxel_z0, g.slab_voxel_z1, ctx->stream);
+  LAUNCHCHK("detile");
+  HIPCHK(hipMemcpyAsync(dst, ctx->d_linear, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  const float* src = nullptr;
+  int ch = 1;
+  switch (which) {
+    case RGBDR_IMG_DEPTH_RAW: src = ctx->d_depth_raw; break;
+    case RGBDR_IMG_DEPTH_MORPH: src = ctx->d_depth_morph; break;
+    case RGBDR_IMG_DEPTH_RG: src = ctx->d_depth_rg; ch = 2; break;
+    case RGBDR_IMG_LAB: src = ctx->d_lab; ch = 3; break;
+    case RGBDR_IMG_DEPTH_B_RG: src = ctx->d_depth_b; ch = 2; break;
+    case RGBDR_IMG_SILHOUETTE: src = ctx->d_sil; break;
+    case RGBDR_IMG_NORMAL: src = ctx->d_normal; ch = 3; break;
+    case RGBDR_IMG_QUALITY: src = ctx->d_quality; break;
+    default: return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "unknown image id");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t img = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * ch;
+  HIPCHK(hipMemcpyAsync(dst, src + img * sensor, img * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!ctx->inv_set[sensor]) return ctx->fail(RGBDR_ERR_STATE, "inverse calibration of this sensor is not set");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const int X = (int)ctx->inv_res[sensor][0], Y = (int)ctx->inv_res[sensor][1];
+  const size_t row = (size_t)X * Y;
+  if (ctx->inv_tiled[sensor]) {
+    if (z0 < g.slab_voxel_z0 || z1 > g.slab_voxel_z1 || z0 >= z1)
+      return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "z rows outside this context's slab");
+    float4* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, row * (size_t)(z1 - z0) * sizeof(float4)));
+    launch_untile_lut(ctx->d_lut_tiled, X, Y, g.tiles[0], g.tiles[1], g.slab_tile_z0, z0, z1, sensor, nsens(ctx), tmp,
+                      ctx->stream);
+    LAUNCHCHK("untile_lut");
+    HIPCHK(hipMemcpyAsync(dst, tmp, row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(tmp));
+  } else {
+    int lo, hi;
+    lut_z_range((int)ctx->inv_res[sensor][2], g.res_volume[2], g.slab_voxel_z0, g.slab_voxel_z1, &lo, &hi);
+    if (z0 < lo || z1 > hi + 1 || z0 >= z1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "texel rows not resident");
+    HIPCHK(hipMemcpyAsync(dst, ctx->d_lut_generic[sensor] + row * (size_t)(z0 - lo),
+                          row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(dst, ctx->d_counters, (size_t)ctx->geo.num_bricks * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* count, float* ratio)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null count");
+  if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "get_occupied before update_occupied_bricks");
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_compact_occupied(ctx->d_mask, (uint32_t)ctx->geo.num_bricks, ctx->d_ids, ctx->d_count + 1, ctx->stream);
+  LAUNCHCHK("compact_occupied");
+  uint32_t c = 0;
+  HIPCHK(hipMemcpyAsync(&c, ctx->d_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *count = c;
+  if (ratio) *ratio = (float)c / (float)ctx->geo.num_bricks;
+  if (ids) {
+    if (capacity < c) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "id buffer too small");
+    HIPCHK(hipMemcpyAsync(ids, ctx->d_ids, (size_t)c * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out)
+{
+  if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  out->base = ctx->d_tsdf_base;
+  out->owned = ctx->d_tsdf_owned;
+  out->layer_bytes = ctx->layer_floats * sizeof(float);
+  out->owned_layers = ctx->geo.slab_tile_z1 - ctx->geo.slab_tile_z0;
+  out->halo_layers = ctx->halo;
+  return RGBDR_OK;
+}
+
+int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
+{
+  if (!ctx || !ptr) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  *ptr = ctx->d_frame + (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sensor;
+  return RGBDR_OK;
+}
+
+void* rgbdr_stream(rgbdr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rgbdr_enable_timers(rgbdr_ctx* ctx, int on)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  ctx->timers = on != 0;
+  return RGBDR_OK;
+}
+
+int rgbdr_enable_timer_accumulation(rgbdr_ctx* ctx, int on)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  ctx->accumulate = on != 0;
+  if (on) ctx->timers = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint32_t* count)
+{
+  if (!ctx || !name || !total_ns || !count) return RGBDR_ERR_INVALID_ARGUMENT;
+  *total_ns = 0;
+  *count = 0;
+  auto it = ctx->tm.find(name);
+  if (it == ctx->tm.end()) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, std::string("no timer ") + name);
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  double total = 0.0;
+  for (auto& ev : it->second.pending) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+    total += (double)ms * 1.0e6;
+    ++*count;
+    it->second.pool.push_back(ev);
+  }
+  it->second.pending.clear();
+  *total_ns = (uint64_t)total;
+  return RGBDR_OK;
+}
+
+int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns)
+{
+  if (!ctx || !name || !ns) return RGBDR_ERR_INVALID_ARGUMENT;
+  auto it = ctx->tm.find(name);
+  if (it == ctx->tm.end() || !it->second.recorded) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, std::string("no timer ") + name);
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventSynchronize(it->second.b));
+  float ms = 0.0f;
+  HIPCHK(hipEventElapsedTime(&ms, it->second.a, it->second.b));
+  *ns = (uint64_t)((double)ms * 1.0e6);
+  return RGBDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+// geometry.cpp -- host-only grid / brick / slab arithmetic.  No device calls, so
+// the `not gpu` tests exercise it through the C ABI without a GPU.
+//
+// Restates (not copies) the reference's CPU-side geometry:
+//   setVoxelSize   framework/reconstruction/recon_integration.cpp:341-354
+//   setBrickSize   :474-484
+//   divideBox      :361-388   (float-accumulating while loops -> m_res_bricks)
+//   Frustum::getCameraPos  framework/calibration/frustum.cpp:21-33,97-111
+#include <cmath>
+#include <cstring>
+
+#include "rgbdr_internal.hpp"
+
+namespace rgbdr {
+
+int slab_range(int tiles_z, int count, int rank, int* t0, int* t1)
+{
+  if (count <= 0) count = 1;
+  if (tiles_z <= 0 || rank < 0 || rank >= count) return RGBDR_ERR_INVALID_ARGUMENT;
+  // whole tile layers, the first (tiles_z % count) slabs get one layer more
+  const int base = tiles_z / count, rem = tiles_z % count;
+  *t0 = rank * base + (rank < rem ? rank : rem);
+  *t1 = *t0 + base + (rank < rem ? 1 : 0);
+  return RGBDR_OK;
+}
+
+int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err)
+{
+  auto fail = [&](const char* m) {
+    if (err) *err = m;
+    return (int)RGBDR_ERR_INVALID_ARGUMENT;
+  };
+  if (!(cfg.voxel_size > 0.0f)) return fail("voxel_size must be > 0");
+  if (!(cfg.brick_size > 0.0f)) return fail("brick_size must be > 0");
+  for (int a = 0; a < 3; ++a)
+    if (!(cfg.bbox_max[a] > cfg.bbox_min[a])) return fail("bbox_max must exceed bbox_min on every axis");
+
+  for (int a = 0; a < 3; ++a) {
+    if (cfg.res_override[a] > 0)
+      g->res_volume[a] = cfg.res_override[a];
+    else
+      g->res_volume[a] = (int)std::ceil((cfg.bbox_max[a] - cfg.bbox_min[a]) / cfg.voxel_size);
+    if (g->res_volume[a] <= 0) return fail("empty volume");
+  }
+  // setBrickSize: m_brick_size = m_voxel_size * round(size / m_voxel_size)
+  float ratio = std::round(cfg.brick_size / cfg.voxel_size);
+  if (ratio < 1.0f) ratio = 1.0f;
+  g->brick_size = cfg.voxel_size * ratio;
+  g->brick_voxels = (int)ratio;
+  // divideBox: count bricks per axis with the reference's accumulating loop; a
+  // rounding residue can add a sliver brick, never lose one that holds voxels
+  for (int a = 0; a < 3; ++a) {
+    const float mn = cfg.bbox_min[a];
+    const float size = cfg.bbox_max[a] - mn;
+    float start = mn;
+    int n = 0;
+    while (size - start + mn > 0.0f) {
+      start += g->brick_size;
+      ++n;
+      if (n > (1 << 20)) return fail("brick grid too fine");
+    }
+    const int need = (g->res_volume[a] + g->brick_voxels - 1) / g->brick_voxels;
+    g->res_bricks[a] = n > need ? n : need;
+  }
+  const long long nb = (long long)g->res_bricks[0] * g->res_bricks[1] * g->res_bricks[2];
+  if (nb > (1ll << 30)) return fail("too many bricks");
+  g->num_bricks = (int)nb;
+  for (int a = 0; a < 3; ++a) g->tiles[a] = (g->res_volume[a] + kTile - 1) / kTile;
+  int count = cfg.slab_count <= 0 ? 1 : cfg.slab_count;
+  if (count > g->tiles[2]) return fail("more slabs than tile layers");
+  int rc = slab_range(g->tiles[2], count, cfg.slab_rank, &g->slab_tile_z0, &g->slab_tile_z1);
+  if (rc != RGBDR_OK) return fail("slab_rank out of range");
+  g->slab_voxel_z0 = g->slab_tile_z0 * kTile;
+  g->slab_voxel_z1 = g->slab_tile_z1 * kTile;
+  if (g->slab_voxel_z1 > g->res_volume[2]) g->slab_voxel_z1 = g->res_volume[2];
+  return RGBDR_OK;
+}
+
+static inline float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void closest_point(const float* p, const float* u, const float* q, const float* v, float* o)
+{
+  const float w0[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+  const float a = dot3(u, u), b = dot3(u, v), c = dot3(v, v), d = dot3(u, w0), e = dot3(v, w0);
+  const float sc = (b * e - c * d) / (a * c - b * b);
+  const float tc = (a * e - b * d) / (a * c - b * b);
+  for (int k = 0; k < 3; ++k) o[k] = ((p[k] + u[k] * sc) + (q[k] + v[k] * tc)) * 0.5f;
+}
+
+void camera_position(const float* xyz, const uint32_t res[3], float out[3])
+{
+  const uint32_t ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;
+  // corner order of getCornerPoints: near face (z = 0) then far face (z = end)
+  const uint32_t cx[8] = {0, 0, ex, ex, 0, 0, ex, ex};
+  const uint32_t cy[8] = {0, ey, ey, 0, 0, ey, ey, 0};
+  const uint32_t cz[8] = {0, 0, 0, 0, ez, ez, ez, ez};
+  float c[8][3];
+  for (int i = 0; i < 8; ++i)
+    std::memcpy(c[i], xyz + (((size_t)cz[i] * res[1] + cy[i]) * res[0] + cx[i]) * 3, 12);
+  float cn[3], cf[3], view[3];
+  for (int k = 0; k < 3; ++k) {
+    cn[k] = (c[0][k] + c[1][k] + c[2][k] + c[3][k]) / 4.0f;
+    cf[k] = (c[4][k] + c[5][k] + c[6][k] + c[7][k]) / 4.0f;
+    view[k] = cf[k] - cn[k];
+  }
+  float pt[4][3];
+  for (int i = 0; i < 4; ++i) {
+    const float edge[3] = {c[i][0] - c[i + 4][0], c[i][1] - c[i + 4][1], c[i][2] - c[i + 4][2]};
+    closest_point(c[i], edge, cn, view, pt[i]);
+  }
+  for (int k = 0; k < 3; ++k) out[k] = (pt[0][k] + pt[1][k] + pt[2][k] + pt[3][k]) / 4.0f;
+}
+
+bool lut_is_one_to_one(const uint32_t lut_res[3], const int32_t vol_res[3])
+{
+  for (int a = 0; a < 3; ++a) {
+    if ((int32_t)lut_res[a] != vol_res[a]) return false;
+    const int n = vol_res[a];
+    const float step = 1.0f / (float)n;
+    for (int i = 0; i < n; ++i) {
+      // the voxel-centre coordinate exactly as the integration kernel forms it
+      const float s = ((float)i + 0.5f) * step;
+      const float t = s * (float)n - 0.5f;
+      if (t != (float)i) return false;
+    }
+  }
+  return true;
+}
+
+void lut_z_range(int rz, int Z, int vz0, int vz1, int* lo, int* hi)
+{
+  const float step = 1.0f / (float)Z;
+  auto texel = [&](int vz) {
+    const float s = ((float)vz + 0.5f) * step;
+    return (int)std::floor(s * (float)rz - 0.5f);
+  };
+  int a = texel(vz0) - 1, b = texel(vz1 > vz0 ? vz1 - 1 : vz0) + 2;
+  if (a < 0) a = 0;
+  if (b > rz - 1) b = rz - 1;
+  if (a > b) a = b;
+  *lo = a;
+  *hi = b;
+}
+
+}  // namespace rgbdr

@@ -1,0 +1,316 @@
+// kernels_integrate.hip -- TSDF integration for gfx950 (MI355X), replacing
+// glsl/tsdf_integration.vs driven by ReconIntegration::integrate
+// (framework/reconstruction/recon_integration.cpp:243-270) and the voxel-centre
+// VBO of VolumeSampler (framework/rendering/volume_sampler.cpp:33-76).
+//
+// Layout (DESIGN.md "Data layout in HBM"):
+//   * TSDF volume: tile-linear, 8x8x8-voxel tiles of 2 KiB, tiles x-fastest.
+//   * 1:1 inverse LUT: per tile, per sensor, three 512-float planes (u, v, d) --
+//     the .w channel of the reference's RGBA32F texels is never read by the
+//     shader (tsdf_integration.vs:31 takes .xyz) and is dropped at upload.
+//     One workgroup (2 wavefronts) sweeps one tile: every LUT plane is a
+//     contiguous 2 KiB stream read with 16-B-per-lane loads, the 2 KiB tile of
+//     TSDF leaves with 16-B-per-lane stores, and the clear to -limit is fused
+//     (no separate memset pass, recon_integration.cpp:249-251).
+//   * generic inverse LUT (resolution != TSDF resolution): the file's x-fastest
+//     RGBA32F volume, sampled with 8 taps per voxel.
+//   * frames: per sensor H*W float4 {depth_b.r, quality, silhouette, depth_b.g}
+//     so one 16-B gather per bilinear tap serves all three samplers of the shader.
+//
+// The per-voxel fold over sensors is order dependent (overwrite-to -limit
+// branches interleaved with a running weighted mean, tsdf_integration.vs:28-55),
+// so sensors stay sequential per lane and voxels are parallel across lanes.
+// Bound: HBM streaming, (4 + 12 N) B per voxel at 1:1.  No MFMA: there is no
+// dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+
+#include "rgbdr_internal.hpp"
+#include "sampling.cuh"
+
+namespace rgbdr {
+
+// One sensor's contribution to one voxel (tsdf_integration.vs:31-54).
+__device__ __forceinline__ void fold_sensor(const float4* __restrict__ frame, int W, int H, float pcx, float pcy,
+                                            float pcz, float limit, float& tsd, float& wsum)
+{
+  const Axis X = axis_linear(pcx, W), Y = axis_linear(pcy, H);
+  const float4* r0 = frame + (size_t)Y.i0 * W;
+  const float4* r1 = frame + (size_t)Y.i1 * W;
+  const float4 p00 = r0[X.i0], p10 = r0[X.i1], p01 = r1[X.i0], p11 = r1[X.i1];
+  const float sil = lerpf(lerpf(p00.z, p10.z, X.a), lerpf(p01.z, p11.z, X.a), Y.a);
+  if (sil < 1.0f && tsd >= limit) {
+    tsd = -limit;
+    return;
+  }
+  // NEAREST depth: floor(s*n) is i0 or i0+1 of the LINEAR footprint, so the
+  // texel is one of the four already loaded
+  const int nx = axis_nearest(pcx, W), ny = axis_nearest(pcy, H);
+  const float d0 = (nx == X.i0) ? p00.x : p10.x;
+  const float d1 = (nx == X.i0) ? p01.x : p11.x;
+  const float depth = (ny == Y.i0) ? d0 : d1;
+  const float sdist = pcz - depth;
+  if (sdist <= -limit) {
+    tsd = -limit;
+  } else if (sdist >= limit) {
+  } else {
+    const float weight = lerpf(lerpf(p00.y, p10.y, X.a), lerpf(p01.y, p11.y, X.a), Y.a);
+    tsd = (tsd * wsum + weight * sdist) / (wsum + weight);
+    wsum += weight;
+  }
+}
+
+__device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx, int vy, int vz)
+{
+  const int bx = vx / p.bv, by = vy / p.bv, bz = vz / p.bv;
+  if (bx >= p.bx || by >= p.by || bz >= p.bz) return false;
+  return p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+}
+
+// ---------------------------------------------------------------------------
+// 1:1 LUT.  128 threads = one tile; thread q owns voxels x0..x0+3 of row (y,z).
+template <int N, bool BRICKS>
+__global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
+{
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch),
+  // so give each XCD one contiguous run of tiles: neighbouring tiles project to
+  // neighbouring pixels and re-use each other's frame texels in that XCD's L2.
+  const unsigned nblk = gridDim.x;
+  unsigned tile = blockIdx.x;
+  if ((nblk & 7u) == 0u) tile = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
+
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % p.TX;
+  const int ty = (tile / p.TX) % p.TY;
+  const int tzl = tile / (p.TX * p.TY);
+  float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
+  const float limit = p.limit;
+
+  bool occ[4] = {true, true, true, true};
+  if (BRICKS) {
+    const int vz = (p.tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx = tx * kTile + lx0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      occ[j] = voxel_occupied(p, vx + j, vy, vz);
+      any |= occ[j];
+    }
+    if (!any) {  // fused clear
+      *out = make_float4(-limit, -limit, -limit, -limit);
+      return;
+    }
+  }
+
+  const float4* lut = reinterpret_cast<const float4*>(p.lut_tiled + (size_t)tile * (N * 3 * kTileVoxels)) + q;
+  float4 U[N], V[N], D[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    U[i] = lut[(i * 3 + 0) * (kTileVoxels / 4)];
+    V[i] = lut[(i * 3 + 1) * (kTileVoxels / 4)];
+    D[i] = lut[(i * 3 + 2) * (kTileVoxels / 4)];
+  }
+  float tsd[4] = {limit, limit, limit, limit};
+  float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float4* frame = p.frame[i];
+    fold_sensor(frame, p.W, p.H, U[i].x, V[i].x, D[i].x, limit, tsd[0], wsum[0]);
+    fold_sensor(frame, p.W, p.H, U[i].y, V[i].y, D[i].y, limit, tsd[1], wsum[1]);
+    fold_sensor(frame, p.W, p.H, U[i].z, V[i].z, D[i].z, limit, tsd[2], wsum[2]);
+    fold_sensor(frame, p.W, p.H, U[i].w, V[i].w, D[i].w, limit, tsd[3], wsum[3]);
+  }
+  if (BRICKS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (!occ[j]) tsd[j] = -limit;
+  }
+  *out = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Generic LUT resolution: 8-tap trilinear of the RGBA32F volume per voxel.
+template <bool BRICKS>
+__global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
+{
+  const unsigned tile = blockIdx.x;
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % p.TX;
+  const int ty = (tile / p.TX) % p.TY;
+  const int tzl = tile / (p.TX * p.TY);
+  const int vz = (p.tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx0 = tx * kTile + lx0;
+  float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
+  const float limit = p.limit;
+  float res[4];
+  // voxel centre exactly as VolumeSampler builds it (volume_sampler.cpp:36-42)
+  const float pz = ((float)vz + 0.5f) * p.stepZ, py = ((float)vy + 0.5f) * p.stepY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int vx = vx0 + j;
+    if (BRICKS && !voxel_occupied(p, vx, vy, vz)) {
+      res[j] = -limit;
+      continue;
+    }
+    if (vx >= p.X || vy >= p.Y || vz >= p.Z) {  // padding voxel of a partial tile
+      res[j] = -limit;
+      continue;
+    }
+    const float px = ((float)vx + 0.5f) * p.stepX;
+    float tsd = limit, wsum = 0.0f;
+    for (int i = 0; i < p.N; ++i) {
+      const float3 pc = tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], px, py, pz);
+      fold_sensor(p.frame[i], p.W, p.H, pc.x, pc.y, pc.z, limit, tsd, wsum);
+    }
+    res[j] = tsd;
+  }
+  *out = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+template <int N>
+static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
+{
+  if (p.use_bricks)
+    hipLaunchKernelGGL((k_integrate_tiled<N, true>), dim3(ntiles), dim3(128), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_integrate_tiled<N, false>), dim3(ntiles), dim3(128), 0, s, p);
+}
+
+void launch_integrate(const IntegrateParams& p, bool one_to_one, hipStream_t s)
+{
+  const unsigned ntiles = (unsigned)p.TX * p.TY * p.ntz;
+  if (!one_to_one) {
+    if (p.use_bricks)
+      hipLaunchKernelGGL((k_integrate_generic<true>), dim3(ntiles), dim3(128), 0, s, p);
+    else
+      hipLaunchKernelGGL((k_integrate_generic<false>), dim3(ntiles), dim3(128), 0, s, p);
+    return;
+  }
+  switch (p.N) {
+    case 1: launch_tiled_n<1>(p, ntiles, s); break;
+    case 2: launch_tiled_n<2>(p, ntiles, s); break;
+    case 3: launch_tiled_n<3>(p, ntiles, s); break;
+    case 4: launch_tiled_n<4>(p, ntiles, s); break;
+    case 5: launch_tiled_n<5>(p, ntiles, s); break;
+    case 6: launch_tiled_n<6>(p, ntiles, s); break;
+    case 7: launch_tiled_n<7>(p, ntiles, s); break;
+    default: launch_tiled_n<8>(p, ntiles, s); break;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tile-linear -> x-fastest linear (readback helper; one thread per voxel)
+__global__ void k_detile(const float* __restrict__ tiled, float* __restrict__ linear, int X, int Y, int TX, int TY,
+                         int tz0, int vz0, int vz1)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, z = vz0 + blockIdx.z;
+  if (x >= X || z >= vz1) return;
+  const size_t tile = ((size_t)(z / kTile - tz0) * TY + (y / kTile)) * TX + (x / kTile);
+  const int in = (z & 7) * 64 + (y & 7) * 8 + (x & 7);
+  linear[((size_t)(z - vz0) * Y + y) * X + x] = tiled[tile * kTileVoxels + in];
+}
+void launch_detile(const float* tiled, float* linear, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
+                   hipStream_t s)
+{
+  dim3 grid((X + 127) / 128, Y, vz1 - vz0);
+  hipLaunchKernelGGL(k_detile, grid, dim3(128), 0, s, tiled, linear, X, Y, TX, TY, tz0, vz0, vz1);
+}
+
+// x-fastest RGBA volume (z rows [src_z0, ...) resident at src) -> tiled planes
+__global__ __launch_bounds__(128) void k_tile_lut(const float4* __restrict__ src, int X, int Y, int Z, int src_z0,
+                                                  int TX, int TY, int tz0, int sensor, int N,
+                                                  float* __restrict__ dst)
+{
+  const unsigned tile = blockIdx.x;
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % TX, ty = (tile / TX) % TY, tzl = tile / (TX * TY);
+  const int vz = (tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx0 = tx * kTile + lx0;
+  float u[4], v[4], d[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int vx = vx0 + j;
+    float4 t = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+    if (vx < X && vy < Y && vz < Z) t = src[((size_t)(vz - src_z0) * Y + vy) * X + vx];
+    u[j] = t.x;
+    v[j] = t.y;
+    d[j] = t.z;
+  }
+  float4* o = reinterpret_cast<float4*>(dst + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
+  o[0] = make_float4(u[0], u[1], u[2], u[3]);
+  o[kTileVoxels / 4] = make_float4(v[0], v[1], v[2], v[3]);
+  o[2 * (kTileVoxels / 4)] = make_float4(d[0], d[1], d[2], d[3]);
+}
+void launch_tile_lut(const float4* src, int X, int Y, int Z, int src_z0, int TX, int TY, int tz0, int ntz, int sensor,
+                     int N, float* dst, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_tile_lut, dim3((unsigned)TX * TY * ntz), dim3(128), 0, s, src, X, Y, Z, src_z0, TX, TY, tz0,
+                     sensor, N, dst);
+}
+
+__global__ void k_untile_lut(const float* __restrict__ tiled, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
+                             int sensor, int N, float4* __restrict__ dst)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, z = vz0 + blockIdx.z;
+  if (x >= X || z >= vz1) return;
+  const size_t tile = ((size_t)(z / kTile - tz0) * TY + (y / kTile)) * TX + (x / kTile);
+  const int in = (z & 7) * 64 + (y & 7) * 8 + (x & 7);
+  const float* b = tiled + (tile * N + sensor) * 3 * kTileVoxels;
+  dst[((size_t)(z - vz0) * Y + y) * X + x] = make_float4(b[in], b[kTileVoxels + in], b[2 * kTileVoxels + in], 0.0f);
+}
+void launch_untile_lut(const float* tiled, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1, int sensor, int N,
+                       float4* dst, hipStream_t s)
+{
+  dim3 grid((X + 127) / 128, Y, vz1 - vz0);
+  hipLaunchKernelGGL(k_untile_lut, grid, dim3(128), 0, s, tiled, X, Y, TX, TY, tz0, vz0, vz1, sensor, N, dst);
+}
+
+// ---------------------------------------------------------------------------
+// Benchmark support: analytic inverse LUT of a pinhole sensor written straight
+// into the tiled planes (SURVEY.md section 8d "LUT generation ... on-device").
+__global__ __launch_bounds__(128) void k_synth_inverse(rgbdr_pinhole cam, int W, int H, float3 bmin, float3 bext, int X,
+                                                       int Y, int Z, int TX, int TY, int tz0, int sensor, int N,
+                                                       float* __restrict__ dst)
+{
+  const unsigned tile = blockIdx.x;
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % TX, ty = (tile / TX) % TY, tzl = tile / (TX * TY);
+  const int vz = (tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx0 = tx * kTile + lx0;
+  float u[4], v[4], d[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int vx = vx0 + j;
+    u[j] = v[j] = d[j] = -1.0f;
+    if (vx >= X || vy >= Y || vz >= Z) continue;
+    const float wx = bmin.x + (((float)vx + 0.5f) / (float)X) * bext.x;
+    const float wy = bmin.y + (((float)vy + 0.5f) / (float)Y) * bext.y;
+    const float wz = bmin.z + (((float)vz + 0.5f) / (float)Z) * bext.z;
+    const float rx = wx - cam.cam_pos[0], ry = wy - cam.cam_pos[1], rz = wz - cam.cam_pos[2];
+    const float xc = rx * cam.right[0] + ry * cam.right[1] + rz * cam.right[2];
+    const float yc = rx * cam.up[0] + ry * cam.up[1] + rz * cam.up[2];
+    const float zc = rx * cam.forward[0] + ry * cam.forward[1] + rz * cam.forward[2];
+    if (!(zc >= cam.depth_min && zc <= cam.depth_max)) continue;
+    const float pxl = cam.fx * xc / zc + cam.cx, pyl = cam.fy * yc / zc + cam.cy;
+    if (!(pxl >= 0.0f && pxl < (float)W && pyl >= 0.0f && pyl < (float)H)) continue;
+    u[j] = pxl / (float)W;
+    v[j] = pyl / (float)H;
+    d[j] = (zc - cam.depth_min) / (cam.depth_max - cam.depth_min);
+  }
+  float4* o = reinterpret_cast<float4*>(dst + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
+  o[0] = make_float4(u[0], u[1], u[2], u[3]);
+  o[kTileVoxels / 4] = make_float4(v[0], v[1], v[2], v[3]);
+  o[2 * (kTileVoxels / 4)] = make_float4(d[0], d[1], d[2], d[3]);
+}
+void launch_synth_inverse(const rgbdr_pinhole& cam, int W, int H, const float bbox_min[3], const float bbox_max[3],
+                          int X, int Y, int Z, int TX, int TY, int tz0, int ntz, int sensor, int N, float* dst,
+                          hipStream_t s)
+{
+  const float3 bmin = make_float3(bbox_min[0], bbox_min[1], bbox_min[2]);
+  const float3 bext = make_float3(bbox_max[0] - bbox_min[0], bbox_max[1] - bbox_min[1], bbox_max[2] - bbox_min[2]);
+  hipLaunchKernelGGL(k_synth_inverse, dim3((unsigned)TX * TY * ntz), dim3(128), 0, s, cam, W, H, bmin, bext, X, Y, Z,
+                     TX, TY, tz0, sensor, N, dst);
+}
+
+}  // namespace rgbdr

@@ -1,0 +1,481 @@
+// kernels_pre.hip -- depth-preprocessing chain for gfx950 (MI355X).
+//
+// One kernel per reference pass so per-pass parity stays checkable:
+//   k_morph      glsl/pre_morph.fs       (NetKinectArray::processDepth, NetKinectArray.cpp:251-290)
+//   k_pre_depth  glsl/pre_depth.fs + inc_color.glsl + inc_bbox_test.glsl   (:331-356)
+//   k_boundary   glsl/pre_boundary.fs    (:362-377)
+//   k_normal     glsl/pre_normal.fs + inc_bricks.glsl mark_brick           (:382-397)
+//   k_quality    glsl/pre_quality.fs     (:400-414)
+// The launch geometry replaces ScreenQuad (one fragment per depth texel,
+// framework/rendering/screen_quad.cpp:7-35): blockIdx.z is the sensor layer,
+// 16x16 pixel blocks (4 wavefronts).  The two 13x13 passes stage their depth
+// window (16+12)^2 in LDS once per block instead of 169 texture fetches per pixel.
+// These passes move ~56 B/pixel of compulsory traffic and are ALU/latency bound;
+// they are reported as time, not as a roofline fraction.
+#include <hip/hip_runtime.h>
+
+#include "rgbdr_internal.hpp"
+#include "sampling.cuh"
+
+namespace rgbdr {
+
+constexpr int BX = 16, BY = 16;   // pixel block
+constexpr int R13 = 6;            // 13x13 window radius
+constexpr int TW = BX + 2 * R13;  // 28
+constexpr int TH = BY + 2 * R13;
+
+// 1 - length(vec2(x,y)) * (1/6) for x,y in [-6,6], filled by the host with the
+// same correctly-rounded sqrtf (pre_depth.fs:37-41,115)
+__constant__ float c_gauss_space[169];
+
+void set_gauss_table(const float* t) { (void)hipMemcpyToSymbol(HIP_SYMBOL(c_gauss_space), t, 169 * sizeof(float)); }
+
+// ---------------------------------------------------------------------------
+__global__ void k_u8_to_unit(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t n)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i] / 255.0f;  // GL_LUMINANCE u8 texture as the sampler returns it
+}
+void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_u8_to_unit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+
+__global__ void k_repack_xyz(const float* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], 0.0f);
+}
+void launch_repack_xyz(const float* src, float4* dst, size_t n, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_repack_xyz, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
+}
+
+// ---------------------------------------------------------------------------
+// pre_morph.fs mode 0 (dilate, :73-112).  The mode-1 pass of the reference is a
+// plain copy (:130-131) of this result, so one kernel produces what
+// m_textures_depth2.front holds after processDepth().
+__device__ __forceinline__ bool morph_valid(float d) { return d > 0.5f && d < 4.5f; }
+
+__global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_all, float* __restrict__ out_all, int W,
+                                                  int H)
+{
+  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  if (px >= W || py >= H) return;
+  const float* in = in_all + (size_t)blockIdx.z * W * H;
+  float* out = out_all + (size_t)blockIdx.z * W * H;
+  const float depth = in[(size_t)py * W + px];
+  float res;
+  if (morph_valid(depth)) {
+    res = depth;
+  } else {
+    float nb[9];
+#pragma unroll
+    for (int y = -1; y < 2; ++y)
+#pragma unroll
+      for (int x = -1; x < 2; ++x)
+        nb[(y + 1) * 3 + (x + 1)] = in[(size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)];
+    float average = 0.0f, num = 0.0f;
+    bool valid = false;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      if (morph_valid(nb[k])) {
+        valid = true;
+        average += nb[k];
+        num += 1.0f;
+      }
+    if (!valid) {
+      res = 0.0f;
+    } else {
+      average /= num;
+      float nd = 0.0f;
+      num = 0.0f;
+      valid = false;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (morph_valid(nb[k]) && fabsf(average - nb[k]) < 0.2f) {
+          valid = true;
+          nd += nb[k];
+          num += 1.0f;
+        }
+      res = valid ? nd / num : 0.0f;
+    }
+  }
+  out[(size_t)py * W + px] = res;
+}
+
+void launch_morph(const PreParams& p, const float* in, float* out, hipStream_t s)
+{
+  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
+  hipLaunchKernelGGL(k_morph, grid, dim3(BX, BY), 0, s, in, out, p.W, p.H);
+}
+
+// ---------------------------------------------------------------------------
+// inc_color.glsl.  With the reference's extra /255 (:14-16) a [0,1] colour never
+// reaches either pow() branch; they are kept for inputs outside that range.
+__device__ __forceinline__ float pivot_rgb(float n)
+{
+  return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : n / 12.92f) * 100.0f;
+}
+__device__ __forceinline__ float pivot_xyz(float n)
+{
+  return n > 0.008856f ? powf(n, 1.0f / 3.0f) : (903.3f * n + 16.0f) / 116.0f;
+}
+__device__ __forceinline__ float3 rgb_to_lab(float3 rgb)
+{
+  const float r = pivot_rgb(rgb.x / 255.0f), g = pivot_rgb(rgb.y / 255.0f), b = pivot_rgb(rgb.z / 255.0f);
+  const float X = r * 0.4124f + g * 0.3576f + b * 0.1805f;
+  const float Y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  const float Z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
+  const float x = pivot_xyz(X / 95.047f), y = pivot_xyz(Y / 100.000f), z = pivot_xyz(Z / 108.883f);
+  return make_float3(fmaxf(0.0f, 116.0f * y - 16.0f), 500.0f * (x - y), 200.0f * (y - z));
+}
+
+__device__ __forceinline__ float3 color_bilinear(const uint8_t* __restrict__ img, int W, int H, float u, float v)
+{
+  const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
+  const uint8_t* p00 = img + ((size_t)Y.i0 * W + X.i0) * 3;
+  const uint8_t* p10 = img + ((size_t)Y.i0 * W + X.i1) * 3;
+  const uint8_t* p01 = img + ((size_t)Y.i1 * W + X.i0) * 3;
+  const uint8_t* p11 = img + ((size_t)Y.i1 * W + X.i1) * 3;
+  float c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t00 = (float)p00[k] / 255.0f, t10 = (float)p10[k] / 255.0f;
+    const float t01 = (float)p01[k] / 255.0f, t11 = (float)p11[k] / 255.0f;
+    c[k] = lerpf(lerpf(t00, t10, X.a), lerpf(t01, t11, X.a), Y.a);
+  }
+  return make_float3(c[0], c[1], c[2]);
+}
+
+// pre_depth.fs:51-72 sample(): optional u8 un-compress
+__device__ __forceinline__ float pd_uncompress(float d, bool compress, float scale, float scaled_near, float near_)
+{
+  if (!compress) return d;
+  if (d < scaled_near) return 0.0f;
+  return (d * d + 0.15f * scaled_near) * scale + near_;
+}
+
+__global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
+{
+  __shared__ float tile[TH][TW + 1];
+  const int l = blockIdx.z;
+  const int W = p.W, H = p.H;
+  const float* depth = p.depth_in + (size_t)l * W * H;
+  const bool compress = p.compress != 0;
+  const float scale = p.far_[l] - p.near_[l];
+  const float scaled_near = scale / 255.0f;
+  const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
+  // stage the (clamped) depth window once per block
+  for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
+    const int ty = i / TW, tx = i - ty * TW;
+    const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
+    tile[ty][tx] = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
+  }
+  __syncthreads();
+  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  if (px >= W || py >= H) return;
+  const size_t o = (size_t)l * W * H + (size_t)py * W + px;
+  const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+  const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
+  const float range = max_ds - min_ds;
+  const float depth0 = tile[threadIdx.y + R13][threadIdx.x + R13];
+  const float depth_norm = (depth0 - min_ds) / range;
+  const float3 pw = tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], p.xyz_res[l][2], 0, u, v, depth_norm);
+  const bool in_box = pw.x >= p.bbox_min[0] && pw.y >= p.bbox_min[1] && pw.z >= p.bbox_min[2] &&
+                      pw.x <= p.bbox_max[0] && pw.y <= p.bbox_max[1] && pw.z <= p.bbox_max[2];
+  const float dn_c = (depth_norm <= 0.0f || depth_norm >= 1.0f) ? 1.0f : depth_norm;
+  const float2 cc = tex3d_uv(p.cv_uv[l], p.uv_res[l][0], p.uv_res[l][1], p.uv_res[l][2], u, v, dn_c);
+  const float3 rgb = color_bilinear(p.color + (size_t)l * p.Wc * p.Hc * 3, p.Wc, p.Hc, cc.x, cc.y);
+  const float3 lab = rgb_to_lab(rgb);
+  p.lab[o * 3 + 0] = lab.x;
+  p.lab[o * 3 + 1] = lab.y;
+  p.lab[o * 3 + 2] = lab.z;
+  float2 out;
+  if (!in_box) {
+    out = make_float2(0.0f, 0.0f);
+  } else if (!p.filter) {
+    out = make_float2(depth_norm, 1.0f);
+  } else {
+    // bilateral_filter, pre_depth.fs:85-127: same tap order (y outer, x inner)
+    const float dist_range_max = 0.35f * (depth0 / 4.5f);
+    const float dist_range_max_inv = 1.0f / dist_range_max;
+    float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f;
+    for (int y = 0; y < 13; ++y) {
+#pragma unroll
+      for (int x = 0; x < 13; ++x) {
+        const float ds = tile[threadIdx.y + y][threadIdx.x + x];
+        const float dr = fabsf(ds - depth0);
+        if ((ds < min_ds) || (ds > max_ds) || (dr > dist_range_max)) continue;
+        const float gs = c_gauss_space[y * 13 + x];
+        const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+        const float ws = gs * gr;
+        depth_bf += ws * ds;
+        w += ws;
+        w_range += gr;
+      }
+    }
+    const float filtered = depth_bf / w;
+    out = make_float2((filtered - min_ds) / range, w_range / 169.0f);
+  }
+  p.depth_rg[o * 2 + 0] = out.x;
+  p.depth_rg[o * 2 + 1] = out.y;
+}
+
+void launch_pre_depth(const PreParams& p, hipStream_t s)
+{
+  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
+  hipLaunchKernelGGL(k_pre_depth, grid, dim3(BX, BY), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float distance3(const float* a, const float* b)
+{
+  const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+__global__ __launch_bounds__(BX* BY) void k_boundary(PreParams p)
+{
+  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int W = p.W, H = p.H;
+  if (px >= W || py >= H) return;
+  const size_t lo = (size_t)blockIdx.z * W * H;
+  const float* drg = p.depth_rg + lo * 2;
+  const float* lab = p.lab + lo * 3;
+  const size_t o = (size_t)py * W + px;
+  float dx = drg[o * 2], dy = drg[o * 2 + 1];
+  float sil = 1.0f;
+  if (dx <= 0.0f) {  // pre_boundary.fs:90-100
+    dy = 0.0f;
+    sil = 0.0f;
+  } else if (!(dy > 0.65f)) {  // :102-113
+    sil = 0.0f;
+    const float* color = lab + o * 3;
+    float total = 0.0f, num = 0.0f;
+    for (int y = -2; y < 3; ++y)
+      for (int x = -2; x < 3; ++x) {
+        const size_t os = (size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1);
+        if (drg[os * 2] > 0.0f && drg[os * 2 + 1] > 0.65f) {
+          num += 1.0f;
+          total += distance3(color, lab + os * 3);
+        }
+      }
+    const float color_dist = (num < 16.0f * 0.5f) ? 1.0f : total / num;
+    if (color_dist > 0.5f || !p.refine) {
+      dx = -1.0f;
+      dy = 0.1f;
+    } else {
+      dy = 1.0f;
+    }
+  } else {
+    dy = 0.0f;
+  }
+  p.depth_b_rg[(lo + o) * 2] = dx;
+  p.depth_b_rg[(lo + o) * 2 + 1] = dy;
+  p.silhouette[lo + o] = sil;
+}
+
+void launch_boundary(const PreParams& p, hipStream_t s)
+{
+  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
+  hipLaunchKernelGGL(k_boundary, grid, dim3(BX, BY), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool unit_outside(float d) { return (d <= 0.0f) || (d >= 1.0f); }
+__device__ __forceinline__ float sign_of(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+// inc_bricks.glsl:40-58.  Positions whose home brick lies outside the brick grid
+// are skipped (the reference indexes out of range there).
+__device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos)
+{
+  const float w[3] = {pos.x, pos.y, pos.z};
+  int idx[3];
+  float diff[3], dabs[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float f = floorf((w[a] - p.bbox_min[a]) / p.brick_size);
+    if (!(f >= 0.0f) || !(f < (float)p.res_bricks[a])) return;
+    idx[a] = (int)f;
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float center = (float)idx[a] * p.brick_size + p.bbox_min[a] + 0.5f * p.brick_size;
+    diff[a] = w[a] - center;
+    dabs[a] = fabsf(diff[a]);
+  }
+  const float min_v = fmaxf(dabs[0], fmaxf(dabs[1], dabs[2]));
+  int nb[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float mc = (dabs[a] < min_v) ? 0.0f : 1.0f;
+    nb[a] = clampi(idx[a] + (int)sign_of(diff[a] * mc), 0, p.res_bricks[a] - 1);
+  }
+  const size_t rx = p.res_bricks[0], ry = p.res_bricks[1];
+  const unsigned inc = (dabs[0] > p.brick_size * 0.1f) ? 1u : 0u;
+  if (inc) atomicAdd(&p.brick_counters[(size_t)nb[2] * ry * rx + (size_t)nb[1] * rx + nb[0]], inc);
+  atomicAdd(&p.brick_counters[(size_t)idx[2] * ry * rx + (size_t)idx[1] * rx + idx[0]], 1u);
+}
+
+__global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
+{
+  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int W = p.W, H = p.H, l = blockIdx.z;
+  if (px >= W || py >= H) return;
+  const size_t lo = (size_t)l * W * H;
+  const float* db = p.depth_b_rg + lo * 2;
+  const size_t o = (size_t)py * W + px;
+  float3 n = make_float3(0.0f, 0.0f, 0.0f);
+  const float depth = db[o * 2];
+  if (!unit_outside(depth)) {
+    const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+    const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
+    const float4* lut = p.cv_xyz[l];
+    const int rx = p.xyz_res[l][0], ry = p.xyz_res[l][1], rz = p.xyz_res[l][2];
+    const float3 world = tex3d_xyz(lut, rx, ry, rz, 0, u, v, depth);
+    if (p.brick_counters) mark_brick(p, world);
+    float dt = db[((size_t)clampi(py + 1, 0, H - 1) * W + px) * 2];
+    float dbm = db[((size_t)clampi(py - 1, 0, H - 1) * W + px) * 2];
+    float dl = db[((size_t)py * W + clampi(px - 1, 0, W - 1)) * 2];
+    float dr = db[((size_t)py * W + clampi(px + 1, 0, W - 1)) * 2];
+    dt = unit_outside(dt) ? depth : dt;
+    dbm = unit_outside(dbm) ? depth : dbm;
+    dl = unit_outside(dl) ? depth : dl;
+    dr = unit_outside(dr) ? depth : dr;
+    const float3 wt = tex3d_xyz(lut, rx, ry, rz, 0, u, v + tsy, dt);
+    const float3 wb = tex3d_xyz(lut, rx, ry, rz, 0, u, v - tsy, dbm);
+    const float3 wl = tex3d_xyz(lut, rx, ry, rz, 0, u - tsx, v, dl);
+    const float3 wr = tex3d_xyz(lut, rx, ry, rz, 0, u + tsx, v, dr);
+    const float ax = wb.x - wt.x, ay = wb.y - wt.y, az = wb.z - wt.z;
+    const float bx = wl.x - wr.x, by = wl.y - wr.y, bz = wl.z - wr.z;
+    const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+    const float len = sqrtf(cx * cx + cy * cy + cz * cz);
+    n = make_float3(cx / len, cy / len, cz / len);
+  }
+  p.normal[(lo + o) * 3 + 0] = n.x;
+  p.normal[(lo + o) * 3 + 1] = n.y;
+  p.normal[(lo + o) * 3 + 2] = n.z;
+}
+
+void launch_normal(const PreParams& p, hipStream_t s)
+{
+  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
+  hipLaunchKernelGGL(k_normal, grid, dim3(BX, BY), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
+{
+  __shared__ float tile[TH][TW + 1];
+  const int l = blockIdx.z;
+  const int W = p.W, H = p.H;
+  const size_t lo = (size_t)l * W * H;
+  const float* db = p.depth_b_rg + lo * 2;
+  const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
+  for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
+    const int ty = i / TW, tx = i - ty * TW;
+    tile[ty][tx] = db[((size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)) * 2];
+  }
+  __syncthreads();
+  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  if (px >= W || py >= H) return;
+  const size_t o = (size_t)py * W + px;
+  const float depth = tile[threadIdx.y + R13][threadIdx.x + R13];
+  float q = 0.0f;
+  if (!unit_outside(depth)) {
+    const float dist_range_max = 0.35f * (depth / 1.0f);
+    const float dist_range_max_inv = 1.0f / dist_range_max;
+    float w_range = 0.0f, border = 0.0f;
+    for (int y = 0; y < 13; ++y) {
+#pragma unroll
+      for (int x = 0; x < 13; ++x) {
+        const float ds = tile[threadIdx.y + y][threadIdx.x + x];
+        const float dr = fabsf(ds - depth);
+        if (unit_outside(ds) || (dr > dist_range_max)) {
+          border += 1.0f;
+          continue;
+        }
+        w_range += 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+      }
+    }
+    const float lateral = 1.0f - border / 169.0f;
+    const float l2 = lateral * lateral, l4 = l2 * l2;
+    q = l4 * l2;
+    const float wr = w_range / 169.0f;
+    const float w2 = wr * wr, w4 = w2 * w2;
+    q *= w4 * w2;
+    q /= depth * 6.5f;
+    const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+    const float3 wp = tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], p.xyz_res[l][2], 0, u, v, depth);
+    const float dx = p.cam_pos[l][0] - wp.x, dy = p.cam_pos[l][1] - wp.y, dz = p.cam_pos[l][2] - wp.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* nrm = p.normal + (lo + o) * 3;
+    const float angle = (dx / len) * nrm[0] + (dy / len) * nrm[1] + (dz / len) * nrm[2];
+    q *= angle * angle;
+  }
+  p.quality[lo + o] = q;
+  // packed texel the integration kernel gathers (one 16-B load per tap)
+  p.frame[lo + o] = make_float4(depth, q, p.silhouette[lo + o], db[o * 2 + 1]);
+}
+
+void launch_quality(const PreParams& p, hipStream_t s)
+{
+  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
+  hipLaunchKernelGGL(k_quality, grid, dim3(BX, BY), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// updateOccupiedBricks (recon_integration.cpp:431-446) without the readback:
+// mask[i] = counter[i] >= min_voxels, count = number of set entries.
+__global__ void k_update_occupied(const uint32_t* __restrict__ counters, uint32_t n, uint32_t min_voxels,
+                                  uint8_t* __restrict__ mask, uint32_t* __restrict__ count)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool occ = (i < n) && (counters[i] >= min_voxels);
+  if (i < n) mask[i] = occ ? 1 : 0;
+  const unsigned long long b = __ballot(occ);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+}
+void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask, uint32_t* count,
+                            hipStream_t s)
+{
+  (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(k_update_occupied, dim3((n + 255) / 256), dim3(256), 0, s, counters, n, min_voxels, mask, count);
+}
+
+// ascending id list for consumers (m_bricks_occupied): one block, chunked scan
+__global__ __launch_bounds__(1024) void k_compact_occupied(const uint8_t* __restrict__ mask, uint32_t n,
+                                                           uint32_t* __restrict__ ids, uint32_t* __restrict__ count)
+{
+  __shared__ uint32_t wave_sums[16];
+  __shared__ uint32_t base;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t start = 0; start < n; start += 1024) {
+    const uint32_t i = start + threadIdx.x;
+    const bool occ = i < n && mask[i];
+    const unsigned long long b = __ballot(occ);
+    const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_sums[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t off = base;
+    for (int w = 0; w < wave; ++w) off += wave_sums[w];
+    if (occ) ids[off + before] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < 16; ++w) t += wave_sums[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_compact_occupied, dim3(1), dim3(1024), 0, s, mask, n, ids, count);
+}
+
+}  // namespace rgbdr

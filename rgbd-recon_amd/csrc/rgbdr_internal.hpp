@@ -1,0 +1,102 @@
+// rgbdr_internal.hpp -- shared between the host API (api.cpp), the host-only
+// geometry code (geometry.cpp) and the kernel launchers (kernels_*.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbdr.h"
+
+namespace rgbdr {
+
+constexpr int kTile = RGBDR_TILE;          // 8
+constexpr int kTileVoxels = 512;           // 8*8*8
+constexpr int kMaxSensors = RGBDR_MAX_SENSORS;
+
+// ---- host-only geometry (geometry.cpp) -------------------------------------
+int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err);
+int slab_range(int tiles_z, int count, int rank, int* t0, int* t1);
+void camera_position(const float* cv_xyz, const uint32_t res[3], float out[3]);
+// true when an inverse LUT of resolution `lut_res` maps every voxel centre of a
+// `vol_res` grid onto exactly one texel with zero interpolation weights
+bool lut_is_one_to_one(const uint32_t lut_res[3], const int32_t vol_res[3]);
+// z texel range [lo, hi] of a LUT with rz texels touched by voxel layers [vz0, vz1) of Z
+void lut_z_range(int rz, int Z, int vz0, int vz1, int* lo, int* hi);
+
+// ---- kernel parameter blocks -------------------------------------------------
+struct PreParams {
+  int N, W, H, Wc, Hc;
+  float bbox_min[3], bbox_max[3];
+  int filter, compress;
+  int refine;
+  // per sensor
+  const float4* cv_xyz[kMaxSensors];  // repacked to 16 B records (w = 0)
+  const float2* cv_uv[kMaxSensors];
+  int xyz_res[kMaxSensors][3];
+  int uv_res[kMaxSensors][3];
+  float cv_min_ds[kMaxSensors], cv_max_ds[kMaxSensors];
+  float near_[kMaxSensors], far_[kMaxSensors];
+  float cam_pos[kMaxSensors][3];
+  // bricks
+  float brick_size;
+  int res_bricks[3];
+  uint32_t* brick_counters;
+  // images, all [N][H][W][channels]
+  const float* depth_in;   // what the "raw_depth" unit holds for the filter pass
+  const uint8_t* color;    // [N][Hc][Wc][3]
+  float* depth_morph;
+  float* depth_rg;
+  float* lab;
+  float* depth_b_rg;
+  float* silhouette;
+  float* normal;
+  float* quality;
+  float4* frame;           // packed {depth_b.r, quality, silhouette, depth_b.g}
+};
+
+struct IntegrateParams {
+  int N, W, H;
+  int X, Y, Z;             // full volume resolution
+  int TX, TY;              // tiles per axis
+  int tz0, ntz;            // first owned tile layer, number of owned tile layers
+  float limit;
+  float stepX, stepY, stepZ;
+  const float4* frame[kMaxSensors];
+  // 1:1 mode: [local tile][sensor][3][512] floats
+  const float* lut_tiled;
+  // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
+  const float4* lut[kMaxSensors];
+  int rx[kMaxSensors], ry[kMaxSensors], rz[kMaxSensors], zoff[kMaxSensors];
+  // bricks
+  int use_bricks;
+  const uint8_t* brick_mask;
+  int bv;
+  int bx, by, bz;
+  float* tsdf;             // first owned tile layer
+};
+
+// ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
+void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
+void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
+void launch_repack_xyz(const float* src_xyz3, float4* dst, size_t n, hipStream_t s);
+void launch_morph(const PreParams& p, const float* in, float* out, hipStream_t s);
+void launch_pre_depth(const PreParams& p, hipStream_t s);
+void launch_boundary(const PreParams& p, hipStream_t s);
+void launch_normal(const PreParams& p, hipStream_t s);
+void launch_quality(const PreParams& p, hipStream_t s);
+void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask,
+                            uint32_t* count, hipStream_t s);
+void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);
+void launch_integrate(const IntegrateParams& p, bool one_to_one, hipStream_t s);
+void launch_detile(const float* tiled, float* linear, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
+                   hipStream_t s);
+void launch_tile_lut(const float4* src_rgba, int X, int Y, int Z, int src_z0, int TX, int TY, int tz0, int ntz,
+                     int sensor, int N, float* dst_tiled, hipStream_t s);
+void launch_untile_lut(const float* tiled, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1, int sensor,
+                       int N, float4* dst_rgba, hipStream_t s);
+void launch_synth_inverse(const rgbdr_pinhole& cam, int W, int H, const float bbox_min[3], const float bbox_max[3],
+                          int X, int Y, int Z, int TX, int TY, int tz0, int ntz, int sensor, int N,
+                          float* dst_tiled, hipStream_t s);
+
+}  // namespace rgbdr

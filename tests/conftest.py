@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    load_package()
+    from rgbd_recon_amd import capi, synth
+
+    class P:
+        pass
+
+    p = P()
+    p.capi, p.synth = capi, synth
+    return p
+
+
+@pytest.fixture(scope="session")
+def orc():
+    return load_oracle()
+
+
+def same_bits(a, b):
+    """bit-exact float comparison: NaN matches NaN, -0 matches +0"""
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def count_diff(a, b):
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    return int(np.sum(~((a == b) | (np.isnan(a) & np.isnan(b)))))

@@ -1,0 +1,137 @@
+"""Host logic of the C-ABI library without a GPU: it loads, exports every symbol
+include/rgbdr.h declares, its geometry agrees with the oracle's restatement of
+setVoxelSize / setBrickSize / divideBox, and it fails loudly (no CPU fallback)
+when no HIP device exists."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rgbdr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rgbdr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.capi.lib()
+    names = declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "librgbdr_hip.so does not export %s" % n
+    # and the Python binding table covers exactly the header
+    assert sorted(pkg.capi.SYMBOLS) == names
+
+
+def test_config_struct_size_is_checked(pkg):
+    capi = pkg.capi
+    cfg = capi.make_config(1, (16, 16))
+    cfg.struct_size = 4
+    h = C.c_void_p()
+    assert capi.lib().rgbdr_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_INVALID_ARGUMENT
+    assert b"struct_size" in capi.lib().rgbdr_last_error(None)
+
+
+@pytest.mark.parametrize("field,value", [("num_sensors", 0), ("num_sensors", 9), ("depth_w", 0), ("tsdf_limit", 0.0),
+                                         ("voxel_size", -1.0), ("compress_rgb", 1)])
+def test_invalid_config_rejected(pkg, field, value):
+    capi = pkg.capi
+    cfg = capi.make_config(2, (16, 16))
+    setattr(cfg, field, value)
+    h = C.c_void_p()
+    rc = capi.lib().rgbdr_create(C.byref(cfg), 0, C.byref(h))
+    assert rc == capi.ERR_INVALID_ARGUMENT and not h.value
+    assert capi.lib().rgbdr_status_string(rc) == b"invalid argument"
+
+
+def test_no_device_fails_loudly(pkg):
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    capi = pkg.capi
+    with pytest.raises(capi.RgbdrError) as e:
+        capi.Context(capi.make_config(1, (16, 16)))
+    assert e.value.status == capi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.parametrize("bmax,voxel,brick", [((1, 2.2, 1), 0.01, 0.1), ((1, 2, 1), 2.0 / 64, 8 * 2.0 / 64),
+                                              ((1, 2, 1), 2.0 / 512, 8 * 2.0 / 512), ((1, 2.2, 1), 0.007, 0.1),
+                                              ((0.5, 1.3, 2.0), 0.013, 0.05)])
+def test_geometry_matches_oracle(pkg, orc, bmax, voxel, brick):
+    capi = pkg.capi
+    bmin = (-1.0, 0.0, -1.0)
+    cfg = capi.make_config(1, (16, 16), bbox_min=bmin, bbox_max=bmax, voxel_size=voxel, brick_size=brick)
+    g = capi.compute_geometry(cfg)
+    assert tuple(g.res_volume) == orc.volume_res(bmin, bmax, voxel)
+    bs = orc.adjust_brick_size(brick, voxel)
+    assert g.brick_size == np.float32(bs)
+    assert g.brick_voxels == int(round(brick / voxel))
+    ref_rb = orc.divide_box(bmin, bmax, bs)
+    need = tuple(-(-r // g.brick_voxels) for r in g.res_volume)
+    assert tuple(g.res_bricks) == tuple(max(a, b) for a, b in zip(ref_rb, need))
+    assert g.num_bricks == g.res_bricks[0] * g.res_bricks[1] * g.res_bricks[2]
+    assert tuple(g.tiles) == tuple(-(-r // 8) for r in g.res_volume)
+    assert (g.slab_tile_z0, g.slab_tile_z1) == (0, g.tiles[2])
+    assert (g.slab_voxel_z0, g.slab_voxel_z1) == (0, g.res_volume[2])
+
+
+def test_res_override(pkg):
+    capi = pkg.capi
+    cfg = capi.make_config(1, (16, 16), voxel_size=2.0 / 64, res_override=(64, 64, 128))
+    assert tuple(capi.compute_geometry(cfg).res_volume) == (64, 64, 128)
+
+
+@pytest.mark.parametrize("tiles,count", [(64, 1), (64, 2), (64, 8), (81, 2), (100, 8), (7, 7), (13, 4)])
+def test_slab_ranges_partition_the_tile_layers(pkg, tiles, count):
+    lib = pkg.capi.lib()
+    prev, sizes = 0, []
+    for r in range(count):
+        a, b = C.c_int(), C.c_int()
+        assert lib.rgbdr_slab_range(tiles, count, r, C.byref(a), C.byref(b)) == 0
+        assert a.value == prev and b.value > a.value
+        sizes.append(b.value - a.value)
+        prev = b.value
+    assert prev == tiles and max(sizes) - min(sizes) <= 1
+    a, b = C.c_int(), C.c_int()
+    assert lib.rgbdr_slab_range(tiles, count, count, C.byref(a), C.byref(b)) == pkg.capi.ERR_INVALID_ARGUMENT
+
+
+def test_slab_geometry_and_too_many_slabs(pkg):
+    capi = pkg.capi
+    cfg = capi.make_config(1, (16, 16), voxel_size=2.0 / 100, slab_rank=1, slab_count=3)   # 100 voxels = 13 tile layers
+    g = capi.compute_geometry(cfg)
+    assert (g.slab_tile_z0, g.slab_tile_z1) == (5, 9)
+    assert (g.slab_voxel_z0, g.slab_voxel_z1) == (40, 72)
+    last = capi.compute_geometry(capi.make_config(1, (16, 16), voxel_size=2.0 / 100, slab_rank=2, slab_count=3))
+    assert last.slab_voxel_z1 == 100          # clipped to the volume, not to the padded tile layer
+    bad = capi.make_config(1, (16, 16), voxel_size=2.0 / 16, slab_rank=0, slab_count=3)    # 2 tile layers
+    with pytest.raises(capi.RgbdrError):
+        capi.compute_geometry(bad)
+
+
+def test_camera_position_matches_oracle(pkg, orc):
+    capi, synth = pkg.capi, pkg.synth
+    for i in range(3):
+        s = synth.Sensor(i, 3, 64, 53)
+        xyz, _ = synth.forward_luts(s, (16, 13, 16))
+        out = (C.c_float * 3)()
+        lut = capi.make_lut(xyz, (16, 13, 16))
+        assert capi.lib().rgbdr_camera_position(C.byref(lut), out) == 0
+        assert np.array_equal(np.array(out[:], np.float32), orc.camera_pos(xyz))
+
+
+def test_product_does_not_touch_the_oracle():
+    """the product path must not import, link or load anything under oracle/"""
+    pk = os.path.join(ROOT, "rgbd-recon_amd")
+    for dp, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h", "Makefile")):
+                text = open(os.path.join(dp, f)).read()
+                assert "pyoracle" not in text and "rgbdr_oracle" not in text and "load_oracle" not in text, f
