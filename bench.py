@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="override the cubic grid size")
     ap.add_argument("--sensors", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=32, help="z rows of the volume the CPU baseline integrates")
+    ap.add_argument("--cpu-rows", type=int, default=64, help="z rows of the volume the CPU baseline integrates")
     args = ap.parse_args()
 
     import torch
@@ -130,8 +130,8 @@ def main():
     int_s = int_ns / max(int_n, 1) * 1e-9
     # algorithmic bytes of one integrate launch on this rank (DESIGN.md "Algorithmic bytes"):
     # one f32 store per voxel + the three f32 LUT planes per voxel and sensor (the
-    # repacked, xyz-only 1:1 LUT) + the packed 16-B frame texels read once
-    bytes_launch = V_local * (4 + 12 * N) + N * W * H * 16
+    # repacked, xyz-only 1:1 LUT) + the packed 8-B frame texels read once
+    bytes_launch = V_local * (4 + 12 * N) + N * W * H * 8
     achieved = bytes_launch / int_s if int_s > 0 else 0.0
     tsdf_full = None
 

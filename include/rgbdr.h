@@ -219,8 +219,8 @@ typedef struct {
   int32_t halo_layers;    /* 0 or 1 on each side */
 } rgbdr_tsdf_device_view;
 int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
-/* device pointer of the packed per-sensor frame the integration kernel gathers
- * from: H*W float4 {depth_b.r, quality, silhouette, depth_b.g} */
+/* device pointer of the packed per-sensor frame the integration kernel samples:
+ * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);
 /* the context's HIP stream (hipStream_t) for callers that enqueue dependent work */
 void* rgbdr_stream(rgbdr_ctx* ctx);

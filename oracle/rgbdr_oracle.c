@@ -600,7 +600,7 @@ ORC_API void orc_integrate(const orc_integrate_params* p, const float* const* cv
   const float stepX = 1.0f / (float)X, stepY = 1.0f / (float)Y, stepZ = 1.0f / (float)Z;
   const float limit = p->limit;
   (void)Z;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
   for (int z = z0; z < z1; ++z) {
     for (int y = 0; y < Y; ++y) {
       for (int x = 0; x < X; ++x) {

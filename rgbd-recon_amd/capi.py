@@ -138,6 +138,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run __graft_entry__.build() (make -C rgbd-recon_amd/csrc)" % LIB_PATH)
+        # The PyTorch wheel bundles its own HIP runtime.  If this library pulled in
+        # /opt/rocm's libamdhip64 first, a later torch.cuda initialisation in the same
+        # process would find two runtimes and report "No HIP GPUs".  Importing torch
+        # first makes its runtime the one both sides share (harness concern only:
+        # a C/C++ host links librgbdr_hip.so against the system ROCm directly).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)
@@ -311,7 +320,7 @@ class Context:
         return out
 
     def readback_image(self, which, sensor):
-        ch = IMG_CHANNELS[which]
+        ch = IMG_CHANNELS.get(which, 1)
         out = np.empty((self.cfg.depth_h, self.cfg.depth_w, ch), dtype=np.float32)
         self._chk(lib().rgbdr_readback_image(self._h, which, sensor, out.ctypes.data_as(_F)))
         return out[..., 0] if ch == 1 else out

@@ -39,7 +39,7 @@ struct rgbdr_ctx {
   // images ([N][H][W][c])
   float *d_depth_raw = nullptr, *d_depth_morph = nullptr, *d_depth_rg = nullptr, *d_lab = nullptr;
   float *d_depth_b = nullptr, *d_sil = nullptr, *d_normal = nullptr, *d_quality = nullptr;
-  float4* d_frame = nullptr;
+  uint2* d_frame = nullptr;
   uint8_t *d_color = nullptr, *d_depth_u8 = nullptr;
   bool frame_uploaded = false, textures_processed = false;
 
@@ -56,6 +56,7 @@ struct rgbdr_ctx {
   bool inv_tiled[kMaxSensors] = {};
   uint32_t inv_res[kMaxSensors][3] = {};
   float* d_lut_tiled = nullptr;
+  int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
   float4* d_lut_generic[kMaxSensors] = {};
   int zoff[kMaxSensors] = {};
 
@@ -140,6 +141,8 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_lut_tiled);
+  (void)hipFree(c->d_win);
+  c->d_win = nullptr;
   c->d_tsdf_base = c->d_tsdf_owned = c->d_linear = nullptr;
   c->d_counters = c->d_ids = nullptr;
   c->d_mask = nullptr;
@@ -269,7 +272,7 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
                 {(void**)&ctx->d_depth_rg, n * 8},    {(void**)&ctx->d_lab, n * 12},
                 {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
-                {(void**)&ctx->d_frame, n * 16},      {(void**)&ctx->d_color, ncol},
+                {(void**)&ctx->d_frame, n * 8},      {(void**)&ctx->d_color, ncol},
                 {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 16}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
@@ -368,6 +371,8 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
   const size_t bytes = ntiles * nsens(ctx) * 3 * kTileVoxels * sizeof(float);
   HIPCHK(hipMalloc((void**)&ctx->d_lut_tiled, bytes));
+  HIPCHK(hipMalloc((void**)&ctx->d_win, ntiles * nsens(ctx) * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_win, 0, ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
   return RGBDR_OK;
 }
 
@@ -409,6 +414,10 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     HIPCHK(hipFree(tmp));
+    launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                        g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                        ctx->stream);
+    LAUNCHCHK("tile_windows");
     ctx->inv_tiled[sensor] = true;
   } else {
     int lo, hi;
@@ -485,6 +494,10 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
                        g.res_volume[1], g.res_volume[2], g.tiles[0], g.tiles[1], g.slab_tile_z0,
                        g.slab_tile_z1 - g.slab_tile_z0, sensor, nsens(ctx), ctx->d_lut_tiled, ctx->stream);
   LAUNCHCHK("synth_inverse");
+  launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                      g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                      ctx->stream);
+  LAUNCHCHK("tile_windows");
   for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = r[a];
   (void)hipFree(ctx->d_lut_generic[sensor]);
   ctx->d_lut_generic[sensor] = nullptr;
@@ -658,6 +671,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
     p.zoff[i] = ctx->zoff[i];
   }
   p.lut_tiled = ctx->d_lut_tiled;
+  p.win = ctx->d_win;
   p.use_bricks = bricks ? 1 : 0;
   p.brick_mask = ctx->d_mask;
   p.bv = g.brick_voxels;

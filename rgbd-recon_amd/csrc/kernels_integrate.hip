@@ -14,8 +14,8 @@
 //     (no separate memset pass, recon_integration.cpp:249-251).
 //   * generic inverse LUT (resolution != TSDF resolution): the file's x-fastest
 //     RGBA32F volume, sampled with 8 taps per voxel.
-//   * frames: per sensor H*W float4 {depth_b.r, quality, silhouette, depth_b.g}
-//     so one 16-B gather per bilinear tap serves all three samplers of the shader.
+//   * frames: per sensor H*W 8-B texels {depth_b.r, quality | !silhouette << 31}:
+//     one texel serves all three samplers of the shader (tsdf_integration.vs:32,40,50).
 //
 // The per-voxel fold over sensors is order dependent (overwrite-to -limit
 // branches interleaved with a running weighted mean, tsdf_integration.vs:28-55),
@@ -29,34 +29,82 @@
 
 namespace rgbdr {
 
-// One sensor's contribution to one voxel (tsdf_integration.vs:31-54).
-__device__ __forceinline__ void fold_sensor(const float4* __restrict__ frame, int W, int H, float pcx, float pcy,
-                                            float pcz, float limit, float& tsd, float& wsum)
+constexpr int kWin = 16;  // frame window edge staged in LDS per (tile, sensor)
+
+// packed frame texel (kernels_pre.hip k_quality): x = depth_b.r, y = quality with
+// "silhouette == 0" in the sign bit
+__device__ __forceinline__ float texel_sil(uint2 t) { return (t.y >> 31) ? 0.0f : 1.0f; }
+__device__ __forceinline__ float texel_quality(uint2 t) { return __uint_as_float(t.y & 0x7fffffffu); }
+__device__ __forceinline__ float texel_depth(uint2 t) { return __uint_as_float(t.x); }
+
+// One sensor's contribution to one voxel (tsdf_integration.vs:31-54) from the
+// 2x2 LINEAR footprint of (pcx, pcy) in that sensor's frame.
+__device__ __forceinline__ void fold_taps(uint2 p00, uint2 p10, uint2 p01, uint2 p11, float ax, float ay, float pcz,
+                                          float limit, float& tsd, float& wsum)
 {
-  const Axis X = axis_linear(pcx, W), Y = axis_linear(pcy, H);
-  const float4* r0 = frame + (size_t)Y.i0 * W;
-  const float4* r1 = frame + (size_t)Y.i1 * W;
-  const float4 p00 = r0[X.i0], p10 = r0[X.i1], p01 = r1[X.i0], p11 = r1[X.i1];
-  const float sil = lerpf(lerpf(p00.z, p10.z, X.a), lerpf(p01.z, p11.z, X.a), Y.a);
+  const float sil = lerpf(lerpf(texel_sil(p00), texel_sil(p10), ax), lerpf(texel_sil(p01), texel_sil(p11), ax), ay);
   if (sil < 1.0f && tsd >= limit) {
     tsd = -limit;
     return;
   }
-  // NEAREST depth: floor(s*n) is i0 or i0+1 of the LINEAR footprint, so the
-  // texel is one of the four already loaded
-  const int nx = axis_nearest(pcx, W), ny = axis_nearest(pcy, H);
-  const float d0 = (nx == X.i0) ? p00.x : p10.x;
-  const float d1 = (nx == X.i0) ? p01.x : p11.x;
-  const float depth = (ny == Y.i0) ? d0 : d1;
+  // NEAREST depth texel = floor(s*n) = j + (a >= 0.5) on each axis (a = frac(s*n - 0.5)):
+  // always one of the four texels of the LINEAR footprint, index clamping included
+  const uint2 n0 = (ax >= 0.5f) ? p10 : p00;
+  const uint2 n1 = (ax >= 0.5f) ? p11 : p01;
+  const float depth = texel_depth((ay >= 0.5f) ? n1 : n0);
   const float sdist = pcz - depth;
   if (sdist <= -limit) {
     tsd = -limit;
   } else if (sdist >= limit) {
   } else {
-    const float weight = lerpf(lerpf(p00.y, p10.y, X.a), lerpf(p01.y, p11.y, X.a), Y.a);
+    const float weight =
+        lerpf(lerpf(texel_quality(p00), texel_quality(p10), ax), lerpf(texel_quality(p01), texel_quality(p11), ax), ay);
     tsd = (tsd * wsum + weight * sdist) / (wsum + weight);
     wsum += weight;
   }
+}
+
+// footprint position of a normalised coordinate: j = floor(s*n - 0.5) saturated to
+// [-1, n], a = fraction (same arithmetic as axis_linear)
+__device__ __forceinline__ int footprint(float s, int n, float& a)
+{
+  const float t = s * (float)n - 0.5f;
+  const float f = floorf(t);
+  a = t - f;
+  return idx_from_floor(f, n);
+}
+
+// global-memory footprint fetch with CLAMP_TO_EDGE
+__device__ __forceinline__ void fetch_global(const uint2* __restrict__ frame, int W, int H, int jx, int jy, uint2& p00,
+                                             uint2& p10, uint2& p01, uint2& p11)
+{
+  const int x0 = clampi(jx, 0, W - 1), x1 = clampi(jx + 1, 0, W - 1);
+  const uint2* r0 = frame + (size_t)clampi(jy, 0, H - 1) * W;
+  const uint2* r1 = frame + (size_t)clampi(jy + 1, 0, H - 1) * W;
+  p00 = r0[x0];
+  p10 = r0[x1];
+  p01 = r1[x0];
+  p11 = r1[x1];
+}
+
+__device__ __forceinline__ void fold_voxel_window(const uint2* __restrict__ win, int wx0, int wy0,
+                                                  const uint2* __restrict__ frame, int W, int H, float pcx, float pcy,
+                                                  float pcz, float limit, float& tsd, float& wsum)
+{
+  float ax, ay;
+  const int jx = footprint(pcx, W, ax), jy = footprint(pcy, H, ay);
+  const int rx = jx - wx0, ry = jy - wy0;
+  uint2 p00, p10, p01, p11;
+  if ((unsigned)rx < (unsigned)(kWin - 1) && (unsigned)ry < (unsigned)(kWin - 1)) {
+    const uint2* r = win + ry * kWin + rx;
+    p00 = r[0];
+    p10 = r[1];
+    p01 = r[kWin];
+    p11 = r[kWin + 1];
+  } else {  // footprint outside the staged window (invalid LUT entry, tile close to the sensor)
+    fetch_global(frame, W, H, jx, jy, p00, p10, p01, p11);
+  }
+  fold_taps(p00, p10, p01, p11, ax, ay, pcz, limit, tsd, wsum);
 }
 
 __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx, int vy, int vz)
@@ -67,27 +115,27 @@ __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx,
 }
 
 // ---------------------------------------------------------------------------
-// 1:1 LUT.  128 threads = one tile; thread q owns voxels x0..x0+3 of row (y,z).
+// 1:1 LUT.  128 threads (2 wavefronts) sweep one 8x8x8 tile; thread q owns voxels
+// x0..x0+3 of row (y,z).  Every global load of the block -- the N*3 LUT planes
+// (16 B per lane, fully coalesced) and the N 16x16 frame windows the tile
+// projects into (origins precomputed per tile at LUT upload) -- is issued before
+// the single barrier, so one memory latency is paid per tile; the 2x2 footprints
+// of all 512 voxels x N sensors are then served from LDS.
 template <int N, bool BRICKS>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch),
-  // so give each XCD one contiguous run of tiles: neighbouring tiles project to
-  // neighbouring pixels and re-use each other's frame texels in that XCD's L2.
-  const unsigned nblk = gridDim.x;
-  unsigned tile = blockIdx.x;
-  if ((nblk & 7u) == 0u) tile = (blockIdx.x & 7u) * (nblk >> 3) + (blockIdx.x >> 3);
-
+  __shared__ uint2 win[N][kWin * kWin];
+  const unsigned tile = blockIdx.x;
   const int q = threadIdx.x;
   const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
-  const int tx = tile % p.TX;
-  const int ty = (tile / p.TX) % p.TY;
-  const int tzl = tile / (p.TX * p.TY);
   float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
   const float limit = p.limit;
 
   bool occ[4] = {true, true, true, true};
   if (BRICKS) {
+    const int tx = tile % p.TX;
+    const int ty = (tile / p.TX) % p.TY;
+    const int tzl = tile / (p.TX * p.TY);
     const int vz = (p.tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx = tx * kTile + lx0;
     bool any = false;
 #pragma unroll
@@ -95,7 +143,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
       occ[j] = voxel_occupied(p, vx + j, vy, vz);
       any |= occ[j];
     }
-    if (!any) {  // fused clear
+    if (!__syncthreads_or(any)) {  // fused clear of a tile without occupied bricks
       *out = make_float4(-limit, -limit, -limit, -limit);
       return;
     }
@@ -109,15 +157,30 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     V[i] = lut[(i * 3 + 1) * (kTileVoxels / 4)];
     D[i] = lut[(i * 3 + 2) * (kTileVoxels / 4)];
   }
+  int wx0[N], wy0[N];
+  {
+    const int wr = q >> 3, wc = (q & 7) * 2;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int d = p.win[(size_t)tile * N + i];
+      wx0[i] = (int)(short)(d & 0xffff);
+      wy0[i] = (int)(short)(d >> 16);
+      const uint2* row = p.frame[i] + (size_t)clampi(wy0[i] + wr, 0, p.H - 1) * p.W;
+      win[i][wr * kWin + wc] = row[clampi(wx0[i] + wc, 0, p.W - 1)];
+      win[i][wr * kWin + wc + 1] = row[clampi(wx0[i] + wc + 1, 0, p.W - 1)];
+    }
+  }
+  __syncthreads();
+
   float tsd[4] = {limit, limit, limit, limit};
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const float4* frame = p.frame[i];
-    fold_sensor(frame, p.W, p.H, U[i].x, V[i].x, D[i].x, limit, tsd[0], wsum[0]);
-    fold_sensor(frame, p.W, p.H, U[i].y, V[i].y, D[i].y, limit, tsd[1], wsum[1]);
-    fold_sensor(frame, p.W, p.H, U[i].z, V[i].z, D[i].z, limit, tsd[2], wsum[2]);
-    fold_sensor(frame, p.W, p.H, U[i].w, V[i].w, D[i].w, limit, tsd[3], wsum[3]);
+    const uint2* frame = p.frame[i];
+    fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].x, V[i].x, D[i].x, limit, tsd[0], wsum[0]);
+    fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].y, V[i].y, D[i].y, limit, tsd[1], wsum[1]);
+    fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].z, V[i].z, D[i].z, limit, tsd[2], wsum[2]);
+    fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].w, V[i].w, D[i].w, limit, tsd[3], wsum[3]);
   }
   if (BRICKS) {
 #pragma unroll
@@ -127,8 +190,54 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
   *out = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
 }
 
+// Window origin of one (tile, sensor): the minimum footprint index over the
+// tile's voxels whose footprint lies inside the image (others -- invalid -1
+// entries, far-off projections -- take the global path in the kernel).
+__global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ lut_tiled, int W, int H, int sensor,
+                                                      int N, int32_t* __restrict__ win)
+{
+  __shared__ int smin[2][2];
+  const unsigned tile = blockIdx.x;
+  const int q = threadIdx.x;
+  const float4* lut = reinterpret_cast<const float4*>(lut_tiled + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
+  const float4 U = lut[0], V = lut[kTileVoxels / 4];
+  const float us[4] = {U.x, U.y, U.z, U.w}, vs[4] = {V.x, V.y, V.z, V.w};
+  int mx = 0x7fffffff, my = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a;
+    const int jx = footprint(us[j], W, a), jy = footprint(vs[j], H, a);
+    if (jx >= -1 && jx <= W - 1 && jy >= -1 && jy <= H - 1) {
+      mx = min(mx, jx);
+      my = min(my, jy);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = min(mx, __shfl_xor(mx, o));
+    my = min(my, __shfl_xor(my, o));
+  }
+  if ((q & 63) == 0) {
+    smin[q >> 6][0] = mx;
+    smin[q >> 6][1] = my;
+  }
+  __syncthreads();
+  if (q == 0) {
+    mx = min(smin[0][0], smin[1][0]);
+    my = min(smin[0][1], smin[1][1]);
+    if (mx == 0x7fffffff) mx = my = 0;
+    win[(size_t)tile * N + sensor] = (int32_t)(((uint32_t)(my & 0xffff) << 16) | (uint32_t)(mx & 0xffff));
+  }
+}
+void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
+                         hipStream_t s)
+{
+  hipLaunchKernelGGL(k_tile_windows, dim3((unsigned)ntiles), dim3(128), 0, s, lut_tiled, W, H, sensor, N, win);
+}
+
 // ---------------------------------------------------------------------------
-// Generic LUT resolution: 8-tap trilinear of the RGBA32F volume per voxel.
+// Generic LUT resolution: 8-tap trilinear of the RGBA32F volume per voxel, frame
+// footprints gathered from global memory.
 template <bool BRICKS>
 __global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
 {
@@ -159,7 +268,11 @@ __global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
     float tsd = limit, wsum = 0.0f;
     for (int i = 0; i < p.N; ++i) {
       const float3 pc = tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], px, py, pz);
-      fold_sensor(p.frame[i], p.W, p.H, pc.x, pc.y, pc.z, limit, tsd, wsum);
+      float ax, ay;
+      const int jx = footprint(pc.x, p.W, ax), jy = footprint(pc.y, p.H, ay);
+      uint2 p00, p10, p01, p11;
+      fetch_global(p.frame[i], p.W, p.H, jx, jy, p00, p10, p01, p11);
+      fold_taps(p00, p10, p01, p11, ax, ay, pc.z, limit, tsd, wsum);
     }
     res[j] = tsd;
   }

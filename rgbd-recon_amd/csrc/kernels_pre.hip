@@ -415,8 +415,11 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
     q *= angle * angle;
   }
   p.quality[lo + o] = q;
-  // packed texel the integration kernel gathers (one 16-B load per tap)
-  p.frame[lo + o] = make_float4(depth, q, p.silhouette[lo + o], db[o * 2 + 1]);
+  // packed 8-B texel the integration kernel samples: depth_b.r and the quality
+  // with "silhouette == 0" folded into its sign bit.  quality is a product of
+  // non-negative factors (or NaN), so the sign bit is free; |NaN| stays NaN.
+  const unsigned qbits = (__float_as_uint(q) & 0x7fffffffu) | (p.silhouette[lo + o] < 1.0f ? 0x80000000u : 0u);
+  p.frame[lo + o] = make_uint2(__float_as_uint(depth), qbits);
 }
 
 void launch_quality(const PreParams& p, hipStream_t s)

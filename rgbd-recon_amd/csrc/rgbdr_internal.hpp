@@ -52,7 +52,7 @@ struct PreParams {
   float* silhouette;
   float* normal;
   float* quality;
-  float4* frame;           // packed {depth_b.r, quality, silhouette, depth_b.g}
+  uint2* frame;            // packed texel for integration: {depth_b.r, quality with !silhouette in the sign bit}
 };
 
 struct IntegrateParams {
@@ -62,9 +62,11 @@ struct IntegrateParams {
   int tz0, ntz;            // first owned tile layer, number of owned tile layers
   float limit;
   float stepX, stepY, stepZ;
-  const float4* frame[kMaxSensors];
-  // 1:1 mode: [local tile][sensor][3][512] floats
+  const uint2* frame[kMaxSensors];
+  // 1:1 mode: [local tile][sensor][3][512] floats, and per (tile, sensor) the
+  // origin of the 16x16 frame window that tile projects into (int16 x | int16 y << 16)
   const float* lut_tiled;
+  const int32_t* win;
   // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
   const float4* lut[kMaxSensors];
   int rx[kMaxSensors], ry[kMaxSensors], rz[kMaxSensors], zoff[kMaxSensors];
@@ -95,6 +97,8 @@ void launch_tile_lut(const float4* src_rgba, int X, int Y, int Z, int src_z0, in
                      int sensor, int N, float* dst_tiled, hipStream_t s);
 void launch_untile_lut(const float* tiled, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1, int sensor,
                        int N, float4* dst_rgba, hipStream_t s);
+void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
+                         hipStream_t s);
 void launch_synth_inverse(const rgbdr_pinhole& cam, int W, int H, const float bbox_min[3], const float bbox_max[3],
                           int X, int Y, int Z, int TX, int TY, int tz0, int ntz, int sensor, int N,
                           float* dst_tiled, hipStream_t s);
