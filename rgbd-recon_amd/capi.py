@@ -285,29 +285,41 @@ class Context:
     # setters
     def set_voxel_size(self, v):
         self._chk(lib().rgbdr_set_voxel_size(self._h, v))
+        self.cfg.voxel_size = v
+        self.cfg.res_override[:] = [0, 0, 0]
         self.geo = self.geometry()
 
     def set_brick_size(self, v):
         self._chk(lib().rgbdr_set_brick_size(self._h, v))
+        self.cfg.brick_size = v
         self.geo = self.geometry()
 
     def set_tsdf_limit(self, v):
         self._chk(lib().rgbdr_set_tsdf_limit(self._h, v))
+        self.cfg.tsdf_limit = v
+
+    def _flag(self, flag, on):
+        self.cfg.flags = (self.cfg.flags | flag) if on else (self.cfg.flags & ~flag)
 
     def set_use_bricks(self, on):
         self._chk(lib().rgbdr_set_use_bricks(self._h, int(on)))
+        self._flag(FLAG_USE_BRICKS, on)
 
     def set_min_voxels_per_brick(self, n):
         self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))
+        self.cfg.min_voxels_per_brick = n
 
     def filter_textures(self, on):
         self._chk(lib().rgbdr_filter_textures(self._h, int(on)))
+        self._flag(FLAG_FILTER, on)
 
     def use_processed_depths(self, on):
         self._chk(lib().rgbdr_use_processed_depths(self._h, int(on)))
+        self._flag(FLAG_PROCESSED, on)
 
     def refine_boundary(self, on):
         self._chk(lib().rgbdr_refine_boundary(self._h, int(on)))
+        self._flag(FLAG_REFINE, on)
 
     def occupied_ratio(self):
         return float(lib().rgbdr_occupied_ratio(self._h))

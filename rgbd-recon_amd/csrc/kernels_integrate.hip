@@ -79,29 +79,33 @@ __device__ __forceinline__ void fetch_global(const uint2* __restrict__ frame, in
                                              uint2& p10, uint2& p01, uint2& p11)
 {
   const int x0 = clampi(jx, 0, W - 1), x1 = clampi(jx + 1, 0, W - 1);
-  const uint2* r0 = frame + (size_t)clampi(jy, 0, H - 1) * W;
-  const uint2* r1 = frame + (size_t)clampi(jy + 1, 0, H - 1) * W;
-  p00 = r0[x0];
-  p10 = r0[x1];
-  p01 = r1[x0];
-  p11 = r1[x1];
+  const int r0 = clampi(jy, 0, H - 1) * W, r1 = clampi(jy + 1, 0, H - 1) * W;
+  p00 = frame[r0 + x0];
+  p10 = frame[r0 + x1];
+  p01 = frame[r1 + x0];
+  p11 = frame[r1 + x1];
 }
 
-__device__ __forceinline__ void fold_voxel_window(const uint2* __restrict__ win, int wx0, int wy0,
+// `win` must point into LDS.  The LDS reads are unconditional (safe cell 0 when the
+// footprint is outside the window) so they stay ds_read instructions; the global
+// fetch is a rare, separate branch.
+__device__ __forceinline__ void fold_voxel_window(const uint2* win, int wx0, int wy0,
                                                   const uint2* __restrict__ frame, int W, int H, float pcx, float pcy,
                                                   float pcz, float limit, float& tsd, float& wsum)
 {
   float ax, ay;
   const int jx = footprint(pcx, W, ax), jy = footprint(pcy, H, ay);
   const int rx = jx - wx0, ry = jy - wy0;
-  uint2 p00, p10, p01, p11;
-  if ((unsigned)rx < (unsigned)(kWin - 1) && (unsigned)ry < (unsigned)(kWin - 1)) {
-    const uint2* r = win + ry * kWin + rx;
-    p00 = r[0];
-    p10 = r[1];
-    p01 = r[kWin];
-    p11 = r[kWin + 1];
-  } else {  // footprint outside the staged window (invalid LUT entry, tile close to the sensor)
+  const bool inside = (unsigned)rx < (unsigned)(kWin - 1) && (unsigned)ry < (unsigned)(kWin - 1);
+  const int cell = inside ? ry * kWin + rx : 0;
+  // explicit LDS address space: keeps these ds_read2_b64 (a generic pointer merged
+  // with the global fallback would turn all eight loads into flat_load)
+  typedef __attribute__((address_space(3))) const unsigned long long lds_texel;
+  lds_texel* w = (lds_texel*)win + cell;
+  const unsigned long long t00 = w[0], t10 = w[1], t01 = w[kWin], t11 = w[kWin + 1];
+  uint2 p00 = make_uint2((unsigned)t00, (unsigned)(t00 >> 32)), p10 = make_uint2((unsigned)t10, (unsigned)(t10 >> 32));
+  uint2 p01 = make_uint2((unsigned)t01, (unsigned)(t01 >> 32)), p11 = make_uint2((unsigned)t11, (unsigned)(t11 >> 32));
+  if (__builtin_expect(!inside, 0)) {  // invalid LUT entry, tile close to the sensor ...
     fetch_global(frame, W, H, jx, jy, p00, p10, p01, p11);
   }
   fold_taps(p00, p10, p01, p11, ax, ay, pcz, limit, tsd, wsum);
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
       const int d = p.win[(size_t)tile * N + i];
       wx0[i] = (int)(short)(d & 0xffff);
       wy0[i] = (int)(short)(d >> 16);
-      const uint2* row = p.frame[i] + (size_t)clampi(wy0[i] + wr, 0, p.H - 1) * p.W;
-      win[i][wr * kWin + wc] = row[clampi(wx0[i] + wc, 0, p.W - 1)];
-      win[i][wr * kWin + wc + 1] = row[clampi(wx0[i] + wc + 1, 0, p.W - 1)];
+      const int row = clampi(wy0[i] + wr, 0, p.H - 1) * p.W;
+      win[i][wr * kWin + wc] = p.frame[i][row + clampi(wx0[i] + wc, 0, p.W - 1)];
+      win[i][wr * kWin + wc + 1] = p.frame[i][row + clampi(wx0[i] + wc + 1, 0, p.W - 1)];
     }
   }
   __syncthreads();
