@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline block refers to.  Run on the
+# GPU box from the repo root:  bash profiles/collect_pmc.sh <tag>
+# Kernel timing (--kernel-trace --stats) and every PMC group are separate runs
+# (MI355X_MICROARCH.md "rocprofv3 PMC slots": FETCH_SIZE takes 3 of 4 TCC slots,
+# WRITE_SIZE 2, SQ has 8).
+TAG=${1:-r01}
+OUT=$PWD/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+ROOT=$PWD
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/bench_stats.json 2>/dev/null
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq1 -- $BENCH > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- $BENCH > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/write -- $BENCH > /dev/null 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- $BENCH > /dev/null 2>&1
+python3 - $OUT <<'PY'
+import csv, glob, sys, json, collections
+out = sys.argv[1]
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + '/*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if 'k_integrate' in k or 'k_pre_depth' in k or 'k_quality' in k or 'k_normal' in k:
+            res[k][r['Counter_Name']].append(float(r['Counter_Value']))
+summary = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in res.items()}
+for f in glob.glob(out + '/stats/*/*kernel_stats.csv'):
+    for r in csv.DictReader(open(f)):
+        if r['Name'] in summary:
+            summary[r['Name']]['avg_ns'] = float(r['AverageNs'])
+            summary[r['Name']]['calls'] = int(r['Calls'])
+json.dump(summary, open(out + '/pmc_summary.json', 'w'), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True))
+PY
