@@ -1,0 +1,70 @@
+// frame_loop.cpp -- the per-frame sequence of source/kinect_client.cpp:572-602
+// (update -> process_textures -> integrate) written against the C++ host mirror,
+// with calibration volumes and a recorded ".stream" frame in the reference's
+// on-disk formats.  Used by tests/test_host_cpp.py as the C++-side drop-in check;
+// also the smallest example of how an application calls the backend.
+//
+//   frame_loop <dir> <num_sensors> <W> <H> <G> <out.tsdf>
+// expects <dir>/s<i>.yml names (only used to derive s<i>.cv_xyz / .cv_uv),
+// <dir>/s<i>.cv_xyz_inv and <dir>/recordings/s<i>.stream.
+#include <cstdio>
+#include <cstdlib>
+#include <exception>
+#include <string>
+
+#include "rgbdr_host.hpp"
+
+using namespace rgbdr::host;
+
+int main(int argc, char** argv)
+{
+  if (argc != 7) {
+    std::fprintf(stderr, "usage: %s <dir> <num_sensors> <W> <H> <G> <out.tsdf>\n", argv[0]);
+    return 2;
+  }
+  try {
+    const std::string dir = std::string(argv[1]) + "/";
+    CalibrationFiles cf;
+    const int n = std::atoi(argv[2]);
+    cf.width = cf.widthC = (unsigned)std::atoi(argv[3]);
+    cf.height = cf.heightC = (unsigned)std::atoi(argv[4]);
+    const int G = std::atoi(argv[5]);
+    std::vector<std::string> streams;
+    for (int i = 0; i < n; ++i) {
+      cf.filenames.push_back(dir + "s" + std::to_string(i) + ".yml");
+      streams.push_back(dir + "recordings/s" + std::to_string(i) + ".stream");
+    }
+    cf.near_.assign(n, 0.5f);
+    cf.far_.assign(n, 4.5f);
+    BoundingBox bbox;
+    bbox.pmax = {{1.0f, 2.0f, 1.0f}};
+    const float voxel = 2.0f / (float)G;
+    Backend be(cf, bbox, 0.01f, voxel, 8.0f * voxel);
+    CalibVolumes cv(be, cf.filenames);
+    cv.loadInverseCalibs(dir);
+    NetKinectArray nka(be);
+    ReconIntegration recon(be);
+    const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
+    nka.readFromFiles(streams, colorsize, depthsize, 0);
+    process_textures(nka, recon);
+    recon.integrate();
+    rgbdr_geometry g;
+    std::vector<float> tsdf = recon.readbackTsdf(&g);
+    FILE* f = std::fopen(argv[6], "wb");
+    if (!f) return 3;
+    std::fwrite(tsdf.data(), sizeof(float), tsdf.size(), f);
+    std::fclose(f);
+    std::printf("res %d %d %d bricks %u occupied %.4f\n", g.res_volume[0], g.res_volume[1], g.res_volume[2],
+                recon.numBricks(), recon.occupiedRatio());
+    // error behaviour mirrors the reference's exception types
+    try {
+      recon.setVoxelSize(-1.0f);
+      return 4;
+    } catch (const std::invalid_argument&) {
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "frame_loop: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,229 @@
+// rgbdr_host.hpp -- C++ host-side mirror of the reference's operator surface for
+// the TSDF-fusion hot path, layered on the C ABI of include/rgbdr.h.
+//
+// The reference drives the path through three in-process classes
+//   kinect::CalibVolumes      framework/calibration/CalibVolumes.hpp:21-81
+//   kinect::NetKinectArray    framework/NetKinectArray.h:36-116
+//   kinect::ReconIntegration  framework/reconstruction/recon_integration.hpp:35-103
+// wired together in source/kinect_client.cpp:240-255 and called per frame in the
+// order of kinect_client.cpp:572-602.  The classes below keep those names, method
+// names, argument meaning and error behaviour (std::invalid_argument /
+// std::out_of_range / std::runtime_error instead of status codes), so a
+// maintainer can swap `kinect::` for `rgbdr::host::` at the call sites; what was
+// an OpenGL texture unit becomes state of the shared rgbdr_ctx.
+//
+// Header-only; link with -lrgbdr_hip.  No OpenGL, no HIP types.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbdr.h"
+
+namespace rgbdr {
+namespace host {
+
+// gloost::BoundingBox stand-in (getPMin / getPMax, external/gloost/BoundingBox.h:64-104)
+struct BoundingBox {
+  std::array<float, 3> pmin{{-1.0f, 0.0f, -1.0f}}, pmax{{1.0f, 2.2f, 1.0f}};  // default of kinect_client.cpp:208-209
+  const std::array<float, 3>& getPMin() const { return pmin; }
+  const std::array<float, 3>& getPMax() const { return pmax; }
+};
+
+// The scalars kinect::CalibrationFiles exposes to the hot path
+// (framework/calibration/calibration_files.hpp:11-44); parsing the sensor .yml
+// files stays with the application.
+struct CalibrationFiles {
+  std::vector<std::string> filenames;  // per-sensor yml paths ("kinect <yml>" lines of the .ks file)
+  unsigned width = 512, height = 424, widthC = 512, heightC = 424;
+  bool compressedDepth = false;
+  int compressedRGB = 0;  // the reference's yml default is 1 (DXT1): not supported by this backend yet
+  std::vector<float> near_, far_;
+  unsigned num() const { return (unsigned)filenames.size(); }
+  unsigned getWidth() const { return width; }
+  unsigned getHeight() const { return height; }
+  unsigned getWidthC() const { return widthC; }
+  unsigned getHeightC() const { return heightC; }
+  bool isCompressedDepth() const { return compressedDepth; }
+  int isCompressedRGB() const { return compressedRGB; }
+};
+
+inline void check(rgbdr_ctx* ctx, int rc)
+{
+  if (rc == RGBDR_OK) return;
+  const std::string msg = std::string(rgbdr_status_string(rc)) + ": " + rgbdr_last_error(ctx);
+  switch (rc) {
+    case RGBDR_ERR_INVALID_ARGUMENT: throw std::invalid_argument(msg);
+    case RGBDR_ERR_OUT_OF_RANGE: throw std::out_of_range(msg);
+    default: throw std::runtime_error(msg);
+  }
+}
+
+// Owns the rgbdr_ctx the three mirrored classes share.
+class Backend {
+ public:
+  Backend(const CalibrationFiles& cf, const BoundingBox& bbox, float limit = 0.01f, float voxel = 0.01f,
+          float brick = 0.1f, int device = 0, int slab_rank = 0, int slab_count = 1)
+  {
+    if (cf.num() == 0) throw std::invalid_argument("no sensors");
+    rgbdr_config c{};
+    c.struct_size = sizeof(c);
+    c.num_sensors = (int32_t)cf.num();
+    c.depth_w = (int32_t)cf.getWidth();
+    c.depth_h = (int32_t)cf.getHeight();
+    c.color_w = (int32_t)cf.getWidthC();
+    c.color_h = (int32_t)cf.getHeightC();
+    for (int a = 0; a < 3; ++a) {
+      c.bbox_min[a] = bbox.getPMin()[a];
+      c.bbox_max[a] = bbox.getPMax()[a];
+    }
+    c.voxel_size = voxel;
+    c.brick_size = brick;
+    c.tsdf_limit = limit;
+    c.min_voxels_per_brick = 10;  // recon_integration.cpp:62
+    c.flags = RGBDR_FLAGS_DEFAULT;
+    c.compress_depth = cf.isCompressedDepth() ? 1 : 0;
+    c.compress_rgb = cf.isCompressedRGB();
+    for (unsigned i = 0; i < RGBDR_MAX_SENSORS; ++i) {
+      c.near_[i] = i < cf.near_.size() ? cf.near_[i] : 0.3f;  // KinectCalibrationFile defaults
+      c.far_[i] = i < cf.far_.size() ? cf.far_[i] : 7.0f;
+    }
+    c.slab_rank = slab_rank;
+    c.slab_count = slab_count;
+    rgbdr_ctx* raw = nullptr;
+    check(nullptr, rgbdr_create(&c, device, &raw));
+    m_ctx.reset(raw, rgbdr_destroy);
+    m_num = cf.num();
+  }
+  rgbdr_ctx* ctx() const { return m_ctx.get(); }
+  unsigned num() const { return m_num; }
+
+ private:
+  std::shared_ptr<rgbdr_ctx> m_ctx;
+  unsigned m_num = 0;
+};
+
+// kinect::CalibVolumes
+class CalibVolumes {
+ public:
+  // calib_volume_files are the yml paths; "<base>.cv_xyz" / "<base>.cv_uv" are read
+  // next to them (CalibVolumes.cpp:34-39)
+  CalibVolumes(Backend& be, std::vector<std::string> const& calib_volume_files) : m_be(be)
+  {
+    for (auto const& f : calib_volume_files) {
+      if (f.size() < 3) throw std::invalid_argument("calibration file name too short");
+      const std::string base = f.substr(0, f.size() - 3);
+      m_cv_xyz_filenames.push_back(base + "cv_xyz");
+      m_cv_uv_filenames.push_back(base + "cv_uv");
+    }
+    for (unsigned i = 0; i < m_cv_xyz_filenames.size(); ++i)
+      check(m_be.ctx(), rgbdr_load_calibration_files(m_be.ctx(), (int)i, m_cv_xyz_filenames[i].c_str(),
+                                                     m_cv_uv_filenames[i].c_str(), nullptr));
+  }
+  // "<path><basename>.cv_xyz_inv" (CalibVolumes.cpp:64-80)
+  void loadInverseCalibs(std::string const& path)
+  {
+    for (unsigned i = 0; i < m_cv_xyz_filenames.size(); ++i) {
+      const std::string& s = m_cv_xyz_filenames[i];
+      const std::string name = s.substr(s.find_last_of("/\\") + 1);
+      const std::string in = path + name + "_inv";
+      check(m_be.ctx(), rgbdr_load_calibration_files(m_be.ctx(), (int)i, nullptr, nullptr, in.c_str()));
+    }
+  }
+  std::vector<std::array<float, 3>> getCameraPositions() const
+  {
+    std::vector<std::array<float, 3>> out(m_cv_xyz_filenames.size());
+    for (unsigned i = 0; i < out.size(); ++i) check(m_be.ctx(), rgbdr_get_camera_position(m_be.ctx(), (int)i, out[i].data()));
+    return out;
+  }
+
+ private:
+  Backend& m_be;
+  std::vector<std::string> m_cv_xyz_filenames, m_cv_uv_filenames;
+};
+
+// kinect::NetKinectArray (ingest + the five pre_* passes).  The ZeroMQ reader
+// thread is transport and stays outside; frames arrive through update().
+class NetKinectArray {
+ public:
+  explicit NetKinectArray(Backend& be) : m_be(be) {}
+  // bool NetKinectArray::update(): upload the newest frame set
+  bool update(const void* depth_all_sensors, const void* color_all_sensors)
+  {
+    check(m_be.ctx(), rgbdr_upload_frame(m_be.ctx(), depth_all_sensors, color_all_sensors));
+    return true;
+  }
+  void processTextures() { check(m_be.ctx(), rgbdr_process_textures(m_be.ctx())); }
+  // The reference re-runs processTextures() inside these three setters without
+  // clearing the brick counters; here the caller re-runs the
+  // process_textures() sequence explicitly.
+  void filterTextures(bool on) { check(m_be.ctx(), rgbdr_filter_textures(m_be.ctx(), on)); }
+  void useProcessedDepths(bool on) { check(m_be.ctx(), rgbdr_use_processed_depths(m_be.ctx(), on)); }
+  void refineBoundary(bool on) { check(m_be.ctx(), rgbdr_refine_boundary(m_be.ctx(), on)); }
+
+  // NetKinectArray::readFromFiles (NetKinectArray.cpp:724-764): one ".stream" file
+  // per sensor, frames of [colorsize bytes][depthsize bytes]; reads frame `index`
+  // of every file into contiguous per-sensor buffers and uploads them.
+  bool readFromFiles(std::vector<std::string> const& stream_files, size_t colorsize, size_t depthsize, size_t index = 0)
+  {
+    std::vector<unsigned char> color(colorsize * stream_files.size()), depth(depthsize * stream_files.size());
+    for (size_t i = 0; i < stream_files.size(); ++i) {
+      FILE* f = std::fopen(stream_files[i].c_str(), "rb");
+      if (!f) throw std::runtime_error("error opening " + stream_files[i]);
+      bool ok = std::fseek(f, (long)((colorsize + depthsize) * index), SEEK_SET) == 0 &&
+                std::fread(color.data() + i * colorsize, 1, colorsize, f) == colorsize &&
+                std::fread(depth.data() + i * depthsize, 1, depthsize, f) == depthsize;
+      std::fclose(f);
+      if (!ok) throw std::runtime_error("short read from " + stream_files[i]);
+    }
+    return update(depth.data(), color.data());
+  }
+
+ private:
+  Backend& m_be;
+};
+
+// kinect::ReconIntegration (the integrate / brick half; draw() is out of scope)
+class ReconIntegration {
+ public:
+  explicit ReconIntegration(Backend& be) : m_be(be) {}
+  void integrate() { check(m_be.ctx(), rgbdr_integrate(m_be.ctx())); }
+  void clearOccupiedBricks() const { check(m_be.ctx(), rgbdr_clear_occupied_bricks(m_be.ctx())); }
+  void updateOccupiedBricks() { check(m_be.ctx(), rgbdr_update_occupied_bricks(m_be.ctx())); }
+  void setVoxelSize(float size) { check(m_be.ctx(), rgbdr_set_voxel_size(m_be.ctx(), size)); }
+  void setTsdfLimit(float limit) { check(m_be.ctx(), rgbdr_set_tsdf_limit(m_be.ctx(), limit)); }
+  void setBrickSize(float size) { check(m_be.ctx(), rgbdr_set_brick_size(m_be.ctx(), size)); }
+  void setUseBricks(bool active) { check(m_be.ctx(), rgbdr_set_use_bricks(m_be.ctx(), active)); }
+  void setMinVoxelsPerBrick(unsigned i) { check(m_be.ctx(), rgbdr_set_min_voxels_per_brick(m_be.ctx(), i)); }
+  unsigned numBricks() const { return rgbdr_num_bricks(m_be.ctx()); }
+  float occupiedRatio() const { return rgbdr_occupied_ratio(m_be.ctx()); }
+  float getBrickSize() const { return rgbdr_get_brick_size(m_be.ctx()); }
+  // no counterpart in the reference (consumers sample texture unit 29)
+  std::vector<float> readbackTsdf(rgbdr_geometry* geo_out = nullptr) const
+  {
+    rgbdr_geometry g;
+    check(m_be.ctx(), rgbdr_get_geometry(m_be.ctx(), &g));
+    std::vector<float> v((size_t)g.res_volume[0] * g.res_volume[1] * (size_t)(g.slab_voxel_z1 - g.slab_voxel_z0));
+    check(m_be.ctx(), rgbdr_readback_tsdf(m_be.ctx(), v.data()));
+    if (geo_out) *geo_out = g;
+    return v;
+  }
+
+ private:
+  Backend& m_be;
+};
+
+// process_textures() of source/kinect_client.cpp:572-580
+inline void process_textures(NetKinectArray& nka, ReconIntegration& recon)
+{
+  recon.clearOccupiedBricks();
+  nka.processTextures();
+  recon.updateOccupiedBricks();
+}
+
+}  // namespace host
+}  // namespace rgbdr
