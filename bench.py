@@ -11,9 +11,9 @@ defaults to is timed separately and reported under "bricked".
 N = 1: BASELINE.json config "4 sensors, 512^3 TSDF, full pre_* chain".
 N > 1: one process per GPU, the volume is split into Z slabs of storage-tile
 layers (no data-path collective for integration; the one exchange per step is the
-one-tile-layer halo to the Z neighbours over RCCL), weak scaling: cubic grids
-512^3 / 640^3 / 800^3 / 1024^3 over the same 2 m box for 1 / 2 / 4 / 8 GPUs, i.e.
-~134 M voxels per GPU.
+one-tile-layer halo to the Z neighbours over RCCL), weak scaling: grids
+512^3 / 512x512x1024 / 512x1024x1024 / 1024^3 over the same 2 m box for 1 / 2 / 4 / 8
+GPUs, i.e. 134 M voxels per GPU (each slab is 2^27 voxels).
 """
 import argparse
 import json
@@ -27,7 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
-GRID_FOR_GPUS = {1: 512, 2: 640, 4: 800, 8: 1024}
+# weak scaling: ~134 M voxels (one 512^3 worth) per GPU over the same 2 m box; every
+# axis stays a power of two so the 1:1 inverse LUT needs no interpolation
+GRID_FOR_GPUS = {1: (512, 512, 512), 2: (512, 512, 1024), 4: (512, 1024, 1024), 8: (1024, 1024, 1024)}
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
 
@@ -36,7 +38,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--grid", type=int, default=0, help="override the cubic grid size")
+    ap.add_argument("--grid", type=int, default=0, help="override with a cubic grid of this size")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: debugging several "
+                                                      "ranks on one GPU, halos staged through the host)")
     ap.add_argument("--sensors", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=64, help="z rows of the volume the CPU baseline integrates")
@@ -54,11 +58,16 @@ def main():
                              % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     load_package()
     from rgbd_recon_amd import capi, synth
@@ -66,10 +75,11 @@ def main():
 
     N = args.sensors
     W, H = 512, 424
-    G = args.grid or GRID_FOR_GPUS.get(world, 512)
+    grid = (args.grid,) * 3 if args.grid else GRID_FOR_GPUS.get(world, (512, 512, 512))
+    G = grid[0]
     scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
     cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=capi.FLAGS_DEFAULT,
-                           slab_rank=rank, slab_count=world)
+                           res_override=grid, slab_rank=rank, slab_count=world)
     ctx = capi.Context(cfg, local_rank)
     g = ctx.geo
     for i in range(N):
@@ -91,7 +101,13 @@ def main():
         ctx.integrate()
         if halo is not None:
             ctx.sync()                       # library stream -> RCCL stream hand-off
-            rdist.exchange_halo(*halo, rank=rank, world=world)
+            if args.backend == "nccl":
+                rdist.exchange_halo(*halo, rank=rank, world=world)
+            else:                            # debugging backend: stage through the host
+                host = [t.cpu() for t in halo]
+                rdist.exchange_halo(*host, rank=rank, world=world)
+                halo[2].copy_(host[2])
+                halo[3].copy_(host[3])
 
     def barrier():
         ctx.sync()
@@ -133,7 +149,6 @@ def main():
     # repacked, xyz-only 1:1 LUT) + the packed 8-B frame texels read once
     bytes_launch = V_local * (4 + 12 * N) + N * W * H * 8
     achieved = bytes_launch / int_s if int_s > 0 else 0.0
-    tsdf_full = None
 
     # ---- brick-skipping mode (reference default) -------------------------------
     dtb, stats_b = timed(True, max(args.steps // 2, 1), 2)
@@ -155,8 +170,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "%d sensors 512x424 -> %d^3 TSDF, full pre_* chain + full-sweep integrate, 1:1 inverse LUT"
-                               % (N, G),
+        "config": {"workload": "%d sensors 512x424 -> %dx%dx%d TSDF, full pre_* chain + full-sweep integrate, 1:1 "
+                               "inverse LUT" % ((N,) + tuple(g.res_volume)),
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
                    "parallelism": "zslab%d" % world if world > 1 else "single"},
         "roofline": {"bound": "hbm", "kernel": "k_integrate_tiled<%d,false>" % N,
@@ -175,7 +190,7 @@ def main():
         try:
             t = json.load(open(traffic_file))
             key = "%dx%d" % (N, G)
-            if key in t:
+            if key in t and world == 1 and tuple(g.res_volume) == (G, G, G):
                 out["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -219,7 +234,7 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
     parity = bool(np.all((ref == hip_rows) | (np.isnan(ref) & np.isnan(hip_rows))))
     t0 = time.perf_counter()
     orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), None, brick_size=g.brick_size,
-                     bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
+                     bv=tuple(g.brick_voxels_axis), res_bricks=tuple(g.res_bricks))
     t_pre = time.perf_counter() - t0
     t_full = t_pre + t_int * (G / rows)
     return {"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads, "kind": "port",

@@ -70,7 +70,8 @@ typedef struct {
   int32_t compress_rgb;          /* yml compress_rgb: 0 = RGB8; 1 (DXT1) / 5 (DXT5) are not supported yet */
   float near_[RGBDR_MAX_SENSORS];/* yml near_far: per sensor (NetKinectArray.cpp:346-347) */
   float far_[RGBDR_MAX_SENSORS];
-  int32_t res_override[3];       /* 0,0,0 = ceil(extent / voxel_size) as setVoxelSize does */
+  int32_t res_override[3];       /* 0,0,0 = ceil(extent / voxel_size) as setVoxelSize does; otherwise the grid
+                                    resolution per axis (voxel edge = extent / res on that axis) */
   int32_t slab_rank, slab_count; /* Z-slab of storage tiles owned by this context; 0,1 (or 0,0) = whole volume */
 } rgbdr_config;
 
@@ -89,7 +90,8 @@ typedef struct {
   int32_t res_volume[3];   /* m_res_volume */
   int32_t res_bricks[3];   /* m_res_bricks */
   float brick_size;        /* adjusted: voxel * round(size / voxel) */
-  int32_t brick_voxels;    /* voxels per brick edge: round(brick_size / voxel_size) */
+  int32_t brick_voxels;    /* voxels per brick edge: round(brick_size / voxel_size) (x axis) */
+  int32_t brick_voxels_axis[3]; /* per axis; differs from brick_voxels only for res_override grids with anisotropic voxels */
   int32_t num_bricks;
   int32_t tiles[3];        /* storage tiles per axis = ceil(res / RGBDR_TILE) */
   int32_t slab_tile_z0, slab_tile_z1; /* tile layers [z0, z1) owned by this slab */

@@ -32,7 +32,7 @@ class NormalParams(C.Structure):
 
 class IntegrateParams(C.Structure):
     _fields_ = [("num_sensors", C.c_int), ("W", C.c_int), ("H", C.c_int), ("res", C.c_int * 3),
-                ("limit", C.c_float), ("bv", C.c_int), ("res_bricks", C.c_int * 3)]
+                ("limit", C.c_float), ("bv", C.c_int * 3), ("res_bricks", C.c_int * 3)]
 
 
 _lib = None
@@ -198,7 +198,7 @@ def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, b
     p.num_sensors, p.W, p.H = n, w, h
     p.res[:] = list(res)
     p.limit = limit
-    p.bv = bv
+    p.bv[:] = [bv] * 3 if np.isscalar(bv) else list(bv)
     p.res_bricks[:] = list(res_bricks)
     arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs])
     inv_res = (C.c_int * (3 * n))()
@@ -269,7 +269,8 @@ def run_pipeline(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_siz
     brick counters, occupied ids and the TSDF volume."""
     n = scene.N
     if res_bricks is None:
-        res_bricks = tuple((r + bv - 1) // bv for r in res)
+        bva = [bv] * 3 if np.isscalar(bv) else list(bv)
+        res_bricks = tuple((r + b - 1) // b for r, b in zip(res, bva))
     nb = res_bricks[0] * res_bricks[1] * res_bricks[2]
     counters = np.zeros(nb, dtype=np.uint32)
     out = {k: [] for k in ("raw", "morph", "depth_rg", "lab", "depth_b", "sil", "normal", "quality")}

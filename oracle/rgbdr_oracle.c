@@ -578,7 +578,7 @@ ORC_API void orc_quality(const float* depth_b_rg, const float* normals, const fl
 /* tsdf_integration.vs (a9) + VolumeSampler voxel positions (a8)              */
 /* Writes voxels z in [z0, z1) of an X*Y*Z x-fastest volume (whole-volume     */
 /* pointer).  `occupied_voxel_mask`, if not NULL, is one byte per brick       */
-/* (brick = bv voxels per axis, bricks x-fastest, res_bricks given): voxels    */
+/* (brick = bv[axis] voxels per axis, bricks x-fastest, res_bricks given): voxels    */
 /* of unoccupied bricks keep the clear value -limit                           */
 /* (framework/reconstruction/recon_integration.cpp:243-270).                  */
 
@@ -587,7 +587,7 @@ typedef struct {
   int W, H;
   int res[3];          /* TSDF resolution m_res_volume */
   float limit;
-  int bv;              /* voxels per brick edge */
+  int bv[3];           /* voxels per brick edge, per axis */
   int res_bricks[3];
 } orc_integrate_params;
 
@@ -606,7 +606,7 @@ ORC_API void orc_integrate(const orc_integrate_params* p, const float* const* cv
       for (int x = 0; x < X; ++x) {
         const size_t o = (size_t)z * X * Y + (size_t)y * X + x;
         if (occupied_brick_mask) {
-          size_t b = ((size_t)(z / p->bv) * p->res_bricks[1] + (size_t)(y / p->bv)) * p->res_bricks[0] + (size_t)(x / p->bv);
+          size_t b = ((size_t)(z / p->bv[2]) * p->res_bricks[1] + (size_t)(y / p->bv[1])) * p->res_bricks[0] + (size_t)(x / p->bv[0]);
           if (!occupied_brick_mask[b]) {
             tsdf[o] = -limit;
             continue;

@@ -48,7 +48,8 @@ class Lut(C.Structure):
 class Geometry(C.Structure):
     _fields_ = [
         ("res_volume", C.c_int32 * 3), ("res_bricks", C.c_int32 * 3),
-        ("brick_size", C.c_float), ("brick_voxels", C.c_int32), ("num_bricks", C.c_int32),
+        ("brick_size", C.c_float), ("brick_voxels", C.c_int32), ("brick_voxels_axis", C.c_int32 * 3),
+        ("num_bricks", C.c_int32),
         ("tiles", C.c_int32 * 3),
         ("slab_tile_z0", C.c_int32), ("slab_tile_z1", C.c_int32),
         ("slab_voxel_z0", C.c_int32), ("slab_voxel_z1", C.c_int32),

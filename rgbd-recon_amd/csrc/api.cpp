@@ -674,7 +674,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.win = ctx->d_win;
   p.use_bricks = bricks ? 1 : 0;
   p.brick_mask = ctx->d_mask;
-  p.bv = g.brick_voxels;
+  p.bvx = g.brick_voxels_axis[0];
+  p.bvy = g.brick_voxels_axis[1];
+  p.bvz = g.brick_voxels_axis[2];
   p.bx = g.res_bricks[0];
   p.by = g.res_bricks[1];
   p.bz = g.res_bricks[2];

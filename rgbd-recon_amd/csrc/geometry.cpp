@@ -47,6 +47,14 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
   if (ratio < 1.0f) ratio = 1.0f;
   g->brick_size = cfg.voxel_size * ratio;
   g->brick_voxels = (int)ratio;
+  for (int a = 0; a < 3; ++a) {
+    g->brick_voxels_axis[a] = g->brick_voxels;
+    if (cfg.res_override[a] > 0) {  // voxel edge on this axis = extent / res
+      const float edge = (cfg.bbox_max[a] - cfg.bbox_min[a]) / (float)cfg.res_override[a];
+      float r = std::round(g->brick_size / edge);
+      g->brick_voxels_axis[a] = r < 1.0f ? 1 : (int)r;
+    }
+  }
   // divideBox: count bricks per axis with the reference's accumulating loop; a
   // rounding residue can add a sliver brick, never lose one that holds voxels
   for (int a = 0; a < 3; ++a) {
@@ -59,7 +67,7 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
       ++n;
       if (n > (1 << 20)) return fail("brick grid too fine");
     }
-    const int need = (g->res_volume[a] + g->brick_voxels - 1) / g->brick_voxels;
+    const int need = (g->res_volume[a] + g->brick_voxels_axis[a] - 1) / g->brick_voxels_axis[a];
     g->res_bricks[a] = n > need ? n : need;
   }
   const long long nb = (long long)g->res_bricks[0] * g->res_bricks[1] * g->res_bricks[2];

@@ -117,7 +117,7 @@ __device__ __forceinline__ void fold_voxel_window(const uint2* win, int wx0, int
 
 __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx, int vy, int vz)
 {
-  const int bx = vx / p.bv, by = vy / p.bv, bz = vz / p.bv;
+  const int bx = vx / p.bvx, by = vy / p.bvy, bz = vz / p.bvz;
   if (bx >= p.bx || by >= p.by || bz >= p.bz) return false;
   return p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
 }
@@ -214,15 +214,27 @@ __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ 
   const float4* lut = reinterpret_cast<const float4*>(lut_tiled + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
   const float4 U = lut[0], V = lut[kTileVoxels / 4];
   const float us[4] = {U.x, U.y, U.z, U.w}, vs[4] = {V.x, V.y, V.z, V.w};
-  int mx = 0x7fffffff, my = 0x7fffffff;
+  int mx = 0x7fffffff, my = 0x7fffffff, ix = 0x7fffffff, iy = 0x7fffffff;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float a;
     const int jx = footprint(us[j], W, a), jy = footprint(vs[j], H, a);
     if (jx >= -1 && jx <= W - 1 && jy >= -1 && jy <= H - 1) {
-      mx = min(mx, jx);
-      my = min(my, jy);
+      // entries carrying the inverter's "outside the frustum" marker (-1,-1) all hit
+      // texel (0,0) through a broadcast global fetch; keep them out of the window
+      // placement unless the whole tile is such (then the window sits at (-1,-1))
+      if (us[j] == -1.0f && vs[j] == -1.0f) {
+        ix = min(ix, jx);
+        iy = min(iy, jy);
+      } else {
+        mx = min(mx, jx);
+        my = min(my, jy);
+      }
     }
+  }
+  if (__syncthreads_and(mx == 0x7fffffff)) {  // no valid footprint in the tile
+    mx = ix;
+    my = iy;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -73,7 +73,7 @@ struct IntegrateParams {
   // bricks
   int use_bricks;
   const uint8_t* brick_mask;
-  int bv;
+  int bvx, bvy, bvz;       // voxels per brick edge, per axis
   int bx, by, bz;
   float* tsdf;             // first owned tile layer
 };

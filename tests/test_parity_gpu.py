@@ -127,6 +127,30 @@ def test_reference_default_grid(pkg, orc):
     ctx.close()
 
 
+def test_anisotropic_override_grid(pkg, orc):
+    """res_override grid (the weak-scaling benchmark grids): voxel edge differs per
+    axis, brick membership follows per axis"""
+    capi, synth = pkg.capi, pkg.synth
+    scene = synth.Scene(2, 64, 53, lut_res=(16, 13, 16))
+    res = (32, 64, 128)
+    cfg = capi.make_config(2, (64, 53), voxel_size=2.0 / 32, brick_size=8 * 2.0 / 32, res_override=res)
+    ctx = capi.Context(cfg, 0)
+    g = ctx.geo
+    assert tuple(g.res_volume) == res and tuple(g.brick_voxels_axis) == (8, 16, 32) and tuple(g.res_bricks) == (4, 4, 4)
+    inv = scene.inverse(res)
+    for i in range(2):
+        ctx.set_calibration(i, scene.xyz[i], (16, 13, 16), scene.uv[i], (16, 13, 16), (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], res)
+    ctx.step(scene.depth, scene.color)
+    ref = orc.run_pipeline(scene, BMIN, BMAX, res, inv, limit=0.01, brick_size=g.brick_size,
+                           bv=tuple(g.brick_voxels_axis), res_bricks=tuple(g.res_bricks))
+    assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+    got = ctx.readback_tsdf()
+    assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+    assert 0 < len(ref["occupied"]) < g.num_bricks
+    ctx.close()
+
+
 def test_edge_cases(pkg, orc):
     scene, ctx, inv = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
     # (a) empty frame: every depth 0
