@@ -92,18 +92,33 @@ def main():
     halo = None
     if world > 1:
         halo = rdist.halo_views(ctx.device_tsdf(), dev)
+        # The library enqueues on a torch stream so that the RCCL exchange can be
+        # ordered against the kernels with events instead of host syncs: the halo of
+        # step k travels on a side stream while step k+1 runs its pre_* chain; only
+        # integrate (which overwrites the layers being sent) waits for it.
+        main = torch.cuda.Stream(dev)
+        side = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(main)
+        ctx.set_stream(main.cuda_stream)
+        int_done, halo_done = torch.cuda.Event(), torch.cuda.Event()
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
         ctx.update_occupied_bricks()
+        if halo is not None:
+            main.wait_event(halo_done)       # no-op until the first exchange was enqueued
         ctx.integrate()
         if halo is not None:
-            ctx.sync()                       # library stream -> RCCL stream hand-off
+            int_done.record(main)
             if args.backend == "nccl":
-                rdist.exchange_halo(*halo, rank=rank, world=world)
+                with torch.cuda.stream(side):
+                    side.wait_event(int_done)
+                    rdist.exchange_halo(*halo, rank=rank, world=world)
+                    halo_done.record(side)
             else:                            # debugging backend: stage through the host
+                int_done.synchronize()
                 host = [t.cpu() for t in halo]
                 rdist.exchange_halo(*host, rank=rank, world=world)
                 halo[2].copy_(host[2])

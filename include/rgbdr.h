@@ -226,6 +226,11 @@ int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);
 /* the context's HIP stream (hipStream_t) for callers that enqueue dependent work */
 void* rgbdr_stream(rgbdr_ctx* ctx);
+/* Enqueue all further work of this context on the caller's stream (hipStream_t of
+ * the same device; NULL restores the context's own stream).  Lets a host that owns
+ * other work on that stream -- e.g. RCCL halo exchanges -- order it against the
+ * kernels without host synchronisation.  The previous stream is drained first. */
+int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream);
 
 /* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
 

@@ -117,6 +117,7 @@ SYMBOLS = {
     "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_stream": (_P, [_P]),
+    "rgbdr_set_stream": (C.c_int, [_P, _P]),
     "rgbdr_enable_timers": (C.c_int, [_P, C.c_int]),
     "rgbdr_timer_ns": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
     "rgbdr_enable_timer_accumulation": (C.c_int, [_P, C.c_int]),
@@ -363,6 +364,10 @@ class Context:
 
     def stream(self):
         return lib().rgbdr_stream(self._h)
+
+    def set_stream(self, hip_stream):
+        """hipStream_t handle as an int (e.g. torch.cuda.Stream.cuda_stream); None = own stream"""
+        self._chk(lib().rgbdr_set_stream(self._h, _P(hip_stream) if hip_stream else None))
 
     def enable_timers(self, on=True):
         self._chk(lib().rgbdr_enable_timers(self._h, int(on)))

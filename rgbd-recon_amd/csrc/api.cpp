@@ -33,7 +33,8 @@ struct rgbdr_ctx {
   rgbdr_config cfg{};
   rgbdr_geometry geo{};
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // where work is enqueued
+  hipStream_t own_stream = nullptr;  // created with the context
   std::string err;
 
   // images ([N][H][W][c])
@@ -259,10 +260,11 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
     rgbdr_destroy(ctx);
     return code;
   };
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     ctx->err = "hipStreamCreate failed";
     return cleanup(RGBDR_ERR_HIP);
   }
+  ctx->stream = ctx->own_stream;
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)cfg->num_sensors * cfg->color_w * cfg->color_h * 3;
   struct {
@@ -322,7 +324,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
         (void)hipEventDestroy(ev.second);
       }
   }
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
@@ -943,6 +945,15 @@ int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
 }
 
 void* rgbdr_stream(rgbdr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return RGBDR_OK;
+}
 
 int rgbdr_enable_timers(rgbdr_ctx* ctx, int on)
 {

@@ -121,8 +121,14 @@ def inverse_lut(s, res, bbox_min=BBOX_MIN, bbox_max=BBOX_MAX, z_range=None):
 class Scene:
     """All inputs of one configuration."""
 
-    def __init__(self, num_sensors, width, height, lut_res=(32, 27, 32), seed=1234, make_frames=True):
+    def __init__(self, num_sensors, width, height, lut_res=(32, 27, 32), seed=1234, make_frames=True, sphere_r=None):
         self.N, self.W, self.H = num_sensors, width, height
+        # SURVEY 8(d) scene: sphere r = 0.5 m.  At small test resolutions a 13x13
+        # window spans most of such a sphere and the bilateral pass rejects every
+        # pixel, so low-resolution scenes use a larger sphere to stay non-trivial.
+        if sphere_r is None:
+            sphere_r = 0.5 if width >= 256 else 0.9
+        self.sphere_r = sphere_r
         self.lut_res = tuple(lut_res)
         self.sensors = [Sensor(i, num_sensors, width, height) for i in range(num_sensors)]
         self.xyz, self.uv = [], []
@@ -131,7 +137,7 @@ class Scene:
             self.xyz.append(a)
             self.uv.append(b)
         if make_frames:
-            self.depth = np.stack([render_depth(s, seed + i) for i, s in enumerate(self.sensors)])
+            self.depth = np.stack([render_depth(s, seed + i, sphere_r=sphere_r) for i, s in enumerate(self.sensors)])
             self.color = np.stack([render_color(s, seed + i) for i, s in enumerate(self.sensors)])
 
     def inverse(self, res, bbox_min=BBOX_MIN, bbox_max=BBOX_MAX):

@@ -86,6 +86,7 @@ def test_sensor_counts(pkg, orc, n):
     ref = oracle_run(orc, scene, ctx, inv)
     check_images(ctx, ref, n)
     assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    assert np.sum(np.abs(ref["tsdf"]) < 0.01) > 50 and len(ref["occupied"]) > 0      # scene is not degenerate
     ctx.close()
 
 
@@ -100,6 +101,7 @@ def test_generic_inverse_lut_resolution(pkg, orc, G, inv_res):
         ref = oracle_run(orc, scene, ctx, inv, use_bricks=bricks)
         got = ctx.readback_tsdf()
         assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+        assert np.sum(np.abs(got) < 0.01) > 100
     ctx.close()
 
 
@@ -124,6 +126,7 @@ def test_reference_default_grid(pkg, orc):
     assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
     got = ctx.readback_tsdf()
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+    assert np.sum(np.abs(got) < 0.01) > 1000 and ref["counters"].sum() > 100
     ctx.close()
 
 
@@ -389,5 +392,26 @@ def test_device_resident_frames(pkg):
     ctx.process_textures()
     ctx.update_occupied_bricks()
     ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.close()
+
+
+def test_external_stream(pkg):
+    """rgbdr_set_stream: the context enqueues on a torch stream, results unchanged"""
+    import torch
+
+    scene, ctx, inv = build(pkg)
+    ctx.step(scene.depth, scene.color)
+    a = ctx.readback_tsdf()
+    s = torch.cuda.Stream()
+    ctx.set_stream(s.cuda_stream)
+    assert ctx.stream() == s.cuda_stream
+    ctx.step(np.zeros_like(scene.depth), scene.color)
+    ctx.step(scene.depth, scene.color)
+    s.synchronize()
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.set_stream(None)
+    assert ctx.stream() != s.cuda_stream
+    ctx.step(scene.depth, scene.color)
     assert same_bits(ctx.readback_tsdf(), a)
     ctx.close()
