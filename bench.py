@@ -43,6 +43,9 @@ def main():
                                                       "ranks on one GPU, halos staged through the host)")
     ap.add_argument("--sensors", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="RGBDR_FLAG_PIPELINE: the pre_* chain of step k+1 overlaps integrate of step k on a second stream "
+                         "(measured slower for the full sweep: integrate already saturates HBM and the CUs)")
     ap.add_argument("--cpu-rows", type=int, default=64, help="z rows of the volume the CPU baseline integrates")
     args = ap.parse_args()
 
@@ -78,7 +81,8 @@ def main():
     grid = (args.grid,) * 3 if args.grid else GRID_FOR_GPUS.get(world, (512, 512, 512))
     G = grid[0]
     scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
-    cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=capi.FLAGS_DEFAULT,
+    flags = capi.FLAGS_DEFAULT | (capi.FLAG_PIPELINE if args.pipeline else 0)
+    cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags,
                            res_override=grid, slab_rank=rank, slab_count=world)
     ctx = capi.Context(cfg, local_rank)
     g = ctx.geo
@@ -188,6 +192,7 @@ def main():
         "config": {"workload": "%d sensors 512x424 -> %dx%dx%d TSDF, full pre_* chain + full-sweep integrate, 1:1 "
                                "inverse LUT" % ((N,) + tuple(g.res_volume)),
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
+                   "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": "zslab%d" % world if world > 1 else "single"},
         "roofline": {"bound": "hbm", "kernel": "k_integrate_tiled<%d,false>" % N,
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -48,7 +48,11 @@ enum {
   RGBDR_FLAG_PROCESSED = 2u,
   RGBDR_FLAG_REFINE = 4u,
   RGBDR_FLAG_USE_BRICKS = 8u,
-  RGBDR_FLAGS_DEFAULT = 15u
+  RGBDR_FLAGS_DEFAULT = 15u,
+  /* not a reference setting: overlap the upload + pre_* chain of frame k+1 (second
+   * HIP stream, double-buffered packed frame / occupied mask) with integrate of
+   * frame k.  Results are identical; only the schedule changes. */
+  RGBDR_FLAG_PIPELINE = 16u
 };
 
 /* Replaces the constructor arguments of NetKinectArray (NetKinectArray.cpp:42),
@@ -181,6 +185,7 @@ int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size);      /* reallocates volume
 int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit);
 int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size);
 int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int active);
+int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on);           /* RGBDR_FLAG_PIPELINE at run time; drains both streams */
 int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n);
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on);         /* unlike the reference these three do not re-run */
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on);    /* processTextures() themselves (SURVEY.md A.5:   */

@@ -18,6 +18,7 @@ ERR_STATE = -6
 
 FLAG_FILTER, FLAG_PROCESSED, FLAG_REFINE, FLAG_USE_BRICKS = 1, 2, 4, 8
 FLAGS_DEFAULT = 15
+FLAG_PIPELINE = 16
 
 IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
 IMG_CHANNELS = {IMG_DEPTH_RAW: 1, IMG_DEPTH_MORPH: 1, IMG_DEPTH_RG: 2, IMG_LAB: 3, IMG_DEPTH_B_RG: 2,
@@ -100,6 +101,7 @@ SYMBOLS = {
     "rgbdr_set_tsdf_limit": (C.c_int, [_P, C.c_float]),
     "rgbdr_set_brick_size": (C.c_int, [_P, C.c_float]),
     "rgbdr_set_use_bricks": (C.c_int, [_P, C.c_int]),
+    "rgbdr_set_pipelined": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
     "rgbdr_filter_textures": (C.c_int, [_P, C.c_int]),
     "rgbdr_use_processed_depths": (C.c_int, [_P, C.c_int]),
@@ -306,6 +308,10 @@ class Context:
     def set_use_bricks(self, on):
         self._chk(lib().rgbdr_set_use_bricks(self._h, int(on)))
         self._flag(FLAG_USE_BRICKS, on)
+
+    def set_pipelined(self, on):
+        self._chk(lib().rgbdr_set_pipelined(self._h, int(on)))
+        self._flag(FLAG_PIPELINE, on)
 
     def set_min_voxels_per_brick(self, n):
         self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))

@@ -35,6 +35,19 @@ struct rgbdr_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // where work is enqueued
   hipStream_t own_stream = nullptr;  // created with the context
+  // Pipelined mode (RGBDR_FLAG_PIPELINE): upload + pre_* chain + occupied update of
+  // frame k+1 run on pre_stream while integrate of frame k runs on `stream`.  The
+  // only state both touch -- packed frame, occupied mask, occupied count -- is
+  // double buffered; events order producer and consumer of each buffer.
+  hipStream_t pre_stream = nullptr;
+  int wbuf = 0, rbuf = 0;            // buffer the next process_textures writes / the latest one written
+  hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
+  bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
+  bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
+  hipStream_t pstream() const { return pipelined() ? pre_stream : stream; }
+  uint2* frame_buf(int b) const { return d_frame + (size_t)b * cfg.num_sensors * cfg.depth_w * cfg.depth_h; }
+  uint8_t* mask_buf(int b) const { return d_mask + (size_t)b * geo.num_bricks; }
+  uint32_t* count_buf(int b) const { return d_count + 4 * b; }
   std::string err;
 
   // images ([N][H][W][c])
@@ -99,7 +112,7 @@ struct rgbdr_ctx {
 static int nsens(const rgbdr_ctx* c) { return c->cfg.num_sensors; }
 static size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->cfg.depth_w * c->cfg.depth_h; }
 
-static void tbegin(rgbdr_ctx* c, const char* name)
+static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
   if (!c->timers) return;
   Timer& t = c->tm[name];
@@ -113,24 +126,24 @@ static void tbegin(rgbdr_ctx* c, const char* name)
       (void)hipEventCreate(&ev.second);
     }
     t.pending.push_back(ev);
-    (void)hipEventRecord(ev.first, c->stream);
+    (void)hipEventRecord(ev.first, st);
     return;
   }
   if (!t.a) {
     (void)hipEventCreate(&t.a);
     (void)hipEventCreate(&t.b);
   }
-  (void)hipEventRecord(t.a, c->stream);
+  (void)hipEventRecord(t.a, st);
 }
-static void tend(rgbdr_ctx* c, const char* name)
+static void tend(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
   if (!c->timers) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
-    if (!t.pending.empty()) (void)hipEventRecord(t.pending.back().second, c->stream);
+    if (!t.pending.empty()) (void)hipEventRecord(t.pending.back().second, st);
     return;
   }
-  (void)hipEventRecord(t.b, c->stream);
+  (void)hipEventRecord(t.b, st);
   t.recorded = true;
 }
 
@@ -173,10 +186,19 @@ static int alloc_volume(rgbdr_ctx* ctx)
   HIPCHK(hipMemsetAsync(ctx->d_tsdf_base, 0, total * sizeof(float), ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks));
+  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
   HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks * 2, ctx->stream));
   ctx->mask_valid = false;
+  return RGBDR_OK;
+}
+
+// drain both streams (readbacks, setters, resizes)
+static int sync_all(rgbdr_ctx* ctx)
+{
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->pre_stream) HIPCHK(hipStreamSynchronize(ctx->pre_stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
 
@@ -265,6 +287,16 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
     return cleanup(RGBDR_ERR_HIP);
   }
   ctx->stream = ctx->own_stream;
+  if (hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking) != hipSuccess) {
+    ctx->err = "hipStreamCreate failed";
+    return cleanup(RGBDR_ERR_HIP);
+  }
+  for (int b = 0; b < 2; ++b)
+    if (hipEventCreateWithFlags(&ctx->ev_pre[b], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_int[b], hipEventDisableTiming) != hipSuccess) {
+      ctx->err = "hipEventCreate failed";
+      return cleanup(RGBDR_ERR_HIP);
+    }
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)cfg->num_sensors * cfg->color_w * cfg->color_h * 3;
   struct {
@@ -274,8 +306,8 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
                 {(void**)&ctx->d_depth_rg, n * 8},    {(void**)&ctx->d_lab, n * 12},
                 {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
-                {(void**)&ctx->d_frame, n * 8},      {(void**)&ctx->d_color, ncol},
-                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 16}};
+                {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol},
+                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 32}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
       ctx->err = "hipMalloc of image buffers failed";
@@ -306,8 +338,14 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
 {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->pre_stream) (void)hipStreamSynchronize(ctx->pre_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_volume(ctx);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->ev_pre[b]) (void)hipEventDestroy(ctx->ev_pre[b]);
+    if (ctx->ev_int[b]) (void)hipEventDestroy(ctx->ev_int[b]);
+  }
+  if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   void* ptrs[] = {ctx->d_depth_raw, ctx->d_depth_morph, ctx->d_depth_rg, ctx->d_lab,   ctx->d_depth_b, ctx->d_sil,
                   ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count};
   for (void* p : ptrs) (void)hipFree(p);
@@ -516,14 +554,15 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   HIPCHK(hipSetDevice(ctx->device));
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
+  hipStream_t ps = ctx->pstream();
   if (ctx->cfg.compress_depth) {
-    HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ctx->stream));
-    launch_u8_to_unit(ctx->d_depth_u8, ctx->d_depth_raw, n, ctx->stream);
+    HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
+    launch_u8_to_unit(ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
     LAUNCHCHK("u8_to_unit");
   } else {
-    HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ps));
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ps));
   ctx->frame_uploaded = true;
   return RGBDR_OK;
 }
@@ -541,7 +580,7 @@ int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->pstream()));
   return RGBDR_OK;
 }
 
@@ -589,29 +628,37 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   p.silhouette = ctx->d_sil;
   p.normal = ctx->d_normal;
   p.quality = ctx->d_quality;
-  p.frame = ctx->d_frame;
   // m_use_processed_depth: the filter pass reads the morph output instead of the
   // raw depth (NetKinectArray.cpp:287-289)
   p.depth_in = (ctx->cfg.flags & RGBDR_FLAG_PROCESSED) ? ctx->d_depth_morph : ctx->d_depth_raw;
 
-  tbegin(ctx, "1preprocess");
-  tbegin(ctx, "morph");
-  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->stream);
-  tend(ctx, "morph");
-  tbegin(ctx, "bilateral");
-  launch_pre_depth(p, ctx->stream);
-  tend(ctx, "bilateral");
-  tbegin(ctx, "boundary");
-  launch_boundary(p, ctx->stream);
-  tend(ctx, "boundary");
-  tbegin(ctx, "normal");
-  launch_normal(p, ctx->stream);
-  tend(ctx, "normal");
-  tbegin(ctx, "quality");
-  launch_quality(p, ctx->stream);
-  tend(ctx, "quality");
-  tend(ctx, "1preprocess");
+  hipStream_t ps = ctx->pstream();
+  const int w = ctx->wbuf;
+  p.frame = ctx->frame_buf(w);
+  if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  tbegin(ctx, "1preprocess", ps);
+  tbegin(ctx, "morph", ps);
+  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ps);
+  tend(ctx, "morph", ps);
+  tbegin(ctx, "bilateral", ps);
+  launch_pre_depth(p, ps);
+  tend(ctx, "bilateral", ps);
+  tbegin(ctx, "boundary", ps);
+  launch_boundary(p, ps);
+  tend(ctx, "boundary", ps);
+  tbegin(ctx, "normal", ps);
+  launch_normal(p, ps);
+  tend(ctx, "normal", ps);
+  tbegin(ctx, "quality", ps);
+  launch_quality(p, ps);
+  tend(ctx, "quality", ps);
+  tend(ctx, "1preprocess", ps);
   LAUNCHCHK("process_textures");
+  ctx->rbuf = w;
+  if (ctx->pipelined()) {
+    HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
+    ctx->ev_pre_rec[w] = true;
+  }
   ctx->textures_processed = true;
   return RGBDR_OK;
 }
@@ -620,11 +667,17 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   HIPCHK(hipSetDevice(ctx->device));
-  tbegin(ctx, "bricks");
-  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick, ctx->d_mask,
-                         ctx->d_count, ctx->stream);
-  tend(ctx, "bricks");
+  hipStream_t ps = ctx->pstream();
+  const int w = ctx->rbuf;  // belongs to the frame process_textures just wrote
+  tbegin(ctx, "bricks", ps);
+  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick,
+                         ctx->mask_buf(w), ctx->count_buf(w), ps);
+  tend(ctx, "bricks", ps);
   LAUNCHCHK("update_occupied");
+  if (ctx->pipelined()) {
+    HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
+    ctx->ev_pre_rec[w] = true;
+  }
   ctx->mask_valid = true;
   return RGBDR_OK;
 }
@@ -665,7 +718,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.stepZ = 1.0f / (float)p.Z;
   const size_t img = (size_t)p.W * p.H;
   for (int i = 0; i < N; ++i) {
-    p.frame[i] = ctx->d_frame + img * i;
+    p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
     p.lut[i] = ctx->d_lut_generic[i];
     p.rx[i] = (int)ctx->inv_res[i][0];
     p.ry[i] = (int)ctx->inv_res[i][1];
@@ -675,7 +728,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.lut_tiled = ctx->d_lut_tiled;
   p.win = ctx->d_win;
   p.use_bricks = bricks ? 1 : 0;
-  p.brick_mask = ctx->d_mask;
+  p.brick_mask = ctx->mask_buf(ctx->rbuf);
   p.bvx = g.brick_voxels_axis[0];
   p.bvy = g.brick_voxels_axis[1];
   p.bvz = g.brick_voxels_axis[2];
@@ -683,10 +736,16 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.by = g.res_bricks[1];
   p.bz = g.res_bricks[2];
   p.tsdf = ctx->d_tsdf_owned;
-  tbegin(ctx, "2integrate");
+  if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+  tbegin(ctx, "2integrate", ctx->stream);
   launch_integrate(p, all_tiled, ctx->stream);
-  tend(ctx, "2integrate");
+  tend(ctx, "2integrate", ctx->stream);
   LAUNCHCHK("integrate");
+  if (ctx->pipelined()) {
+    HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
+    ctx->ev_int_rec[ctx->rbuf] = true;
+    ctx->wbuf = ctx->rbuf ^ 1;  // the next frame's pre_* chain may run while this sweep reads rbuf
+  }
   return RGBDR_OK;
 }
 
@@ -703,9 +762,7 @@ int rgbdr_step(rgbdr_ctx* ctx, const void* depth, const void* color)
 int rgbdr_sync(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return RGBDR_OK;
+  return sync_all(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -713,8 +770,7 @@ int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "voxel size must be > 0");
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   rgbdr_config old = ctx->cfg;
   ctx->cfg.voxel_size = size;
   ctx->cfg.res_override[0] = ctx->cfg.res_override[1] = ctx->cfg.res_override[2] = 0;
@@ -732,8 +788,7 @@ int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "brick size must be > 0");
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   rgbdr_config trial = ctx->cfg;
   trial.brick_size = size;
   rgbdr_geometry g;
@@ -750,9 +805,10 @@ int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
   ctx->d_mask = nullptr;
   HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks));
+  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
   HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks * 2, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->mask_valid = false;
   return RGBDR_OK;
 }
@@ -775,6 +831,15 @@ static int set_flag(rgbdr_ctx* ctx, uint32_t flag, int on)
   return RGBDR_OK;
 }
 int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_USE_BRICKS, on); }
+int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  int rc = sync_all(ctx);
+  if (rc != RGBDR_OK) return rc;
+  ctx->wbuf = ctx->rbuf;  // keep reading what was written last
+  ctx->ev_pre_rec[0] = ctx->ev_pre_rec[1] = ctx->ev_int_rec[0] = ctx->ev_int_rec[1] = false;
+  return set_flag(ctx, RGBDR_FLAG_PIPELINE, on);
+}
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_PROCESSED, on); }
 int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }
@@ -794,7 +859,8 @@ float rgbdr_occupied_ratio(rgbdr_ctx* ctx)
   if (!ctx || !ctx->mask_valid) return 0.0f;
   (void)hipSetDevice(ctx->device);
   uint32_t c = 0;
-  if (hipMemcpyAsync(&c, ctx->d_count, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0.0f;
+  if (ctx->pre_stream && hipStreamSynchronize(ctx->pre_stream) != hipSuccess) return 0.0f;
+  if (hipMemcpyAsync(&c, ctx->count_buf(ctx->rbuf), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0.0f;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0.0f;
   return (float)c / (float)ctx->geo.num_bricks;
 }
@@ -819,6 +885,7 @@ int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   const rgbdr_geometry& g = ctx->geo;
   const size_t n = (size_t)g.res_volume[0] * g.res_volume[1] * (size_t)(g.slab_voxel_z1 - g.slab_voxel_z0);
@@ -855,6 +922,7 @@ int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst)
     case RGBDR_IMG_QUALITY: src = ctx->d_quality; break;
     default: return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "unknown image id");
   }
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   const size_t img = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * ch;
   HIPCHK(hipMemcpyAsync(dst, src + img * sensor, img * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -898,6 +966,7 @@ int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpyAsync(dst, ctx->d_counters, (size_t)ctx->geo.num_bricks * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -909,11 +978,13 @@ int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* c
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null count");
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "get_occupied before update_occupied_bricks");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
-  launch_compact_occupied(ctx->d_mask, (uint32_t)ctx->geo.num_bricks, ctx->d_ids, ctx->d_count + 1, ctx->stream);
+  launch_compact_occupied(ctx->mask_buf(ctx->rbuf), (uint32_t)ctx->geo.num_bricks, ctx->d_ids,
+                          ctx->count_buf(ctx->rbuf) + 1, ctx->stream);
   LAUNCHCHK("compact_occupied");
   uint32_t c = 0;
-  HIPCHK(hipMemcpyAsync(&c, ctx->d_count + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(&c, ctx->count_buf(ctx->rbuf) + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   *count = c;
   if (ratio) *ratio = (float)c / (float)ctx->geo.num_bricks;
@@ -940,7 +1011,7 @@ int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
 {
   if (!ctx || !ptr) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
-  *ptr = ctx->d_frame + (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sensor;
+  *ptr = ctx->frame_buf(ctx->rbuf) + (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sensor;
   return RGBDR_OK;
 }
 
@@ -949,8 +1020,7 @@ void* rgbdr_stream(rgbdr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return RGBDR_OK;
 }
