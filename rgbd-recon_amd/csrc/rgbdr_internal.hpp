@@ -76,6 +76,7 @@ struct IntegrateParams {
   int bvx, bvy, bvz;       // voxels per brick edge, per axis
   int bx, by, bz;
   float* tsdf;             // first owned tile layer
+  unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
 };
 
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
