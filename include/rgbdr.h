@@ -52,7 +52,13 @@ enum {
   /* not a reference setting: overlap the upload + pre_* chain of frame k+1 (second
    * HIP stream, double-buffered packed frame / occupied mask) with integrate of
    * frame k.  Results are identical; only the schedule changes. */
-  RGBDR_FLAG_PIPELINE = 16u
+  RGBDR_FLAG_PIPELINE = 16u,
+  /* An inverse LUT whose resolution differs from the TSDF grid is normally
+   * resampled once, at upload, at the voxel centres (the LINEAR lookup of
+   * tsdf_integration.vs:31 is static between frames) so that integrate() streams it
+   * like a 1:1 LUT.  This flag keeps the file's volume resident instead and evaluates
+   * the 8-tap lookup per frame (less HBM for LUTs much coarser than the grid). */
+  RGBDR_FLAG_NO_RESAMPLE = 32u
 };
 
 /* Replaces the constructor arguments of NetKinectArray (NetKinectArray.cpp:42),
@@ -204,10 +210,10 @@ int rgbdr_get_camera_position(const rgbdr_ctx* ctx, int sensor, float out[3]);
 int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst);
 /* one per-sensor image, H*W*channels f32, row-major */
 int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst);
-/* Inspection of the resident inverse LUT of one sensor: voxel-grid z rows [z0, z1)
- * (1:1 LUT) or texel z rows (other resolutions) as x-fastest RGBA32F records.
- * The .w channel is returned as 0 for a 1:1 LUT: it is dropped at upload because
- * the shader never reads it (tsdf_integration.vs:31). */
+/* Inspection of the resident inverse LUT of one sensor as x-fastest RGBA32F records:
+ * grid layout (1:1 or resampled LUT): the looked-up (u,v,d) of voxel rows [z0, z1),
+ * .w = 0 (never read by the shader, tsdf_integration.vs:31, dropped at upload);
+ * RGBDR_FLAG_NO_RESAMPLE: texel z rows [z0, z1) of the file's volume. */
 int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst);
 /* SSBO binding 3 payload after the 8-uint header: one u32 counter per brick */
 int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst);

@@ -19,6 +19,7 @@ ERR_STATE = -6
 FLAG_FILTER, FLAG_PROCESSED, FLAG_REFINE, FLAG_USE_BRICKS = 1, 2, 4, 8
 FLAGS_DEFAULT = 15
 FLAG_PIPELINE = 16
+FLAG_NO_RESAMPLE = 32
 
 IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
 IMG_CHANNELS = {IMG_DEPTH_RAW: 1, IMG_DEPTH_MORPH: 1, IMG_DEPTH_RG: 2, IMG_LAB: 3, IMG_DEPTH_B_RG: 2,

@@ -68,6 +68,7 @@ struct rgbdr_ctx {
   // inverse calibration
   bool inv_set[kMaxSensors] = {};
   bool inv_tiled[kMaxSensors] = {};
+  bool inv_resampled[kMaxSensors] = {};  // tiled planes hold the LUT resampled at voxel centres
   uint32_t inv_res[kMaxSensors][3] = {};
   float* d_lut_tiled = nullptr;
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
@@ -165,7 +166,7 @@ static void free_volume(rgbdr_ctx* c)
   for (int i = 0; i < kMaxSensors; ++i) {
     (void)hipFree(c->d_lut_generic[i]);
     c->d_lut_generic[i] = nullptr;
-    c->inv_set[i] = c->inv_tiled[i] = false;
+    c->inv_set[i] = c->inv_tiled[i] = c->inv_resampled[i] = false;
   }
 }
 
@@ -430,6 +431,7 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
   (void)hipFree(ctx->d_lut_generic[sensor]);
   ctx->d_lut_generic[sensor] = nullptr;
   ctx->inv_set[sensor] = false;
+  ctx->inv_resampled[sensor] = false;
   for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = inv->res[a];
   if (lut_is_one_to_one(inv->res, g.res_volume)) {
     int rc = ensure_tiled_lut(ctx);
@@ -470,6 +472,30 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->zoff[sensor] = lo;
     ctx->inv_tiled[sensor] = false;
+    // Resample the LUT at the voxel centres once, into the grid layout the tiled
+    // kernel streams (the lookup is static between frames).  Falls back to the
+    // per-frame 8-tap kernel when the flag forbids it or HBM is too small.
+    if (!(ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE)) {
+      bool other_generic = false;
+      for (int i = 0; i < nsens(ctx); ++i) other_generic = other_generic || (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i]);
+      if (!other_generic && ensure_tiled_lut(ctx) == RGBDR_OK) {
+        launch_resample_lut(ctx->d_lut_generic[sensor], X, Y, Z, lo, g.res_volume[0], g.res_volume[1], g.res_volume[2],
+                            g.tiles[0], g.tiles[1], g.slab_tile_z0, g.slab_tile_z1 - g.slab_tile_z0, sensor, nsens(ctx),
+                            ctx->d_lut_tiled, ctx->stream);
+        LAUNCHCHK("resample_lut");
+        launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                            g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                            ctx->stream);
+        LAUNCHCHK("tile_windows");
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_lut_generic[sensor]);
+        ctx->d_lut_generic[sensor] = nullptr;
+        ctx->inv_tiled[sensor] = true;
+        ctx->inv_resampled[sensor] = true;
+      } else {
+        (void)hipGetLastError();  // a failed allocation is not an error here: keep the generic copy
+      }
+    }
   }
   ctx->inv_set[sensor] = true;
   return RGBDR_OK;
@@ -938,9 +964,11 @@ int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z
   if (!ctx->inv_set[sensor]) return ctx->fail(RGBDR_ERR_STATE, "inverse calibration of this sensor is not set");
   HIPCHK(hipSetDevice(ctx->device));
   const rgbdr_geometry& g = ctx->geo;
-  const int X = (int)ctx->inv_res[sensor][0], Y = (int)ctx->inv_res[sensor][1];
+  const bool tiled = ctx->inv_tiled[sensor];
+  const int X = tiled ? g.res_volume[0] : (int)ctx->inv_res[sensor][0];
+  const int Y = tiled ? g.res_volume[1] : (int)ctx->inv_res[sensor][1];
   const size_t row = (size_t)X * Y;
-  if (ctx->inv_tiled[sensor]) {
+  if (tiled) {
     if (z0 < g.slab_voxel_z0 || z1 > g.slab_voxel_z1 || z0 >= z1)
       return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "z rows outside this context's slab");
     float4* tmp = nullptr;

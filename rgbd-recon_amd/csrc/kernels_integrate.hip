@@ -447,6 +447,45 @@ void launch_tile_lut(const float4* src, int X, int Y, int Z, int src_z0, int TX,
                      sensor, N, dst);
 }
 
+// Inverse LUT of any resolution -> grid layout: evaluates the LINEAR lookup
+// texture(cv_xyz_inv[i], position) of tsdf_integration.vs:31 once per voxel centre
+// at upload time (LUT and grid are static between frames, so the per-frame result
+// is bit-identical) and stores it in the tiled planes the 1:1 kernel streams.
+__global__ __launch_bounds__(128) void k_resample_lut(const float4* __restrict__ src, int rx, int ry, int rz, int zoff,
+                                                      int X, int Y, int Z, int TX, int TY, int tz0, int sensor, int N,
+                                                      float* __restrict__ dst)
+{
+  const unsigned tile = blockIdx.x;
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % TX, ty = (tile / TX) % TY, tzl = tile / (TX * TY);
+  const int vz = (tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx0 = tx * kTile + lx0;
+  const float stepX = 1.0f / (float)X, stepY = 1.0f / (float)Y, stepZ = 1.0f / (float)Z;
+  const float pz = ((float)vz + 0.5f) * stepZ, py = ((float)vy + 0.5f) * stepY;
+  float u[4], v[4], d[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int vx = vx0 + j;
+    u[j] = v[j] = d[j] = -1.0f;
+    if (vx >= X || vy >= Y || vz >= Z) continue;  // padding voxel of a partial tile
+    const float px = ((float)vx + 0.5f) * stepX;
+    const float3 pc = tex3d_xyz(src, rx, ry, rz, zoff, px, py, pz);
+    u[j] = pc.x;
+    v[j] = pc.y;
+    d[j] = pc.z;
+  }
+  float4* o = reinterpret_cast<float4*>(dst + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
+  o[0] = make_float4(u[0], u[1], u[2], u[3]);
+  o[kTileVoxels / 4] = make_float4(v[0], v[1], v[2], v[3]);
+  o[2 * (kTileVoxels / 4)] = make_float4(d[0], d[1], d[2], d[3]);
+}
+void launch_resample_lut(const float4* src, int rx, int ry, int rz, int zoff, int X, int Y, int Z, int TX, int TY,
+                         int tz0, int ntz, int sensor, int N, float* dst, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_resample_lut, dim3((unsigned)TX * TY * ntz), dim3(128), 0, s, src, rx, ry, rz, zoff, X, Y, Z, TX,
+                     TY, tz0, sensor, N, dst);
+}
+
 __global__ void k_untile_lut(const float* __restrict__ tiled, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
                              int sensor, int N, float4* __restrict__ dst)
 {

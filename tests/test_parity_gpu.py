@@ -90,11 +90,14 @@ def test_sensor_counts(pkg, orc, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("resample", [True, False])
 @pytest.mark.parametrize("G,inv_res", [(64, (45, 45, 45)), (64, (90, 70, 80)), (50, None), (40, (64, 64, 64))])
-def test_generic_inverse_lut_resolution(pkg, orc, G, inv_res):
+def test_generic_inverse_lut_resolution(pkg, orc, G, inv_res, resample):
     """inverse LUT at a resolution != the TSDF grid (and a non-power-of-two grid):
-    the 8-tap trilinear path"""
-    scene, ctx, inv = build(pkg, G=G, inv_res=inv_res)
+    the 8-tap trilinear lookup, either evaluated once at upload into the grid layout
+    (default) or per frame (RGBDR_FLAG_NO_RESAMPLE)"""
+    flags = 15 | (0 if resample else pkg.capi.FLAG_NO_RESAMPLE)
+    scene, ctx, inv = build(pkg, G=G, inv_res=inv_res, flags=flags)
     for bricks in (True, False):
         ctx.set_use_bricks(bricks)
         ctx.step(scene.depth, scene.color)
