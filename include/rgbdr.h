@@ -77,7 +77,7 @@ typedef struct {
   uint32_t min_voxels_per_brick; /* default 10 */
   uint32_t flags;                /* RGBDR_FLAG_* */
   int32_t compress_depth;        /* yml compress_depth: 0 = f32 metres, 1 = u8 */
-  int32_t compress_rgb;          /* yml compress_rgb: 0 = RGB8; 1 (DXT1) / 5 (DXT5) are not supported yet */
+  int32_t compress_rgb;          /* yml compress_rgb: 0 = RGB8, 1 = DXT1 (the yml default), 5 = DXT5 */
   float near_[RGBDR_MAX_SENSORS];/* yml near_far: per sensor (NetKinectArray.cpp:346-347) */
   float far_[RGBDR_MAX_SENSORS];
   int32_t res_override[3];       /* 0,0,0 = ceil(extent / voxel_size) as setVoxelSize does; otherwise the grid
@@ -169,7 +169,10 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
 /* ---- per-frame calls (order is the contract, kinect_client.cpp:572-602) -- */
 
 /* NetKinectArray::update (NetKinectArray.cpp:226-238): depth = N*H*W f32 (or u8
- * when compress_depth), color = N*Hc*Wc*3 u8; host pointers, copied. */
+ * when compress_depth); color = N*Hc*Wc*3 u8, or N frames of DXT1 (8 B per 4x4
+ * block) / DXT5 (16 B) blocks when compress_rgb is 1 / 5 -- decoded on the device
+ * to RGB8 with the arithmetic of the reference's own CPU decoder (squish,
+ * NetKinectArray.cpp:633); host pointers, copied. */
 int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color);
 /* same for buffers already resident on this context's device */
 int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth_dev, const void* color_dev);
@@ -215,6 +218,8 @@ int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst);
  * .w = 0 (never read by the shader, tsdf_integration.vs:31, dropped at upload);
  * RGBDR_FLAG_NO_RESAMPLE: texel z rows [z0, z1) of the file's volume. */
 int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst);
+/* the colour array as sampled (RGB8, decoded when the frames are DXT): Hc*Wc*3 bytes */
+int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst);
 /* SSBO binding 3 payload after the 8-uint header: one u32 counter per brick */
 int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst);
 /* m_bricks_occupied (ascending ids) and m_ratio_occupied */

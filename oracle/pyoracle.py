@@ -120,6 +120,13 @@ def rgb_to_lab(rgb):
     return out
 
 
+def decode_dxt(blocks, W, H, mode):
+    b = np.ascontiguousarray(blocks, dtype=np.uint8)
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    lib().orc_decode_dxt(_p(b), W, H, mode, _p(out))
+    return out
+
+
 def pre_depth(depth, color, cv_xyz, cv_uv, limits, bbox_min, bbox_max, filter_textures=True, compress=False,
               near=0.5, far=4.5):
     depth, cv_xyz, cv_uv = f32(depth), f32(cv_xyz), f32(cv_uv)

@@ -13,6 +13,7 @@
 
 #include <DataTypes.h>
 #include <calibration/calibration_volume.hpp>
+#include <squish.h>  // external/squish: the reference's own CPU decoder of its DXT colour frames
 
 extern "C" {
 
@@ -79,6 +80,13 @@ void ref_get_trilinear(const float* data, unsigned w, unsigned h, unsigned d, fl
   out[0] = r.x;
   out[1] = r.y;
   out[2] = r.z;
+}
+
+// squish::DecompressImage as NetKinectArray::writeCurrentTexture calls it
+// (framework/NetKinectArray.cpp:633); mode 1 = kDxt1, 5 = kDxt5; rgba out
+void ref_squish_decompress(unsigned char* rgba, int width, int height, const void* blocks, int mode)
+{
+  squish::DecompressImage(rgba, width, height, blocks, mode == 1 ? squish::kDxt1 : squish::kDxt5);
 }
 
 }  // extern "C"

@@ -293,6 +293,56 @@ ORC_API void orc_rgb_to_lab(const float* rgb, float* lab)
 }
 
 /* ------------------------------------------------------------------------- */
+/* DXT1 / DXT5 colour frames -> RGB8.  The GL driver decodes the compressed    */
+/* colour array in the reference (NetKinectArray.cpp:149-156); the reference's  */
+/* own CPU decode of the same frames is squish::DecompressImage                 */
+/* (NetKinectArray.cpp:633, external/squish/colourblock.cpp:140-214), whose     */
+/* integer arithmetic is restated here and pinned against it in oracle/_ref.    */
+/* mode 1 = DXT1 (8-B blocks), mode 5 = DXT5 (16-B blocks, colour at +8).      */
+
+static void unpack565(const uint8_t* p, uint8_t* c)
+{
+  int value = (int)p[0] | ((int)p[1] << 8);
+  uint8_t r = (uint8_t)((value >> 11) & 0x1f), g = (uint8_t)((value >> 5) & 0x3f), b = (uint8_t)(value & 0x1f);
+  c[0] = (uint8_t)((r << 3) | (r >> 2));
+  c[1] = (uint8_t)((g << 2) | (g >> 4));
+  c[2] = (uint8_t)((b << 3) | (b >> 2));
+}
+
+ORC_API void orc_decode_dxt(const uint8_t* blocks, int W, int H, int mode, uint8_t* rgb)
+{
+  const int bpb = mode == 1 ? 8 : 16;
+  const uint8_t* src = blocks;
+  for (int y = 0; y < H; y += 4) {
+    for (int x = 0; x < W; x += 4) {
+      const uint8_t* cb = src + (mode == 1 ? 0 : 8);
+      uint8_t codes[4][3];
+      unpack565(cb, codes[0]);
+      unpack565(cb + 2, codes[1]);
+      int a = (int)cb[0] | ((int)cb[1] << 8), b = (int)cb[2] | ((int)cb[3] << 8);
+      for (int i = 0; i < 3; ++i) {
+        int c = codes[0][i], d = codes[1][i];
+        if (mode == 1 && a <= b) {
+          codes[2][i] = (uint8_t)((c + d) / 2);
+          codes[3][i] = 0;
+        } else {
+          codes[2][i] = (uint8_t)((2 * c + d) / 3);
+          codes[3][i] = (uint8_t)((c + 2 * d) / 3);
+        }
+      }
+      for (int py = 0; py < 4; ++py)
+        for (int px = 0; px < 4; ++px) {
+          int sx = x + px, sy = y + py;
+          if (sx >= W || sy >= H) continue;
+          int idx = (cb[4 + py] >> (2 * px)) & 3;
+          for (int k = 0; k < 3; ++k) rgb[((size_t)sy * W + sx) * 3 + k] = codes[idx][k];
+        }
+      src += bpb;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* pre_depth.fs (a3): bilateral filter + Lab colour                           */
 
 typedef struct {

@@ -115,6 +115,7 @@ SYMBOLS = {
     "rgbdr_readback_tsdf": (C.c_int, [_P, _F]),
     "rgbdr_readback_image": (C.c_int, [_P, C.c_int, C.c_int, _F]),
     "rgbdr_readback_inverse_calibration": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _F]),
+    "rgbdr_readback_color": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint8)]),
     "rgbdr_readback_brick_counters": (C.c_int, [_P, _U32]),
     "rgbdr_get_occupied": (C.c_int, [_P, _U32, C.c_size_t, C.POINTER(C.c_size_t), _F]),
     "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
@@ -163,7 +164,8 @@ def lib():
 
 def make_config(num_sensors, depth_wh, color_wh=None, bbox_min=(-1.0, 0.0, -1.0), bbox_max=(1.0, 2.0, 1.0),
                 voxel_size=0.01, brick_size=None, tsdf_limit=0.01, min_voxels=10, flags=FLAGS_DEFAULT,
-                compress_depth=0, near=0.5, far=4.5, res_override=(0, 0, 0), slab_rank=0, slab_count=1):
+                compress_depth=0, compress_rgb=0, near=0.5, far=4.5, res_override=(0, 0, 0), slab_rank=0,
+                slab_count=1):
     c = Config()
     c.struct_size = C.sizeof(Config)
     c.num_sensors = num_sensors
@@ -177,7 +179,7 @@ def make_config(num_sensors, depth_wh, color_wh=None, bbox_min=(-1.0, 0.0, -1.0)
     c.min_voxels_per_brick = min_voxels
     c.flags = flags
     c.compress_depth = compress_depth
-    c.compress_rgb = 0
+    c.compress_rgb = compress_rgb
     for i in range(MAX_SENSORS):
         c.near_[i] = near
         c.far_[i] = far
@@ -261,7 +263,7 @@ class Context:
     # per frame
     def update(self, depth, color):
         d = np.ascontiguousarray(depth)
-        c = np.ascontiguousarray(color, dtype=np.uint8)
+        c = np.ascontiguousarray(color, dtype=np.uint8)   # RGB8 pixels or DXT blocks
         self._chk(lib().rgbdr_upload_frame(self._h, d.ctypes.data, c.ctypes.data))
 
     def update_device(self, depth_ptr, color_ptr):
@@ -350,6 +352,11 @@ class Context:
         x, y = res_xy if res_xy else (self.geo.res_volume[0], self.geo.res_volume[1])
         out = np.empty((z1 - z0, y, x, 4), dtype=np.float32)
         self._chk(lib().rgbdr_readback_inverse_calibration(self._h, sensor, z0, z1, out.ctypes.data_as(_F)))
+        return out
+
+    def readback_color(self, sensor):
+        out = np.empty((self.cfg.color_h, self.cfg.color_w, 3), dtype=np.uint8)
+        self._chk(lib().rgbdr_readback_color(self._h, sensor, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
     def readback_brick_counters(self):

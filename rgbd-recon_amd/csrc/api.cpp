@@ -54,7 +54,7 @@ struct rgbdr_ctx {
   float *d_depth_raw = nullptr, *d_depth_morph = nullptr, *d_depth_rg = nullptr, *d_lab = nullptr;
   float *d_depth_b = nullptr, *d_sil = nullptr, *d_normal = nullptr, *d_quality = nullptr;
   uint2* d_frame = nullptr;
-  uint8_t *d_color = nullptr, *d_depth_u8 = nullptr;
+  uint8_t *d_color = nullptr, *d_depth_u8 = nullptr, *d_color_dxt = nullptr;
   bool frame_uploaded = false, textures_processed = false;
 
   // forward calibration
@@ -111,6 +111,14 @@ struct rgbdr_ctx {
   } while (0)
 
 static int nsens(const rgbdr_ctx* c) { return c->cfg.num_sensors; }
+// bytes of one sensor's colour frame as the caller hands it over (NetKinectArray.cpp:120-131)
+static size_t color_frame_bytes(const rgbdr_config& c)
+{
+  const size_t blocks = (size_t)((c.color_w + 3) / 4) * ((c.color_h + 3) / 4);
+  if (c.compress_rgb == 1) return blocks * 8;
+  if (c.compress_rgb == 5) return blocks * 16;
+  return (size_t)c.color_w * c.color_h * 3;
+}
 static size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->cfg.depth_w * c->cfg.depth_h; }
 
 static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
@@ -257,7 +265,8 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
   if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1)
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must be positive");
   if (!(cfg->tsdf_limit > 0.0f)) return bad(RGBDR_ERR_INVALID_ARGUMENT, "tsdf_limit must be > 0");
-  if (cfg->compress_rgb != 0) return bad(RGBDR_ERR_INVALID_ARGUMENT, "compress_rgb (DXT) frames are not supported yet");
+  if (cfg->compress_rgb != 0 && cfg->compress_rgb != 1 && cfg->compress_rgb != 5)
+    return bad(RGBDR_ERR_INVALID_ARGUMENT, "compress_rgb must be 0 (RGB8), 1 (DXT1) or 5 (DXT5)");
   rgbdr_geometry g;
   std::string e;
   int rc = compute_geometry(*cfg, &g, &e);
@@ -308,7 +317,8 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
                 {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
                 {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol},
-                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 32}};
+                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 32},
+                {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
       ctx->err = "hipMalloc of image buffers failed";
@@ -348,7 +358,8 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   }
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   void* ptrs[] = {ctx->d_depth_raw, ctx->d_depth_morph, ctx->d_depth_rg, ctx->d_lab,   ctx->d_depth_b, ctx->d_sil,
-                  ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count};
+                  ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count,
+                  ctx->d_color_dxt};
   for (void* p : ptrs) (void)hipFree(p);
   for (int i = 0; i < kMaxSensors; ++i) {
     (void)hipFree(ctx->d_cv_xyz[i]);
@@ -588,7 +599,15 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   } else {
     HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ps));
   }
-  HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ps));
+  if (ctx->cfg.compress_rgb) {
+    const size_t layer = color_frame_bytes(ctx->cfg);
+    HIPCHK(hipMemcpyAsync(ctx->d_color_dxt, color, layer * nsens(ctx), kind, ps));
+    launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx), layer,
+                      ctx->d_color, ps);
+    LAUNCHCHK("decode_dxt");
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ps));
+  }
   ctx->frame_uploaded = true;
   return RGBDR_OK;
 }
@@ -987,6 +1006,18 @@ int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z
                           row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t img = (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3;
+  HIPCHK(hipMemcpyAsync(dst, ctx->d_color + img * sensor, img, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
 

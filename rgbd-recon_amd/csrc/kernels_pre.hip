@@ -52,6 +52,65 @@ void launch_repack_xyz(const float* src, float4* dst, size_t n, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
+// DXT1 / DXT5 colour frames -> RGB8 at upload.  The GL driver decodes the
+// compressed colour array in the reference (NetKinectArray.cpp:149-156); this
+// follows the integer arithmetic of the reference's own CPU decode of the same
+// frames, squish (NetKinectArray.cpp:633, external/squish/colourblock.cpp:140-214).
+// One thread per 4x4 block.
+__device__ __forceinline__ void unpack565(const uint8_t* p, int* c)
+{
+  const int value = (int)p[0] | ((int)p[1] << 8);
+  const int r = (value >> 11) & 0x1f, g = (value >> 5) & 0x3f, b = value & 0x1f;
+  c[0] = ((r << 3) | (r >> 2)) & 0xff;
+  c[1] = ((g << 2) | (g >> 4)) & 0xff;
+  c[2] = ((b << 3) | (b >> 2)) & 0xff;
+}
+
+__global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int H, int mode, size_t layer_bytes,
+                             uint8_t* __restrict__ rgb_all)
+{
+  const int bw = (W + 3) / 4, bh = (H + 3) / 4;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bw * bh) return;
+  const uint8_t* src = blocks_all + (size_t)blockIdx.y * layer_bytes + (size_t)b * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8);
+  uint8_t* rgb = rgb_all + (size_t)blockIdx.y * W * H * 3;
+  int codes[4][3];
+  unpack565(src, codes[0]);
+  unpack565(src + 2, codes[1]);
+  const int a = (int)src[0] | ((int)src[1] << 8), bb = (int)src[2] | ((int)src[3] << 8);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = codes[0][i], d = codes[1][i];
+    if (mode == 1 && a <= bb) {
+      codes[2][i] = (c + d) / 2;
+      codes[3][i] = 0;
+    } else {
+      codes[2][i] = (2 * c + d) / 3;
+      codes[3][i] = (c + 2 * d) / 3;
+    }
+  }
+  const int x0 = (b % bw) * 4, y0 = (b / bw) * 4;
+  for (int py = 0; py < 4; ++py) {
+    const int bits = src[4 + py];
+    for (int px = 0; px < 4; ++px) {
+      const int sx = x0 + px, sy = y0 + py;
+      if (sx >= W || sy >= H) continue;
+      const int idx = (bits >> (2 * px)) & 3;
+      uint8_t* o = rgb + ((size_t)sy * W + sx) * 3;
+      o[0] = (uint8_t)codes[idx][0];
+      o[1] = (uint8_t)codes[idx][1];
+      o[2] = (uint8_t)codes[idx][2];
+    }
+  }
+}
+void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, size_t layer_bytes, uint8_t* rgb,
+                       hipStream_t s)
+{
+  const int nb = ((W + 3) / 4) * ((H + 3) / 4);
+  hipLaunchKernelGGL(k_decode_dxt, dim3((nb + 127) / 128, N), dim3(128), 0, s, blocks, W, H, mode, layer_bytes, rgb);
+}
+
+// ---------------------------------------------------------------------------
 // pre_morph.fs mode 0 (dilate, :73-112).  The mode-1 pass of the reference is a
 // plain copy (:130-131) of this result, so one kernel produces what
 // m_textures_depth2.front holds after processDepth().

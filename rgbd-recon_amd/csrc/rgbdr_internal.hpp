@@ -82,6 +82,8 @@ struct IntegrateParams {
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
+void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, size_t layer_bytes, uint8_t* rgb,
+                       hipStream_t s);
 void launch_repack_xyz(const float* src_xyz3, float4* dst, size_t n, hipStream_t s);
 void launch_morph(const PreParams& p, const float* in, float* out, hipStream_t s);
 void launch_pre_depth(const PreParams& p, hipStream_t s);

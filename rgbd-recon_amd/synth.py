@@ -165,3 +165,47 @@ def compress_depth_u8(depth_m, near=0.5, far=4.5):
     v = np.sqrt(np.maximum((depth_m - near) / scale - 0.15 * sn, 0.0))
     out = np.where(depth_m > 0, np.clip(np.round(v * 255.0), 0, 255), 0)
     return out.astype(np.uint8)
+
+
+def encode_dxt(img, mode=1):
+    """Simple DXT1 / DXT5 encoder for test inputs (per 4x4 block: endpoints = max /
+    min colour in RGB565, nearest of the four palette entries).  Returns the block
+    stream in the layout squish / GL use (blocks row-major, 8 or 16 bytes each)."""
+    H, W = img.shape[:2]
+    bh, bw = (H + 3) // 4, (W + 3) // 4
+    pad = np.zeros((bh * 4, bw * 4, 3), np.int32)
+    pad[:H, :W] = img
+    pad[H:, :W] = pad[H - 1:H, :W]
+    pad[:, W:] = pad[:, W - 1:W]
+    blk = pad.reshape(bh, 4, bw, 4, 3).transpose(0, 2, 1, 3, 4).reshape(bh * bw, 16, 3)
+    hi, lo = blk.max(axis=1), blk.min(axis=1)
+
+    def to565(c):
+        return ((c[:, 0] >> 3) << 11) | ((c[:, 1] >> 2) << 5) | (c[:, 2] >> 3)
+
+    def from565(v):
+        r, g, b = (v >> 11) & 31, (v >> 5) & 63, v & 31
+        return np.stack([(r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2)], axis=-1)
+
+    c0, c1 = to565(hi), to565(lo)
+    swap = c0 < c1
+    c0, c1 = np.where(swap, c1, c0), np.where(swap, c0, c1)            # c0 >= c1
+    e0, e1 = from565(c0), from565(c1)
+    four = (c0 > c1) | (mode != 1)                                      # 4-colour mode
+    p2 = np.where(four[:, None], (2 * e0 + e1) // 3, (e0 + e1) // 2)
+    p3 = np.where(four[:, None], (e0 + 2 * e1) // 3, 0)
+    pal = np.stack([e0, e1, p2, p3], axis=1)                            # [nb, 4, 3]
+    dist = ((blk[:, :, None, :] - pal[:, None, :, :]) ** 2).sum(-1)    # [nb, 16, 4]
+    if mode == 1:
+        dist[:, :, 3] += np.where(four, 0, 1 << 30)[:, None]           # never pick transparent black
+    idx = dist.argmin(-1).astype(np.uint32)                            # [nb, 16]
+    bits = (idx << (2 * np.arange(16, dtype=np.uint32))[None, :]).sum(axis=1).astype(np.uint32)
+    out = np.zeros((bh * bw, 8 if mode == 1 else 16), np.uint8)
+    o = 0 if mode == 1 else 8
+    out[:, o + 0], out[:, o + 1] = c0 & 255, c0 >> 8
+    out[:, o + 2], out[:, o + 3] = c1 & 255, c1 >> 8
+    for k in range(4):
+        out[:, o + 4 + k] = (bits >> (8 * k)) & 255
+    if mode != 1:
+        out[:, 0] = out[:, 1] = 255                                      # opaque alpha block
+    return out.reshape(-1)

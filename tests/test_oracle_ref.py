@@ -76,3 +76,18 @@ def test_trilinear_matches_reference_cpu_helper(ref, orc):
         # texel coordinate t <-> normalised s = (t + 0.5) / n
         got = orc.tex3d(vol, (x + 0.5) / 8, (y + 0.5) / 7, (z + 0.5) / 6)
         np.testing.assert_allclose(got, np.array(out[:]), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("mode", [1, 5])
+@pytest.mark.parametrize("wh", [(64, 52), (61, 54), (4, 4), (7, 3)])
+def test_dxt_decode_matches_reference_squish(ref, orc, mode, wh):
+    """DXT colour frames: the oracle's decoder against squish::DecompressImage, the
+    decoder the reference itself applies to its DXT1 frames (NetKinectArray.cpp:633)"""
+    W, H = wh
+    nb = ((W + 3) // 4) * ((H + 3) // 4)
+    rng = np.random.default_rng(W * 100 + H + mode)
+    blocks = rng.integers(0, 256, nb * (8 if mode == 1 else 16), dtype=np.uint8)
+    got = orc.decode_dxt(blocks, W, H, mode)
+    rgba = np.zeros((H, W, 4), np.uint8)
+    ref.ref_squish_decompress(rgba.ctypes.data_as(C.c_void_p), W, H, blocks.ctypes.data_as(C.c_void_p), mode)
+    assert np.array_equal(got, rgba[..., :3])

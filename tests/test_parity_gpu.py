@@ -448,3 +448,31 @@ def test_pipelined_mode_is_schedule_only(pkg):
     ctx.step(frames[2], scene.color)
     assert same_bits(ctx.readback_tsdf(), want[2])
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [1, 5])
+def test_dxt_compressed_colour_frames(pkg, orc, mode):
+    """compress_rgb 1 (DXT1, the reference's yml default) and 5 (DXT5): frames are
+    decoded on the device exactly as the reference's CPU decoder (squish) does"""
+    capi, synth = pkg.capi, pkg.synth
+    scene, ctx, inv = build(pkg, compress_rgb=mode)
+    W, H = 128, 106
+    blocks = np.stack([synth.encode_dxt(scene.color[i], mode) for i in range(2)])
+    rng = np.random.default_rng(9)
+    blocks[1, : blocks.shape[1] // 4] = rng.integers(0, 256, blocks.shape[1] // 4, dtype=np.uint8)   # arbitrary blocks too
+    ctx.step(scene.depth, blocks)
+    decoded = np.stack([orc.decode_dxt(blocks[i], W, H, mode) for i in range(2)])
+    for i in range(2):
+        assert np.array_equal(ctx.readback_color(i), decoded[i])
+    assert np.mean(np.abs(decoded[0].astype(int) - scene.color[0].astype(int))) < 6      # the encoder is sane
+
+    class Decoded:
+        pass
+
+    s2 = Decoded()
+    s2.__dict__.update(scene.__dict__)
+    s2.color = decoded
+    ref = oracle_run(orc, s2, ctx, inv)
+    check_images(ctx, ref, 2)
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    ctx.close()
