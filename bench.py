@@ -226,6 +226,20 @@ def main():
         dist.destroy_process_group()
 
 
+def available_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU
+    quota (the GPU box reports 256 logical CPUs but grants 16 CPUs of time; running
+    256 OpenMP threads there is 20x slower than 16-32)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
     """Times the CPU oracle ("port") on this box's host cores: the whole pre_*
     chain for the frame set, plus integrate() on a slab of `rows` z rows of the
@@ -233,7 +247,7 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
     whole grid.  The slab result is also compared with the HIP TSDF (parity at
     the benchmark's full size)."""
     orc = load_oracle()
-    cores = os.cpu_count() or 1
+    cores = available_cpus()
     threads = orc.set_threads(cores)
     g = ctx.geo
     ctx.set_use_bricks(False)
@@ -258,7 +272,7 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
     t_pre = time.perf_counter() - t0
     t_full = t_pre + t_int * (G / rows)
     return {"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
-            "sample": "oracle (OpenMP, %d threads): full pre_* chain of the %d-sensor frame (%.2f s) + integrate of %d of %d "
+            "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota): full pre_* chain of the %d-sensor frame (%.2f s) + integrate of %d of %d "
                       "z rows of the same volume (median of 3: %.2f s), extrapolated to the grid"
                       % (threads, N, t_pre, rows, G, t_int),
             "integrate_mvoxels_per_s": round(G * G * rows / t_int / 1e6, 2),
