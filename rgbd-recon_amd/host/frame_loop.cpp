@@ -7,6 +7,11 @@
 //   frame_loop <dir> <num_sensors> <W> <H> <G> <out.tsdf>
 // expects <dir>/s<i>.yml names (only used to derive s<i>.cv_xyz / .cv_uv),
 // <dir>/s<i>.cv_xyz_inv and <dir>/recordings/s<i>.stream.
+//   frame_loop --ks <scene.ks> <voxel_size> <out.tsdf>
+// reads the scene the way kinect_client does: `.ks` (kinect / bbx lines), the sensor
+// ymls (sizes, near_far, compress_rgb / compress_depth), <yml base>.cv_xyz / .cv_uv,
+// <ks dir>/<base>.cv_xyz_inv and recordings/<base>.stream relative to the working
+// directory (NetKinectArray.cpp:727-731).
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -16,8 +21,46 @@
 
 using namespace rgbdr::host;
 
+static int run_ks(const char* ks_path, float voxel, const char* out_path)
+{
+  KsFile ks = parseKs(ks_path);
+  CalibrationFiles cf = parseCalibrationFiles(ks.calib_filenames);
+  Backend be(cf, ks.bbox, 0.01f, voxel, 0.1f);
+  CalibVolumes cv(be, cf.filenames);
+  cv.loadInverseCalibs(ks.resource_path);
+  NetKinectArray nka(be);
+  ReconIntegration recon(be);
+  std::vector<std::string> streams;
+  for (auto const& yml : cf.filenames) {
+    std::string base = yml.substr(yml.find_last_of("/\\") + 1);
+    base = base.substr(0, base.size() - 4);
+    streams.push_back("recordings/" + base + ".stream");
+  }
+  nka.readFromFiles(streams, colorFrameBytes(cf), depthFrameBytes(cf), 0);
+  process_textures(nka, recon);
+  recon.integrate();
+  rgbdr_geometry g;
+  std::vector<float> tsdf = recon.readbackTsdf(&g);
+  FILE* f = std::fopen(out_path, "wb");
+  if (!f) return 3;
+  std::fwrite(tsdf.data(), sizeof(float), tsdf.size(), f);
+  std::fclose(f);
+  std::printf("sensors %u depth %ux%u color %ux%u compress_rgb %d compress_depth %d res %d %d %d bricks %u occupied %.4f\n",
+              cf.num(), cf.width, cf.height, cf.widthC, cf.heightC, cf.compressedRGB, (int)cf.compressedDepth,
+              g.res_volume[0], g.res_volume[1], g.res_volume[2], recon.numBricks(), recon.occupiedRatio());
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
+  if (argc == 5 && std::string(argv[1]) == "--ks") {
+    try {
+      return run_ks(argv[2], (float)std::atof(argv[3]), argv[4]);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "frame_loop: %s\n", e.what());
+      return 1;
+    }
+  }
   if (argc != 7) {
     std::fprintf(stderr, "usage: %s <dir> <num_sensors> <W> <H> <G> <out.tsdf>\n", argv[0]);
     return 2;

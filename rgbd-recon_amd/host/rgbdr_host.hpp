@@ -17,6 +17,8 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -35,13 +37,13 @@ struct BoundingBox {
 };
 
 // The scalars kinect::CalibrationFiles exposes to the hot path
-// (framework/calibration/calibration_files.hpp:11-44); parsing the sensor .yml
-// files stays with the application.
+// (framework/calibration/calibration_files.hpp:11-44); parseCalibrationFiles()
+// below fills it from the sensor .yml files.
 struct CalibrationFiles {
   std::vector<std::string> filenames;  // per-sensor yml paths ("kinect <yml>" lines of the .ks file)
   unsigned width = 512, height = 424, widthC = 512, heightC = 424;
   bool compressedDepth = false;
-  int compressedRGB = 0;  // the reference's yml default is 1 (DXT1): not supported by this backend yet
+  int compressedRGB = 0;  // 0 RGB8, 1 DXT1 (the reference's yml default), 5 DXT5
   std::vector<float> near_, far_;
   unsigned num() const { return (unsigned)filenames.size(); }
   unsigned getWidth() const { return width; }
@@ -51,6 +53,124 @@ struct CalibrationFiles {
   bool isCompressedDepth() const { return compressedDepth; }
   int isCompressedRGB() const { return compressedRGB; }
 };
+
+// --- scene / sensor description files -------------------------
+
+// The `.ks` scene file as source/kinect_client.cpp:194-238 reads it: whitespace
+// tokens, `kinect <yml>` (relative to the .ks directory unless absolute) and
+// `bbx x0 y0 z0 x1 y1 z1`; everything else is ignored.
+struct KsFile {
+  std::vector<std::string> calib_filenames;
+  BoundingBox bbox;
+  std::string resource_path;  // directory of the .ks file, with trailing '/'
+};
+
+inline KsFile parseKs(std::string const& file_name)
+{
+  const std::string ext = file_name.substr(file_name.find_last_of(".") + 1);
+  if (ext != "ks") throw std::invalid_argument{"No .ks file specified"};
+  KsFile ks;
+  const size_t slash = file_name.find_last_of("/\\");
+  ks.resource_path = (slash == std::string::npos ? std::string(".") : file_name.substr(0, slash)) + '/';
+  std::ifstream in(file_name);
+  if (!in) throw std::invalid_argument{"cannot open " + file_name};
+  std::string token;
+  while (in >> token) {
+    if (token == "kinect") {
+      in >> token;
+      if (token[0] == '/' || (token.size() > 1 && token[1] == ':'))
+        ks.calib_filenames.push_back(token);
+      else
+        ks.calib_filenames.push_back(ks.resource_path + token);
+    } else if (token == "bbx") {
+      in >> ks.bbox.pmin[0] >> ks.bbox.pmin[1] >> ks.bbox.pmin[2] >> ks.bbox.pmax[0] >> ks.bbox.pmax[1] >> ks.bbox.pmax[2];
+    }
+  }
+  return ks;
+}
+
+// The sensor `.yml` token scanner of KinectCalibrationFile::parse
+// (framework/calibration/KinectCalibrationFile.cpp:166-353): a key token, then a
+// stand-alone "[" token, then values of which all but the last carry a trailing
+// comma.  Only the keys the hot path needs are read; defaults as in the
+// reference (:88-95): near 0.3, far 7.0, compress_rgb 1 (DXT1), compress_depth 0.
+inline CalibrationFiles parseCalibrationFiles(std::vector<std::string> const& calib_filenames)
+{
+  if (calib_filenames.empty()) throw std::invalid_argument{"no calibration files"};
+  CalibrationFiles cf;
+  cf.filenames = calib_filenames;
+  auto advance = [](std::ifstream& f, const char* what) {
+    std::string t;
+    while (f >> t)
+      if (t == what) return;
+  };
+  auto komma = [](std::ifstream& f) {  // getNextTokenAsFloat: drop the trailing comma
+    std::string t;
+    f >> t;
+    return (float)std::atof(t.substr(0, t.empty() ? 0 : t.size() - 1).c_str());
+  };
+  auto plain = [](std::ifstream& f) {  // getNextFloat
+    std::string t;
+    f >> t;
+    return (float)std::atof(t.c_str());
+  };
+  for (size_t i = 0; i < calib_filenames.size(); ++i) {
+    std::ifstream f(calib_filenames[i]);
+    if (!f) throw std::invalid_argument{"cannot open " + calib_filenames[i]};
+    float near_ = 0.3f, far_ = 7.0f;
+    unsigned w = 0, h = 0, wc = 0, hc = 0;
+    int crgb = 1;
+    bool cdepth = false;
+    std::string token;
+    while (f >> token) {
+      if (token == "rgb_size:") {
+        advance(f, "[");
+        wc = (unsigned)komma(f);
+        hc = (unsigned)plain(f);
+      } else if (token == "depth_size:") {
+        advance(f, "[");
+        w = (unsigned)komma(f);
+        h = (unsigned)plain(f);
+      } else if (token == "near_far:") {
+        advance(f, "[");
+        near_ = komma(f);
+        far_ = plain(f);
+      } else if (token == "compress_rgb:") {
+        advance(f, "[");
+        crgb = (int)(unsigned)komma(f);
+        plain(f);
+      } else if (token == "compress_depth:") {
+        advance(f, "[");
+        cdepth = (bool)((unsigned)komma(f));
+        plain(f);
+      }
+    }
+    cf.near_.push_back(near_);
+    cf.far_.push_back(far_);
+    if (i == 0) {  // element [0] decides sizes and compression of all sensors (calibration_files.cpp:26-33)
+      cf.width = w;
+      cf.height = h;
+      cf.widthC = wc;
+      cf.heightC = hc;
+      cf.compressedRGB = crgb;
+      cf.compressedDepth = cdepth;
+    }
+  }
+  return cf;
+}
+
+// frame sizes of NetKinectArray::init (NetKinectArray.cpp:120-144)
+inline size_t colorFrameBytes(CalibrationFiles const& cf)
+{
+  const size_t blocks = (size_t)((cf.widthC + 3) / 4) * ((cf.heightC + 3) / 4);
+  if (cf.compressedRGB == 1) return blocks * 8;
+  if (cf.compressedRGB == 5) return blocks * 16;
+  return (size_t)cf.widthC * cf.heightC * 3;
+}
+inline size_t depthFrameBytes(CalibrationFiles const& cf)
+{
+  return (size_t)cf.width * cf.height * (cf.compressedDepth ? 1 : 4);
+}
 
 inline void check(rgbdr_ctx* ctx, int rc)
 {

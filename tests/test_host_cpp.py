@@ -47,3 +47,54 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+
+
+@pytest.mark.gpu
+def test_frame_loop_from_ks_scene_with_reference_defaults(pkg, orc, tmp_path):
+    """`.ks` + sensor `.yml` + LUT files + `.stream` recordings exactly as the
+    reference lays them out, at its default operating point (voxel 0.01, brick 0.1,
+    bbox up to y = 2.2, DXT1 colour, inverse LUT finer than the grid)"""
+    synth = pkg.synth
+    n, W, H = 2, 64, 52
+    scene = synth.Scene(n, W, H, lut_res=(16, 13, 16), seed=55)
+    bmin, bmax = (-1.0, 0.0, -1.0), (1.0, 2.2, 1.0)
+    inv_res = (90, 99, 90)
+    inv = [synth.inverse_lut(s, inv_res, bmin, bmax) for s in scene.sensors]
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "calib"))
+    os.makedirs(os.path.join(d, "recordings"))
+    blocks = [synth.encode_dxt(scene.color[i], 1) for i in range(n)]
+    with open(os.path.join(d, "scene.ks"), "w") as f:
+        f.write("serverport 127.0.0.1:7000\n")
+        for i in range(n):
+            f.write("kinect calib/k%d.yml\n" % i)
+        f.write("bbx -1.0 0.0 -1.0 1.0 2.2 1.0\n")
+    for i in range(n):
+        with open(os.path.join(d, "calib", "k%d.yml" % i), "w") as f:
+            f.write("%%YAML:1.0\nrgb_size: [ %d, %d ]\ndepth_size: [ %d, %d ]\nnear_far: [ 0.5, 4.5 ]\n" % (W, H, W, H))
+            if i == 0:
+                f.write("compress_rgb: [ 1, 0 ]\ncompress_depth: [ 0, 0 ]\n")
+        assert orc.lut_write(os.path.join(d, "calib", "k%d.cv_xyz" % i), scene.xyz[i], 3) == 0
+        assert orc.lut_write(os.path.join(d, "calib", "k%d.cv_uv" % i), scene.uv[i], 2) == 0
+        assert orc.lut_write(os.path.join(d, "k%d.cv_xyz_inv" % i), inv[i], 4) == 0
+        with open(os.path.join(d, "recordings", "k%d.stream" % i), "wb") as f:
+            f.write(blocks[i].tobytes())
+            f.write(scene.depth[i].tobytes())
+    out = os.path.join(d, "out.tsdf")
+    r = subprocess.run([EXE, "--ks", os.path.join(d, "scene.ks"), "0.01", out], capture_output=True, text=True, cwd=d)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("sensors 2 depth 64x52 color 64x52 compress_rgb 1 compress_depth 0 res 200 221 200")
+    got = np.fromfile(out, dtype=np.float32).reshape(200, 221, 200)
+    cfg = pkg.capi.make_config(n, (W, H), bbox_min=bmin, bbox_max=bmax, voxel_size=0.01, brick_size=0.1)
+    g = pkg.capi.compute_geometry(cfg)
+
+    class Decoded:
+        pass
+
+    s2 = Decoded()
+    s2.__dict__.update(scene.__dict__)
+    s2.color = np.stack([orc.decode_dxt(blocks[i], W, H, 1) for i in range(n)])
+    ref = orc.run_pipeline(s2, bmin, bmax, (200, 221, 200), inv, brick_size=g.brick_size, bv=g.brick_voxels,
+                           res_bricks=tuple(g.res_bricks))
+    assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+    assert np.sum(np.abs(got) < 0.01) > 1000
