@@ -163,6 +163,20 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* c
  * any path may be NULL to skip it. */
 int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv_xyz,
                                  const char* path_cv_uv, const char* path_cv_xyz_inv);
+/* CalibrationInverter::calculateInverseVolumes (framework/calibration/
+ * calibration_inverter.cpp:99-155, the offline CGAL tool source/calib_inverter.cpp)
+ * on the device, from the cv_xyz volume set_calibration uploaded: frustum reject ->
+ * (-1,-1,-1,-1), else the inverse-distance-weighted index of the 8 nearest cv_xyz
+ * samples, (index + 0.5) / dims, 1.  The k-d tree search is replaced by a local
+ * search on the warped sample grid with a (2*window+1)^3 candidate window
+ * (window <= 0 selects the default 2).
+ *   compute_inverse_calibration: directly at this context's grid resolution into the
+ *     resident grid layout (what `calib_inverter` + loadInverseCalibs would produce
+ *     for a LUT at 1:1);
+ *   generate_inverse_lut: a volume of any resolution as x-fastest RGBA32F records in
+ *     host memory, ready to be written as a `.cv_xyz_inv` file. */
+int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window);
+int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3], int window, float* dst);
 /* benchmark support: fill sensor's inverse LUT on the device at 1:1 TSDF resolution */
 int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam);
 

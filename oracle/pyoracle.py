@@ -223,6 +223,25 @@ def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, b
     return out
 
 
+def frustum_planes(cv_xyz):
+    cv_xyz = f32(cv_xyz)
+    res = (C.c_int * 3)(cv_xyz.shape[2], cv_xyz.shape[1], cv_xyz.shape[0])
+    out = np.zeros((6, 4), dtype=np.float32)
+    lib().orc_frustum_planes(_p(cv_xyz), res, _p(out))
+    return out
+
+
+def inverse_volume(cv_xyz, bbox_min, bbox_max, vol_res, z_range=None):
+    """CalibrationInverter::calculateInverseVolumes for one sensor: [Z,Y,X,4]"""
+    cv_xyz = f32(cv_xyz)
+    res = (C.c_int * 3)(cv_xyz.shape[2], cv_xyz.shape[1], cv_xyz.shape[0])
+    vr = (C.c_int * 3)(*vol_res)
+    z0, z1 = (0, vol_res[2]) if z_range is None else z_range
+    out = np.empty((z1 - z0, vol_res[1], vol_res[0], 4), dtype=np.float32)
+    lib().orc_inverse_volume(_p(cv_xyz), res, _p(f32(bbox_min)), _p(f32(bbox_max)), vr, z0, z1, _p(out))
+    return out
+
+
 def volume_res(bbox_min, bbox_max, voxel):
     res = (C.c_int * 3)()
     lib().orc_volume_res(_p(f32(bbox_min)), _p(f32(bbox_max)), voxel, res)

@@ -739,6 +739,129 @@ ORC_API void orc_camera_pos(const float* cv_xyz, const int* res, float* out)
 }
 
 /* ------------------------------------------------------------------------- */
+/* Frustum planes + inside test (framework/calibration/frustum.cpp:36-43,      */
+/* :113-177) and the offline inverter CalibrationInverter::calculateInverse-    */
+/* Volumes (framework/calibration/calibration_inverter.cpp:55-69, :99-155).     */
+/* The reference finds the 8 nearest cv_xyz samples with a CGAL k-d tree (not    */
+/* available here, version unpinned: "parity unpinned"); this restatement does   */
+/* an exact brute-force search, orders the neighbours by ascending squared       */
+/* distance (ties: lower sample index in getXyzSamples order, x outer / z inner) */
+/* and accumulates the inverse-distance weights in that order.                   */
+
+static void corner_points(const float* cv_xyz, const int* res, float c[8][3])
+{
+  const int ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;
+  const int cx[8] = {0, 0, ex, ex, 0, 0, ex, ex};
+  const int cy[8] = {0, ey, ey, 0, 0, ey, ey, 0};
+  const int cz[8] = {0, 0, 0, 0, ez, ez, ez, ez};
+  for (int i = 0; i < 8; ++i)
+    for (int k = 0; k < 3; ++k) c[i][k] = cv_xyz[(((size_t)cz[i] * res[1] + cy[i]) * res[0] + cx[i]) * 3 + k];
+}
+
+ORC_API void orc_frustum_planes(const float* cv_xyz, const int* res, float* planes /* 6 x 4 */)
+{
+  float c[8][3], e[12][3], sc[6][3], n[6][3];
+  corner_points(cv_xyz, res, c);
+  const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+  for (int i = 0; i < 12; ++i)
+    for (int k = 0; k < 3; ++k) e[i][k] = (c[ea[i]][k] + c[eb[i]][k]) * 0.5f;
+  /* getSideCenters: near, far, left, right, top, bottom */
+  const int sq[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 4, 5}, {2, 3, 6, 7}, {1, 2, 5, 6}, {0, 3, 4, 7}};
+  for (int i = 0; i < 6; ++i)
+    for (int k = 0; k < 3; ++k) sc[i][k] = (c[sq[i][0]][k] + c[sq[i][1]][k] + c[sq[i][2]][k] + c[sq[i][3]][k]) / 4.0f;
+  /* getSideNormals: cross(e[a]-e[b], e[c]-e[d]) normalised */
+  const int nq[6][4] = {{0, 2, 3, 2}, {4, 6, 5, 7}, {0, 4, 9, 8}, {2, 6, 11, 10}, {9, 10, 1, 5}, {8, 11, 7, 3}};
+  for (int i = 0; i < 6; ++i) {
+    float a[3], b[3], x[3];
+    for (int k = 0; k < 3; ++k) {
+      a[k] = e[nq[i][0]][k] - e[nq[i][1]][k];
+      b[k] = e[nq[i][2]][k] - e[nq[i][3]][k];
+    }
+    cross3(a, b, x);
+    normalize3(x, n[i]);
+    planes[4 * i + 0] = n[i][0];
+    planes[4 * i + 1] = n[i][1];
+    planes[4 * i + 2] = n[i][2];
+    planes[4 * i + 3] = -dot3(n[i], sc[i]);
+  }
+}
+
+static inline int frustum_inside(const float* planes, const float* p)
+{
+  for (int i = 0; i < 6; ++i) {
+    /* glm::dot(vec4, vec4): (x*x + y*y) + (z*z + w*w) */
+    const float d = (planes[4 * i] * p[0] + planes[4 * i + 1] * p[1]) + (planes[4 * i + 2] * p[2] + planes[4 * i + 3] * 1.0f);
+    if (d < 0.0f) return 0;
+  }
+  return 1;
+}
+
+ORC_API int orc_frustum_inside(const float* planes, const float* p) { return frustum_inside(planes, p); }
+
+ORC_API void orc_inverse_volume(const float* cv_xyz, const int* res, const float* bbox_min, const float* bbox_max,
+                                const int* vol_res, int z0, int z1, float* out /* RGBA, rows [z0,z1) */)
+{
+  float planes[24];
+  orc_frustum_planes(cv_xyz, res, planes);
+  const int rx = res[0], ry = res[1], rz = res[2];
+  float step[3], start[3];
+  for (int a = 0; a < 3; ++a) {
+    const float vstep = 1.0f / (float)vol_res[a];
+    step[a] = (bbox_max[a] - bbox_min[a]) * vstep;
+    start[a] = bbox_min[a] + step[a] * 0.5f;
+  }
+#pragma omp parallel for collapse(2) schedule(dynamic, 8)
+  for (int z = z0; z < z1; ++z) {
+    for (int y = 0; y < vol_res[1]; ++y) {
+      for (int x = 0; x < vol_res[0]; ++x) {
+        float* o = out + (((size_t)(z - z0) * vol_res[1] + y) * vol_res[0] + x) * 4;
+        const float p[3] = {start[0] + (float)x * step[0], start[1] + (float)y * step[1], start[2] + (float)z * step[2]};
+        if (!frustum_inside(planes, p)) {
+          o[0] = o[1] = o[2] = o[3] = -1.0f;
+          continue;
+        }
+        float bd[8];
+        int bi[8], bxyz[8][3], n = 0;
+        for (int sx = 0; sx < rx; ++sx)
+          for (int sy = 0; sy < ry; ++sy)
+            for (int sz = 0; sz < rz; ++sz) {
+              const float* sp = cv_xyz + (((size_t)sz * ry + sy) * rx + sx) * 3;
+              const float d[3] = {p[0] - sp[0], p[1] - sp[1], p[2] - sp[2]};
+              const float d2 = dot3(d, d);
+              const int lin = (sx * ry + sy) * rz + sz;
+              if (n == 8 && !(d2 < bd[7] || (d2 == bd[7] && lin < bi[7]))) continue;
+              int k = n < 8 ? n : 7;
+              while (k > 0 && (d2 < bd[k - 1] || (d2 == bd[k - 1] && lin < bi[k - 1]))) {
+                bd[k] = bd[k - 1];
+                bi[k] = bi[k - 1];
+                memcpy(bxyz[k], bxyz[k - 1], sizeof(bxyz[0]));
+                --k;
+              }
+              bd[k] = d2;
+              bi[k] = lin;
+              bxyz[k][0] = sx;
+              bxyz[k][1] = sy;
+              bxyz[k][2] = sz;
+              if (n < 8) ++n;
+            }
+        float tw = 0.0f, wi[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < n; ++k) {
+          const float w = 1.0f / sqrtf(bd[k]);
+          wi[0] += w * (float)bxyz[k][0];
+          wi[1] += w * (float)bxyz[k][1];
+          wi[2] += w * (float)bxyz[k][2];
+          tw += w;
+        }
+        o[0] = (wi[0] / tw + 0.5f) / (float)rx;
+        o[1] = (wi[1] / tw + 0.5f) / (float)ry;
+        o[2] = (wi[2] / tw + 0.5f) / (float)rz;
+        o[3] = 1.0f;
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Grid geometry (a8): setVoxelSize / setBrickSize / divideBox                */
 /* framework/reconstruction/recon_integration.cpp:341-354, :474-484, :361-388 */
 

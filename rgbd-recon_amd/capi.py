@@ -90,6 +90,8 @@ SYMBOLS = {
     "rgbdr_set_inverse_calibration": (C.c_int, [_P, C.c_int, _LUT]),
     "rgbdr_load_calibration_files": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]),
     "rgbdr_synth_inverse_calibration": (C.c_int, [_P, C.c_int, C.POINTER(Pinhole)]),
+    "rgbdr_compute_inverse_calibration": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rgbdr_generate_inverse_lut": (C.c_int, [_P, C.c_int, _U32, C.c_int, _F]),
     "rgbdr_upload_frame": (C.c_int, [_P, _P, _P]),
     "rgbdr_upload_frame_device": (C.c_int, [_P, _P, _P]),
     "rgbdr_clear_occupied_bricks": (C.c_int, [_P]),
@@ -251,6 +253,15 @@ class Context:
     def load_calibration_files(self, sensor, xyz=None, uv=None, inv=None):
         enc = lambda s: s.encode() if s else None
         self._chk(lib().rgbdr_load_calibration_files(self._h, sensor, enc(xyz), enc(uv), enc(inv)))
+
+    def compute_inverse_calibration(self, sensor, window=0):
+        self._chk(lib().rgbdr_compute_inverse_calibration(self._h, sensor, window))
+
+    def generate_inverse_lut(self, sensor, res, window=0):
+        out = np.empty((res[2], res[1], res[0], 4), dtype=np.float32)
+        r = (C.c_uint32 * 3)(*res)
+        self._chk(lib().rgbdr_generate_inverse_lut(self._h, sensor, r, window, out.ctypes.data_as(_F)))
+        return out
 
     def synth_inverse_calibration(self, sensor, pinhole):
         self._chk(lib().rgbdr_synth_inverse_calibration(self._h, sensor, C.byref(pinhole)))

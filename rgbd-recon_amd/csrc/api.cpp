@@ -63,6 +63,7 @@ struct rgbdr_ctx {
   uint32_t xyz_res[kMaxSensors][3] = {}, uv_res[kMaxSensors][3] = {};
   float min_ds[kMaxSensors] = {}, max_ds[kMaxSensors] = {};
   float cam_pos[kMaxSensors][3] = {};
+  float planes[kMaxSensors][6][4] = {};  // Frustum::getPlanes of cv_xyz
   bool have_calib[kMaxSensors] = {};
 
   // inverse calibration
@@ -412,6 +413,7 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, cons
   ctx->min_ds[sensor] = xyz->depth_limits[0];
   ctx->max_ds[sensor] = xyz->depth_limits[1];
   camera_position((const float*)xyz->data, xyz->res, ctx->cam_pos[sensor]);
+  frustum_planes((const float*)xyz->data, xyz->res, ctx->planes[sensor]);
   ctx->have_calib[sensor] = true;
   return RGBDR_OK;
 }
@@ -580,6 +582,92 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
   ctx->d_lut_generic[sensor] = nullptr;
   ctx->inv_tiled[sensor] = true;
   ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+// CalibrationInverter::calculateInverseVolumes on the device (kernels_invert.hip)
+static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res[3], int window, InvertParams* p)
+{
+  *p = InvertParams{};
+  p->xyz = ctx->d_cv_xyz[sensor];
+  p->rx = (int)ctx->xyz_res[sensor][0];
+  p->ry = (int)ctx->xyz_res[sensor][1];
+  p->rz = (int)ctx->xyz_res[sensor][2];
+  std::memcpy(p->planes, ctx->planes[sensor], sizeof(p->planes));
+  for (int a = 0; a < 3; ++a) {
+    const float vstep = 1.0f / (float)vol_res[a];
+    p->step[a] = (ctx->cfg.bbox_max[a] - ctx->cfg.bbox_min[a]) * vstep;
+    p->start[a] = ctx->cfg.bbox_min[a] + p->step[a] * 0.5f;
+  }
+  p->X = vol_res[0];
+  p->Y = vol_res[1];
+  p->TX = (vol_res[0] + kTile - 1) / kTile;
+  p->TY = (vol_res[1] + kTile - 1) / kTile;
+  p->window = window < 1 ? 2 : window;
+  p->sensor = sensor;
+  p->N = ctx->cfg.num_sensors;
+}
+
+int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "compute_inverse_calibration before set_calibration");
+  if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int i = 0; i < nsens(ctx); ++i)
+    if (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i])
+      return ctx->fail(RGBDR_ERR_STATE, "other sensors hold file-layout inverse LUTs (RGBDR_FLAG_NO_RESAMPLE)");
+  int rc = ensure_tiled_lut(ctx);
+  if (rc != RGBDR_OK) return rc;
+  const rgbdr_geometry& g = ctx->geo;
+  InvertParams p;
+  fill_invert_params(ctx, sensor, g.res_volume, window, &p);
+  p.z0 = g.slab_voxel_z0;
+  p.nz = g.slab_voxel_z1 - g.slab_voxel_z0;
+  p.out_tiled = ctx->d_lut_tiled;
+  launch_invert_lut(p, ctx->stream);
+  LAUNCHCHK("invert_lut");
+  launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                      g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                      ctx->stream);
+  LAUNCHCHK("tile_windows");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = (uint32_t)g.res_volume[a];
+  ctx->inv_tiled[sensor] = true;
+  ctx->inv_resampled[sensor] = false;
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3], int window, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!res || !dst || res[0] < 1 || res[1] < 1 || res[2] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad resolution / destination");
+  if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "generate_inverse_lut before set_calibration");
+  if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int32_t vr[3] = {(int32_t)res[0], (int32_t)res[1], (int32_t)res[2]};
+  InvertParams p;
+  fill_invert_params(ctx, sensor, vr, window, &p);
+  const size_t row = (size_t)res[0] * res[1];
+  const int chunk = 64;
+  float4* tmp = nullptr;
+  HIPCHK(hipMalloc((void**)&tmp, row * chunk * sizeof(float4)));
+  for (int z = 0; z < (int)res[2]; z += chunk) {
+    p.z0 = z;
+    p.nz = z + chunk <= (int)res[2] ? chunk : (int)res[2] - z;
+    p.out_linear = tmp;
+    launch_invert_lut(p, ctx->stream);
+    LAUNCHCHK("invert_lut");
+    HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  HIPCHK(hipFree(tmp));
   return RGBDR_OK;
 }
 

@@ -119,6 +119,38 @@ void camera_position(const float* xyz, const uint32_t res[3], float out[3])
   for (int k = 0; k < 3; ++k) out[k] = (pt[0][k] + pt[1][k] + pt[2][k] + pt[3][k]) / 4.0f;
 }
 
+void frustum_planes(const float* xyz, const uint32_t res[3], float planes[6][4])
+{
+  const uint32_t ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;
+  const uint32_t cx[8] = {0, 0, ex, ex, 0, 0, ex, ex};
+  const uint32_t cy[8] = {0, ey, ey, 0, 0, ey, ey, 0};
+  const uint32_t cz[8] = {0, 0, 0, 0, ez, ez, ez, ez};
+  float c[8][3], e[12][3];
+  for (int i = 0; i < 8; ++i)
+    std::memcpy(c[i], xyz + (((size_t)cz[i] * res[1] + cy[i]) * res[0] + cx[i]) * 3, 12);
+  // edge centres, side centres and side normals in the reference's numbering
+  static const int ea[12] = {0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3}, eb[12] = {1, 2, 3, 0, 5, 6, 7, 4, 4, 5, 6, 7};
+  for (int i = 0; i < 12; ++i)
+    for (int k = 0; k < 3; ++k) e[i][k] = (c[ea[i]][k] + c[eb[i]][k]) * 0.5f;
+  static const int side[6][4] = {{0, 1, 2, 3}, {4, 5, 6, 7}, {0, 1, 4, 5}, {2, 3, 6, 7}, {1, 2, 5, 6}, {0, 3, 4, 7}};
+  static const int nrm[6][4] = {{0, 2, 3, 2}, {4, 6, 5, 7}, {0, 4, 9, 8}, {2, 6, 11, 10}, {9, 10, 1, 5}, {8, 11, 7, 3}};
+  for (int i = 0; i < 6; ++i) {
+    float centre[3], a[3], b[3];
+    for (int k = 0; k < 3; ++k) {
+      centre[k] = (c[side[i][0]][k] + c[side[i][1]][k] + c[side[i][2]][k] + c[side[i][3]][k]) / 4.0f;
+      a[k] = e[nrm[i][0]][k] - e[nrm[i][1]][k];
+      b[k] = e[nrm[i][2]][k] - e[nrm[i][3]][k];
+    }
+    const float x[3] = {a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]};
+    const float len = std::sqrt(dot3(x, x));
+    const float n[3] = {x[0] / len, x[1] / len, x[2] / len};
+    planes[i][0] = n[0];
+    planes[i][1] = n[1];
+    planes[i][2] = n[2];
+    planes[i][3] = -dot3(n, centre);
+  }
+}
+
 bool lut_is_one_to_one(const uint32_t lut_res[3], const int32_t vol_res[3])
 {
   for (int a = 0; a < 3; ++a) {

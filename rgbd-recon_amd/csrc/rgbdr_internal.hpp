@@ -18,6 +18,8 @@ constexpr int kMaxSensors = RGBDR_MAX_SENSORS;
 int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err);
 int slab_range(int tiles_z, int count, int rank, int* t0, int* t1);
 void camera_position(const float* cv_xyz, const uint32_t res[3], float out[3]);
+// Frustum::getPlanes of the 8 corner samples of cv_xyz (frustum.cpp:113-177)
+void frustum_planes(const float* cv_xyz, const uint32_t res[3], float planes[6][4]);
 // true when an inverse LUT of resolution `lut_res` maps every voxel centre of a
 // `vol_res` grid onto exactly one texel with zero interpolation weights
 bool lut_is_one_to_one(const uint32_t lut_res[3], const int32_t vol_res[3]);
@@ -79,7 +81,22 @@ struct IntegrateParams {
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
 };
 
+struct InvertParams {
+  const float4* xyz;       // forward LUT, 16-B records, x fastest
+  int rx, ry, rz;
+  float planes[6][4];      // Frustum::getPlanes
+  float start[3], step[3]; // sample position = start + index * step (calibration_inverter.cpp:105-125)
+  int X, Y;                // inverse volume resolution in x, y
+  int z0, nz;              // z rows [z0, z0 + nz) handled by this launch
+  int TX, TY;              // tiles in x, y
+  int window;              // index radius R of the candidate window
+  float4* out_linear;      // [nz][Y][X] RGBA records, or
+  float* out_tiled;        // grid layout planes of `sensor` ([tile][N][3][512], z0 must be tile aligned)
+  int sensor, N;
+};
+
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
+void launch_invert_lut(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
 void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, size_t layer_bytes, uint8_t* rgb,

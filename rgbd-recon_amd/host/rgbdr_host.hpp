@@ -254,6 +254,14 @@ class CalibVolumes {
       check(m_be.ctx(), rgbdr_load_calibration_files(m_be.ctx(), (int)i, nullptr, nullptr, in.c_str()));
     }
   }
+  // What the offline tool `calib_inverter` (CalibrationInverter::calculateInverseVolumes,
+  // calibration_inverter.cpp:99-155) followed by loadInverseCalibs would provide, computed
+  // on the device at the grid resolution from the cv_xyz volumes already loaded.
+  void computeInverseCalibs(int window = 2)
+  {
+    for (unsigned i = 0; i < m_cv_xyz_filenames.size(); ++i)
+      check(m_be.ctx(), rgbdr_compute_inverse_calibration(m_be.ctx(), (int)i, window));
+  }
   std::vector<std::array<float, 3>> getCameraPositions() const
   {
     std::vector<std::array<float, 3>> out(m_cv_xyz_filenames.size());

@@ -21,7 +21,10 @@ class Sensor:
         self.forward = fwd / np.linalg.norm(fwd)
         r = np.cross(self.forward, np.array([0.0, 1.0, 0.0]))
         self.right = r / np.linalg.norm(r)
-        self.up = np.cross(self.right, self.forward)
+        # image y runs downwards (as in the reference's Kinect calibrations): the index
+        # -> world map of cv_xyz is then left-handed, which is the orientation
+        # Frustum::getPlanes (frustum.cpp:149-166) needs for its normals to point inwards
+        self.up = -np.cross(self.right, self.forward)
         self.W, self.H = width, height
         self.fx = self.fy = 365.0 * width / 512.0
         self.cx, self.cy = width / 2.0, height / 2.0
