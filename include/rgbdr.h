@@ -262,6 +262,36 @@ void* rgbdr_stream(rgbdr_ctx* ctx);
  * kernels without host synchronisation.  The previous stream is drained first. */
 int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream);
 
+/* ---- ray-marching the volume (consumer of the TSDF) ---------- */
+
+/* The uniforms ReconIntegration::draw uploads for glsl/tsdf_raymarch.{vs,fs}
+ * (framework/reconstruction/recon_integration.cpp:177-241), computed by the host
+ * exactly as there (glm / gloost); all matrices column-major as glGetFloatv returns
+ * them. */
+typedef struct {
+  float modelview[16];           /* GL_MODELVIEW_MATRIX */
+  float projection[16];          /* GL_PROJECTION_MATRIX */
+  float normal_matrix[16];       /* inverseTranspose(modelview * vol_to_world), :200-201 */
+  float gl_normal_matrix_inv[16];/* inverse(gl_NormalMatrix), only read in shade mode 2 (shading.glsl:66) */
+  float vol_to_world[16];        /* translate(bbox_min) * scale(bbox extent), recon_integration.cpp:66-72 */
+  float vol_to_world_inv[16];    /* the shader calls inverse() on these two per fragment (:387-388) */
+  float modelview_inv[16];
+  float img_to_eye[16];          /* inverse(viewport_scale * viewport_translate * projection), :185-194 */
+  float camera_pos[3];           /* camera in volume space, :203-206 */
+  int32_t width, height;         /* viewport */
+  int32_t shade_mode;            /* UBO Settings.g_shade_mode: 0 colour, 1 shaded, 2 normal, 3 camera influence */
+  int32_t skip_space;            /* brick depth-peel start positions (8f-4): not implemented, must be 0 */
+} rgbdr_view;
+
+/* ReconIntegration::draw: one ray per pixel through the whole TSDF volume (step
+ * limit/2, secant refinement at the zero crossing, gradient normal, quality /
+ * (distance + 0.01) colour blend).  Outputs (host pointers, any may be NULL):
+ * color = height*width RGBA32F, depth = gl_FragDepth, num_samples = the
+ * tex_num_samples image; pixels the ray-marcher discards keep the cleared values of
+ * ViewLod::enable: (0,1,0,0), depth 1.  Needs the whole volume in this context
+ * (slab_count == 1) and a completed integrate(). */
+int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, float* depth, float* num_samples);
+
 /* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
 
 /* names: "morph","bilateral","boundary","normal","quality","1preprocess",

@@ -35,6 +35,20 @@ class IntegrateParams(C.Structure):
                 ("limit", C.c_float), ("bv", C.c_int * 3), ("res_bricks", C.c_int * 3)]
 
 
+class View(C.Structure):
+    """orc_view (same layout as rgbdr_view)"""
+    _fields_ = [("modelview", C.c_float * 16), ("projection", C.c_float * 16), ("normal_matrix", C.c_float * 16),
+                ("gl_normal_matrix_inv", C.c_float * 16), ("vol_to_world", C.c_float * 16),
+                ("vol_to_world_inv", C.c_float * 16), ("modelview_inv", C.c_float * 16), ("img_to_eye", C.c_float * 16),
+                ("camera_pos", C.c_float * 3), ("width", C.c_int), ("height", C.c_int), ("shade_mode", C.c_int),
+                ("skip_space", C.c_int)]
+
+
+class RaymarchParams(C.Structure):
+    _fields_ = [("num_sensors", C.c_int), ("W", C.c_int), ("H", C.c_int), ("Wc", C.c_int), ("Hc", C.c_int),
+                ("res", C.c_int * 3), ("limit", C.c_float)]
+
+
 _lib = None
 
 
@@ -240,6 +254,36 @@ def inverse_volume(cv_xyz, bbox_min, bbox_max, vol_res, z_range=None):
     out = np.empty((z1 - z0, vol_res[1], vol_res[0], 4), dtype=np.float32)
     lib().orc_inverse_volume(_p(cv_xyz), res, _p(f32(bbox_min)), _p(f32(bbox_max)), vr, z0, z1, _p(out))
     return out
+
+
+def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit=0.01):
+    """tsdf [Z,Y,X]; inv_luts [Iz,Iy,Ix,4]; uv_luts [Rz,Ry,Rx,2]; colors u8 [Hc,Wc,3]"""
+    v = View.from_buffer_copy(view_bytes)
+    n = len(inv_luts)
+    tsdf = f32(tsdf)
+    inv = [f32(a) for a in inv_luts]
+    uv = [f32(a) for a in uv_luts]
+    col = [np.ascontiguousarray(a, dtype=np.uint8) for a in colors]
+    db = [f32(a) for a in depth_bs]
+    q = [f32(a) for a in quals]
+    p = RaymarchParams()
+    p.num_sensors = n
+    p.H, p.W = q[0].shape
+    p.Hc, p.Wc = col[0].shape[:2]
+    p.res[:] = [tsdf.shape[2], tsdf.shape[1], tsdf.shape[0]]
+    p.limit = limit
+    arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs])
+    inv_res = (C.c_int * (3 * n))()
+    uv_res = (C.c_int * (3 * n))()
+    for i in range(n):
+        inv_res[3 * i:3 * i + 3] = [inv[i].shape[2], inv[i].shape[1], inv[i].shape[0]]
+        uv_res[3 * i:3 * i + 3] = [uv[i].shape[2], uv[i].shape[1], uv[i].shape[0]]
+    color = np.empty((v.height, v.width, 4), dtype=np.float32)
+    depth = np.empty((v.height, v.width), dtype=np.float32)
+    ns = np.empty((v.height, v.width), dtype=np.float32)
+    lib().orc_raymarch(C.byref(v), C.byref(p), _p(tsdf), arr(inv), inv_res, arr(uv), uv_res, arr(col), arr(db), arr(q),
+                       _p(color), _p(depth), _p(ns))
+    return color, depth, ns
 
 
 def volume_res(bbox_min, bbox_max, voxel):

@@ -739,6 +739,231 @@ ORC_API void orc_camera_pos(const float* cv_xyz, const int* res, float* out)
 }
 
 /* ------------------------------------------------------------------------- */
+/* tsdf_raymarch.{vs,fs} + shading.glsl (f-2): one ray per pixel of the viewport. */
+/* The reference rasterises the unit cube and interpolates pass_Position          */
+/* (tsdf_raymarch.vs:13-16); every fragment of a pixel marches the same ray from  */
+/* CameraPos, so this restatement builds that ray from the pixel centre through    */
+/* the far-plane point screenToVol((px+.5, py+.5, 1)) (:384-390) and treats a pixel */
+/* as covered when the ray meets the unit cube in front of the camera.  All        */
+/* matrices are the host-side uniforms ReconIntegration::draw uploads              */
+/* (recon_integration.cpp:177-241), column-major, passed in verbatim.              */
+
+typedef struct {
+  float modelview[16], projection[16];
+  float normal_matrix[16];         /* inverseTranspose(modelview * vol_to_world) */
+  float gl_normal_matrix_inv[16];  /* inverse(gl_NormalMatrix), shade mode 2 */
+  float vol_to_world[16], vol_to_world_inv[16], modelview_inv[16];
+  float img_to_eye[16];            /* inverse(viewport_scale * viewport_translate * projection) */
+  float camera_pos[3];             /* volume space */
+  int width, height;
+  int shade_mode;
+  int skip_space;                  /* depth peels (f-4) not restated: must be 0 */
+} orc_view;
+
+typedef struct {
+  int num_sensors, W, H, Wc, Hc;
+  int res[3];                      /* TSDF */
+  float limit;
+} orc_raymarch_params;
+
+static inline void mat4_mul_vec4(const float* m, const float* v, float* o)
+{
+  /* glm: m[0]*v.x + m[1]*v.y + (m[2]*v.z + m[3]*v.w), columns m[c] = m + 4c */
+  for (int r = 0; r < 4; ++r) o[r] = (m[r] * v[0] + m[4 + r] * v[1]) + (m[8 + r] * v[2] + m[12 + r] * v[3]);
+}
+
+static inline float tsdf_sample(const float* tsdf, const int* res, const float* p)
+{
+  float o;
+  tex3d_linear(tsdf, 1, 1, res[0], res[1], res[2], p[0], p[1], p[2], &o);
+  return o;
+}
+
+static void rm_gradient(const float* tsdf, const int* res, const float* pos, float sd, float* g)
+{
+  float d[3];
+  for (int a = 0; a < 3; ++a) {
+    float pp[3] = {pos[0], pos[1], pos[2]}, pm[3] = {pos[0], pos[1], pos[2]};
+    pp[a] = pos[a] + sd;
+    pm[a] = pos[a] - sd;
+    d[a] = tsdf_sample(tsdf, res, pp) - tsdf_sample(tsdf, res, pm);
+  }
+  float n[3];
+  normalize3(d, n);
+  g[0] = -n[0];
+  g[1] = -n[1];
+  g[2] = -n[2];
+}
+
+static const float rm_camera_colors[5][3] = {{228, 26, 28}, {55, 126, 184}, {77, 175, 74}, {152, 78, 163}, {255, 127, 0}};
+
+ORC_API void orc_raymarch(const orc_view* vw, const orc_raymarch_params* p, const float* tsdf /* Z*Y*X */,
+                          const float* const* cv_xyz_inv /* RGBA */, const int* inv_res, const float* const* cv_uv,
+                          const int* uv_res, const uint8_t* const* colors, const float* const* depth_b_rg,
+                          const float* const* quality, float* out_color /* H*W*4 */, float* out_depth /* H*W */,
+                          float* out_samples /* H*W */)
+{
+  const float limit = p->limit, sd = limit * 0.5f;
+  /* gl_ModelViewMatrix * vol_to_world (the shader's left-to-right product, :123), glm association */
+  float mvw[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      mvw[4 * c + r] = vw->modelview[r] * vw->vol_to_world[4 * c] + vw->modelview[4 + r] * vw->vol_to_world[4 * c + 1] +
+                       vw->modelview[8 + r] * vw->vol_to_world[4 * c + 2] + vw->modelview[12 + r] * vw->vol_to_world[4 * c + 3];
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < vw->height; ++py) {
+    for (int px = 0; px < vw->width; ++px) {
+      const size_t o = (size_t)py * vw->width + px;
+      /* cleared framebuffer: ViewLod::enable, glClearColor(0,1,0,0), depth 1 */
+      out_color[o * 4 + 0] = 0.0f;
+      out_color[o * 4 + 1] = 1.0f;
+      out_color[o * 4 + 2] = 0.0f;
+      out_color[o * 4 + 3] = 0.0f;
+      out_depth[o] = 1.0f;
+      out_samples[o] = 0.0f;
+      /* ray through the pixel centre: screenToVol of the far-plane point */
+      const float frag[4] = {(float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f};
+      float pc[4], es[4], ws[4], tv[4];
+      mat4_mul_vec4(vw->img_to_eye, frag, pc);
+      es[0] = pc[0] / pc[3];
+      es[1] = pc[1] / pc[3];
+      es[2] = pc[2] / pc[3];
+      es[3] = 1.0f;
+      mat4_mul_vec4(vw->modelview_inv, es, ws);
+      mat4_mul_vec4(vw->vol_to_world_inv, ws, tv);
+      float dir[3] = {tv[0] - vw->camera_pos[0], tv[1] - vw->camera_pos[1], tv[2] - vw->camera_pos[2]}, nd[3];
+      normalize3(dir, nd);
+      const float step[3] = {nd[0] * sd, nd[1] * sd, nd[2] * sd};
+      /* intersectBox(CameraPos, sampleStep), :371-382 */
+      float tmin[3], tmax[3];
+      for (int a = 0; a < 3; ++a) {
+        const float inv = 1.0f / step[a];
+        const float tb = inv * (0.0f - vw->camera_pos[a]), tt = inv * (1.0f - vw->camera_pos[a]);
+        tmin[a] = fminf(tt, tb);
+        tmax[a] = fmaxf(tt, tb);
+      }
+      const float t0 = fmaxf(fmaxf(tmin[0], tmin[1]), fmaxf(tmin[0], tmin[2]));
+      const float t1 = fminf(fminf(tmax[0], tmax[1]), fminf(tmax[0], tmax[2]));
+      const int is_t0 = t0 <= t1;
+      if (!is_t0 || !(t1 > 0.0f)) continue; /* the cube is not rasterised onto this pixel */
+      float t_near = is_t0 ? t0 : t1;
+      t_near = t_near < 0.0f ? 0.0f : t_near;
+      const float t_far = is_t0 ? t1 : t0;
+      float sp[3] = {vw->camera_pos[0] + step[0] * t_near, vw->camera_pos[1] + step[1] * t_near,
+                     vw->camera_pos[2] + step[2] * t_near};
+      const float fmaxs = ceilf(fabsf(t_far - t_near));
+      const unsigned max_num = fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs;
+      float prev = -limit;
+      unsigned num = 0;
+      int hit = 0;
+      while (num < max_num) {
+        num += 1u;
+        const float density = tsdf_sample(tsdf, p->res, sp);
+        if (density > 0.0f) {
+          const float f = prev / (density - prev);
+          for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - step[a]) - step[a] * f;
+          hit = 1;
+          break;
+        }
+        prev = density;
+        for (int a = 0; a < 3; ++a) sp[a] += step[a];
+      }
+      out_samples[o] = (float)num * 0.0027f;
+      if (!hit) continue; /* discard */
+      /* submitFragment, :116-142 */
+      float g[3], g4[4], vn4[4], vn[3];
+      rm_gradient(tsdf, p->res, sp, sd, g);
+      g4[0] = g[0];
+      g4[1] = g[1];
+      g4[2] = g[2];
+      g4[3] = 0.0f;
+      mat4_mul_vec4(vw->normal_matrix, g4, vn4);
+      normalize3(vn4, vn);
+      const float sp4[4] = {sp[0], sp[1], sp[2], 1.0f};
+      float vp[4];
+      mat4_mul_vec4(mvw, sp4, vp);
+      float rgba[4];
+      /* per-sensor lookups shared by blendColors / blendCameras */
+      float tc[3] = {0, 0, 0}, tc2[3] = {0, 0, 0}, tw = 0.0f, tw2 = 0.0f, cw[3] = {0, 0, 0}, cwt = 0.0f;
+      for (int i = 0; i < p->num_sensors; ++i) {
+        float pcal[3], pcol[2], col[3];
+        tex3d_linear(cv_xyz_inv[i], 4, 3, inv_res[3 * i], inv_res[3 * i + 1], inv_res[3 * i + 2], sp[0], sp[1], sp[2], pcal);
+        tex3d_linear(cv_uv[i], 2, 2, uv_res[3 * i], uv_res[3 * i + 1], uv_res[3 * i + 2], pcal[0], pcal[1], pcal[2], pcol);
+        tex2d_linear_rgb8(colors[i], p->Wc, p->Hc, pcol[0], pcol[1], col);
+        const int ix = axis_nearest(pcal[0], p->W), iy = axis_nearest(pcal[1], p->H);
+        const float depth = depth_b_rg[i][((size_t)iy * p->W + ix) * 2];
+        const float dist = fabsf(depth - pcal[2]);
+        float q = 0.0f;
+        if (dist < limit) tex2d_linear(quality[i], 1, 1, p->W, p->H, pcal[0], pcal[1], &q);
+        for (int k = 0; k < 3; ++k) {
+          tc[k] += col[k] * q / (dist + 0.01f);
+          tc2[k] += col[k] / dist;
+          if (i < 5) cw[k] += (rm_camera_colors[i][k] / 255.0f) * q;
+        }
+        tw += q / (dist + 0.01f);
+        tw2 += 1.0f / dist;
+        cwt += q;
+      }
+      if (vw->shade_mode == 3) { /* blendCameras, :354-369 */
+        for (int k = 0; k < 3; ++k) rgba[k] = (cwt <= 0.0f) ? 1.0f : cw[k] / cwt;
+        rgba[3] = 1.0f;
+      } else {
+        float diff[4];
+        if (tw > 0.0f) {
+          for (int k = 0; k < 3; ++k) diff[k] = tc[k] / tw;
+          diff[3] = 1.0f;
+        } else {
+          for (int k = 0; k < 3; ++k) diff[k] = tc2[k] / tw2;
+          diff[3] = -1.0f;
+        }
+        if (vw->shade_mode == 0) {
+          rgba[0] = diff[0];
+          rgba[1] = diff[1];
+          rgba[2] = diff[2];
+        } else if (vw->shade_mode == 1) { /* phong, shading.glsl:32-64 */
+          const float lp[3] = {1.5f, 1.0f, 1.0f};
+          float tl[3] = {lp[0] - vp[0], lp[1] - vp[1], lp[2] - vp[2]}, tln[3];
+          normalize3(tl, tln);
+          const float la = dot3(vn, tln);
+          float dc = 0.0f, sl = 0.0f;
+          if (!(la <= 0.0f)) {
+            dc = fmaxf(la, 0.0f);
+            const float nv[3] = {-vp[0], -vp[1], -vp[2]};
+            float tvw[3], hw[3], hn[3];
+            normalize3(nv, tvw);
+            hw[0] = tln[0] + tvw[0];
+            hw[1] = tln[1] + tvw[1];
+            hw[2] = tln[2] + tvw[2];
+            normalize3(hw, hn);
+            const float ra = dot3(hn, vn);
+            /* pow(reflectedAngle, 20): products, like the other constant exponents */
+            const float r2 = ra * ra, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+            sl = r16 * r4;
+            const float a = (1.0f - la) * (1.0f - la);
+            sl *= 1.0f - a * a * a;
+          }
+          const float ld[3] = {1.0f, 0.9f, 0.7f};
+          for (int k = 0; k < 3; ++k) rgba[k] = (ld[k] * 0.2f) * 0.5f + ld[k] * 0.5f * dc + 1.0f * 0.5f * sl;
+        } else if (vw->shade_mode == 2) {
+          const float v4[4] = {vn[0], vn[1], vn[2], 0.0f};
+          float r4[4];
+          mat4_mul_vec4(vw->gl_normal_matrix_inv, v4, r4);
+          rgba[0] = r4[0];
+          rgba[1] = r4[1];
+          rgba[2] = r4[2];
+        } else {
+          rgba[0] = rgba[1] = rgba[2] = 1.0f;
+        }
+        rgba[3] = diff[3];
+      }
+      for (int k = 0; k < 4; ++k) out_color[o * 4 + k] = rgba[k];
+      /* gl_FragDepth, :133 (projection[2].z = m[10], projection[3].z = m[14]) */
+      out_depth[o] = (vw->projection[10] * vp[2] + vw->projection[14]) / -vp[2] * 0.5f + 0.5f;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Frustum planes + inside test (framework/calibration/frustum.cpp:36-43,      */
 /* :113-177) and the offline inverter CalibrationInverter::calculateInverse-    */
 /* Volumes (framework/calibration/calibration_inverter.cpp:55-69, :99-155).     */

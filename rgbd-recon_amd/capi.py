@@ -68,6 +68,58 @@ class Pinhole(C.Structure):
     ]
 
 
+class View(C.Structure):
+    """rgbdr_view: the uniforms of tsdf_raymarch.{vs,fs}"""
+    _fields_ = [("modelview", C.c_float * 16), ("projection", C.c_float * 16), ("normal_matrix", C.c_float * 16),
+                ("gl_normal_matrix_inv", C.c_float * 16), ("vol_to_world", C.c_float * 16),
+                ("vol_to_world_inv", C.c_float * 16), ("modelview_inv", C.c_float * 16), ("img_to_eye", C.c_float * 16),
+                ("camera_pos", C.c_float * 3), ("width", C.c_int32), ("height", C.c_int32), ("shade_mode", C.c_int32),
+                ("skip_space", C.c_int32)]
+
+
+def make_view(eye, target, up, fovy_deg, width, height, bbox_min, bbox_max, near=0.1, far=10.0, shade_mode=0):
+    """Builds the ray-marcher's uniforms the way ReconIntegration::draw does
+    (recon_integration.cpp:177-241) from a look-at camera and a perspective
+    projection; float64 algebra, stored as float32 column-major."""
+    eye, target, up = (np.asarray(a, dtype=np.float64) for a in (eye, target, up))
+    f = target - eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, up)
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    mv = np.eye(4)
+    mv[0, :3], mv[1, :3], mv[2, :3] = s, u, -f
+    mv[:3, 3] = -mv[:3, :3] @ eye
+    t = 1.0 / np.tan(np.radians(fovy_deg) / 2.0)
+    proj = np.zeros((4, 4))
+    proj[0, 0], proj[1, 1] = t / (width / height), t
+    proj[2, 2], proj[2, 3], proj[3, 2] = (far + near) / (near - far), 2 * far * near / (near - far), -1.0
+    bmin, bmax = np.asarray(bbox_min, dtype=np.float64), np.asarray(bbox_max, dtype=np.float64)
+    v2w = np.eye(4)
+    v2w[:3, :3] = np.diag(bmax - bmin)
+    v2w[:3, 3] = bmin
+    vp_scale = np.diag([width * 0.5, height * 0.5, 0.5, 1.0])
+    vp_trans = np.eye(4)
+    vp_trans[:3, 3] = 1.0
+    v = View()
+
+    def put(name, m):
+        getattr(v, name)[:] = np.asarray(m, dtype=np.float32).T.reshape(-1).tolist()   # column-major
+
+    put("modelview", mv)
+    put("projection", proj)
+    put("normal_matrix", np.linalg.inv(mv @ v2w).T)
+    put("gl_normal_matrix_inv", np.linalg.inv(np.linalg.inv(mv).T))
+    put("vol_to_world", v2w)
+    put("vol_to_world_inv", np.linalg.inv(v2w))
+    put("modelview_inv", np.linalg.inv(mv))
+    put("img_to_eye", np.linalg.inv(vp_scale @ vp_trans @ proj))
+    cam = np.linalg.inv(v2w) @ (np.linalg.inv(mv) @ np.array([0.0, 0.0, 0.0, 1.0]))
+    v.camera_pos[:] = cam[:3].astype(np.float32).tolist()
+    v.width, v.height, v.shade_mode, v.skip_space = width, height, shade_mode, 0
+    return v
+
+
 class TsdfDeviceView(C.Structure):
     _fields_ = [("base", C.c_void_p), ("owned", C.c_void_p), ("layer_bytes", C.c_size_t),
                 ("owned_layers", C.c_int32), ("halo_layers", C.c_int32)]
@@ -122,6 +174,7 @@ SYMBOLS = {
     "rgbdr_get_occupied": (C.c_int, [_P, _U32, C.c_size_t, C.POINTER(C.c_size_t), _F]),
     "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_stream": (_P, [_P]),
     "rgbdr_set_stream": (C.c_int, [_P, _P]),
     "rgbdr_enable_timers": (C.c_int, [_P, C.c_int]),
@@ -381,6 +434,16 @@ class Context:
         ratio = C.c_float()
         self._chk(lib().rgbdr_get_occupied(self._h, ids.ctypes.data_as(_U32), ids.size, C.byref(n), C.byref(ratio)))
         return ids[: n.value].copy(), ratio.value
+
+    def raymarch(self, view):
+        """(color [H,W,4], depth [H,W], num_samples [H,W]) of ReconIntegration::draw"""
+        h, w = view.height, view.width
+        color = np.empty((h, w, 4), dtype=np.float32)
+        depth = np.empty((h, w), dtype=np.float32)
+        ns = np.empty((h, w), dtype=np.float32)
+        self._chk(lib().rgbdr_raymarch(self._h, C.byref(view), color.ctypes.data_as(_F), depth.ctypes.data_as(_F),
+                                       ns.ctypes.data_as(_F)))
+        return color, depth, ns
 
     def device_tsdf(self):
         v = TsdfDeviceView()

@@ -82,6 +82,9 @@ struct rgbdr_ctx {
   int halo = 0;
   float* d_linear = nullptr;  // readback scratch
   size_t linear_floats = 0;
+  float* d_view = nullptr;    // ray-march outputs: rgba, depth, samples
+  size_t view_pixels = 0;
+  bool integrated = false;
 
   // bricks
   uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
@@ -161,6 +164,10 @@ static void free_volume(rgbdr_ctx* c)
 {
   (void)hipFree(c->d_tsdf_base);
   (void)hipFree(c->d_linear);
+  (void)hipFree(c->d_view);
+  c->d_view = nullptr;
+  c->view_pixels = 0;
+  c->integrated = false;
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
@@ -874,6 +881,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   launch_integrate(p, all_tiled, ctx->stream);
   tend(ctx, "2integrate", ctx->stream);
   LAUNCHCHK("integrate");
+  ctx->integrated = true;
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
     ctx->ev_int_rec[ctx->rbuf] = true;
@@ -1159,6 +1167,82 @@ int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
   if (!ctx || !ptr) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   *ptr = ctx->frame_buf(ctx->rbuf) + (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sensor;
+  return RGBDR_OK;
+}
+
+int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
+  if (v->skip_space) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "skip_space (brick depth peels) is not implemented");
+  if (ctx->cfg.slab_count > 1) return ctx->fail(RGBDR_ERR_STATE, "raymarch needs the whole volume in one context");
+  if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
+  const int N = nsens(ctx);
+  bool tiled = true;
+  for (int i = 0; i < N; ++i) tiled = tiled && ctx->inv_tiled[i];
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)v->width * v->height;
+  if (ctx->view_pixels < npix) {
+    (void)hipFree(ctx->d_view);
+    ctx->d_view = nullptr;
+    ctx->view_pixels = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 6 * sizeof(float)));
+    ctx->view_pixels = npix;
+  }
+  const rgbdr_geometry& g = ctx->geo;
+  RaymarchParams p{};
+  std::memcpy(p.projection, v->projection, 64);
+  std::memcpy(p.normal_matrix, v->normal_matrix, 64);
+  std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);
+  std::memcpy(p.vol_to_world_inv, v->vol_to_world_inv, 64);
+  std::memcpy(p.modelview_inv, v->modelview_inv, 64);
+  std::memcpy(p.img_to_eye, v->img_to_eye, 64);
+  // gl_ModelViewMatrix * vol_to_world, evaluated once (the shader forms it per fragment, :123)
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      p.mv_vol_to_world[4 * c + r] = v->modelview[r] * v->vol_to_world[4 * c] + v->modelview[4 + r] * v->vol_to_world[4 * c + 1] +
+                                     v->modelview[8 + r] * v->vol_to_world[4 * c + 2] + v->modelview[12 + r] * v->vol_to_world[4 * c + 3];
+  std::memcpy(p.camera_pos, v->camera_pos, 12);
+  p.width = v->width;
+  p.height = v->height;
+  p.shade_mode = v->shade_mode;
+  p.limit = ctx->cfg.tsdf_limit;
+  p.N = N;
+  p.W = ctx->cfg.depth_w;
+  p.H = ctx->cfg.depth_h;
+  p.Wc = ctx->cfg.color_w;
+  p.Hc = ctx->cfg.color_h;
+  p.X = g.res_volume[0];
+  p.Y = g.res_volume[1];
+  p.Z = g.res_volume[2];
+  p.TX = g.tiles[0];
+  p.TY = g.tiles[1];
+  p.tsdf = ctx->d_tsdf_owned;
+  p.lut_tiled = tiled ? ctx->d_lut_tiled : nullptr;
+  const size_t img = (size_t)p.W * p.H;
+  for (int i = 0; i < N; ++i) {
+    p.lut[i] = ctx->d_lut_generic[i];
+    p.rx[i] = (int)ctx->inv_res[i][0];
+    p.ry[i] = (int)ctx->inv_res[i][1];
+    p.rz[i] = (int)ctx->inv_res[i][2];
+    p.zoff[i] = ctx->zoff[i];
+    p.cv_uv[i] = ctx->d_cv_uv[i];
+    for (int a = 0; a < 3; ++a) p.uv_res[i][a] = (int)ctx->uv_res[i][a];
+    p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
+  }
+  p.color = ctx->d_color;
+  p.out_color = (float4*)ctx->d_view;
+  p.out_depth = ctx->d_view + npix * 4;
+  p.out_samples = ctx->d_view + npix * 5;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch");
+  if (color) HIPCHK(hipMemcpyAsync(color, p.out_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth) HIPCHK(hipMemcpyAsync(depth, p.out_depth, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (num_samples) HIPCHK(hipMemcpyAsync(num_samples, p.out_samples, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
 

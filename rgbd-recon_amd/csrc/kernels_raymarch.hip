@@ -1,0 +1,224 @@
+// kernels_raymarch.hip -- TSDF ray-marcher, the consumer of the
+// volume: glsl/tsdf_raymarch.{vs,fs} + glsl/shading.glsl driven by
+// ReconIntegration::draw (framework/reconstruction/recon_integration.cpp:177-241).
+//
+// One thread per viewport pixel (16x16 pixel blocks: neighbouring rays touch
+// neighbouring tiles).  The reference rasterises the unit cube and every fragment
+// of a pixel marches the same ray from CameraPos; here the ray is built from the
+// pixel centre (screenToVol of the far-plane point, tsdf_raymarch.fs:384-390) and a
+// pixel is covered when its ray meets the unit cube in front of the camera.  The
+// volume is sampled LINEAR + CLAMP_TO_EDGE straight from the tile-linear layout
+// (sampler unit 29 in the reference), the per-sensor colour blend samples the
+// resident inverse LUT (grid layout, or the file volume with
+// RGBDR_FLAG_NO_RESAMPLE), cv_uv, the RGB8 colour frames and the packed
+// depth/quality frames.  Latency / gather bound; reported as time.
+#include <hip/hip_runtime.h>
+
+#include "rgbdr_internal.hpp"
+#include "sampling.cuh"
+
+namespace rgbdr {
+
+__device__ __forceinline__ float4 mat4_mul(const float* m, float x, float y, float z, float w)
+{
+  float4 o;
+  o.x = (m[0] * x + m[4] * y) + (m[8] * z + m[12] * w);
+  o.y = (m[1] * x + m[5] * y) + (m[9] * z + m[13] * w);
+  o.z = (m[2] * x + m[6] * y) + (m[10] * z + m[14] * w);
+  o.w = (m[3] * x + m[7] * y) + (m[11] * z + m[15] * w);
+  return o;
+}
+
+__device__ __forceinline__ float tile_at(const float* __restrict__ v, int TX, int TY, int x, int y, int z)
+{
+  return v[((size_t)((z >> 3) * TY + (y >> 3)) * TX + (x >> 3)) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7))];
+}
+
+// texture(volume_tsdf, pos).r
+__device__ __forceinline__ float tsdf_sample(const RaymarchParams& p, float px, float py, float pz)
+{
+  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y), Z = axis_linear(pz, p.Z);
+  const float t000 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i0, Z.i0), t100 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i0, Z.i0);
+  const float t010 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i1, Z.i0), t110 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i1, Z.i0);
+  const float t001 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i0, Z.i1), t101 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i0, Z.i1);
+  const float t011 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i1, Z.i1), t111 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i1, Z.i1);
+  return lerpf(lerpf(lerpf(t000, t100, X.a), lerpf(t010, t110, X.a), Y.a),
+               lerpf(lerpf(t001, t101, X.a), lerpf(t011, t111, X.a), Y.a), Z.a);
+}
+
+// texture(cv_xyz_inv[i], pos).xyz from the grid-layout planes ([tile][N][3][512])
+__device__ __forceinline__ float3 lut_planes_sample(const RaymarchParams& p, int sensor, float px, float py, float pz)
+{
+  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y), Z = axis_linear(pz, p.Z);
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    auto at = [&](int x, int y, int z) {
+      const size_t tile = (size_t)((z >> 3) * p.TY + (y >> 3)) * p.TX + (x >> 3);
+      return p.lut_tiled[((tile * p.N + sensor) * 3 + c) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7))];
+    };
+    r[c] = lerpf(lerpf(lerpf(at(X.i0, Y.i0, Z.i0), at(X.i1, Y.i0, Z.i0), X.a), lerpf(at(X.i0, Y.i1, Z.i0), at(X.i1, Y.i1, Z.i0), X.a), Y.a),
+                 lerpf(lerpf(at(X.i0, Y.i0, Z.i1), at(X.i1, Y.i0, Z.i1), X.a), lerpf(at(X.i0, Y.i1, Z.i1), at(X.i1, Y.i1, Z.i1), X.a), Y.a),
+                 Z.a);
+  }
+  return make_float3(r[0], r[1], r[2]);
+}
+
+__device__ __forceinline__ float3 normalize3(float x, float y, float z)
+{
+  const float l = sqrtf(x * x + y * y + z * z);
+  return make_float3(x / l, y / l, z / l);
+}
+
+__constant__ float c_camera_colors[5][3] = {{228, 26, 28}, {55, 126, 184}, {77, 175, 74}, {152, 78, 163}, {255, 127, 0}};
+
+__global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
+{
+  const int px = blockIdx.x * 16 + threadIdx.x, py = blockIdx.y * 16 + threadIdx.y;
+  if (px >= p.width || py >= p.height) return;
+  const size_t o = (size_t)py * p.width + px;
+  const float limit = p.limit, sd = limit * 0.5f;
+  float4 rgba = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
+  float fdepth = 1.0f, fsamples = 0.0f;
+  do {
+    const float4 pc = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
+    const float4 ws = mat4_mul(p.modelview_inv, pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, 1.0f);
+    const float4 tv = mat4_mul(p.vol_to_world_inv, ws.x, ws.y, ws.z, ws.w);
+    const float3 nd = normalize3(tv.x - p.camera_pos[0], tv.y - p.camera_pos[1], tv.z - p.camera_pos[2]);
+    const float step[3] = {nd.x * sd, nd.y * sd, nd.z * sd};
+    float tmin[3], tmax[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float inv = 1.0f / step[a];
+      const float tb = inv * (0.0f - p.camera_pos[a]), tt = inv * (1.0f - p.camera_pos[a]);
+      tmin[a] = fminf(tt, tb);
+      tmax[a] = fmaxf(tt, tb);
+    }
+    const float t0 = fmaxf(fmaxf(tmin[0], tmin[1]), fmaxf(tmin[0], tmin[2]));
+    const float t1 = fminf(fminf(tmax[0], tmax[1]), fminf(tmax[0], tmax[2]));
+    if (!(t0 <= t1) || !(t1 > 0.0f)) break;  // cube not rasterised onto this pixel
+    const float t_near = t0 < 0.0f ? 0.0f : t0;
+    float sp[3] = {p.camera_pos[0] + step[0] * t_near, p.camera_pos[1] + step[1] * t_near, p.camera_pos[2] + step[2] * t_near};
+    const float fmaxs = ceilf(fabsf(t1 - t_near));
+    const unsigned max_num = fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs;
+    float prev = -limit;
+    unsigned num = 0;
+    bool hit = false;
+    while (num < max_num) {
+      num += 1u;
+      const float density = tsdf_sample(p, sp[0], sp[1], sp[2]);
+      if (density > 0.0f) {
+        const float f = prev / (density - prev);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - step[a]) - step[a] * f;
+        hit = true;
+        break;
+      }
+      prev = density;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sp[a] += step[a];
+    }
+    fsamples = (float)num * 0.0027f;
+    if (!hit) break;  // discard
+    // submitFragment
+    const float gx = tsdf_sample(p, sp[0] + sd, sp[1], sp[2]) - tsdf_sample(p, sp[0] - sd, sp[1], sp[2]);
+    const float gy = tsdf_sample(p, sp[0], sp[1] + sd, sp[2]) - tsdf_sample(p, sp[0], sp[1] - sd, sp[2]);
+    const float gz = tsdf_sample(p, sp[0], sp[1], sp[2] + sd) - tsdf_sample(p, sp[0], sp[1], sp[2] - sd);
+    const float3 gn = normalize3(gx, gy, gz);
+    const float4 vn4 = mat4_mul(p.normal_matrix, -gn.x, -gn.y, -gn.z, 0.0f);
+    const float3 vn = normalize3(vn4.x, vn4.y, vn4.z);
+    const float4 vp = mat4_mul(p.mv_vol_to_world, sp[0], sp[1], sp[2], 1.0f);
+    float tc[3] = {0, 0, 0}, tc2[3] = {0, 0, 0}, tw = 0.0f, tw2 = 0.0f, cw[3] = {0, 0, 0}, cwt = 0.0f;
+    for (int i = 0; i < p.N; ++i) {
+      const float3 pcal = p.lut_tiled ? lut_planes_sample(p, i, sp[0], sp[1], sp[2])
+                                      : tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], sp[0], sp[1], sp[2]);
+      const float2 pcol = tex3d_uv(p.cv_uv[i], p.uv_res[i][0], p.uv_res[i][1], p.uv_res[i][2], pcal.x, pcal.y, pcal.z);
+      const Axis CX = axis_linear(pcol.x, p.Wc), CY = axis_linear(pcol.y, p.Hc);
+      const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
+      float col[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+        const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+        col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
+      }
+      const uint2* frame = p.frame[i];
+      const int ix = axis_nearest(pcal.x, p.W), iy = axis_nearest(pcal.y, p.H);
+      const float depth = __uint_as_float(frame[(size_t)iy * p.W + ix].x);
+      const float dist = fabsf(depth - pcal.z);
+      float q = 0.0f;
+      if (dist < limit) {
+        const Axis QX = axis_linear(pcal.x, p.W), QY = axis_linear(pcal.y, p.H);
+        const float q00 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i0].y & 0x7fffffffu), q10 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i1].y & 0x7fffffffu);
+        const float q01 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i0].y & 0x7fffffffu), q11 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i1].y & 0x7fffffffu);
+        q = lerpf(lerpf(q00, q10, QX.a), lerpf(q01, q11, QX.a), QY.a);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        tc[k] += col[k] * q / (dist + 0.01f);
+        tc2[k] += col[k] / dist;
+        if (i < 5) cw[k] += (c_camera_colors[i][k] / 255.0f) * q;
+      }
+      tw += q / (dist + 0.01f);
+      tw2 += 1.0f / dist;
+      cwt += q;
+    }
+    if (p.shade_mode == 3) {
+      rgba = make_float4(cwt <= 0.0f ? 1.0f : cw[0] / cwt, cwt <= 0.0f ? 1.0f : cw[1] / cwt, cwt <= 0.0f ? 1.0f : cw[2] / cwt, 1.0f);
+    } else {
+      float diff[4];
+      if (tw > 0.0f) {
+        diff[0] = tc[0] / tw;
+        diff[1] = tc[1] / tw;
+        diff[2] = tc[2] / tw;
+        diff[3] = 1.0f;
+      } else {
+        diff[0] = tc2[0] / tw2;
+        diff[1] = tc2[1] / tw2;
+        diff[2] = tc2[2] / tw2;
+        diff[3] = -1.0f;
+      }
+      float r[3] = {1.0f, 1.0f, 1.0f};
+      if (p.shade_mode == 0) {
+        r[0] = diff[0];
+        r[1] = diff[1];
+        r[2] = diff[2];
+      } else if (p.shade_mode == 1) {
+        const float3 tln = normalize3(1.5f - vp.x, 1.0f - vp.y, 1.0f - vp.z);
+        const float la = vn.x * tln.x + vn.y * tln.y + vn.z * tln.z;
+        float dc = 0.0f, sl = 0.0f;
+        if (!(la <= 0.0f)) {
+          dc = fmaxf(la, 0.0f);
+          const float3 tvw = normalize3(-vp.x, -vp.y, -vp.z);
+          const float3 hn = normalize3(tln.x + tvw.x, tln.y + tvw.y, tln.z + tvw.z);
+          const float ra = hn.x * vn.x + hn.y * vn.y + hn.z * vn.z;
+          const float r2 = ra * ra, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+          sl = r16 * r4;
+          const float a = (1.0f - la) * (1.0f - la);
+          sl *= 1.0f - a * a * a;
+        }
+        const float ld[3] = {1.0f, 0.9f, 0.7f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[k] = (ld[k] * 0.2f) * 0.5f + ld[k] * 0.5f * dc + 1.0f * 0.5f * sl;
+      } else if (p.shade_mode == 2) {
+        const float4 r4 = mat4_mul(p.gl_normal_matrix_inv, vn.x, vn.y, vn.z, 0.0f);
+        r[0] = r4.x;
+        r[1] = r4.y;
+        r[2] = r4.z;
+      }
+      rgba = make_float4(r[0], r[1], r[2], diff[3]);
+    }
+    fdepth = (p.projection[10] * vp.z + p.projection[14]) / -vp.z * 0.5f + 0.5f;
+  } while (false);
+  p.out_color[o] = rgba;
+  p.out_depth[o] = fdepth;
+  p.out_samples[o] = fsamples;
+}
+
+void launch_raymarch(const RaymarchParams& p, hipStream_t s)
+{
+  dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
+  hipLaunchKernelGGL(k_raymarch, grid, dim3(16, 16), 0, s, p);
+}
+
+}  // namespace rgbdr

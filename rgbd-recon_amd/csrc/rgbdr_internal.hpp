@@ -95,6 +95,30 @@ struct InvertParams {
   int sensor, N;
 };
 
+struct RaymarchParams {
+  // uniforms of tsdf_raymarch.fs (column-major matrices)
+  float projection[16], normal_matrix[16], gl_normal_matrix_inv[16];
+  float vol_to_world_inv[16], modelview_inv[16], img_to_eye[16];
+  float mv_vol_to_world[16];   // gl_ModelViewMatrix * vol_to_world
+  float camera_pos[3];
+  int width, height, shade_mode;
+  float limit;
+  int N, W, H, Wc, Hc;
+  int X, Y, Z, TX, TY;
+  const float* tsdf;           // tile-linear, whole volume
+  const float* lut_tiled;      // grid-layout inverse LUT planes, or null ->
+  const float4* lut[kMaxSensors];
+  int rx[kMaxSensors], ry[kMaxSensors], rz[kMaxSensors], zoff[kMaxSensors];
+  const float2* cv_uv[kMaxSensors];
+  int uv_res[kMaxSensors][3];
+  const uint8_t* color;        // [N][Hc][Wc][3]
+  const uint2* frame[kMaxSensors];
+  float4* out_color;
+  float* out_depth;
+  float* out_samples;
+};
+void launch_raymarch(const RaymarchParams& p, hipStream_t s);
+
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__

@@ -1,0 +1,90 @@
+"""The TSDF ray-marcher (glsl/tsdf_raymarch.fs + shading.glsl) on the
+device against its oracle restatement: bit-exact colour, gl_FragDepth and sample
+counts for every shade mode, from outside and inside the volume."""
+import numpy as np
+import pytest
+
+from conftest import count_diff, same_bits
+
+pytestmark = pytest.mark.gpu
+BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
+
+
+def setup(pkg, orc, flags=15, inv_res=None, G=64):
+    capi, synth = pkg.capi, pkg.synth
+    scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32))
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags), 0)
+    inv_res = inv_res or (G, G, G)
+    inv = scene.inverse(inv_res)
+    for i in range(2):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    return scene, ctx, inv
+
+
+def oracle_images(orc, ctx, scene, inv_for_oracle, view):
+    tsdf = ctx.readback_tsdf()
+    db = [ctx.readback_image(4, i) for i in range(2)]
+    q = [ctx.readback_image(7, i) for i in range(2)]
+    return orc.raymarch(bytes(view), tsdf, inv_for_oracle, scene.uv, [scene.color[i] for i in range(2)], db, q)
+
+
+@pytest.mark.parametrize("shade_mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("eye", [(2.2, 1.6, 1.9), (0.85, 1.7, 0.8)])      # outside / inside the box
+def test_raymarch_matches_oracle(pkg, orc, shade_mode, eye):
+    scene, ctx, inv = setup(pkg, orc)
+    view = pkg.capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=shade_mode)
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images(orc, ctx, scene, inv, view)
+    assert same_bits(ns, rn), count_diff(ns, rn)
+    assert same_bits(depth, rd), count_diff(depth, rd)
+    assert same_bits(color, rc), count_diff(color, rc)
+    hit = depth < 1.0
+    assert 0.02 < hit.mean() < 0.98                    # some rays hit the surface, some are discarded
+    assert np.all(color[~hit] == np.float32([0, 1, 0, 0]))
+    assert ns.max() > 0.1
+    ctx.close()
+
+
+def test_raymarch_with_file_layout_lut(pkg, orc):
+    """RGBDR_FLAG_NO_RESAMPLE: colours are looked up through the file-resolution LUT"""
+    scene, ctx, inv = setup(pkg, orc, flags=15 | pkg.capi.FLAG_NO_RESAMPLE, inv_res=(45, 50, 45))
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 80, 60, BMIN, BMAX)
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images(orc, ctx, scene, inv, view)
+    assert same_bits(color, rc) and same_bits(depth, rd) and same_bits(ns, rn)
+    ctx.close()
+
+
+def test_raymarch_with_resampled_lut(pkg, orc):
+    """default handling of a non-1:1 LUT: the ray-marcher samples the resident
+    (resampled, grid-layout) LUT -- equal to the oracle fed with that LUT"""
+    scene, ctx, inv = setup(pkg, orc, inv_res=(45, 50, 45))
+    resident = [ctx.readback_inverse_calibration(i, 0, 64) for i in range(2)]
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 80, 60, BMIN, BMAX)
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images(orc, ctx, scene, resident, view)
+    assert same_bits(color, rc) and same_bits(depth, rd) and same_bits(ns, rn)
+    ctx.close()
+
+
+def test_raymarch_errors(pkg, orc):
+    capi = pkg.capi
+    scene, ctx, inv = setup(pkg, orc, G=32)
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 32, 24, BMIN, BMAX)
+    view.skip_space = 1
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx.raymarch(view)
+    assert e.value.status == capi.ERR_INVALID_ARGUMENT
+    view.skip_space, view.shade_mode = 0, 7
+    with pytest.raises(capi.RgbdrError):
+        ctx.raymarch(view)
+    ctx.close()
+    ctx2 = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
+    view.shade_mode = 0
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx2.raymarch(view)
+    assert e.value.status == capi.ERR_STATE
+    ctx2.close()
