@@ -292,6 +292,12 @@ typedef struct {
  * (slab_count == 1) and a completed integrate(). */
 int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, float* depth, float* num_samples);
 
+/* ReconIntegration::fillColors (recon_integration.cpp:280-339): screen-space hole
+ * filling of the frame the last rgbdr_raymarch produced -- the tsdf_inpaint.fs pyramid
+ * over the ViewLod atlas, then tsdf_colorfill.fs (first LOD with alpha > 0, blended
+ * with the next two).  color = height*width RGBA32F, depth = height*width. */
+int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
+
 /* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
 
 /* names: "morph","bilateral","boundary","normal","quality","1preprocess",

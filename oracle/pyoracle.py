@@ -286,6 +286,23 @@ def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit
     return color, depth, ns
 
 
+def fill_colors(color, depth):
+    color, depth = f32(color), f32(depth)
+    h, w = depth.shape
+    oc = np.empty((h, w, 4), dtype=np.float32)
+    od = np.empty((h, w), dtype=np.float32)
+    lib().orc_fill_colors(_p(color), _p(depth), w, h, _p(oc), _p(od), None)
+    return oc, od
+
+
+def fill_layout(w, h):
+    n, fw = C.c_int(), C.c_int()
+    off = (C.c_int * 40)()
+    res = (C.c_int * 40)()
+    lib().orc_fill_layout(w, h, C.byref(n), C.byref(fw), off, res)
+    return n.value, fw.value, np.array(off[:]).reshape(20, 2), np.array(res[:]).reshape(20, 2)
+
+
 def volume_res(bbox_min, bbox_max, voxel):
     res = (C.c_int * 3)()
     lib().orc_volume_res(_p(f32(bbox_min)), _p(f32(bbox_max)), voxel, res)

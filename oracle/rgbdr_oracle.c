@@ -956,11 +956,260 @@ ORC_API void orc_raymarch(const orc_view* vw, const orc_raymarch_params* p, cons
         }
         rgba[3] = diff[3];
       }
+      /* gl_FragDepth, :133 (projection[2].z = m[10], projection[3].z = m[14]); it is clamped
+       * to the depth range and tested GL_LESS against the cleared 1.0
+       * (source/kinect_client.cpp:993-994), so a surface at or beyond the far plane is dropped */
+      const float fd = (vw->projection[10] * vp[2] + vw->projection[14]) / -vp[2] * 0.5f + 0.5f;
+      const float dclamped = fminf(fmaxf(fd, 0.0f), 1.0f);
+      if (!(dclamped < 1.0f)) continue;
       for (int k = 0; k < 4; ++k) out_color[o * 4 + k] = rgba[k];
-      /* gl_FragDepth, :133 (projection[2].z = m[10], projection[3].z = m[14]) */
-      out_depth[o] = (vw->projection[10] * vp[2] + vw->projection[14]) / -vp[2] * 0.5f + 0.5f;
+      out_depth[o] = dclamped;
     }
   }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Hole filling of the ray-marched frame (f-2): ReconIntegration::fillColors    */
+/* (recon_integration.cpp:280-339) with glsl/framebuffer_transfer.fs,            */
+/* glsl/tsdf_inpaint.fs, glsl/tsdf_colorfill.fs and the LOD atlas of ViewLod      */
+/* (framework/rendering/view_lod.cpp:24-61: 1.5*W x H, LOD i at (W, H - sum h_j)). */
+/* Two atlases ping-pong in the reference: the "native" one accumulates the LODs, */
+/* the other holds a copy of it squeezed by 2/3 in x (framebuffer_transfer.fs     */
+/* fetches at pass_TexCoord * resolution_full).  Conventions where GL leaves the  */
+/* result open: texelFetch outside the texture returns 0; uniform array entries   */
+/* beyond num_lods are 0; clamp(x, lo, hi) = min(max(x, lo), hi) also for lo > hi; */
+/* the colour atlas is sampled LINEAR with MIRRORED_REPEAT (view_lod.cpp:52-53).   */
+
+typedef struct {
+  int W, H, FW, num_lods;
+  int off[20][2], res[20][2];
+} fc_layout;
+
+static void fc_make_layout(int W, int H, fc_layout* L)
+{
+  memset(L, 0, sizeof(*L));
+  L->W = W;
+  L->H = H;
+  L->FW = (int)((float)W * 1.5f);
+  int m = W < H ? W : H;
+  L->num_lods = 1 + (int)floorf(log2f((float)m));
+  if (L->num_lods > 20) L->num_lods = 20;
+  int ox = W, oy = H;
+  for (int i = 0; i < L->num_lods; ++i) {
+    L->res[i][0] = (int)floorf((float)W / powf(2.0f, (float)i));
+    L->res[i][1] = (int)floorf((float)H / powf(2.0f, (float)i));
+    if (i > 0) {
+      oy -= L->res[i][1];
+      L->off[i][0] = ox;
+      L->off[i][1] = oy;
+    }
+  }
+}
+
+ORC_API void orc_fill_layout(int W, int H, int* num_lods, int* full_w, int* off /* 20x2 */, int* res /* 20x2 */)
+{
+  fc_layout L;
+  fc_make_layout(W, H, &L);
+  *num_lods = L.num_lods;
+  *full_w = L.FW;
+  memcpy(off, L.off, sizeof(L.off));
+  memcpy(res, L.res, sizeof(L.res));
+}
+
+static inline void fc_fetch(const float* col, const float* dep, const fc_layout* L, int x, int y, float* c, float* d)
+{
+  if (x < 0 || y < 0 || x >= L->FW || y >= L->H) {
+    c[0] = c[1] = c[2] = c[3] = 0.0f;
+    *d = 0.0f;
+    return;
+  }
+  memcpy(c, col + ((size_t)y * L->FW + x) * 4, 16);
+  *d = dep[(size_t)y * L->FW + x];
+}
+
+static inline int fc_mirror(int i, int n)
+{
+  int period = 2 * n;
+  int k = i % period;
+  if (k < 0) k += period;
+  return k < n ? k : period - 1 - k;
+}
+
+/* texture(texture_color, p): LINEAR, MIRRORED_REPEAT, p normalised over the atlas */
+static void fc_texture(const float* col, const fc_layout* L, float u, float v, float* out)
+{
+  const float tx = u * (float)L->FW - 0.5f, ty = v * (float)L->H - 0.5f;
+  const float fx = floorf(tx), fy = floorf(ty);
+  const float ax = tx - fx, ay = ty - fy;
+  const int jx = idx_from_floor(fx, L->FW * 4), jy = idx_from_floor(fy, L->H * 4);
+  const int x0 = fc_mirror(jx, L->FW), x1 = fc_mirror(jx + 1, L->FW), y0 = fc_mirror(jy, L->H), y1 = fc_mirror(jy + 1, L->H);
+  for (int c = 0; c < 4; ++c) {
+    const float t00 = col[((size_t)y0 * L->FW + x0) * 4 + c], t10 = col[((size_t)y0 * L->FW + x1) * 4 + c];
+    const float t01 = col[((size_t)y1 * L->FW + x0) * 4 + c], t11 = col[((size_t)y1 * L->FW + x1) * 4 + c];
+    out[c] = lerpf(lerpf(t00, t10, ax), lerpf(t01, t11, ax), ay);
+  }
+}
+
+static void fc_clear(float* col, float* dep, const fc_layout* L)
+{
+  for (size_t i = 0; i < (size_t)L->FW * L->H; ++i) {
+    col[4 * i] = 0.0f;
+    col[4 * i + 1] = 1.0f;
+    col[4 * i + 2] = 0.0f;
+    col[4 * i + 3] = 0.0f;
+    dep[i] = 1.0f;
+  }
+}
+
+/* framebuffer_transfer.fs into the LOD-0 viewport of a freshly cleared atlas */
+static void fc_transfer(const float* scol, const float* sdep, float* dcol, float* ddep, const fc_layout* L)
+{
+  fc_clear(dcol, ddep, L);
+  for (int py = 0; py < L->H; ++py)
+    for (int px = 0; px < L->W; ++px) {
+      const float u = ((float)px + 0.5f) / (float)L->W, v = ((float)py + 0.5f) / (float)L->H;
+      const int sx = (int)(u * (float)L->FW), sy = (int)(v * (float)L->H);
+      fc_fetch(scol, sdep, L, sx, sy, dcol + ((size_t)py * L->FW + px) * 4, ddep + (size_t)py * L->FW + px);
+    }
+}
+
+/* tsdf_inpaint.fs: reads the squeezed atlas, writes LOD `lod + 1` of the native one */
+static void fc_inpaint(const float* scol, const float* sdep, float* ncol, float* ndep, const fc_layout* L, int lod)
+{
+  const int i = lod + 1;
+  for (int fy = 0; fy < L->res[i][1]; ++fy)
+    for (int fx = 0; fx < L->res[i][0]; ++fx) {
+      const int gx = L->off[i][0] + fx, gy = L->off[i][1] + fy; /* gl_FragCoord, pixel_center_integer */
+      const float tcx = ((float)gx - (float)L->off[i][0]) / (float)L->res[i][0];
+      const float tcy = ((float)gy - (float)L->off[i][1]) / (float)L->res[i][1];
+      const int lx = (int)((float)L->off[lod][0] + (float)L->res[lod][0] * tcx);
+      const int ly = (int)((float)L->off[lod][1] + (float)L->res[lod][1] * tcy);
+      const int pix = (int)((float)lx * (2.0f / 3.0f)), piy = (int)((float)ly * 1.0f);
+      float samples[16][4], depth_av = 0.0f;
+      int num = 0;
+      for (int x = 0; x < 4; ++x)
+        for (int y = 0; y < 4; ++y) {
+          const int tx = pix + (int)((float)x - 4.0f * 0.5f + 1.0f), ty = piy + (int)((float)y - 4.0f * 0.5f + 1.0f);
+          float c[4], d;
+          fc_fetch(scol, sdep, L, tx, ty, c, &d);
+          if (c[3] <= 0.0f) {
+            c[0] = -1.0f;
+          } else {
+            depth_av += d;
+            ++num;
+          }
+          float* sm = samples[x + y * 4];
+          sm[0] = c[0];
+          sm[1] = c[1];
+          sm[2] = c[2];
+          sm[3] = d;
+        }
+      float* oc = ncol + ((size_t)gy * L->FW + gx) * 4;
+      float* od = ndep + (size_t)gy * L->FW + gx;
+      if (num == 0) {
+        float c[4], d;
+        fc_fetch(scol, sdep, L, pix, piy, c, &d);
+        *od = d;
+        if (d < 1.0f) {
+          oc[0] = 0.0f;
+          oc[1] = 0.0f;
+          oc[2] = 0.0f;
+          oc[3] = -1.0f;
+        } else {
+          oc[0] = 0.0f;
+          oc[1] = 1.0f;
+          oc[2] = 0.0f;
+          oc[3] = 0.0f;
+        }
+        continue;
+      }
+      depth_av /= (float)num;
+      float tc[3] = {0, 0, 0}, td = 0.0f, tw = 0.0f;
+      for (int k = 0; k < 16; ++k)
+        if (samples[k][0] >= 0.0f && samples[k][3] >= depth_av) {
+          tc[0] += samples[k][0] * 1.0f;
+          tc[1] += samples[k][1] * 1.0f;
+          tc[2] += samples[k][2] * 1.0f;
+          td += samples[k][3] * 1.0f;
+          tw += 1.0f;
+        }
+      oc[0] = tc[0] / tw;
+      oc[1] = tc[1] / tw;
+      oc[2] = tc[2] / tw;
+      oc[3] = 1.0f;
+      *od = td / tw;
+    }
+}
+
+static inline float fc_clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* tsdf_colorfill.fs into the W x H default framebuffer */
+static void fc_colorfill(const float* ncol, const float* ndep, const fc_layout* L, float* out_col, float* out_dep)
+{
+  const float rix = 1.0f / (float)L->FW, riy = 1.0f / (float)L->H; /* resolution_inv */
+  for (int py = 0; py < L->H; ++py)
+    for (int px = 0; px < L->W; ++px) {
+      const float tcx = (float)px / (float)L->res[0][0], tcy = (float)py / (float)L->res[0][1];
+      const float ptx = ((float)px + 0.5f) / (float)L->W, pty = ((float)py + 0.5f) / (float)L->H; /* pass_TexCoord */
+      float c[4] = {0, 0, 0, 0}, d;
+      int level = 0;
+      for (; level < L->num_lods; ++level) {
+        const int cx = (int)((float)L->off[level][0] + (float)L->res[level][0] * tcx);
+        const int cy = (int)((float)L->off[level][1] + (float)L->res[level][1] * tcy);
+        fc_fetch(ncol, ndep, L, cx, cy, c, &d);
+        if (c[3] > 0.0f) break;
+      }
+      if (level > 0) {
+        float p[2][2];
+        for (int k = 0; k < 2; ++k) {
+          const int l = level + 1 + k; /* level+1 -> p1, level+2 -> p2 */
+          const float ox = l < 20 ? (float)L->off[l][0] : 0.0f, oy = l < 20 ? (float)L->off[l][1] : 0.0f;
+          const float rx = l < 20 ? (float)L->res[l][0] : 0.0f, ry = l < 20 ? (float)L->res[l][1] : 0.0f;
+          p[k][0] = fc_clampf(ox + rx * ptx, ox + 0.5f, (ox + rx) - 0.5f) * rix;
+          p[k][1] = fc_clampf(oy + ry * pty, oy + 0.5f, (oy + ry) - 0.5f) * riy;
+        }
+        float c1[4], c2[4];
+        fc_texture(ncol, L, p[0][0], p[0][1], c1);
+        fc_texture(ncol, L, p[1][0], p[1][1], c2);
+        const float w1 = sqrtf(ptx * ptx + pty * pty); /* distance(pass_TexCoord, floor(pass_TexCoord)) */
+        const float w2 = 1.0f - w1;
+        for (int k = 0; k < 4; ++k) c[k] = (c1[k] * w1 + c2[k] * w2) / (w1 + w2);
+      }
+      float c0[4], d0;
+      fc_fetch(ncol, ndep, L, (int)((float)L->off[0][0] + (float)L->res[0][0] * tcx),
+               (int)((float)L->off[0][1] + (float)L->res[0][1] * tcy), c0, &d0);
+      memcpy(out_col + ((size_t)py * L->W + px) * 4, c, 16);
+      out_dep[(size_t)py * L->W + px] = d0;
+    }
+}
+
+ORC_API void orc_fill_colors(const float* color /* H*W*4 */, const float* depth /* H*W */, int W, int H,
+                             float* out_color, float* out_depth, float* atlas_color /* H*FW*4 or NULL */)
+{
+  fc_layout L;
+  fc_make_layout(W, H, &L);
+  const size_t n = (size_t)L.FW * H;
+  float* ncol = (float*)malloc(n * 16);
+  float* ndep = (float*)malloc(n * 4);
+  float* scol = (float*)malloc(n * 16);
+  float* sdep = (float*)malloc(n * 4);
+  /* m_view_inpaint after draw(): cleared atlas with the ray-marched frame in LOD 0 */
+  fc_clear(ncol, ndep, &L);
+  for (int y = 0; y < H; ++y) {
+    memcpy(ncol + (size_t)y * L.FW * 4, color + (size_t)y * W * 4, (size_t)W * 16);
+    memcpy(ndep + (size_t)y * L.FW, depth + (size_t)y * W, (size_t)W * 4);
+  }
+  fc_transfer(ncol, ndep, scol, sdep, &L);
+  for (int i = 1; i < L.num_lods; ++i) {
+    fc_inpaint(scol, sdep, ncol, ndep, &L, i - 1);
+    fc_transfer(ncol, ndep, scol, sdep, &L);
+  }
+  fc_colorfill(ncol, ndep, &L, out_color, out_depth);
+  if (atlas_color) memcpy(atlas_color, ncol, n * 16);
+  free(ncol);
+  free(ndep);
+  free(scol);
+  free(sdep);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -84,6 +84,9 @@ struct rgbdr_ctx {
   size_t linear_floats = 0;
   float* d_view = nullptr;    // ray-march outputs: rgba, depth, samples
   size_t view_pixels = 0;
+  int view_w = 0, view_h = 0; // size of the last ray-marched frame
+  float* d_fill = nullptr;    // hole-fill atlases (2 x colour + depth) and the filled frame
+  size_t fill_floats = 0;
   bool integrated = false;
 
   // bricks
@@ -165,8 +168,10 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_tsdf_base);
   (void)hipFree(c->d_linear);
   (void)hipFree(c->d_view);
-  c->d_view = nullptr;
-  c->view_pixels = 0;
+  (void)hipFree(c->d_fill);
+  c->d_view = c->d_fill = nullptr;
+  c->view_pixels = c->fill_floats = 0;
+  c->view_w = c->view_h = 0;
   c->integrated = false;
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
@@ -1239,9 +1244,44 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   launch_raymarch(p, ctx->stream);
   tend(ctx, "draw", ctx->stream);
   LAUNCHCHK("raymarch");
+  ctx->view_w = v->width;
+  ctx->view_h = v->height;
   if (color) HIPCHK(hipMemcpyAsync(color, p.out_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (depth) HIPCHK(hipMemcpyAsync(depth, p.out_depth, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (num_samples) HIPCHK(hipMemcpyAsync(num_samples, p.out_samples, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "fill_colors before raymarch");
+  HIPCHK(hipSetDevice(ctx->device));
+  FillLayout L;
+  make_fill_layout(ctx->view_w, ctx->view_h, &L);
+  const size_t na = (size_t)L.FW * L.H, npix = (size_t)L.W * L.H;
+  const size_t need = na * 10 + npix * 5;  // two atlases (rgba + depth) + the filled frame
+  if (ctx->fill_floats < need) {
+    (void)hipFree(ctx->d_fill);
+    ctx->d_fill = nullptr;
+    ctx->fill_floats = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_fill, need * sizeof(float)));
+    ctx->fill_floats = need;
+  }
+  float4* ncol = (float4*)ctx->d_fill;
+  float4* scol = (float4*)(ctx->d_fill + na * 4);
+  float4* ocol = (float4*)(ctx->d_fill + na * 8);
+  float* ndep = ctx->d_fill + na * 8 + npix * 4;
+  float* sdep = ndep + na;
+  float* odep = sdep + na;
+  tbegin(ctx, "holefill", ctx->stream);
+  launch_fill_colors(L, (const float4*)ctx->d_view, ctx->d_view + npix * 4, ncol, ndep, scol, sdep, ocol, odep,
+                     ctx->stream);
+  tend(ctx, "holefill", ctx->stream);
+  LAUNCHCHK("fill_colors");
+  if (color) HIPCHK(hipMemcpyAsync(color, ocol, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth) HIPCHK(hipMemcpyAsync(depth, odep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }

@@ -119,6 +119,26 @@ void camera_position(const float* xyz, const uint32_t res[3], float out[3])
   for (int k = 0; k < 3; ++k) out[k] = (pt[0][k] + pt[1][k] + pt[2][k] + pt[3][k]) / 4.0f;
 }
 
+void make_fill_layout(int W, int H, FillLayout* L)
+{
+  std::memset(L, 0, sizeof(*L));
+  L->W = W;
+  L->H = H;
+  L->FW = (int)((float)W * 1.5f);  // m_resolution_full = uvec2{width * 1.5f, height}
+  L->num_lods = 1 + (int)std::floor(std::log2((float)(W < H ? W : H)));
+  if (L->num_lods > 20) L->num_lods = 20;  // the shaders' uniform arrays hold 20 entries
+  int oy = H;
+  for (int i = 0; i < L->num_lods; ++i) {
+    L->res[i][0] = (int)std::floor((float)W / std::pow(2.0f, (float)i));
+    L->res[i][1] = (int)std::floor((float)H / std::pow(2.0f, (float)i));
+    if (i > 0) {
+      oy -= L->res[i][1];
+      L->off[i][0] = W;
+      L->off[i][1] = oy;
+    }
+  }
+}
+
 void frustum_planes(const float* xyz, const uint32_t res[3], float planes[6][4])
 {
   const uint32_t ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
   if (px >= p.width || py >= p.height) return;
   const size_t o = (size_t)py * p.width + px;
   const float limit = p.limit, sd = limit * 0.5f;
-  float4 rgba = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
+  const float4 cleared = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
+  float4 rgba = cleared;
   float fdepth = 1.0f, fsamples = 0.0f;
   do {
     const float4 pc = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
@@ -208,7 +209,13 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
       }
       rgba = make_float4(r[0], r[1], r[2], diff[3]);
     }
-    fdepth = (p.projection[10] * vp.z + p.projection[14]) / -vp.z * 0.5f + 0.5f;
+    // gl_FragDepth is clamped to the depth range and tested GL_LESS against the cleared 1.0
+    const float fd = (p.projection[10] * vp.z + p.projection[14]) / -vp.z * 0.5f + 0.5f;
+    fdepth = fminf(fmaxf(fd, 0.0f), 1.0f);
+    if (!(fdepth < 1.0f)) {
+      rgba = cleared;
+      fdepth = 1.0f;
+    }
   } while (false);
   p.out_color[o] = rgba;
   p.out_depth[o] = fdepth;

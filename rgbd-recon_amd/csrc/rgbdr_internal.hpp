@@ -119,6 +119,15 @@ struct RaymarchParams {
 };
 void launch_raymarch(const RaymarchParams& p, hipStream_t s);
 
+// LOD atlas of ViewLod::setResolution (framework/rendering/view_lod.cpp:24-61)
+struct FillLayout {
+  int W, H, FW, num_lods;
+  int off[20][2], res[20][2];
+};
+void make_fill_layout(int W, int H, FillLayout* L);  // geometry.cpp
+void launch_fill_colors(const FillLayout& L, const float4* frame_col, const float* frame_dep, float4* ncol, float* ndep,
+                        float4* scol, float* sdep, float4* out_col, float* out_dep, hipStream_t s);
+
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__

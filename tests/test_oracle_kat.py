@@ -239,3 +239,50 @@ def test_camera_position_recovers_pinhole(orc, pkg):
     s = pkg.synth.Sensor(1, 4, 64, 53)
     xyz, _ = pkg.synth.forward_luts(s, (16, 13, 16))
     np.testing.assert_allclose(orc.camera_pos(xyz), s.pos, atol=2e-4)
+
+
+# ---- hole filling of the ray-marched frame (fillColors) ----------------------
+def test_fill_layout_matches_viewlod(orc):
+    n, fw, off, res = orc.fill_layout(1280, 720)
+    assert n == 10 and fw == 1920                       # 1 + floor(log2(720)), 1.5 * W
+    assert tuple(res[0]) == (1280, 720) and tuple(res[1]) == (640, 360) and tuple(res[9]) == (2, 1)
+    assert tuple(off[0]) == (0, 0) and tuple(off[1]) == (1280, 360) and tuple(off[2]) == (1280, 180)
+    assert np.all(off[n:] == 0) and np.all(res[n:] == 0)
+
+
+def test_fill_colors_keeps_covered_pixels_and_fills_holes(orc):
+    W, H = 64, 48
+    rng = np.random.default_rng(4)
+    color = np.zeros((H, W, 4), np.float32)
+    color[..., :3] = rng.random((H, W, 3))
+    color[..., 3] = 1.0
+    depth = np.full((H, W), 0.5, np.float32)
+    # a hole in the cleared state the ray-marcher leaves: (0,1,0,0), depth 1
+    color[20:24, 30:34] = (0.0, 1.0, 0.0, 0.0)
+    depth[20:24, 30:34] = 1.0
+    oc, od = orc.fill_colors(color, depth)
+    covered = np.ones((H, W), bool)
+    covered[20:24, 30:34] = False
+    assert np.array_equal(oc[covered], color[covered])          # level 0 hit: unchanged
+    assert np.array_equal(od, depth)                            # depth comes from LOD 0 always
+    hole = oc[20:24, 30:34]
+    assert np.all(hole[..., 3] > 0) and np.all(hole[..., :3] >= 0) and np.all(hole[..., :3] <= 1)
+    assert not np.any((hole[..., 0] == 0) & (hole[..., 1] == 1) & (hole[..., 2] == 0))   # no clear colour left
+
+
+def test_fill_colors_prefers_far_samples(orc):
+    # tsdf_inpaint.fs keeps samples with depth >= the mean depth of the valid ones: the hole
+    # between a near red and a far blue surface is filled with blue
+    W, H = 32, 32
+    rng = np.random.default_rng(8)
+    jitter = (rng.random((H, W)) * 1e-3).astype(np.float32)    # exactly equal depths make sum/n round above
+    color = np.zeros((H, W, 4), np.float32)                    # every sample and the shader divides 0 by 0
+    depth = np.ones((H, W), np.float32)
+    color[:, :14] = (1, 0, 0, 1)
+    depth[:, :14] = 0.2 + jitter[:, :14]
+    color[:, 18:] = (0, 0, 1, 1)
+    depth[:, 18:] = 0.8 + jitter[:, 18:]
+    color[:, 14:18] = (0, 1, 0, 0)
+    oc, _ = orc.fill_colors(color, depth)
+    mid = oc[8:24, 15:17, :3]
+    assert np.all(np.isfinite(mid)) and np.all(mid[..., 2] > mid[..., 0])

@@ -88,3 +88,28 @@ def test_raymarch_errors(pkg, orc):
         ctx2.raymarch(view)
     assert e.value.status == capi.ERR_STATE
     ctx2.close()
+
+
+@pytest.mark.parametrize("wh", [(96, 72), (130, 75)])
+def test_fill_colors_matches_oracle(pkg, orc, wh):
+    scene, ctx, inv = setup(pkg, orc)
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, wh[0], wh[1], BMIN, BMAX)
+    color, depth, _ = ctx.raymarch(view)
+    fc, fd = ctx.fill_colors(wh[0], wh[1])
+    rc, rd = orc.fill_colors(color, depth)
+    assert same_bits(fd, rd), count_diff(fd, rd)
+    assert same_bits(fc, rc), count_diff(fc, rc)
+    holes = color[..., 3] <= 0
+    assert holes.mean() > 0.05 and (fc[..., 3] > 0)[holes].mean() > 0.5     # holes exist and get filled
+    if wh == (96, 72):        # (for sizes where res * (px / res) rounds below px the shader reads a neighbour)
+        assert same_bits(fc[~holes], color[~holes])
+    ctx.close()
+
+
+def test_fill_colors_needs_a_frame(pkg):
+    capi = pkg.capi
+    ctx = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx.fill_colors(8, 8)
+    assert e.value.status == capi.ERR_STATE
+    ctx.close()
