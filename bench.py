@@ -215,6 +215,25 @@ def main():
         except Exception:
             pass
 
+    # ---- consumer of the volume (BASELINE config 5 names the post-pass): extra keys ----
+    if world == 1:
+        try:
+            ctx.set_use_bricks(False)
+            ctx.integrate()
+            ctx.enable_timers(True)
+            view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
+                                  synth.BBOX_MAX)
+            ctx.raymarch(view)
+            _, depth_img, _ = ctx.raymarch(view)
+            ctx.fill_colors(1280, 720)
+            ctx.fill_colors(1280, 720)
+            out["post_pass"] = {"viewport": [1280, 720], "raymarch_ms": round(ctx.timer_ns("draw") * 1e-6, 4),
+                                "holefill_ms": round(ctx.timer_ns("holefill") * 1e-6, 4),
+                                "surface_pixels": round(float((depth_img < 1).mean()), 4)}
+            ctx.enable_timers(False)
+        except capi.RgbdrError as e:           # never let the extra keys break the headline
+            out["post_pass"] = {"error": str(e)}
+
     # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)

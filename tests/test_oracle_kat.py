@@ -286,3 +286,15 @@ def test_fill_colors_prefers_far_samples(orc):
     oc, _ = orc.fill_colors(color, depth)
     mid = oc[8:24, 15:17, :3]
     assert np.all(np.isfinite(mid)) and np.all(mid[..., 2] > mid[..., 0])
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """the C restatement driven over every entry point (NaN / inf / invalid-LUT inputs
+    included) under AddressSanitizer + UBSan; GPU sanitizers do not exist on the pool"""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "-C", os.path.join(root, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "selftest done" in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
