@@ -280,7 +280,7 @@ typedef struct {
   float camera_pos[3];           /* camera in volume space, :203-206 */
   int32_t width, height;         /* viewport */
   int32_t shade_mode;            /* UBO Settings.g_shade_mode: 0 colour, 1 shaded, 2 normal, 3 camera influence */
-  int32_t skip_space;            /* brick depth-peel start positions (8f-4): not implemented, must be 0 */
+  int32_t skip_space;            /* m_skip_space && m_use_bricks: start each ray at the brick depth peels */
 } rgbdr_view;
 
 /* ReconIntegration::draw: one ray per pixel through the whole TSDF volume (step
@@ -291,6 +291,12 @@ typedef struct {
  * ViewLod::enable: (0,1,0,0), depth 1.  Needs the whole volume in this context
  * (slab_count == 1) and a completed integrate(). */
 int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, float* depth, float* num_samples);
+
+/* ReconIntegration::drawDepthLimits (recon_integration.cpp:409-429, glsl/bricks.*): the
+ * occupied bricks' depth peels for `view`: height*width RGBA32F texels (nearest face z,
+ * -farthest face z, nearest back-face z, 0), cleared value (1,0,1,0).  rgbdr_raymarch runs
+ * it by itself when view->skip_space is set; this entry point exposes the image. */
+int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels);
 
 /* ReconIntegration::fillColors (recon_integration.cpp:280-339): screen-space hole
  * filling of the frame the last rgbdr_raymarch produced -- the tsdf_inpaint.fs pyramid

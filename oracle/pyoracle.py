@@ -256,7 +256,24 @@ def inverse_volume(cv_xyz, bbox_min, bbox_max, vol_res, z_range=None):
     return out
 
 
-def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit=0.01):
+class BrickGrid(C.Structure):
+    _fields_ = [("bbox_min", C.c_float * 3), ("brick_size", C.c_float), ("res_bricks", C.c_int * 3)]
+
+
+def depth_peels(view_bytes, bbox_min, brick_size, res_bricks, counters, mask):
+    v = View.from_buffer_copy(view_bytes)
+    g = BrickGrid()
+    g.bbox_min[:] = list(bbox_min)
+    g.brick_size = brick_size
+    g.res_bricks[:] = list(res_bricks)
+    c = np.ascontiguousarray(counters, dtype=np.uint32)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty((v.height, v.width, 4), dtype=np.float32)
+    lib().orc_depth_peels(C.byref(v), C.byref(g), _p(c), _p(m), _p(out))
+    return out
+
+
+def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit=0.01, peels=None):
     """tsdf [Z,Y,X]; inv_luts [Iz,Iy,Ix,4]; uv_luts [Rz,Ry,Rx,2]; colors u8 [Hc,Wc,3]"""
     v = View.from_buffer_copy(view_bytes)
     n = len(inv_luts)
@@ -281,8 +298,9 @@ def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit
     color = np.empty((v.height, v.width, 4), dtype=np.float32)
     depth = np.empty((v.height, v.width), dtype=np.float32)
     ns = np.empty((v.height, v.width), dtype=np.float32)
+    pk = f32(peels) if peels is not None else None
     lib().orc_raymarch(C.byref(v), C.byref(p), _p(tsdf), arr(inv), inv_res, arr(uv), uv_res, arr(col), arr(db), arr(q),
-                       _p(color), _p(depth), _p(ns))
+                       _p(pk) if pk is not None else None, _p(color), _p(depth), _p(ns))
     return color, depth, ns
 
 

@@ -757,7 +757,7 @@ typedef struct {
   float camera_pos[3];             /* volume space */
   int width, height;
   int shade_mode;
-  int skip_space;                  /* depth peels (f-4) not restated: must be 0 */
+  int skip_space;                  /* start positions from the brick depth peels (getStartPos) */
 } orc_view;
 
 typedef struct {
@@ -770,6 +770,184 @@ static inline void mat4_mul_vec4(const float* m, const float* v, float* o)
 {
   /* glm: m[0]*v.x + m[1]*v.y + (m[2]*v.z + m[3]*v.w), columns m[c] = m + 4c */
   for (int r = 0; r < 4; ++r) o[r] = (m[r] * v[0] + m[4 + r] * v[1]) + (m[8 + r] * v[2] + m[12 + r] * v[3]);
+}
+
+/* ---- brick depth peels (f-4): ReconIntegration::drawDepthLimits (recon_integration.cpp:409-429)
+ * with glsl/bricks.{vs,gs,fs}: the occupied bricks are drawn as instanced unit cubes, no
+ * culling, no depth test, MIN blending into an RGBA32F target cleared to (1,0,1,0); the
+ * fragment shader writes (z, -z, front-facing ? 1 : z, 1) and the geometry shader drops a
+ * face whose neighbour brick across it has a counter > 10 (inc_bricks.glsl:60-62).  Per pixel
+ * that is: r = nearest emitted face, -g = farthest, b = nearest back face.  Restated per
+ * ray: walk the brick grid along the pixel's ray; entering an occupied brick is a front
+ * face, leaving one a back face (the unit-cube strip is wound counter-clockwise seen from
+ * outside); faces outside the depth range [0,1] are clipped.  A neighbour outside the
+ * grid counts as not occupied (the shader indexes out of range there). */
+
+typedef struct {
+  float bbox_min[3];
+  float brick_size;
+  int res_bricks[3];
+} orc_brick_grid;
+
+static inline float peel_z(const float* pmv, const float* o, const float* d, float t)
+{
+  const float w4[4] = {o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t, 1.0f};
+  float c[4];
+  mat4_mul_vec4(pmv, w4, c);
+  return (c[2] / c[3]) * 0.5f + 0.5f;
+}
+
+static inline int grid_counter_gt10(const orc_brick_grid* g, const uint32_t* counters, const int* c)
+{
+  if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->res_bricks[0] || c[1] >= g->res_bricks[1] || c[2] >= g->res_bricks[2]) return 0;
+  return counters[((size_t)c[2] * g->res_bricks[1] + c[1]) * g->res_bricks[0] + c[0]] > 10u;
+}
+static inline int grid_in_list(const orc_brick_grid* g, const uint8_t* mask, const int* c)
+{
+  if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->res_bricks[0] || c[1] >= g->res_bricks[1] || c[2] >= g->res_bricks[2]) return 0;
+  return mask[((size_t)c[2] * g->res_bricks[1] + c[1]) * g->res_bricks[0] + c[0]] != 0;
+}
+
+/* one pixel: out = (r, g, b, a) */
+static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_brick_grid* g, const uint32_t* counters,
+                             const uint8_t* mask, int px, int py, float* out)
+{
+  out[0] = 1.0f;
+  out[1] = 0.0f;
+  out[2] = 1.0f;
+  out[3] = 0.0f;
+  /* world-space ray: camera -> far-plane point of the pixel centre */
+  const float z4[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+  float o4[4], pc[4], es[4], f4[4];
+  mat4_mul_vec4(vw->modelview_inv, z4, o4);
+  const float frag[4] = {(float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f};
+  mat4_mul_vec4(vw->img_to_eye, frag, pc);
+  es[0] = pc[0] / pc[3];
+  es[1] = pc[1] / pc[3];
+  es[2] = pc[2] / pc[3];
+  es[3] = 1.0f;
+  mat4_mul_vec4(vw->modelview_inv, es, f4);
+  const float o[3] = {o4[0], o4[1], o4[2]};
+  const float d[3] = {f4[0] - o4[0], f4[1] - o4[1], f4[2] - o4[2]};
+  /* clip the segment t in [0,1] against the brick grid's box */
+  float t0 = 0.0f, t1 = 1.0f;
+  for (int a = 0; a < 3; ++a) {
+    const float lo = g->bbox_min[a], hi = g->bbox_min[a] + g->brick_size * (float)g->res_bricks[a];
+    const float inv = 1.0f / d[a];
+    const float ta = (lo - o[a]) * inv, tb = (hi - o[a]) * inv;
+    t0 = fmaxf(t0, fminf(ta, tb));
+    t1 = fminf(t1, fmaxf(ta, tb));
+  }
+  if (!(t0 < t1)) return;
+  /* Amanatides-Woo walk */
+  int cell[3], stepi[3];
+  float tmax[3], tdelta[3];
+  const float tstart = t0;
+  for (int a = 0; a < 3; ++a) {
+    const float pos = (o[a] + d[a] * tstart - g->bbox_min[a]) / g->brick_size;
+    int c = (int)floorf(pos);
+    if (c < 0) c = 0;
+    if (c > g->res_bricks[a] - 1) c = g->res_bricks[a] - 1;
+    cell[a] = c;
+    if (d[a] > 0.0f) {
+      stepi[a] = 1;
+      tmax[a] = (g->bbox_min[a] + g->brick_size * (float)(c + 1) - o[a]) / d[a];
+      tdelta[a] = g->brick_size / d[a];
+    } else if (d[a] < 0.0f) {
+      stepi[a] = -1;
+      tmax[a] = (g->bbox_min[a] + g->brick_size * (float)c - o[a]) / d[a];
+      tdelta[a] = -g->brick_size / d[a];
+    } else {
+      stepi[a] = 0;
+      tmax[a] = INFINITY;
+      tdelta[a] = INFINITY;
+    }
+  }
+  float r = 1.0f, gneg = 0.0f, b = 1.0f;
+  /* entry into the grid from outside (t0 > 0): previous cell is outside the grid */
+  int prev_in_grid = 0, prev[3] = {-1, -1, -1};
+  float tcur = t0;
+  int first = 1;
+  for (int iter = 0; iter < 4096; ++iter) {
+    /* boundary between prev and cell at tcur (skipped for the start cell when the ray begins inside it) */
+    if (!(first && !(t0 > 0.0f))) {
+      const int cur_list = grid_in_list(g, mask, cell);
+      const int prev_list = prev_in_grid ? grid_in_list(g, mask, prev) : 0;
+      if (cur_list || prev_list) {
+        const float z = peel_z(pmv, o, d, tcur);
+        if (z >= 0.0f && z <= 1.0f) {
+          if (cur_list && !(prev_in_grid && grid_counter_gt10(g, counters, prev))) { /* front face of `cell` */
+            r = fminf(r, z);
+            gneg = fminf(gneg, -z);
+          }
+          if (prev_list && !grid_counter_gt10(g, counters, cell)) { /* back face of `prev` */
+            r = fminf(r, z);
+            gneg = fminf(gneg, -z);
+            b = fminf(b, z);
+          }
+        }
+      }
+    }
+    first = 0;
+    /* advance to the next cell */
+    int a = 0;
+    if (tmax[1] < tmax[a]) a = 1;
+    if (tmax[2] < tmax[a]) a = 2;
+    const float tnext = tmax[a];
+    if (!(tnext < t1)) {
+      /* leaving through the grid's outer box at t1: back face of the last cell */
+      if (grid_in_list(g, mask, cell)) {
+        const float z = peel_z(pmv, o, d, t1);
+        if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
+          r = fminf(r, z);
+          gneg = fminf(gneg, -z);
+          b = fminf(b, z);
+        }
+      }
+      break;
+    }
+    prev[0] = cell[0];
+    prev[1] = cell[1];
+    prev[2] = cell[2];
+    prev_in_grid = 1;
+    cell[a] += stepi[a];
+    tmax[a] += tdelta[a];
+    tcur = tnext;
+    if (cell[a] < 0 || cell[a] >= g->res_bricks[a]) {
+      /* stepped out of the grid: back face of prev */
+      if (grid_in_list(g, mask, prev)) {
+        const float z = peel_z(pmv, o, d, tcur);
+        if (z >= 0.0f && z <= 1.0f) {
+          r = fminf(r, z);
+          gneg = fminf(gneg, -z);
+          b = fminf(b, z);
+        }
+      }
+      break;
+    }
+  }
+  out[0] = r;
+  out[1] = gneg;
+  out[2] = b;
+  out[3] = 0.0f;
+}
+
+static void mat4_mul_mat4(const float* a, const float* bm, float* o)
+{
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      o[4 * c + r] = a[r] * bm[4 * c] + a[4 + r] * bm[4 * c + 1] + a[8 + r] * bm[4 * c + 2] + a[12 + r] * bm[4 * c + 3];
+}
+
+ORC_API void orc_depth_peels(const orc_view* vw, const orc_brick_grid* g, const uint32_t* counters,
+                             const uint8_t* mask, float* out /* H*W*4 */)
+{
+  float pmv[16];
+  mat4_mul_mat4(vw->projection, vw->modelview, pmv); /* gl_ProjectionMatrix * gl_ModelViewMatrix, bricks.vs:19 */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int py = 0; py < vw->height; ++py)
+    for (int px = 0; px < vw->width; ++px)
+      depth_peel_pixel(vw, pmv, g, counters, mask, px, py, out + ((size_t)py * vw->width + px) * 4);
 }
 
 static inline float tsdf_sample(const float* tsdf, const int* res, const float* p)
@@ -800,8 +978,8 @@ static const float rm_camera_colors[5][3] = {{228, 26, 28}, {55, 126, 184}, {77,
 ORC_API void orc_raymarch(const orc_view* vw, const orc_raymarch_params* p, const float* tsdf /* Z*Y*X */,
                           const float* const* cv_xyz_inv /* RGBA */, const int* inv_res, const float* const* cv_uv,
                           const int* uv_res, const uint8_t* const* colors, const float* const* depth_b_rg,
-                          const float* const* quality, float* out_color /* H*W*4 */, float* out_depth /* H*W */,
-                          float* out_samples /* H*W */)
+                          const float* const* quality, const float* peels /* H*W*4 when skip_space */,
+                          float* out_color /* H*W*4 */, float* out_depth /* H*W */, float* out_samples /* H*W */)
 {
   const float limit = p->limit, sd = limit * 0.5f;
   /* gl_ModelViewMatrix * vol_to_world (the shader's left-to-right product, :123), glm association */
@@ -851,8 +1029,38 @@ ORC_API void orc_raymarch(const orc_view* vw, const orc_raymarch_params* p, cons
       const float t_far = is_t0 ? t1 : t0;
       float sp[3] = {vw->camera_pos[0] + step[0] * t_near, vw->camera_pos[1] + step[1] * t_near,
                      vw->camera_pos[2] + step[2] * t_near};
-      const float fmaxs = ceilf(fabsf(t_far - t_near));
-      const unsigned max_num = fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs;
+      float fmaxs = ceilf(fabsf(t_far - t_near));
+      if (vw->skip_space) { /* getStartPos, :392-401 */
+        float dr = peels[o * 4 + 0];
+        const float dg = peels[o * 4 + 1], dbk = peels[o * 4 + 2];
+        dr = (dr >= dbk) ? 0.0f : dr; /* gl_DepthRange.near */
+        float pf[3], pb[3];
+        for (int k = 0; k < 2; ++k) {
+          const float fr[4] = {(float)px + 0.5f, (float)py + 0.5f, k == 0 ? dr : -dg, 1.0f};
+          float a4[4], e4[4], w4[4], v4[4];
+          mat4_mul_vec4(vw->img_to_eye, fr, a4);
+          e4[0] = a4[0] / a4[3];
+          e4[1] = a4[1] / a4[3];
+          e4[2] = a4[2] / a4[3];
+          e4[3] = 1.0f;
+          mat4_mul_vec4(vw->modelview_inv, e4, w4);
+          mat4_mul_vec4(vw->vol_to_world_inv, w4, v4);
+          float* dst = k == 0 ? pf : pb;
+          dst[0] = v4[0];
+          dst[1] = v4[1];
+          dst[2] = v4[2];
+        }
+        if (dr >= 1.0f) {
+          pb[0] = pf[0];
+          pb[1] = pf[1];
+          pb[2] = pf[2];
+        }
+        sp[0] = pf[0];
+        sp[1] = pf[1];
+        sp[2] = pf[2];
+        fmaxs = ceilf(distance3(pf, pb) / sd);
+      }
+      const unsigned max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs);
       float prev = -limit;
       unsigned num = 0;
       int hit = 0;

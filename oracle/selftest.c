@@ -144,7 +144,19 @@ int main(void)
   float* on = malloc(sizeof(float) * 24 * 18);
   for (int mode = 0; mode < 4; ++mode) {
     v.shade_mode = mode;
-    orc_raymarch(&v, &rp, tsdf, invs, inv_res, uvs, uv_res, cols, dbs, qs, oc, od, on);
+    orc_raymarch(&v, &rp, tsdf, invs, inv_res, uvs, uv_res, cols, dbs, qs, NULL, oc, od, on);
+  }
+  {
+    orc_brick_grid bg = {{0.0f, 0.0f, 0.0f}, 0.125f, {8, 8, 8}};
+    float* peels = malloc(sizeof(float) * 24 * 18 * 4);
+    uint8_t mask512[512];
+    for (int i = 0; i < 512; ++i) mask512[i] = bricks[i] >= 3u;
+    orc_depth_peels(&v, &bg, bricks, mask512, peels);
+    v.skip_space = 1;
+    v.shade_mode = 0;
+    orc_raymarch(&v, &rp, tsdf, invs, inv_res, uvs, uv_res, cols, dbs, qs, peels, oc, od, on);
+    v.skip_space = 0;
+    printf("peels %.6f\n", checksum(peels, 24 * 18 * 4));
   }
   printf("raymarch %.6f %.6f\n", checksum(oc, 24 * 18 * 4), checksum(on, 24 * 18));
   float* fc = malloc(sizeof(float) * 24 * 18 * 4);

@@ -176,6 +176,7 @@ SYMBOLS = {
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_draw_depth_limits": (C.c_int, [_P, C.POINTER(View), _F]),
     "rgbdr_stream": (_P, [_P]),
     "rgbdr_set_stream": (C.c_int, [_P, _P]),
     "rgbdr_enable_timers": (C.c_int, [_P, C.c_int]),
@@ -445,6 +446,11 @@ class Context:
         self._chk(lib().rgbdr_raymarch(self._h, C.byref(view), color.ctypes.data_as(_F), depth.ctypes.data_as(_F),
                                        ns.ctypes.data_as(_F)))
         return color, depth, ns
+
+    def draw_depth_limits(self, view):
+        out = np.empty((view.height, view.width, 4), dtype=np.float32)
+        self._chk(lib().rgbdr_draw_depth_limits(self._h, C.byref(view), out.ctypes.data_as(_F)))
+        return out
 
     def fill_colors(self, width, height):
         """ReconIntegration::fillColors on the last ray-marched frame"""

@@ -1175,12 +1175,70 @@ int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
   return RGBDR_OK;
 }
 
+// d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4)
+static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
+{
+  if (ctx->view_pixels >= npix) return RGBDR_OK;
+  (void)hipFree(ctx->d_view);
+  ctx->d_view = nullptr;
+  ctx->view_pixels = 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 10 * sizeof(float)));
+  ctx->view_pixels = npix;
+  return RGBDR_OK;
+}
+
+static void mat4_product(const float* a, const float* b, float* o)  // glm association, column-major
+{
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) o[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3];
+}
+
+// ReconIntegration::drawDepthLimits into the peel image of the view buffers
+static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
+{
+  if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "depth limits before update_occupied_bricks");
+  PeelParams p{};
+  mat4_product(v->projection, v->modelview, p.pmv);
+  std::memcpy(p.modelview_inv, v->modelview_inv, 64);
+  std::memcpy(p.img_to_eye, v->img_to_eye, 64);
+  p.width = v->width;
+  p.height = v->height;
+  for (int a = 0; a < 3; ++a) {
+    p.bbox_min[a] = ctx->cfg.bbox_min[a];
+    p.res_bricks[a] = ctx->geo.res_bricks[a];
+  }
+  p.brick_size = ctx->geo.brick_size;
+  p.counters = ctx->d_counters;
+  p.mask = ctx->mask_buf(ctx->rbuf);
+  p.out = out;
+  tbegin(ctx, "brickdraw", ctx->stream);
+  launch_depth_peels(p, ctx->stream);
+  tend(ctx, "brickdraw", ctx->stream);
+  LAUNCHCHK("depth_peels");
+  return RGBDR_OK;
+}
+
+int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)v->width * v->height;
+  int rc = ensure_view_buffers(ctx, npix);
+  if (rc != RGBDR_OK) return rc;
+  float4* out = (float4*)(ctx->d_view + npix * 6);
+  rc = draw_depth_limits(ctx, v, out);
+  if (rc != RGBDR_OK) return rc;
+  if (peels) HIPCHK(hipMemcpyAsync(peels, out, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
 int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
   if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
-  if (v->skip_space) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "skip_space (brick depth peels) is not implemented");
   if (ctx->cfg.slab_count > 1) return ctx->fail(RGBDR_ERR_STATE, "raymarch needs the whole volume in one context");
   if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
   const int N = nsens(ctx);
@@ -1188,15 +1246,18 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   for (int i = 0; i < N; ++i) tiled = tiled && ctx->inv_tiled[i];
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)v->width * v->height;
-  if (ctx->view_pixels < npix) {
-    (void)hipFree(ctx->d_view);
-    ctx->d_view = nullptr;
-    ctx->view_pixels = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 6 * sizeof(float)));
-    ctx->view_pixels = npix;
+  {
+    int rc_ = ensure_view_buffers(ctx, npix);
+    if (rc_ != RGBDR_OK) return rc_;
   }
   const rgbdr_geometry& g = ctx->geo;
   RaymarchParams p{};
+  p.skip_space = v->skip_space ? 1 : 0;
+  p.peels = (const float4*)(ctx->d_view + npix * 6);
+  if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
+    int rc_ = draw_depth_limits(ctx, v, (float4*)(ctx->d_view + npix * 6));
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   std::memcpy(p.projection, v->projection, 64);
   std::memcpy(p.normal_matrix, v->normal_matrix, 64);
   std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);

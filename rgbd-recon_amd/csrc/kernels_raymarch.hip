@@ -100,8 +100,33 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
     if (!(t0 <= t1) || !(t1 > 0.0f)) break;  // cube not rasterised onto this pixel
     const float t_near = t0 < 0.0f ? 0.0f : t0;
     float sp[3] = {p.camera_pos[0] + step[0] * t_near, p.camera_pos[1] + step[1] * t_near, p.camera_pos[2] + step[2] * t_near};
-    const float fmaxs = ceilf(fabsf(t1 - t_near));
-    const unsigned max_num = fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs;
+    float fmaxs = ceilf(fabsf(t1 - t_near));
+    if (p.skip_space) {  // getStartPos, tsdf_raymarch.fs:392-401
+      const float4 dmm = p.peels[o];
+      const float dr = (dmm.x >= dmm.z) ? 0.0f : dmm.x;  // closest back face is the closest face -> gl_DepthRange.near
+      float pf[3], pb[3];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float4 a4 = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, k == 0 ? dr : -dmm.y, 1.0f);
+        const float4 w4 = mat4_mul(p.modelview_inv, a4.x / a4.w, a4.y / a4.w, a4.z / a4.w, 1.0f);
+        const float4 v4 = mat4_mul(p.vol_to_world_inv, w4.x, w4.y, w4.z, w4.w);
+        float* dst = k == 0 ? pf : pb;
+        dst[0] = v4.x;
+        dst[1] = v4.y;
+        dst[2] = v4.z;
+      }
+      if (dr >= 1.0f) {
+        pb[0] = pf[0];
+        pb[1] = pf[1];
+        pb[2] = pf[2];
+      }
+      sp[0] = pf[0];
+      sp[1] = pf[1];
+      sp[2] = pf[2];
+      const float ex = pf[0] - pb[0], ey = pf[1] - pb[1], ez = pf[2] - pb[2];
+      fmaxs = ceilf(sqrtf(ex * ex + ey * ey + ez * ez) / sd);
+    }
+    const unsigned max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs);
     float prev = -limit;
     unsigned num = 0;
     bool hit = false;
@@ -220,6 +245,149 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
   p.out_color[o] = rgba;
   p.out_depth[o] = fdepth;
   p.out_samples[o] = fsamples;
+}
+
+// ---------------------------------------------------------------------------
+// Brick depth peels: ReconIntegration::drawDepthLimits with
+// glsl/bricks.{vs,gs,fs} -- instanced unit cubes of the occupied bricks, MIN blending
+// of (z, -z, front ? 1 : z) into a target cleared to (1,0,1,0), faces towards a
+// neighbour with counter > 10 dropped by the geometry shader.  Per pixel: walk the
+// brick grid along the ray (Amanatides-Woo); entering an occupied brick is a front
+// face, leaving one a back face; faces outside the depth range are clipped.
+__device__ __forceinline__ float peel_z(const PeelParams& p, const float* o, const float* d, float t)
+{
+  const float4 c = mat4_mul(p.pmv, o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t, 1.0f);
+  return (c.z / c.w) * 0.5f + 0.5f;
+}
+__device__ __forceinline__ bool peel_in_grid(const PeelParams& p, const int* c)
+{
+  return !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= p.res_bricks[0] || c[1] >= p.res_bricks[1] || c[2] >= p.res_bricks[2]);
+}
+__device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
+{
+  return peel_in_grid(p, c) && p.counters[((size_t)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0]] > 10u;
+}
+__device__ __forceinline__ bool peel_listed(const PeelParams& p, const int* c)
+{
+  return peel_in_grid(p, c) && p.mask[((size_t)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0]] != 0;
+}
+
+__global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
+{
+  const int px = blockIdx.x * 16 + threadIdx.x, py = blockIdx.y * 16 + threadIdx.y;
+  if (px >= p.width || py >= p.height) return;
+  float r = 1.0f, gneg = 0.0f, b = 1.0f;
+  do {
+    const float4 o4 = mat4_mul(p.modelview_inv, 0.0f, 0.0f, 0.0f, 1.0f);
+    const float4 pc = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
+    const float4 f4 = mat4_mul(p.modelview_inv, pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, 1.0f);
+    const float o[3] = {o4.x, o4.y, o4.z};
+    const float d[3] = {f4.x - o4.x, f4.y - o4.y, f4.z - o4.z};
+    float t0 = 0.0f, t1 = 1.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float lo = p.bbox_min[a], hi = p.bbox_min[a] + p.brick_size * (float)p.res_bricks[a];
+      const float inv = 1.0f / d[a];
+      const float ta = (lo - o[a]) * inv, tb = (hi - o[a]) * inv;
+      t0 = fmaxf(t0, fminf(ta, tb));
+      t1 = fminf(t1, fmaxf(ta, tb));
+    }
+    if (!(t0 < t1)) break;
+    int cell[3], stepi[3], prev[3] = {-1, -1, -1};
+    float tmax[3], tdelta[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float pos = (o[a] + d[a] * t0 - p.bbox_min[a]) / p.brick_size;
+      int c = (int)floorf(pos);
+      c = clampi(c, 0, p.res_bricks[a] - 1);
+      cell[a] = c;
+      if (d[a] > 0.0f) {
+        stepi[a] = 1;
+        tmax[a] = (p.bbox_min[a] + p.brick_size * (float)(c + 1) - o[a]) / d[a];
+        tdelta[a] = p.brick_size / d[a];
+      } else if (d[a] < 0.0f) {
+        stepi[a] = -1;
+        tmax[a] = (p.bbox_min[a] + p.brick_size * (float)c - o[a]) / d[a];
+        tdelta[a] = -p.brick_size / d[a];
+      } else {
+        stepi[a] = 0;
+        tmax[a] = __builtin_inff();
+        tdelta[a] = __builtin_inff();
+      }
+    }
+    bool prev_in_grid = false, first = true;
+    float tcur = t0;
+    for (int iter = 0; iter < 4096; ++iter) {
+      if (!(first && !(t0 > 0.0f))) {
+        const bool cur_list = peel_listed(p, cell);
+        const bool prev_list = prev_in_grid && peel_listed(p, prev);
+        if (cur_list || prev_list) {
+          const float z = peel_z(p, o, d, tcur);
+          if (z >= 0.0f && z <= 1.0f) {
+            if (cur_list && !(prev_in_grid && peel_gt10(p, prev))) {
+              r = fminf(r, z);
+              gneg = fminf(gneg, -z);
+            }
+            if (prev_list && !peel_gt10(p, cell)) {
+              r = fminf(r, z);
+              gneg = fminf(gneg, -z);
+              b = fminf(b, z);
+            }
+          }
+        }
+      }
+      first = false;
+      int a = 0;
+      if (tmax[1] < tmax[a]) a = 1;
+      if (tmax[2] < tmax[a]) a = 2;
+      const float tnext = tmax[a];
+      if (!(tnext < t1)) {
+        if (peel_listed(p, cell)) {
+          const float z = peel_z(p, o, d, t1);
+          if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
+            r = fminf(r, z);
+            gneg = fminf(gneg, -z);
+            b = fminf(b, z);
+          }
+        }
+        break;
+      }
+      prev[0] = cell[0];
+      prev[1] = cell[1];
+      prev[2] = cell[2];
+      prev_in_grid = true;
+      // no runtime-indexed register arrays: step the selected axis explicitly
+      if (a == 0) {
+        cell[0] += stepi[0];
+        tmax[0] += tdelta[0];
+      } else if (a == 1) {
+        cell[1] += stepi[1];
+        tmax[1] += tdelta[1];
+      } else {
+        cell[2] += stepi[2];
+        tmax[2] += tdelta[2];
+      }
+      tcur = tnext;
+      if (!peel_in_grid(p, cell)) {
+        if (peel_listed(p, prev)) {
+          const float z = peel_z(p, o, d, tcur);
+          if (z >= 0.0f && z <= 1.0f) {
+            r = fminf(r, z);
+            gneg = fminf(gneg, -z);
+            b = fminf(b, z);
+          }
+        }
+        break;
+      }
+    }
+  } while (false);
+  p.out[(size_t)py * p.width + px] = make_float4(r, gneg, b, 0.0f);
+}
+
+void launch_depth_peels(const PeelParams& p, hipStream_t s)
+{
+  dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
+  hipLaunchKernelGGL(k_depth_peels, grid, dim3(16, 16), 0, s, p);
 }
 
 void launch_raymarch(const RaymarchParams& p, hipStream_t s)

@@ -113,11 +113,26 @@ struct RaymarchParams {
   int uv_res[kMaxSensors][3];
   const uint8_t* color;        // [N][Hc][Wc][3]
   const uint2* frame[kMaxSensors];
+  int skip_space;              // start positions from the depth peels (getStartPos)
+  const float4* peels;
   float4* out_color;
   float* out_depth;
   float* out_samples;
 };
 void launch_raymarch(const RaymarchParams& p, hipStream_t s);
+
+// ReconIntegration::drawDepthLimits (glsl/bricks.{vs,gs,fs}) per pixel
+struct PeelParams {
+  float pmv[16];               // gl_ProjectionMatrix * gl_ModelViewMatrix
+  float modelview_inv[16], img_to_eye[16];
+  int width, height;
+  float bbox_min[3], brick_size;
+  int res_bricks[3];
+  const uint32_t* counters;
+  const uint8_t* mask;
+  float4* out;
+};
+void launch_depth_peels(const PeelParams& p, hipStream_t s);
 
 // LOD atlas of ViewLod::setResolution (framework/rendering/view_lod.cpp:24-61)
 struct FillLayout {

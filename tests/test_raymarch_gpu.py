@@ -74,11 +74,7 @@ def test_raymarch_errors(pkg, orc):
     capi = pkg.capi
     scene, ctx, inv = setup(pkg, orc, G=32)
     view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 32, 24, BMIN, BMAX)
-    view.skip_space = 1
-    with pytest.raises(capi.RgbdrError) as e:
-        ctx.raymarch(view)
-    assert e.value.status == capi.ERR_INVALID_ARGUMENT
-    view.skip_space, view.shade_mode = 0, 7
+    view.shade_mode = 7
     with pytest.raises(capi.RgbdrError):
         ctx.raymarch(view)
     ctx.close()
@@ -113,3 +109,44 @@ def test_fill_colors_needs_a_frame(pkg):
         ctx.fill_colors(8, 8)
     assert e.value.status == capi.ERR_STATE
     ctx.close()
+
+
+@pytest.mark.parametrize("eye", [(2.2, 1.6, 1.9), (0.85, 1.7, 0.8), (0.05, 1.95, 0.02)])
+def test_depth_peels_and_space_skipping(pkg, orc, eye):
+    """drawDepthLimits + the skipSpace start positions of the ray-marcher (f-4)"""
+    scene, ctx, inv = setup(pkg, orc)
+    ctx.set_use_bricks(True)
+    ctx.step(scene.depth, scene.color)
+    g = ctx.geo
+    view = pkg.capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX)
+    peels = ctx.draw_depth_limits(view)
+    counters = ctx.readback_brick_counters()
+    ids, _ = ctx.get_occupied()
+    mask = np.zeros(g.num_bricks, np.uint8)
+    mask[ids] = 1
+    ref = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), counters, mask)
+    assert same_bits(peels, ref), count_diff(peels, ref)
+    touched = peels[..., 0] < 1.0
+    assert 0.02 < touched.mean() < 0.98
+    assert np.all(peels[~touched] == np.float32([1, 0, 1, 0]))
+    assert np.all(-peels[touched][:, 1] >= peels[touched][:, 0])            # farthest >= nearest
+    # ray-march with space skipping == oracle with the same peels; surfaces agree with the full march
+    view.skip_space = 1
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images_skip(orc, ctx, scene, inv, view, ref)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc)
+    view.skip_space = 0
+    _, depth_full, ns_full = ctx.raymarch(view)
+    hit_skip, hit_full = depth < 1, depth_full < 1
+    assert (hit_skip & ~hit_full).mean() < 0.01
+    both = hit_skip & hit_full
+    assert both.mean() > 0.02 and np.percentile(np.abs(depth[both] - depth_full[both]), 99) < 5e-3
+    assert ns.sum() < 0.8 * ns_full.sum()                                     # fewer samples marched
+    ctx.close()
+
+
+def oracle_images_skip(orc, ctx, scene, inv, view, peels):
+    tsdf = ctx.readback_tsdf()
+    db = [ctx.readback_image(4, i) for i in range(2)]
+    q = [ctx.readback_image(7, i) for i in range(2)]
+    return orc.raymarch(bytes(view), tsdf, inv, scene.uv, [scene.color[i] for i in range(2)], db, q, peels=peels)
