@@ -73,9 +73,11 @@ def render_depth(s, seed, noise_sigma=0.002, hole_fraction=0.02, sphere_c=(0.0, 
     return depth.astype(np.float32)
 
 
-def render_color(s, seed):
-    """procedural RGB8 checker"""
-    y, x = np.meshgrid(np.arange(s.H), np.arange(s.W), indexing="ij")
+def render_color(s, seed, wh=None):
+    """procedural RGB8 checker (optionally at a colour resolution != the depth resolution;
+    cv_uv is normalised, so it addresses either)"""
+    w, h = wh if wh else (s.W, s.H)
+    y, x = np.meshgrid(np.arange(h) * s.H // h, np.arange(w) * s.W // w, indexing="ij")
     rng = np.random.default_rng(seed + 7919)
     base = ((x // 16 + y // 16) % 2).astype(np.float64)
     img = np.stack([40 + 180 * base, 60 + 120 * (1 - base), 90 + 100 * ((x // 32) % 2)], axis=-1)
@@ -124,7 +126,8 @@ def inverse_lut(s, res, bbox_min=BBOX_MIN, bbox_max=BBOX_MAX, z_range=None):
 class Scene:
     """All inputs of one configuration."""
 
-    def __init__(self, num_sensors, width, height, lut_res=(32, 27, 32), seed=1234, make_frames=True, sphere_r=None):
+    def __init__(self, num_sensors, width, height, lut_res=(32, 27, 32), seed=1234, make_frames=True, sphere_r=None,
+                 color_wh=None):
         self.N, self.W, self.H = num_sensors, width, height
         # SURVEY 8(d) scene: sphere r = 0.5 m.  At small test resolutions a 13x13
         # window spans most of such a sphere and the bilateral pass rejects every
@@ -141,7 +144,7 @@ class Scene:
             self.uv.append(b)
         if make_frames:
             self.depth = np.stack([render_depth(s, seed + i, sphere_r=sphere_r) for i, s in enumerate(self.sensors)])
-            self.color = np.stack([render_color(s, seed + i) for i, s in enumerate(self.sensors)])
+            self.color = np.stack([render_color(s, seed + i, color_wh) for i, s in enumerate(self.sensors)])
 
     def inverse(self, res, bbox_min=BBOX_MIN, bbox_max=BBOX_MAX):
         return [inverse_lut(s, res, bbox_min, bbox_max) for s in self.sensors]

@@ -133,6 +133,26 @@ def test_reference_default_grid(pkg, orc):
     ctx.close()
 
 
+def test_colour_resolution_differs_from_depth_resolution(pkg, orc):
+    """rgb_size != depth_size (e.g. Kinect V2: 1280x1080 colour, 512x424 depth), odd sizes"""
+    capi, synth = pkg.capi, pkg.synth
+    W, H, Wc, Hc = 131, 107, 203, 97
+    scene = synth.Scene(2, W, H, lut_res=(32, 27, 32), color_wh=(Wc, Hc))
+    assert scene.color.shape == (2, Hc, Wc, 3)
+    ctx = capi.Context(capi.make_config(2, (W, H), color_wh=(Wc, Hc), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64), 0)
+    inv = scene.inverse((64, 64, 64))
+    for i in range(2):
+        ctx.set_calibration(i, scene.xyz[i], (32, 27, 32), scene.uv[i], (32, 27, 32), (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
+    ctx.step(scene.depth, scene.color)
+    ref = oracle_run(orc, scene, ctx, inv)
+    check_images(ctx, ref, 2)
+    assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    assert np.sum(np.abs(ref["tsdf"]) < 0.01) > 200
+    ctx.close()
+
+
 def test_anisotropic_override_grid(pkg, orc):
     """res_override grid (the weak-scaling benchmark grids): voxel edge differs per
     axis, brick membership follows per axis"""
