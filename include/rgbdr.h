@@ -316,6 +316,10 @@ int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns);
  * number of intervals since the previous call, and resets them
  * (TimerDatabase running mean, timer_database.cpp:59-121). */
 int rgbdr_enable_timer_accumulation(rgbdr_ctx* ctx, int on);
+/* 2 (default): all timers; 1: only the totals ("1preprocess", "2integrate", "bricks",
+ * "draw", ...), not the five pre_* passes inside "1preprocess" -- every timer costs two
+ * event records on the stream between small kernels. */
+int rgbdr_set_timer_detail(rgbdr_ctx* ctx, int detail);
 int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint32_t* count);
 
 #ifdef __cplusplus

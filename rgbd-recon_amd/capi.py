@@ -183,6 +183,7 @@ SYMBOLS = {
     "rgbdr_timer_ns": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64)]),
     "rgbdr_enable_timer_accumulation": (C.c_int, [_P, C.c_int]),
     "rgbdr_timer_stats": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "rgbdr_set_timer_detail": (C.c_int, [_P, C.c_int]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librgbdr_hip.so")
@@ -476,6 +477,9 @@ class Context:
 
     def enable_timer_accumulation(self, on=True):
         self._chk(lib().rgbdr_enable_timer_accumulation(self._h, int(on)))
+
+    def set_timer_detail(self, detail):
+        self._chk(lib().rgbdr_set_timer_detail(self._h, detail))
 
     def timer_stats(self, name):
         """(total_ns, count) over the intervals since the last call; resets them"""

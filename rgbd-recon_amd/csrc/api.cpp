@@ -95,6 +95,7 @@ struct rgbdr_ctx {
   bool mask_valid = false;
 
   bool timers = false, accumulate = false;
+  int timer_detail = 2;  // 1: only "1preprocess" / "2integrate" / "bricks" ...; 2: also the five pre_* passes
   std::map<std::string, Timer> tm;
 
   int fail(int code, const std::string& m)
@@ -128,9 +129,13 @@ static size_t color_frame_bytes(const rgbdr_config& c)
 }
 static size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->cfg.depth_w * c->cfg.depth_h; }
 
+// the per-pass timers sit inside "1preprocess"; every timer is two event records on
+// the stream, so a host that only wants the totals can switch them off (detail 1)
+static bool timer_is_pass(const char* n) { return n[0] == 'm' || (n[0] == 'b' && n[1] != 'r') || n[0] == 'n' || n[0] == 'q'; }
+
 static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
-  if (!c->timers) return;
+  if (!c->timers || (c->timer_detail < 2 && timer_is_pass(name))) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -153,7 +158,7 @@ static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 }
 static void tend(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
-  if (!c->timers) return;
+  if (!c->timers || (c->timer_detail < 2 && timer_is_pass(name))) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
     if (!t.pending.empty()) (void)hipEventRecord(t.pending.back().second, st);
@@ -1354,6 +1359,13 @@ int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return RGBDR_OK;
+}
+
+int rgbdr_set_timer_detail(rgbdr_ctx* ctx, int detail)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  ctx->timer_detail = detail < 2 ? 1 : 2;
   return RGBDR_OK;
 }
 

@@ -345,10 +345,30 @@ void launch_boundary(const PreParams& p, hipStream_t s)
 __device__ __forceinline__ bool unit_outside(float d) { return (d <= 0.0f) || (d >= 1.0f); }
 __device__ __forceinline__ float sign_of(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 
-// inc_bricks.glsl:40-58.  Positions whose home brick lies outside the brick grid
-// are skipped (the reference indexes out of range there).
-__device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos)
+// Wave-aggregated counter increment: lanes of a wavefront that hit the same brick
+// (a 16x4 pixel patch usually lands in one or two bricks) are combined into a single
+// atomicAdd of their summed increments -- integer sums, so the counters are identical
+// to per-pixel atomics.  `id` < 0 means "no increment from this lane".
+__device__ __forceinline__ void wave_add(uint32_t* counters, int id, unsigned inc)
 {
+  unsigned long long todo = __ballot(id >= 0 && inc != 0u);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int lid = __shfl(id, leader);
+    const unsigned long long same = __ballot(id == lid && inc != 0u) & todo;
+    // sum of the increments of the matching lanes (increments are 0 or 1 here)
+    if ((int)(threadIdx.y * BX + threadIdx.x) % 64 == leader) atomicAdd(&counters[lid], (unsigned)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+// inc_bricks.glsl:40-58.  Positions whose home brick lies outside the brick grid
+// are skipped (the reference indexes out of range there).  Returns the
+// two counter ids (or -1) and the neighbour increment; the caller adds them wave-wide.
+__device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos, int& home_id, int& nb_id, unsigned& nb_inc)
+{
+  home_id = nb_id = -1;
+  nb_inc = 0u;
   const float w[3] = {pos.x, pos.y, pos.z};
   int idx[3];
   float diff[3], dabs[3];
@@ -371,10 +391,10 @@ __device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos)
     const float mc = (dabs[a] < min_v) ? 0.0f : 1.0f;
     nb[a] = clampi(idx[a] + (int)sign_of(diff[a] * mc), 0, p.res_bricks[a] - 1);
   }
-  const size_t rx = p.res_bricks[0], ry = p.res_bricks[1];
-  const unsigned inc = (dabs[0] > p.brick_size * 0.1f) ? 1u : 0u;
-  if (inc) atomicAdd(&p.brick_counters[(size_t)nb[2] * ry * rx + (size_t)nb[1] * rx + nb[0]], inc);
-  atomicAdd(&p.brick_counters[(size_t)idx[2] * ry * rx + (size_t)idx[1] * rx + idx[0]], 1u);
+  const int rx = p.res_bricks[0], ry = p.res_bricks[1];
+  nb_inc = (dabs[0] > p.brick_size * 0.1f) ? 1u : 0u;
+  nb_id = (nb[2] * ry + nb[1]) * rx + nb[0];
+  home_id = (idx[2] * ry + idx[1]) * rx + idx[0];
 }
 
 __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
@@ -387,13 +407,15 @@ __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
   const size_t o = (size_t)py * W + px;
   float3 n = make_float3(0.0f, 0.0f, 0.0f);
   const float depth = db[o * 2];
+  int home_id = -1, nb_id = -1;
+  unsigned nb_inc = 0u;
   if (!unit_outside(depth)) {
     const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
     const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
     const float4* lut = p.cv_xyz[l];
     const int rx = p.xyz_res[l][0], ry = p.xyz_res[l][1], rz = p.xyz_res[l][2];
     const float3 world = tex3d_xyz(lut, rx, ry, rz, 0, u, v, depth);
-    if (p.brick_counters) mark_brick(p, world);
+    if (p.brick_counters) mark_brick(p, world, home_id, nb_id, nb_inc);
     float dt = db[((size_t)clampi(py + 1, 0, H - 1) * W + px) * 2];
     float dbm = db[((size_t)clampi(py - 1, 0, H - 1) * W + px) * 2];
     float dl = db[((size_t)py * W + clampi(px - 1, 0, W - 1)) * 2];
@@ -415,6 +437,10 @@ __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
   p.normal[(lo + o) * 3 + 0] = n.x;
   p.normal[(lo + o) * 3 + 1] = n.y;
   p.normal[(lo + o) * 3 + 2] = n.z;
+  if (p.brick_counters) {  // reconverged: every live lane of the wavefront takes part
+    wave_add(p.brick_counters, nb_id, nb_inc);
+    wave_add(p.brick_counters, home_id, 1u);
+  }
 }
 
 void launch_normal(const PreParams& p, hipStream_t s)
