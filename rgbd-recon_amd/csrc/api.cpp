@@ -1008,12 +1008,10 @@ uint32_t rgbdr_num_bricks(const rgbdr_ctx* ctx) { return ctx ? (uint32_t)ctx->ge
 float rgbdr_occupied_ratio(rgbdr_ctx* ctx)
 {
   if (!ctx || !ctx->mask_valid) return 0.0f;
-  (void)hipSetDevice(ctx->device);
-  uint32_t c = 0;
-  if (ctx->pre_stream && hipStreamSynchronize(ctx->pre_stream) != hipSuccess) return 0.0f;
-  if (hipMemcpyAsync(&c, ctx->count_buf(ctx->rbuf), 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return 0.0f;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return 0.0f;
-  return (float)c / (float)ctx->geo.num_bricks;
+  size_t n = 0;
+  float ratio = 0.0f;
+  if (rgbdr_get_occupied(ctx, nullptr, 0, &n, &ratio) != RGBDR_OK) return 0.0f;
+  return ratio;
 }
 
 int rgbdr_get_geometry(const rgbdr_ctx* ctx, rgbdr_geometry* out)

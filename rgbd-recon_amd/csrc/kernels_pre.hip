@@ -515,21 +515,19 @@ void launch_quality(const PreParams& p, hipStream_t s)
 
 // ---------------------------------------------------------------------------
 // updateOccupiedBricks (recon_integration.cpp:431-446) without the readback:
-// mask[i] = counter[i] >= min_voxels, count = number of set entries.
+// mask[i] = counter[i] >= min_voxels.  The occupied count / ratio / id list are only
+// produced when a consumer asks (k_compact_occupied), not every frame.
 __global__ void k_update_occupied(const uint32_t* __restrict__ counters, uint32_t n, uint32_t min_voxels,
-                                  uint8_t* __restrict__ mask, uint32_t* __restrict__ count)
+                                  uint8_t* __restrict__ mask)
 {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool occ = (i < n) && (counters[i] >= min_voxels);
-  if (i < n) mask[i] = occ ? 1 : 0;
-  const unsigned long long b = __ballot(occ);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+  if (i < n) mask[i] = counters[i] >= min_voxels ? 1 : 0;
 }
 void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask, uint32_t* count,
                             hipStream_t s)
 {
-  (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
-  hipLaunchKernelGGL(k_update_occupied, dim3((n + 255) / 256), dim3(256), 0, s, counters, n, min_voxels, mask, count);
+  (void)count;
+  hipLaunchKernelGGL(k_update_occupied, dim3((n + 255) / 256), dim3(256), 0, s, counters, n, min_voxels, mask);
 }
 
 // ascending id list for consumers (m_bricks_occupied): one block, chunked scan
