@@ -304,7 +304,12 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
                      bv=tuple(g.brick_voxels_axis), res_bricks=tuple(g.res_bricks))
     t_pre = time.perf_counter() - t0
     t_full = t_pre + t_int * (G / rows)
-    return {"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
+    try:   # the reference's own per-resize / per-frame CPU work on this path, single-threaded as in the reference
+        ref_cpu = orc.reference_cpu_work(synth.BBOX_MIN, synth.BBOX_MAX, tuple(g.res_volume), g.brick_size,
+                                         ctx.readback_brick_counters(), 10)
+    except MemoryError:
+        ref_cpu = None
+    return {"reference_cpu_work": ref_cpu,"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads, "kind": "port",
             "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota): full pre_* chain of the %d-sensor frame (%.2f s) + integrate of %d of %d "
                       "z rows of the same volume (median of 3: %.2f s), extrapolated to the grid"
                       % (threads, N, t_pre, rows, G, t_int),

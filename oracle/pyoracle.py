@@ -345,6 +345,39 @@ def update_occupied(counters, min_voxels):
     return ids[:n].copy(), ratio.value
 
 
+def reference_cpu_work(bbox_min, bbox_max, dims, brick_size, counters, min_voxels):
+    """Times the reference's genuinely-CPU work on this path:
+    VolumeSampler::resize, divideBox + containedVoxels, the updateOccupiedBricks filter."""
+    import time
+
+    l = lib()
+    l.orc_contained_voxels.restype = C.c_double
+    x, y, z = dims
+    n = x * y * z
+    pos = np.empty(n * 3, dtype=np.float32)
+    t0 = time.perf_counter()
+    l.orc_volume_sampler_resize(x, y, z, _p(pos))
+    t_resize = time.perf_counter() - t0
+    del pos
+    idx = np.empty(n + n // 8, dtype=np.uint32)
+    cnt = C.c_size_t()
+    d = (C.c_int * 3)(x, y, z)
+    t0 = time.perf_counter()
+    l.orc_contained_voxels(_p(f32(bbox_min)), _p(f32(bbox_max)), C.c_float(brick_size), d, _p(idx), C.c_size_t(idx.size),
+                           C.byref(cnt))
+    t_div = time.perf_counter() - t0
+    del idx
+    c = np.ascontiguousarray(counters, dtype=np.uint32)
+    ids = np.empty_like(c)
+    ratio = C.c_float()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        l.orc_update_occupied(_p(c), c.size, min_voxels, _p(ids), C.byref(ratio))
+    t_upd = (time.perf_counter() - t0) / 10
+    return {"volume_sampler_resize_s": round(t_resize, 3), "divide_box_contained_voxels_s": round(t_div, 3),
+            "brick_voxel_indices": int(cnt.value), "update_occupied_filter_ms": round(t_upd * 1e3, 4)}
+
+
 def lut_write(path, data, floats):
     data = f32(data)
     rz, ry, rx = data.shape[:3]

@@ -1603,6 +1603,47 @@ ORC_API double orc_volume_sampler_resize(int X, int Y, int Z, float* pos /* X*Y*
   return acc;
 }
 
+/* divideBox + VolumeSampler::containedVoxels (recon_integration.cpp:361-388,
+ * volume_sampler.cpp:50-62): the per-brick voxel index vectors the reference builds
+ * on the CPU at every resize (4 B per voxel), y / x / z loop order and the
+ * float -> unsigned truncation of pos / step included.  bench.py times it; returns
+ * the number of indices and a checksum. */
+ORC_API double orc_contained_voxels(const float* bbox_min, const float* bbox_max, float brick_size, const int* dims,
+                                    uint32_t* indices /* capacity >= 2 * X*Y*Z */, size_t capacity, size_t* count)
+{
+  const float size[3] = {bbox_max[0] - bbox_min[0], bbox_max[1] - bbox_min[1], bbox_max[2] - bbox_min[2]};
+  const float stepv[3] = {1.0f / (float)dims[0], 1.0f / (float)dims[1], 1.0f / (float)dims[2]};
+  size_t k = 0;
+  double acc = 0.0;
+  float start[3] = {bbox_min[0], bbox_min[1], bbox_min[2]};
+  while (size[2] - start[2] + bbox_min[2] > 0.0f) {
+    while (size[1] - start[1] + bbox_min[1] > 0.0f) {
+      while (size[0] - start[0] + bbox_min[0] > 0.0f) {
+        float pos[3], bs[3];
+        for (int a = 0; a < 3; ++a) {
+          bs[a] = fminf(brick_size, size[a] - start[a] + bbox_min[a]) / size[a];
+          pos[a] = (start[a] - bbox_min[a]) / size[a];
+        }
+        for (unsigned y = (unsigned)(pos[1] / stepv[1]); (float)y < (pos[1] + bs[1]) / stepv[1]; ++y)
+          for (unsigned x = (unsigned)(pos[0] / stepv[0]); (float)x < (pos[0] + bs[0]) / stepv[0]; ++x)
+            for (unsigned z = (unsigned)(pos[2] / stepv[2]); (float)z < (pos[2] + bs[2]) / stepv[2]; ++z) {
+              const uint32_t id = z * (unsigned)dims[0] * (unsigned)dims[1] + y * (unsigned)dims[0] + x;
+              if (k < capacity) indices[k] = id;
+              ++k;
+              acc += (double)(id & 1023u);
+            }
+        start[0] += brick_size;
+      }
+      start[0] = bbox_min[0];
+      start[1] += brick_size;
+    }
+    start[1] = bbox_min[1];
+    start[2] += brick_size;
+  }
+  *count = k;
+  return acc;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Calibration-volume file format (framework/calibration/calibration_volume.hpp:30-79) */
 
