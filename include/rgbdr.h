@@ -106,6 +106,9 @@ typedef struct {
   int32_t tiles[3];        /* storage tiles per axis = ceil(res / RGBDR_TILE) */
   int32_t slab_tile_z0, slab_tile_z1; /* tile layers [z0, z1) owned by this slab */
   int32_t slab_voxel_z0, slab_voxel_z1; /* voxel layers [z0, z1) owned (clipped to res_volume[2]) */
+  int32_t halo_tile_layers; /* 0 for a whole volume; else the tile layers of TSDF / grid-layout LUT kept on each side
+                               of a slab so a ray-marcher can sample, refine and take gradients across the slab
+                               faces: ceil((tsdf_limit * res_z + 2) / 8), at least 1 */
 } rgbdr_geometry;
 
 /* Which per-sensor image rgbdr_readback_image returns (the textures of
@@ -248,7 +251,7 @@ typedef struct {
   void* owned;            /* first float of the first owned tile layer */
   size_t layer_bytes;     /* bytes of one tile layer = tiles[0]*tiles[1]*512*4 */
   int32_t owned_layers;
-  int32_t halo_layers;    /* 0 or 1 on each side */
+  int32_t halo_layers;    /* rgbdr_geometry.halo_tile_layers on each side */
 } rgbdr_tsdf_device_view;
 int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
@@ -289,8 +292,23 @@ typedef struct {
  * color = height*width RGBA32F, depth = gl_FragDepth, num_samples = the
  * tex_num_samples image; pixels the ray-marcher discards keep the cleared values of
  * ViewLod::enable: (0,1,0,0), depth 1.  Needs the whole volume in this context
- * (slab_count == 1) and a completed integrate(). */
+ * (slab_count == 1; for Z slabs see rgbdr_raymarch_find / _shade) and a completed
+ * integrate(). */
 int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, float* depth, float* num_samples);
+
+/* Ray-marching a volume that is split into Z slabs (one context per GPU).  Every rank
+ * marches the same sample sequence per pixel; a sample belongs to the slab that owns the
+ * voxel row its LINEAR footprint starts at.  rgbdr_raymarch_find writes, per pixel, the
+ * index of the first sample this slab owns with density > 0 (0x7fffffff: none) into a
+ * device buffer of height*width int32; the host takes the element-wise MINIMUM of that
+ * buffer over all slabs (e.g. all-reduce MIN over RCCL, in place); rgbdr_raymarch_shade
+ * then refines and shades exactly the pixels whose minimum this slab owns, returns the
+ * cleared values elsewhere, and overwrites the buffer with 0x7fffffff where it did not
+ * shade -- so the frames of all slabs composite by selection, bit-identical to
+ * rgbdr_raymarch on a single context.  Needs the TSDF halo layers to be current
+ * (rgbdr_device_tsdf + the neighbour exchange of rgbd-recon_amd/dist.py). */
+int rgbdr_raymarch_find(rgbdr_ctx* ctx, const rgbdr_view* view, void** first_hit_device);
+int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, float* depth, float* num_samples);
 
 /* ReconIntegration::drawDepthLimits (recon_integration.cpp:409-429, glsl/bricks.*): the
  * occupied bricks' depth peels for `view`: height*width RGBA32F texels (nearest face z,

@@ -1060,7 +1060,7 @@ ORC_API void orc_raymarch(const orc_view* vw, const orc_raymarch_params* p, cons
         sp[2] = pf[2];
         fmaxs = ceilf(distance3(pf, pb) / sd);
       }
-      const unsigned max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs);
+      const unsigned max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 2147483520.0f ? 2147483520u : (unsigned)fmaxs);
       float prev = -limit;
       unsigned num = 0;
       int hit = 0;

@@ -55,6 +55,7 @@ class Geometry(C.Structure):
         ("tiles", C.c_int32 * 3),
         ("slab_tile_z0", C.c_int32), ("slab_tile_z1", C.c_int32),
         ("slab_voxel_z0", C.c_int32), ("slab_voxel_z1", C.c_int32),
+        ("halo_tile_layers", C.c_int32),
     ]
 
 
@@ -176,6 +177,8 @@ SYMBOLS = {
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
+    "rgbdr_raymarch_shade": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_draw_depth_limits": (C.c_int, [_P, C.POINTER(View), _F]),
     "rgbdr_stream": (_P, [_P]),
     "rgbdr_set_stream": (C.c_int, [_P, _P]),
@@ -446,6 +449,21 @@ class Context:
         ns = np.empty((h, w), dtype=np.float32)
         self._chk(lib().rgbdr_raymarch(self._h, C.byref(view), color.ctypes.data_as(_F), depth.ctypes.data_as(_F),
                                        ns.ctypes.data_as(_F)))
+        return color, depth, ns
+
+    def raymarch_find(self, view):
+        """device pointer (int) of the height*width int32 first-hit buffer of this slab"""
+        ptr = _P()
+        self._chk(lib().rgbdr_raymarch_find(self._h, C.byref(view), C.byref(ptr)))
+        return ptr.value
+
+    def raymarch_shade(self, view):
+        h, w = view.height, view.width
+        color = np.empty((h, w, 4), dtype=np.float32)
+        depth = np.empty((h, w), dtype=np.float32)
+        ns = np.empty((h, w), dtype=np.float32)
+        self._chk(lib().rgbdr_raymarch_shade(self._h, C.byref(view), color.ctypes.data_as(_F), depth.ctypes.data_as(_F),
+                                             ns.ctypes.data_as(_F)))
         return color, depth, ns
 
     def draw_depth_limits(self, view):

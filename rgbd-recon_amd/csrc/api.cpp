@@ -71,7 +71,8 @@ struct rgbdr_ctx {
   bool inv_tiled[kMaxSensors] = {};
   bool inv_resampled[kMaxSensors] = {};  // tiled planes hold the LUT resampled at voxel centres
   uint32_t inv_res[kMaxSensors][3] = {};
-  float* d_lut_tiled = nullptr;
+  float* d_lut_tiled = nullptr;       // grid-layout LUT planes of the OWNED tile layers ...
+  float* d_lut_tiled_base = nullptr;  // ... inside an allocation with `halo` more layers on each side
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
   float4* d_lut_generic[kMaxSensors] = {};
   int zoff[kMaxSensors] = {};
@@ -181,7 +182,8 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
-  (void)hipFree(c->d_lut_tiled);
+  (void)hipFree(c->d_lut_tiled_base);
+  c->d_lut_tiled_base = nullptr;
   (void)hipFree(c->d_win);
   c->d_win = nullptr;
   c->d_tsdf_base = c->d_tsdf_owned = c->d_linear = nullptr;
@@ -206,7 +208,7 @@ static int alloc_volume(rgbdr_ctx* ctx)
   const rgbdr_geometry& g = ctx->geo;
   ctx->layer_floats = (size_t)g.tiles[0] * g.tiles[1] * kTileVoxels;
   const int owned = g.slab_tile_z1 - g.slab_tile_z0;
-  ctx->halo = (ctx->cfg.slab_count > 1) ? 1 : 0;
+  ctx->halo = g.halo_tile_layers;
   const size_t total = ctx->layer_floats * (size_t)(owned + 2 * ctx->halo);
   HIPCHK(hipMalloc((void**)&ctx->d_tsdf_base, total * sizeof(float)));
   ctx->d_tsdf_owned = ctx->d_tsdf_base + ctx->layer_floats * ctx->halo;
@@ -435,13 +437,34 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, cons
   return RGBDR_OK;
 }
 
+// Tile layers [t0, t1) of the grid-layout LUT that are resident: the owned layers plus
+// `halo` layers on each side where the volume has them; dst = where layer t0 lives.
+struct LutExtent {
+  int t0, t1, vz0, vz1;
+  float* dst;
+};
+static LutExtent lut_extent(const rgbdr_ctx* ctx)
+{
+  const rgbdr_geometry& g = ctx->geo;
+  LutExtent e;
+  e.t0 = g.slab_tile_z0 - ctx->halo < 0 ? 0 : g.slab_tile_z0 - ctx->halo;
+  e.t1 = g.slab_tile_z1 + ctx->halo > g.tiles[2] ? g.tiles[2] : g.slab_tile_z1 + ctx->halo;
+  e.vz0 = e.t0 * kTile;
+  e.vz1 = e.t1 * kTile > g.res_volume[2] ? g.res_volume[2] : e.t1 * kTile;
+  const ptrdiff_t layer = (ptrdiff_t)g.tiles[0] * g.tiles[1] * ctx->cfg.num_sensors * 3 * kTileVoxels;
+  e.dst = ctx->d_lut_tiled + (ptrdiff_t)(e.t0 - g.slab_tile_z0) * layer;
+  return e;
+}
+
 static int ensure_tiled_lut(rgbdr_ctx* ctx)
 {
   if (ctx->d_lut_tiled) return RGBDR_OK;
   const rgbdr_geometry& g = ctx->geo;
   const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
-  const size_t bytes = ntiles * nsens(ctx) * 3 * kTileVoxels * sizeof(float);
-  HIPCHK(hipMalloc((void**)&ctx->d_lut_tiled, bytes));
+  const size_t layer = (size_t)g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
+  const size_t layers = (size_t)(g.slab_tile_z1 - g.slab_tile_z0) + 2 * (size_t)ctx->halo;
+  HIPCHK(hipMalloc((void**)&ctx->d_lut_tiled_base, layer * layers * sizeof(float)));
+  ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
   HIPCHK(hipMalloc((void**)&ctx->d_win, ntiles * nsens(ctx) * sizeof(int32_t)));
   HIPCHK(hipMemsetAsync(ctx->d_win, 0, ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
   return RGBDR_OK;
@@ -471,15 +494,15 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
     float4* tmp = nullptr;
     const size_t row = (size_t)X * Y;
     HIPCHK(hipMalloc((void**)&tmp, row * kTile * chunk_layers * sizeof(float4)));
-    for (int tz = g.slab_tile_z0; tz < g.slab_tile_z1; tz += chunk_layers) {
-      const int tz_end = tz + chunk_layers < g.slab_tile_z1 ? tz + chunk_layers : g.slab_tile_z1;
+    const LutExtent ext = lut_extent(ctx);
+    for (int tz = ext.t0; tz < ext.t1; tz += chunk_layers) {
+      const int tz_end = tz + chunk_layers < ext.t1 ? tz + chunk_layers : ext.t1;
       const int vz0 = tz * kTile;
       int vz1 = tz_end * kTile;
       if (vz1 > Z) vz1 = Z;
       HIPCHK(hipMemcpyAsync(tmp, host + row * vz0, row * (size_t)(vz1 - vz0) * sizeof(float4), hipMemcpyHostToDevice,
                             ctx->stream));
-      float* dst = ctx->d_lut_tiled +
-                   (size_t)(tz - g.slab_tile_z0) * g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
+      float* dst = ext.dst + (size_t)(tz - ext.t0) * g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
       launch_tile_lut(tmp, X, Y, Z, vz0, g.tiles[0], g.tiles[1], tz, tz_end - tz, sensor, nsens(ctx), dst,
                       ctx->stream);
       LAUNCHCHK("tile_lut");
@@ -493,7 +516,8 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
     ctx->inv_tiled[sensor] = true;
   } else {
     int lo, hi;
-    lut_z_range(Z, g.res_volume[2], g.slab_voxel_z0, g.slab_voxel_z1, &lo, &hi);
+    const LutExtent ext = lut_extent(ctx);
+    lut_z_range(Z, g.res_volume[2], ext.vz0, ext.vz1, &lo, &hi);
     const size_t row = (size_t)X * Y;
     const size_t cnt = row * (size_t)(hi - lo + 1);
     HIPCHK(hipMalloc((void**)&ctx->d_lut_generic[sensor], cnt * sizeof(float4)));
@@ -509,9 +533,9 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
       bool other_generic = false;
       for (int i = 0; i < nsens(ctx); ++i) other_generic = other_generic || (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i]);
       if (!other_generic && ensure_tiled_lut(ctx) == RGBDR_OK) {
+        const LutExtent ex2 = lut_extent(ctx);
         launch_resample_lut(ctx->d_lut_generic[sensor], X, Y, Z, lo, g.res_volume[0], g.res_volume[1], g.res_volume[2],
-                            g.tiles[0], g.tiles[1], g.slab_tile_z0, g.slab_tile_z1 - g.slab_tile_z0, sensor, nsens(ctx),
-                            ctx->d_lut_tiled, ctx->stream);
+                            g.tiles[0], g.tiles[1], ex2.t0, ex2.t1 - ex2.t0, sensor, nsens(ctx), ex2.dst, ctx->stream);
         LAUNCHCHK("resample_lut");
         launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
                             g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
@@ -586,9 +610,10 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
     return ctx->fail(RGBDR_ERR_STATE, "synthetic inverse LUT needs a grid whose voxel centres hit texel centres exactly");
   int rc = ensure_tiled_lut(ctx);
   if (rc != RGBDR_OK) return rc;
+  const LutExtent ext = lut_extent(ctx);
   launch_synth_inverse(*cam, ctx->cfg.depth_w, ctx->cfg.depth_h, ctx->cfg.bbox_min, ctx->cfg.bbox_max, g.res_volume[0],
-                       g.res_volume[1], g.res_volume[2], g.tiles[0], g.tiles[1], g.slab_tile_z0,
-                       g.slab_tile_z1 - g.slab_tile_z0, sensor, nsens(ctx), ctx->d_lut_tiled, ctx->stream);
+                       g.res_volume[1], g.res_volume[2], g.tiles[0], g.tiles[1], ext.t0, ext.t1 - ext.t0, sensor,
+                       nsens(ctx), ext.dst, ctx->stream);
   LAUNCHCHK("synth_inverse");
   launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
                       g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
@@ -640,9 +665,10 @@ int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
   const rgbdr_geometry& g = ctx->geo;
   InvertParams p;
   fill_invert_params(ctx, sensor, g.res_volume, window, &p);
-  p.z0 = g.slab_voxel_z0;
-  p.nz = g.slab_voxel_z1 - g.slab_voxel_z0;
-  p.out_tiled = ctx->d_lut_tiled;
+  const LutExtent ext = lut_extent(ctx);
+  p.z0 = ext.vz0;
+  p.nz = ext.vz1 - ext.vz0;
+  p.out_tiled = ext.dst;
   launch_invert_lut(p, ctx->stream);
   LAUNCHCHK("invert_lut");
   launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
@@ -1104,7 +1130,8 @@ int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z
     HIPCHK(hipFree(tmp));
   } else {
     int lo, hi;
-    lut_z_range((int)ctx->inv_res[sensor][2], g.res_volume[2], g.slab_voxel_z0, g.slab_voxel_z1, &lo, &hi);
+    const LutExtent ext = lut_extent(ctx);
+    lut_z_range((int)ctx->inv_res[sensor][2], g.res_volume[2], ext.vz0, ext.vz1, &lo, &hi);
     if (z0 < lo || z1 > hi + 1 || z0 >= z1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "texel rows not resident");
     HIPCHK(hipMemcpyAsync(dst, ctx->d_lut_generic[sensor] + row * (size_t)(z0 - lo),
                           row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
@@ -1178,14 +1205,14 @@ int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
   return RGBDR_OK;
 }
 
-// d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4)
+// d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4), first-hit index (1)
 static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
 {
   if (ctx->view_pixels >= npix) return RGBDR_OK;
   (void)hipFree(ctx->d_view);
   ctx->d_view = nullptr;
   ctx->view_pixels = 0;
-  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 10 * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 11 * sizeof(float)));
   ctx->view_pixels = npix;
   return RGBDR_OK;
 }
@@ -1237,12 +1264,11 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
   return RGBDR_OK;
 }
 
-int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+// uniforms + resident data of the ray-marcher for `v`; runs the depth peels when asked
+static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
 {
-  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
   if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
-  if (ctx->cfg.slab_count > 1) return ctx->fail(RGBDR_ERR_STATE, "raymarch needs the whole volume in one context");
   if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
   const int N = nsens(ctx);
   bool tiled = true;
@@ -1254,7 +1280,12 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
     if (rc_ != RGBDR_OK) return rc_;
   }
   const rgbdr_geometry& g = ctx->geo;
-  RaymarchParams p{};
+  if (ctx->cfg.slab_count > 1) {
+    const int rows = (int)std::ceil(ctx->cfg.tsdf_limit * (float)g.res_volume[2]) + 2;
+    if (rows > ctx->halo * kTile) return ctx->fail(RGBDR_ERR_STATE, "tsdf_limit grew beyond what the slab halo covers; recreate the context");
+  }
+  RaymarchParams& p = *pp;
+  p = RaymarchParams{};
   p.skip_space = v->skip_space ? 1 : 0;
   p.peels = (const float4*)(ctx->d_view + npix * 6);
   if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
@@ -1268,10 +1299,7 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   std::memcpy(p.modelview_inv, v->modelview_inv, 64);
   std::memcpy(p.img_to_eye, v->img_to_eye, 64);
   // gl_ModelViewMatrix * vol_to_world, evaluated once (the shader forms it per fragment, :123)
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 4; ++r)
-      p.mv_vol_to_world[4 * c + r] = v->modelview[r] * v->vol_to_world[4 * c] + v->modelview[4 + r] * v->vol_to_world[4 * c + 1] +
-                                     v->modelview[8 + r] * v->vol_to_world[4 * c + 2] + v->modelview[12 + r] * v->vol_to_world[4 * c + 3];
+  mat4_product(v->modelview, v->vol_to_world, p.mv_vol_to_world);
   std::memcpy(p.camera_pos, v->camera_pos, 12);
   p.width = v->width;
   p.height = v->height;
@@ -1287,8 +1315,13 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   p.Z = g.res_volume[2];
   p.TX = g.tiles[0];
   p.TY = g.tiles[1];
-  p.tsdf = ctx->d_tsdf_owned;
-  p.lut_tiled = tiled ? ctx->d_lut_tiled : nullptr;
+  p.tz_alloc0 = g.slab_tile_z0 - ctx->halo;
+  p.own_z0 = g.slab_voxel_z0;
+  p.own_z1 = g.slab_voxel_z1;
+  p.res_z0 = (g.slab_tile_z0 - ctx->halo) * kTile < 0 ? 0 : (g.slab_tile_z0 - ctx->halo) * kTile;
+  p.res_z1 = (g.slab_tile_z1 + ctx->halo) * kTile > g.res_volume[2] ? g.res_volume[2] : (g.slab_tile_z1 + ctx->halo) * kTile;
+  p.tsdf = ctx->d_tsdf_base;
+  p.lut_tiled = tiled ? ctx->d_lut_tiled_base : nullptr;
   const size_t img = (size_t)p.W * p.H;
   for (int i = 0; i < N; ++i) {
     p.lut[i] = ctx->d_lut_generic[i];
@@ -1304,17 +1337,67 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   p.out_color = (float4*)ctx->d_view;
   p.out_depth = ctx->d_view + npix * 4;
   p.out_samples = ctx->d_view + npix * 5;
-  tbegin(ctx, "draw", ctx->stream);
-  launch_raymarch(p, ctx->stream);
-  tend(ctx, "draw", ctx->stream);
-  LAUNCHCHK("raymarch");
+  p.khit = (int*)(ctx->d_view + npix * 10);
   ctx->view_w = v->width;
   ctx->view_h = v->height;
+  return RGBDR_OK;
+}
+
+static int download_view(rgbdr_ctx* ctx, const RaymarchParams& p, float* color, float* depth, float* num_samples)
+{
+  const size_t npix = (size_t)p.width * p.height;
   if (color) HIPCHK(hipMemcpyAsync(color, p.out_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (depth) HIPCHK(hipMemcpyAsync(depth, p.out_depth, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (num_samples) HIPCHK(hipMemcpyAsync(num_samples, p.out_samples, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
+}
+
+int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->cfg.slab_count > 1)
+    return ctx->fail(RGBDR_ERR_STATE, "a Z slab cannot ray-march alone: use rgbdr_raymarch_find / _shade across the slabs");
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, v, &p);
+  if (rc != RGBDR_OK) return rc;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, 0, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch");
+  return download_view(ctx, p, color, depth, num_samples);
+}
+
+int rgbdr_raymarch_find(rgbdr_ctx* ctx, const rgbdr_view* v, void** first_hit_device)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, v, &p);
+  if (rc != RGBDR_OK) return rc;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, 1, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch_find");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (first_hit_device) *first_hit_device = p.khit;
+  return RGBDR_OK;
+}
+
+int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!v || ctx->view_w != v->width || ctx->view_h != v->height)
+    return ctx->fail(RGBDR_ERR_STATE, "raymarch_shade needs rgbdr_raymarch_find of the same view first");
+  const int skip = v->skip_space;
+  rgbdr_view v2 = *v;
+  v2.skip_space = 0;  // the peels of the find pass are still in the view buffers
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, &v2, &p);
+  if (rc != RGBDR_OK) return rc;
+  p.skip_space = skip ? 1 : 0;
+  launch_raymarch(p, 2, ctx->stream);
+  LAUNCHCHK("raymarch_shade");
+  return download_view(ctx, p, color, depth, num_samples);
 }
 
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)

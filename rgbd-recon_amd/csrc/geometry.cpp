@@ -81,6 +81,14 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
   g->slab_voxel_z0 = g->slab_tile_z0 * kTile;
   g->slab_voxel_z1 = g->slab_tile_z1 * kTile;
   if (g->slab_voxel_z1 > g->res_volume[2]) g->slab_voxel_z1 = g->res_volume[2];
+  g->halo_tile_layers = 0;
+  if (count > 1) {
+    // a ray-marcher stepping limit/2 samples, refines and takes +-limit/2 gradients up to
+    // limit * res_z + 2 voxel rows beyond the rows a slab owns (DESIGN.md "Multi-GPU")
+    const int rows = (int)std::ceil(cfg.tsdf_limit * (float)g->res_volume[2]) + 2;
+    g->halo_tile_layers = rows <= kTile ? 1 : (rows + kTile - 1) / kTile;
+    if (g->slab_tile_z1 - g->slab_tile_z0 < g->halo_tile_layers) return fail("slab thinner than its halo");
+  }
   return RGBDR_OK;
 }
 

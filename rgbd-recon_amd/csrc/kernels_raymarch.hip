@@ -29,32 +29,56 @@ __device__ __forceinline__ float4 mat4_mul(const float* m, float x, float y, flo
   return o;
 }
 
-__device__ __forceinline__ float tile_at(const float* __restrict__ v, int TX, int TY, int x, int y, int z)
+// tile-linear fetch; `tz_alloc0` = global index of the first resident tile layer (a Z slab
+// keeps halo layers below / above the layers it owns; 0 for a whole volume)
+__device__ __forceinline__ float tile_at(const float* __restrict__ v, int TX, int TY, int tz_alloc0, int x, int y, int z)
 {
-  return v[((size_t)((z >> 3) * TY + (y >> 3)) * TX + (x >> 3)) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7))];
+  return v[((size_t)(((z >> 3) - tz_alloc0) * TY + (y >> 3)) * TX + (x >> 3)) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7))];
+}
+
+// A Z slab holds voxel rows [res_z0, res_z1) only.  Every sample the slab protocol needs lies
+// inside them.  A refined position that is NaN (the TSDF holds NaN where the
+// reference's weighting divides 0 by 0) selects texel 0 in GL; its weights are NaN too, so the
+// value read does not matter and the nearest resident row is read instead -- as it is with
+// stale halos -- rather than faulting.  No-op for a whole volume.
+__device__ __forceinline__ Axis resident_rows(const RaymarchParams& p, Axis z)
+{
+  z.i0 = clampi(z.i0, p.res_z0, p.res_z1 - 1);
+  z.i1 = clampi(z.i1, p.res_z0, p.res_z1 - 1);
+  return z;
 }
 
 // texture(volume_tsdf, pos).r
 __device__ __forceinline__ float tsdf_sample(const RaymarchParams& p, float px, float py, float pz)
 {
-  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y), Z = axis_linear(pz, p.Z);
-  const float t000 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i0, Z.i0), t100 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i0, Z.i0);
-  const float t010 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i1, Z.i0), t110 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i1, Z.i0);
-  const float t001 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i0, Z.i1), t101 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i0, Z.i1);
-  const float t011 = tile_at(p.tsdf, p.TX, p.TY, X.i0, Y.i1, Z.i1), t111 = tile_at(p.tsdf, p.TX, p.TY, X.i1, Y.i1, Z.i1);
+  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y);
+  const Axis Z = resident_rows(p, axis_linear(pz, p.Z));
+  const int a0 = p.tz_alloc0;
+  const float t000 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i0, Y.i0, Z.i0), t100 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i1, Y.i0, Z.i0);
+  const float t010 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i0, Y.i1, Z.i0), t110 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i1, Y.i1, Z.i0);
+  const float t001 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i0, Y.i0, Z.i1), t101 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i1, Y.i0, Z.i1);
+  const float t011 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i0, Y.i1, Z.i1), t111 = tile_at(p.tsdf, p.TX, p.TY, a0, X.i1, Y.i1, Z.i1);
   return lerpf(lerpf(lerpf(t000, t100, X.a), lerpf(t010, t110, X.a), Y.a),
                lerpf(lerpf(t001, t101, X.a), lerpf(t011, t111, X.a), Y.a), Z.a);
+}
+
+// the voxel row the LINEAR footprint of a sample starts at decides which Z slab owns it
+__device__ __forceinline__ bool sample_owned(const RaymarchParams& p, float pz)
+{
+  const int z0 = axis_linear(pz, p.Z).i0;
+  return z0 >= p.own_z0 && z0 < p.own_z1;
 }
 
 // texture(cv_xyz_inv[i], pos).xyz from the grid-layout planes ([tile][N][3][512])
 __device__ __forceinline__ float3 lut_planes_sample(const RaymarchParams& p, int sensor, float px, float py, float pz)
 {
-  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y), Z = axis_linear(pz, p.Z);
+  const Axis X = axis_linear(px, p.X), Y = axis_linear(py, p.Y);
+  const Axis Z = resident_rows(p, axis_linear(pz, p.Z));
   float r[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     auto at = [&](int x, int y, int z) {
-      const size_t tile = (size_t)((z >> 3) * p.TY + (y >> 3)) * p.TX + (x >> 3);
+      const size_t tile = (size_t)(((z >> 3) - p.tz_alloc0) * p.TY + (y >> 3)) * p.TX + (x >> 3);
       return p.lut_tiled[((tile * p.N + sensor) * 3 + c) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7))];
     };
     r[c] = lerpf(lerpf(lerpf(at(X.i0, Y.i0, Z.i0), at(X.i1, Y.i0, Z.i0), X.a), lerpf(at(X.i0, Y.i1, Z.i0), at(X.i1, Y.i1, Z.i0), X.a), Y.a),
@@ -72,176 +96,250 @@ __device__ __forceinline__ float3 normalize3(float x, float y, float z)
 
 __constant__ float c_camera_colors[5][3] = {{228, 26, 28}, {55, 126, 184}, {77, 175, 74}, {152, 78, 163}, {255, 127, 0}};
 
+struct Ray {
+  float sp[3], step[3];
+  unsigned max_num;
+  bool covered;
+};
+
+// ray of a pixel: direction, first sample position and sample budget (main(), :62-86)
+__device__ __forceinline__ Ray ray_setup(const RaymarchParams& p, int px, int py, size_t o)
+{
+  Ray r;
+  r.covered = false;
+  r.max_num = 0u;
+  const float sd = p.limit * 0.5f;
+  const float4 pc = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
+  const float4 ws = mat4_mul(p.modelview_inv, pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, 1.0f);
+  const float4 tv = mat4_mul(p.vol_to_world_inv, ws.x, ws.y, ws.z, ws.w);
+  const float3 nd = normalize3(tv.x - p.camera_pos[0], tv.y - p.camera_pos[1], tv.z - p.camera_pos[2]);
+  r.step[0] = nd.x * sd;
+  r.step[1] = nd.y * sd;
+  r.step[2] = nd.z * sd;
+  float tmin[3], tmax[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float inv = 1.0f / r.step[a];
+    const float tb = inv * (0.0f - p.camera_pos[a]), tt = inv * (1.0f - p.camera_pos[a]);
+    tmin[a] = fminf(tt, tb);
+    tmax[a] = fmaxf(tt, tb);
+  }
+  const float t0 = fmaxf(fmaxf(tmin[0], tmin[1]), fmaxf(tmin[0], tmin[2]));
+  const float t1 = fminf(fminf(tmax[0], tmax[1]), fminf(tmax[0], tmax[2]));
+  if (!(t0 <= t1) || !(t1 > 0.0f)) return r;  // cube not rasterised onto this pixel
+  r.covered = true;
+  const float t_near = t0 < 0.0f ? 0.0f : t0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) r.sp[a] = p.camera_pos[a] + r.step[a] * t_near;
+  float fmaxs = ceilf(fabsf(t1 - t_near));
+  if (p.skip_space) {  // getStartPos, tsdf_raymarch.fs:392-401
+    const float4 dmm = p.peels[o];
+    const float dr = (dmm.x >= dmm.z) ? 0.0f : dmm.x;  // closest back face is the closest face -> gl_DepthRange.near
+    float pf[3], pb[3];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float4 a4 = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, k == 0 ? dr : -dmm.y, 1.0f);
+      const float4 w4 = mat4_mul(p.modelview_inv, a4.x / a4.w, a4.y / a4.w, a4.z / a4.w, 1.0f);
+      const float4 v4 = mat4_mul(p.vol_to_world_inv, w4.x, w4.y, w4.z, w4.w);
+      float* dst = k == 0 ? pf : pb;
+      dst[0] = v4.x;
+      dst[1] = v4.y;
+      dst[2] = v4.z;
+    }
+    if (dr >= 1.0f) {
+      pb[0] = pf[0];
+      pb[1] = pf[1];
+      pb[2] = pf[2];
+    }
+    r.sp[0] = pf[0];
+    r.sp[1] = pf[1];
+    r.sp[2] = pf[2];
+    const float ex = pf[0] - pb[0], ey = pf[1] - pb[1], ez = pf[2] - pb[2];
+    fmaxs = ceilf(sqrtf(ex * ex + ey * ey + ez * ez) / sd);
+  }
+  r.max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 2147483520.0f ? 2147483520u : (unsigned)fmaxs);
+  return r;
+}
+
+// submitFragment (:116-142) at the refined position + the depth clamp / GL_LESS test
+__device__ __forceinline__ void shade_fragment(const RaymarchParams& p, const float* sp, float4& rgba, float& fdepth)
+{
+  const float limit = p.limit, sd = limit * 0.5f;
+  const float gx = tsdf_sample(p, sp[0] + sd, sp[1], sp[2]) - tsdf_sample(p, sp[0] - sd, sp[1], sp[2]);
+  const float gy = tsdf_sample(p, sp[0], sp[1] + sd, sp[2]) - tsdf_sample(p, sp[0], sp[1] - sd, sp[2]);
+  const float gz = tsdf_sample(p, sp[0], sp[1], sp[2] + sd) - tsdf_sample(p, sp[0], sp[1], sp[2] - sd);
+  const float3 gn = normalize3(gx, gy, gz);
+  const float4 vn4 = mat4_mul(p.normal_matrix, -gn.x, -gn.y, -gn.z, 0.0f);
+  const float3 vn = normalize3(vn4.x, vn4.y, vn4.z);
+  const float4 vp = mat4_mul(p.mv_vol_to_world, sp[0], sp[1], sp[2], 1.0f);
+  float tc[3] = {0, 0, 0}, tc2[3] = {0, 0, 0}, tw = 0.0f, tw2 = 0.0f, cw[3] = {0, 0, 0}, cwt = 0.0f;
+  for (int i = 0; i < p.N; ++i) {
+    const float3 pcal = p.lut_tiled ? lut_planes_sample(p, i, sp[0], sp[1], sp[2])
+                                    : tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], sp[0], sp[1], sp[2]);
+    const float2 pcol = tex3d_uv(p.cv_uv[i], p.uv_res[i][0], p.uv_res[i][1], p.uv_res[i][2], pcal.x, pcal.y, pcal.z);
+    const Axis CX = axis_linear(pcol.x, p.Wc), CY = axis_linear(pcol.y, p.Hc);
+    const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
+    float col[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+      const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+      col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
+    }
+    const uint2* frame = p.frame[i];
+    const int ix = axis_nearest(pcal.x, p.W), iy = axis_nearest(pcal.y, p.H);
+    const float depth = __uint_as_float(frame[(size_t)iy * p.W + ix].x);
+    const float dist = fabsf(depth - pcal.z);
+    float q = 0.0f;
+    if (dist < limit) {
+      const Axis QX = axis_linear(pcal.x, p.W), QY = axis_linear(pcal.y, p.H);
+      const float q00 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i0].y & 0x7fffffffu), q10 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i1].y & 0x7fffffffu);
+      const float q01 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i0].y & 0x7fffffffu), q11 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i1].y & 0x7fffffffu);
+      q = lerpf(lerpf(q00, q10, QX.a), lerpf(q01, q11, QX.a), QY.a);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tc[k] += col[k] * q / (dist + 0.01f);
+      tc2[k] += col[k] / dist;
+      if (i < 5) cw[k] += (c_camera_colors[i][k] / 255.0f) * q;
+    }
+    tw += q / (dist + 0.01f);
+    tw2 += 1.0f / dist;
+    cwt += q;
+  }
+  if (p.shade_mode == 3) {
+    rgba = make_float4(cwt <= 0.0f ? 1.0f : cw[0] / cwt, cwt <= 0.0f ? 1.0f : cw[1] / cwt, cwt <= 0.0f ? 1.0f : cw[2] / cwt, 1.0f);
+  } else {
+    float diff[4];
+    if (tw > 0.0f) {
+      diff[0] = tc[0] / tw;
+      diff[1] = tc[1] / tw;
+      diff[2] = tc[2] / tw;
+      diff[3] = 1.0f;
+    } else {
+      diff[0] = tc2[0] / tw2;
+      diff[1] = tc2[1] / tw2;
+      diff[2] = tc2[2] / tw2;
+      diff[3] = -1.0f;
+    }
+    float r[3] = {1.0f, 1.0f, 1.0f};
+    if (p.shade_mode == 0) {
+      r[0] = diff[0];
+      r[1] = diff[1];
+      r[2] = diff[2];
+    } else if (p.shade_mode == 1) {
+      const float3 tln = normalize3(1.5f - vp.x, 1.0f - vp.y, 1.0f - vp.z);
+      const float la = vn.x * tln.x + vn.y * tln.y + vn.z * tln.z;
+      float dc = 0.0f, sl = 0.0f;
+      if (!(la <= 0.0f)) {
+        dc = fmaxf(la, 0.0f);
+        const float3 tvw = normalize3(-vp.x, -vp.y, -vp.z);
+        const float3 hn = normalize3(tln.x + tvw.x, tln.y + tvw.y, tln.z + tvw.z);
+        const float ra = hn.x * vn.x + hn.y * vn.y + hn.z * vn.z;
+        const float r2 = ra * ra, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+        sl = r16 * r4;
+        const float a = (1.0f - la) * (1.0f - la);
+        sl *= 1.0f - a * a * a;
+      }
+      const float ld[3] = {1.0f, 0.9f, 0.7f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[k] = (ld[k] * 0.2f) * 0.5f + ld[k] * 0.5f * dc + 1.0f * 0.5f * sl;
+    } else if (p.shade_mode == 2) {
+      const float4 r4 = mat4_mul(p.gl_normal_matrix_inv, vn.x, vn.y, vn.z, 0.0f);
+      r[0] = r4.x;
+      r[1] = r4.y;
+      r[2] = r4.z;
+    }
+    rgba = make_float4(r[0], r[1], r[2], diff[3]);
+  }
+  // gl_FragDepth is clamped to the depth range and tested GL_LESS against the cleared 1.0
+  const float fd = (p.projection[10] * vp.z + p.projection[14]) / -vp.z * 0.5f + 0.5f;
+  fdepth = fminf(fmaxf(fd, 0.0f), 1.0f);
+  if (!(fdepth < 1.0f)) {
+    rgba = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
+    fdepth = 1.0f;
+  }
+}
+
+constexpr int kNoHit = 0x7fffffff;
+
+// MODE 0: whole volume in this context, march + shade.
+// MODE 1 (Z slab, "find"): index of the first sample this slab owns whose density is > 0.
+// MODE 2 (Z slab, "shade"): with the minimum of those indices over all slabs in khit, the
+//         slab that owns that sample refines and shades it; the others mark the pixel kNoHit.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
 {
   const int px = blockIdx.x * 16 + threadIdx.x, py = blockIdx.y * 16 + threadIdx.y;
   if (px >= p.width || py >= p.height) return;
   const size_t o = (size_t)py * p.width + px;
-  const float limit = p.limit, sd = limit * 0.5f;
-  const float4 cleared = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
-  float4 rgba = cleared;
+  const float limit = p.limit;
+  float4 rgba = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
   float fdepth = 1.0f, fsamples = 0.0f;
-  do {
-    const float4 pc = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
-    const float4 ws = mat4_mul(p.modelview_inv, pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, 1.0f);
-    const float4 tv = mat4_mul(p.vol_to_world_inv, ws.x, ws.y, ws.z, ws.w);
-    const float3 nd = normalize3(tv.x - p.camera_pos[0], tv.y - p.camera_pos[1], tv.z - p.camera_pos[2]);
-    const float step[3] = {nd.x * sd, nd.y * sd, nd.z * sd};
-    float tmin[3], tmax[3];
+  int khit = kNoHit;
+  Ray r = ray_setup(p, px, py, o);
+  if (r.covered) {
+    float sp[3] = {r.sp[0], r.sp[1], r.sp[2]};
+    if (MODE == 0) {
+      float prev = -limit;
+      unsigned num = 0;
+      bool hit = false;
+      while (num < r.max_num) {
+        num += 1u;
+        const float density = tsdf_sample(p, sp[0], sp[1], sp[2]);
+        if (density > 0.0f) {
+          const float f = prev / (density - prev);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float inv = 1.0f / step[a];
-      const float tb = inv * (0.0f - p.camera_pos[a]), tt = inv * (1.0f - p.camera_pos[a]);
-      tmin[a] = fminf(tt, tb);
-      tmax[a] = fmaxf(tt, tb);
-    }
-    const float t0 = fmaxf(fmaxf(tmin[0], tmin[1]), fmaxf(tmin[0], tmin[2]));
-    const float t1 = fminf(fminf(tmax[0], tmax[1]), fminf(tmax[0], tmax[2]));
-    if (!(t0 <= t1) || !(t1 > 0.0f)) break;  // cube not rasterised onto this pixel
-    const float t_near = t0 < 0.0f ? 0.0f : t0;
-    float sp[3] = {p.camera_pos[0] + step[0] * t_near, p.camera_pos[1] + step[1] * t_near, p.camera_pos[2] + step[2] * t_near};
-    float fmaxs = ceilf(fabsf(t1 - t_near));
-    if (p.skip_space) {  // getStartPos, tsdf_raymarch.fs:392-401
-      const float4 dmm = p.peels[o];
-      const float dr = (dmm.x >= dmm.z) ? 0.0f : dmm.x;  // closest back face is the closest face -> gl_DepthRange.near
-      float pf[3], pb[3];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float4 a4 = mat4_mul(p.img_to_eye, (float)px + 0.5f, (float)py + 0.5f, k == 0 ? dr : -dmm.y, 1.0f);
-        const float4 w4 = mat4_mul(p.modelview_inv, a4.x / a4.w, a4.y / a4.w, a4.z / a4.w, 1.0f);
-        const float4 v4 = mat4_mul(p.vol_to_world_inv, w4.x, w4.y, w4.z, w4.w);
-        float* dst = k == 0 ? pf : pb;
-        dst[0] = v4.x;
-        dst[1] = v4.y;
-        dst[2] = v4.z;
-      }
-      if (dr >= 1.0f) {
-        pb[0] = pf[0];
-        pb[1] = pf[1];
-        pb[2] = pf[2];
-      }
-      sp[0] = pf[0];
-      sp[1] = pf[1];
-      sp[2] = pf[2];
-      const float ex = pf[0] - pb[0], ey = pf[1] - pb[1], ez = pf[2] - pb[2];
-      fmaxs = ceilf(sqrtf(ex * ex + ey * ey + ez * ez) / sd);
-    }
-    const unsigned max_num = !(fmaxs > 0.0f) ? 0u : (fmaxs >= 4294967040.0f ? 4294967040u : (unsigned)fmaxs);
-    float prev = -limit;
-    unsigned num = 0;
-    bool hit = false;
-    while (num < max_num) {
-      num += 1u;
-      const float density = tsdf_sample(p, sp[0], sp[1], sp[2]);
-      if (density > 0.0f) {
-        const float f = prev / (density - prev);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - step[a]) - step[a] * f;
-        hit = true;
-        break;
-      }
-      prev = density;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) sp[a] += step[a];
-    }
-    fsamples = (float)num * 0.0027f;
-    if (!hit) break;  // discard
-    // submitFragment
-    const float gx = tsdf_sample(p, sp[0] + sd, sp[1], sp[2]) - tsdf_sample(p, sp[0] - sd, sp[1], sp[2]);
-    const float gy = tsdf_sample(p, sp[0], sp[1] + sd, sp[2]) - tsdf_sample(p, sp[0], sp[1] - sd, sp[2]);
-    const float gz = tsdf_sample(p, sp[0], sp[1], sp[2] + sd) - tsdf_sample(p, sp[0], sp[1], sp[2] - sd);
-    const float3 gn = normalize3(gx, gy, gz);
-    const float4 vn4 = mat4_mul(p.normal_matrix, -gn.x, -gn.y, -gn.z, 0.0f);
-    const float3 vn = normalize3(vn4.x, vn4.y, vn4.z);
-    const float4 vp = mat4_mul(p.mv_vol_to_world, sp[0], sp[1], sp[2], 1.0f);
-    float tc[3] = {0, 0, 0}, tc2[3] = {0, 0, 0}, tw = 0.0f, tw2 = 0.0f, cw[3] = {0, 0, 0}, cwt = 0.0f;
-    for (int i = 0; i < p.N; ++i) {
-      const float3 pcal = p.lut_tiled ? lut_planes_sample(p, i, sp[0], sp[1], sp[2])
-                                      : tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], sp[0], sp[1], sp[2]);
-      const float2 pcol = tex3d_uv(p.cv_uv[i], p.uv_res[i][0], p.uv_res[i][1], p.uv_res[i][2], pcal.x, pcal.y, pcal.z);
-      const Axis CX = axis_linear(pcol.x, p.Wc), CY = axis_linear(pcol.y, p.Hc);
-      const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
-      float col[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-        const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-        col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
-      }
-      const uint2* frame = p.frame[i];
-      const int ix = axis_nearest(pcal.x, p.W), iy = axis_nearest(pcal.y, p.H);
-      const float depth = __uint_as_float(frame[(size_t)iy * p.W + ix].x);
-      const float dist = fabsf(depth - pcal.z);
-      float q = 0.0f;
-      if (dist < limit) {
-        const Axis QX = axis_linear(pcal.x, p.W), QY = axis_linear(pcal.y, p.H);
-        const float q00 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i0].y & 0x7fffffffu), q10 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i1].y & 0x7fffffffu);
-        const float q01 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i0].y & 0x7fffffffu), q11 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i1].y & 0x7fffffffu);
-        q = lerpf(lerpf(q00, q10, QX.a), lerpf(q01, q11, QX.a), QY.a);
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        tc[k] += col[k] * q / (dist + 0.01f);
-        tc2[k] += col[k] / dist;
-        if (i < 5) cw[k] += (c_camera_colors[i][k] / 255.0f) * q;
-      }
-      tw += q / (dist + 0.01f);
-      tw2 += 1.0f / dist;
-      cwt += q;
-    }
-    if (p.shade_mode == 3) {
-      rgba = make_float4(cwt <= 0.0f ? 1.0f : cw[0] / cwt, cwt <= 0.0f ? 1.0f : cw[1] / cwt, cwt <= 0.0f ? 1.0f : cw[2] / cwt, 1.0f);
-    } else {
-      float diff[4];
-      if (tw > 0.0f) {
-        diff[0] = tc[0] / tw;
-        diff[1] = tc[1] / tw;
-        diff[2] = tc[2] / tw;
-        diff[3] = 1.0f;
-      } else {
-        diff[0] = tc2[0] / tw2;
-        diff[1] = tc2[1] / tw2;
-        diff[2] = tc2[2] / tw2;
-        diff[3] = -1.0f;
-      }
-      float r[3] = {1.0f, 1.0f, 1.0f};
-      if (p.shade_mode == 0) {
-        r[0] = diff[0];
-        r[1] = diff[1];
-        r[2] = diff[2];
-      } else if (p.shade_mode == 1) {
-        const float3 tln = normalize3(1.5f - vp.x, 1.0f - vp.y, 1.0f - vp.z);
-        const float la = vn.x * tln.x + vn.y * tln.y + vn.z * tln.z;
-        float dc = 0.0f, sl = 0.0f;
-        if (!(la <= 0.0f)) {
-          dc = fmaxf(la, 0.0f);
-          const float3 tvw = normalize3(-vp.x, -vp.y, -vp.z);
-          const float3 hn = normalize3(tln.x + tvw.x, tln.y + tvw.y, tln.z + tvw.z);
-          const float ra = hn.x * vn.x + hn.y * vn.y + hn.z * vn.z;
-          const float r2 = ra * ra, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
-          sl = r16 * r4;
-          const float a = (1.0f - la) * (1.0f - la);
-          sl *= 1.0f - a * a * a;
+          for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - r.step[a]) - r.step[a] * f;
+          hit = true;
+          break;
         }
-        const float ld[3] = {1.0f, 0.9f, 0.7f};
+        prev = density;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) r[k] = (ld[k] * 0.2f) * 0.5f + ld[k] * 0.5f * dc + 1.0f * 0.5f * sl;
-      } else if (p.shade_mode == 2) {
-        const float4 r4 = mat4_mul(p.gl_normal_matrix_inv, vn.x, vn.y, vn.z, 0.0f);
-        r[0] = r4.x;
-        r[1] = r4.y;
-        r[2] = r4.z;
+        for (int a = 0; a < 3; ++a) sp[a] += r.step[a];
       }
-      rgba = make_float4(r[0], r[1], r[2], diff[3]);
+      fsamples = (float)num * 0.0027f;
+      if (hit) shade_fragment(p, sp, rgba, fdepth);
+    } else if (MODE == 1) {
+      for (unsigned k = 0; k < r.max_num; ++k) {
+        if (sample_owned(p, sp[2]) && tsdf_sample(p, sp[0], sp[1], sp[2]) > 0.0f) {
+          khit = (int)k;
+          break;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) sp[a] += r.step[a];
+      }
+    } else {
+      const int kmin = p.khit[o];
+      if (kmin == kNoHit) {
+        fsamples = (float)r.max_num * 0.0027f;
+      } else {
+        fsamples = (float)((unsigned)kmin + 1u) * 0.0027f;
+        float prev_sp[3] = {sp[0], sp[1], sp[2]};
+        for (int k = 0; k < kmin; ++k) {  // the same accumulation the single-volume march performs
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            prev_sp[a] = sp[a];
+            sp[a] += r.step[a];
+          }
+        }
+        if (sample_owned(p, sp[2])) {
+          khit = kmin;
+          const float prev = kmin == 0 ? -limit : tsdf_sample(p, prev_sp[0], prev_sp[1], prev_sp[2]);
+          const float density = tsdf_sample(p, sp[0], sp[1], sp[2]);
+          const float f = prev / (density - prev);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - r.step[a]) - r.step[a] * f;
+          shade_fragment(p, sp, rgba, fdepth);
+        }
+      }
     }
-    // gl_FragDepth is clamped to the depth range and tested GL_LESS against the cleared 1.0
-    const float fd = (p.projection[10] * vp.z + p.projection[14]) / -vp.z * 0.5f + 0.5f;
-    fdepth = fminf(fmaxf(fd, 0.0f), 1.0f);
-    if (!(fdepth < 1.0f)) {
-      rgba = cleared;
-      fdepth = 1.0f;
-    }
-  } while (false);
+  }
+  if (MODE == 1) {
+    p.khit[o] = khit;
+    return;
+  }
+  if (MODE == 2) p.khit[o] = khit;  // kNoHit unless this slab shaded the pixel
   p.out_color[o] = rgba;
   p.out_depth[o] = fdepth;
   p.out_samples[o] = fsamples;
@@ -390,10 +488,15 @@ void launch_depth_peels(const PeelParams& p, hipStream_t s)
   hipLaunchKernelGGL(k_depth_peels, grid, dim3(16, 16), 0, s, p);
 }
 
-void launch_raymarch(const RaymarchParams& p, hipStream_t s)
+void launch_raymarch(const RaymarchParams& p, int mode, hipStream_t s)
 {
   dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
-  hipLaunchKernelGGL(k_raymarch, grid, dim3(16, 16), 0, s, p);
+  if (mode == 0)
+    hipLaunchKernelGGL(k_raymarch<0>, grid, dim3(16, 16), 0, s, p);
+  else if (mode == 1)
+    hipLaunchKernelGGL(k_raymarch<1>, grid, dim3(16, 16), 0, s, p);
+  else
+    hipLaunchKernelGGL(k_raymarch<2>, grid, dim3(16, 16), 0, s, p);
 }
 
 }  // namespace rgbdr

@@ -105,8 +105,12 @@ struct RaymarchParams {
   float limit;
   int N, W, H, Wc, Hc;
   int X, Y, Z, TX, TY;
-  const float* tsdf;           // tile-linear, whole volume
-  const float* lut_tiled;      // grid-layout inverse LUT planes, or null ->
+  int tz_alloc0;               // global index of the first resident tile layer of tsdf / lut_tiled
+  int own_z0, own_z1;          // voxel rows this context owns (slab modes)
+  int res_z0, res_z1;          // voxel rows resident in this context (owned + halo)
+  int* khit;                   // per pixel first-hit sample index (slab modes)
+  const float* tsdf;           // tile-linear, resident layers
+  const float* lut_tiled;      // grid-layout inverse LUT planes (resident layers), or null ->
   const float4* lut[kMaxSensors];
   int rx[kMaxSensors], ry[kMaxSensors], rz[kMaxSensors], zoff[kMaxSensors];
   const float2* cv_uv[kMaxSensors];
@@ -119,7 +123,7 @@ struct RaymarchParams {
   float* out_depth;
   float* out_samples;
 };
-void launch_raymarch(const RaymarchParams& p, hipStream_t s);
+void launch_raymarch(const RaymarchParams& p, int mode, hipStream_t s);  // 0 whole volume, 1 slab find, 2 slab shade
 
 // ReconIntegration::drawDepthLimits (glsl/bricks.{vs,gs,fs}) per pixel
 struct PeelParams {

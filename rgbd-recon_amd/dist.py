@@ -28,11 +28,13 @@ def wrap_device_floats(ptr, nfloats, device):
 
 
 def halo_views(view, device):
-    """(send_lo, send_hi, recv_lo, recv_hi) float tensors aliasing the layers of a
-    rgbdr_tsdf_device_view with halo_layers == 1."""
-    n = view.layer_bytes // 4
+    """(send_lo, send_hi, recv_lo, recv_hi) float tensors aliasing the h = halo_layers
+    boundary tile layers of a rgbdr_tsdf_device_view: the h lowest / highest owned
+    layers and the h-layer halos below / above them (each one contiguous range)."""
+    h = view.halo_layers
+    n = h * view.layer_bytes // 4
     base, owned = int(view.base), int(view.owned)
-    last = owned + (view.owned_layers - 1) * view.layer_bytes
+    last = owned + (view.owned_layers - h) * view.layer_bytes
     hi_halo = owned + view.owned_layers * view.layer_bytes
     return (wrap_device_floats(owned, n, device), wrap_device_floats(last, n, device),
             wrap_device_floats(base, n, device), wrap_device_floats(hi_halo, n, device))
@@ -54,3 +56,69 @@ def exchange_halo(send_lo, send_hi, recv_lo, recv_hi, rank=None, world=None, gro
     if ops:
         for r in dist.batch_isend_irecv(ops):
             r.wait()
+
+
+NO_HIT = 0x7FFFFFFF
+
+
+def wrap_device_int32(ptr, n, device):
+    class _P32:
+        def __init__(self):
+            self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+    return torch.as_tensor(_P32(), device=device)
+
+
+def exchange_halo_via_host(views, rank=None, world=None, group=None):
+    """exchange_halo for a backend without device transport (gloo when several ranks
+    share one GPU for debugging): the four halo_views are staged through the host."""
+    host = [t.cpu() for t in views]
+    exchange_halo(host[0], host[1], host[2], host[3], rank=rank, world=world, group=group)
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    if rank > 0:
+        views[2].copy_(host[2])
+    if rank < world - 1:
+        views[3].copy_(host[3])
+
+
+def composite_slab_frames(color, depth, mine, group=None):
+    """Frames of the slabs -> one frame, by selection: `mine` marks the pixels this rank
+    shaded (at most one rank per pixel), everything else holds the cleared values.
+    The reduction runs on the int32 bit patterns: adding zeros to an integer is exact,
+    so the owner's value arrives bit for bit (-0.0 and NaN payloads included)."""
+    col = torch.where(mine[..., None], color, torch.zeros_like(color)).contiguous().view(torch.int32)
+    dep = torch.where(mine, depth, torch.zeros_like(depth)).contiguous().view(torch.int32)
+    own = mine.to(torch.int32)
+    dist.all_reduce(col, group=group)
+    dist.all_reduce(dep, group=group)
+    dist.all_reduce(own, group=group)
+    col, dep = col.view(torch.float32), dep.view(torch.float32)
+    none = own == 0                                                  # no slab hit: the cleared frame
+    col[none] = torch.tensor([0.0, 1.0, 0.0, 0.0], device=col.device)
+    dep[none] = 1.0
+    return col, dep
+
+
+def raymarch_slabs(ctx, view, device, group=None, via_host=False):
+    """Ray-march a volume split into Z slabs across the ranks of `group` (the TSDF halos
+    must be current): every rank finds its first owned hit sample per pixel, one
+    all-reduce MIN picks the global first hit, the owning rank shades it, and a second
+    reduction composites the frames.  Returns (color [H,W,4], depth [H,W],
+    num_samples [H,W]) torch tensors, identical on every rank and bit-identical to
+    rgbdr_raymarch on a single context (tests/test_raymarch_gpu.py, tests/test_dist_gpu.py)."""
+    h, w = view.height, view.width
+    k = wrap_device_int32(ctx.raymarch_find(view), h * w, device)
+    if via_host:
+        kh = k.cpu()
+        dist.all_reduce(kh, op=dist.ReduceOp.MIN, group=group)
+        k.copy_(kh)
+        torch.cuda.synchronize(device)
+    else:
+        dist.all_reduce(k, op=dist.ReduceOp.MIN, group=group)
+        torch.cuda.synchronize(device)
+    color, depth, ns = ctx.raymarch_shade(view)
+    out_dev = torch.device("cpu") if via_host else device
+    mine = (k != NO_HIT).reshape(h, w).to(out_dev)
+    col, dep = composite_slab_frames(torch.from_numpy(color).to(out_dev), torch.from_numpy(depth).to(out_dev), mine, group)
+    return col, dep, torch.from_numpy(ns).to(out_dev)

@@ -1,0 +1,57 @@
+"""One rank of the multi-process slab test (tests/test_dist_gpu.py); launched by
+`python -m torch.distributed.run`.  All ranks share cuda:0 and talk over gloo, with
+the device buffers staged through the host -- the same rgbd_recon_amd.dist functions
+run over RCCL with one GPU per rank."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
+
+
+def main():
+    out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32))
+    inv = scene.inverse((G, G, G))
+
+    def make(**slab):
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, tsdf_limit=limit, **slab), 0)
+        for i in range(2):
+            ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+        ctx.step(scene.depth, scene.color)
+        ctx.sync()
+        return ctx
+
+    ctx = make(slab_rank=rank, slab_count=world)
+    rdist.exchange_halo_via_host(rdist.halo_views(ctx.device_tsdf(), dev), rank=rank, world=world)
+    torch.cuda.synchronize()
+    whole = make() if rank == 0 else None
+    for n, (shade_mode, eye, skip) in enumerate([(0, (2.2, 1.6, 1.9), 0), (1, (0.85, 1.7, 0.8), 1)]):
+        view = capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=shade_mode)
+        view.skip_space = skip
+        col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=True)
+        np.savez(os.path.join(out_dir, "slab_r%d_v%d.npz" % (rank, n)), color=col.numpy(), depth=dep.numpy(), ns=ns.numpy())
+        if whole is not None:
+            c, d, s = whole.raymarch(view)
+            np.savez(os.path.join(out_dir, "whole_v%d.npz" % n), color=c, depth=d, ns=s)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

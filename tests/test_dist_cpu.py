@@ -88,3 +88,46 @@ def test_slab_halo_exchange_gloo(world, tmp_path, orc, pkg):
             assert np.all(np.isnan(slab[-1]))
         covered += t1 - t0
     assert covered == g.tiles[2]
+
+
+def _composite_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+
+    load_package()
+    from rgbd_recon_amd import dist as rdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(5)
+    h, w = 9, 13
+    owner = rng.integers(-1, world, size=(h, w))                     # -1: no slab hit the pixel
+    truth = rng.standard_normal((h, w, 4)).astype(np.float32)
+    truth[0, 0] = [-0.0, np.nan, np.inf, -1.0]                       # bit patterns a float sum would lose
+    owner[0, 0] = world - 1
+    tdepth = rng.random((h, w)).astype(np.float32)
+    mine = torch.from_numpy(owner == rank)
+    color = np.tile(np.float32([0, 1, 0, 0]), (h, w, 1))
+    depth = np.ones((h, w), np.float32)
+    color[owner == rank], depth[owner == rank] = truth[owner == rank], tdepth[owner == rank]
+    col, dep = rdist.composite_slab_frames(torch.from_numpy(color), torch.from_numpy(depth), mine)
+    np.savez(os.path.join(tmp, "comp%d.npz" % rank), col=col.numpy(), dep=dep.numpy(), owner=owner, truth=truth, tdepth=tdepth)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_frame_compositing_gloo(world, tmp_path, pkg):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_composite_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "comp%d.npz" % r))
+        hit = z["owner"] >= 0
+        want_c = np.where(hit[..., None], z["truth"], np.float32([0, 1, 0, 0]))
+        want_d = np.where(hit, z["tdepth"], np.float32(1))
+        assert want_c.view(np.uint32).tolist() == z["col"].view(np.uint32).tolist()
+        assert want_d.view(np.uint32).tolist() == z["dep"].view(np.uint32).tolist()

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
 
 
-def setup(pkg, orc, flags=15, inv_res=None, G=64):
+def setup(pkg, orc, flags=15, inv_res=None, G=64, **cfg):
     capi, synth = pkg.capi, pkg.synth
     scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32))
-    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags), 0)
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags, **cfg), 0)
     inv_res = inv_res or (G, G, G)
     inv = scene.inverse(inv_res)
     for i in range(2):
@@ -150,3 +150,63 @@ def oracle_images_skip(orc, ctx, scene, inv, view, peels):
     db = [ctx.readback_image(4, i) for i in range(2)]
     q = [ctx.readback_image(7, i) for i in range(2)]
     return orc.raymarch(bytes(view), tsdf, inv, scene.uv, [scene.color[i] for i in range(2)], db, q, peels=peels)
+
+
+@pytest.mark.parametrize("count,G,tsdf_limit", [(2, 64, 0.03), (3, 64, 0.03), (4, 128, 0.03), (2, 96, 0.1)])
+@pytest.mark.parametrize("skip", [0, 1])
+def test_slab_raymarch_equals_whole_volume(pkg, orc, count, G, tsdf_limit, skip):
+    """Z slabs: find -> element-wise MIN of the first-hit indices -> shade -> select.
+    The slab contexts live on one GPU here; the halo layers and the MIN that RCCL
+    carries between ranks (rgbd_recon_amd.dist) are moved with torch copies."""
+    import torch
+
+    from rgbd_recon_amd import dist as rdist
+
+    dev = torch.device("cuda:0")
+    scene, whole, inv = setup(pkg, orc, tsdf_limit=tsdf_limit, G=G)
+    ctxs = [setup(pkg, orc, tsdf_limit=tsdf_limit, G=G, slab_rank=r, slab_count=count)[1] for r in range(count)]
+    if skip:
+        for c in [whole] + ctxs:
+            c.set_use_bricks(True)
+            c.step(scene.depth, scene.color)
+    halo = ctxs[0].geo.halo_tile_layers
+    assert halo == -(-int(np.ceil(np.float32(tsdf_limit) * np.float32(G)) + 2) // 8)
+    views = []
+    for c in ctxs:
+        c.sync()
+        views.append(rdist.halo_views(c.device_tsdf(), dev))       # send_lo, send_hi, recv_lo, recv_hi
+    for r in range(count - 1):
+        views[r + 1][2].copy_(views[r][1])                           # r's top layers -> (r+1)'s lower halo
+        views[r][3].copy_(views[r + 1][0])                           # (r+1)'s bottom layers -> r's upper halo
+    torch.cuda.synchronize()
+    for shade_mode, eye in [(0, (2.2, 1.6, 1.9)), (1, (0.85, 1.7, 0.8)), (2, (0.1, 1.2, 2.4))]:
+        view = pkg.capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=shade_mode)
+        view.skip_space = skip
+        ref_c, ref_d, ref_n = whole.raymarch(view)
+        npix = view.width * view.height
+        ks = [rdist.wrap_device_int32(c.raymarch_find(view), npix, dev) for c in ctxs]
+        kmin = torch.stack(ks).min(dim=0).values
+        owners_with_hits = sum(int((k != rdist.NO_HIT).any()) for k in ks)
+        for k in ks:
+            k.copy_(kmin)
+        torch.cuda.synchronize()
+        color = np.tile(np.float32([0, 1, 0, 0]), (view.height, view.width, 1))
+        depth = np.ones((view.height, view.width), np.float32)
+        shaded = np.zeros((view.height, view.width), np.int32)
+        for c, k in zip(ctxs, ks):
+            cc, dd, nn = c.raymarch_shade(view)
+            assert same_bits(nn, ref_n)                              # every slab knows the sample count
+            mine = (k.cpu().numpy() != rdist.NO_HIT).reshape(view.height, view.width)
+            color[mine], depth[mine] = cc[mine], dd[mine]
+            shaded += mine
+            assert np.all(dd[~mine] == 1.0) and np.all(cc[~mine] == np.float32([0, 1, 0, 0]))
+        assert shaded.max() == 1                                     # exactly one owner per hit pixel
+        assert same_bits(depth, ref_d), count_diff(depth, ref_d)
+        assert same_bits(color, ref_c), count_diff(color, ref_c)
+        assert (ref_d < 1).mean() > 0.02
+        if shade_mode == 0:
+            assert owners_with_hits >= 2                             # the surface really spans slabs
+    with pytest.raises(pkg.capi.RgbdrError):
+        ctxs[0].raymarch(view)                                       # a slab cannot march alone
+    for c in [whole] + ctxs:
+        c.close()
