@@ -322,6 +322,12 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels
  * with the next two).  color = height*width RGBA32F, depth = height*width. */
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
+/* Makes a frame composited from several slab contexts (rgbdr_raymarch_shade + selection)
+ * the "last ray-marched frame" of this context, so that rgbdr_fill_colors can run on it
+ * (the framebuffer ReconIntegration::fillColors reads, recon_integration.cpp:283-296).
+ * color = height*width RGBA32F, depth = height*width, host memory. */
+int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* color, const float* depth);
+
 /* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
 
 /* names: "morph","bilateral","boundary","normal","quality","1preprocess",

@@ -177,6 +177,7 @@ SYMBOLS = {
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
     "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
     "rgbdr_raymarch_shade": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_draw_depth_limits": (C.c_int, [_P, C.POINTER(View), _F]),
@@ -477,6 +478,13 @@ class Context:
         depth = np.empty((height, width), dtype=np.float32)
         self._chk(lib().rgbdr_fill_colors(self._h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
+
+    def upload_view_frame(self, color, depth):
+        color = np.ascontiguousarray(color, dtype=np.float32)
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        h, w = depth.shape
+        assert color.shape == (h, w, 4)
+        self._chk(lib().rgbdr_upload_view_frame(self._h, w, h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
 
     def device_tsdf(self):
         v = TsdfDeviceView()

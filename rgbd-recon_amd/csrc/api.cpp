@@ -1433,6 +1433,23 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
   return RGBDR_OK;
 }
 
+int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* color, const float* depth)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (width < 1 || height < 1 || !color || !depth) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view frame");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)width * height;
+  int rc = ensure_view_buffers(ctx, npix);
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_view, color, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_view + npix * 4, depth, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->view_w = width;
+  ctx->view_h = height;
+  return RGBDR_OK;
+}
+
 void* rgbdr_stream(rgbdr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
