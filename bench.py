@@ -93,7 +93,7 @@ def main():
     d_color = torch.from_numpy(scene.color).to(dev)
     torch.cuda.synchronize()
 
-    halo = None
+    halo, transport = None, None
     if world > 1:
         halo = rdist.halo_views(ctx.device_tsdf(), dev)
         # The library enqueues on a torch stream so that the RCCL exchange can be
@@ -105,6 +105,24 @@ def main():
         torch.cuda.set_stream(main)
         ctx.set_stream(main.cuda_stream)
         int_done, halo_done = torch.cuda.Event(), torch.cuda.Event()
+        # Probe the device transport once before anything is timed.  If RCCL point-to-point
+        # on these buffers fails on this node, say so in the JSON line and carry the halos
+        # over a gloo group through the host instead of losing the whole scaling run.
+        transport = {"kind": "rccl" if args.backend == "nccl" else args.backend + " (host-staged)", "group": None}
+        if args.backend == "nccl":
+            fallback = dist.new_group(backend="gloo")
+            ok, why = 1, ""
+            try:
+                ctx.sync()
+                rdist.exchange_halo(*halo, rank=rank, world=world)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- reported, not swallowed
+                ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fallback)
+            if int(flag[0]) == 0:
+                transport = {"kind": "gloo (host-staged; RCCL p2p failed: %s)" % (why or "on another rank"), "group": fallback}
+                sys.stderr.write("[bench rank %d] %s\n" % (rank, transport["kind"]))
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
@@ -116,14 +134,14 @@ def main():
         ctx.integrate()
         if halo is not None:
             int_done.record(main)
-            if args.backend == "nccl":
+            if transport["kind"] == "rccl":
                 with torch.cuda.stream(side):
                     side.wait_event(int_done)
                     rdist.exchange_halo(*halo, rank=rank, world=world)
                     halo_done.record(side)
-            else:                            # debugging backend: stage through the host
+            else:                            # debugging backend / fallback: stage through the host
                 int_done.synchronize()
-                rdist.exchange_halo_via_host(halo, rank=rank, world=world)
+                rdist.exchange_halo_via_host(halo, rank=rank, world=world, group=transport["group"])
 
     def barrier():
         ctx.sync()
@@ -198,7 +216,8 @@ def main():
                                "inverse LUT" % ((N,) + tuple(g.res_volume)),
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
-                   "parallelism": "zslab%d" % world if world > 1 else "single"},
+                   "parallelism": "zslab%d" % world if world > 1 else "single",
+                   "halo_transport": transport["kind"] if world > 1 else None},
         "roofline": {"bound": "hbm", "kernel": "k_integrate_tiled<%d,false>" % N,
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
