@@ -222,7 +222,8 @@ def main():
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
-                     "launches_timed": int_n},
+                     "launches_timed": int_n,
+                     "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1]},
         "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
         "bricked": {"ms_per_step": round(dtb / bsteps * 1e3, 4),
                     "value": round(V_total / (dtb / bsteps) / 1e6, 1),

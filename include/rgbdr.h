@@ -322,6 +322,15 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels
  * with the next two).  color = height*width RGBA32F, depth = height*width. */
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
+/* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the
+ * driver placed that allocation (stable per allocation, several per cent apart), so the
+ * library times the LUT stream on up to RGBDR_ARENA_TRIALS (environment, default 8, 1 =
+ * off) candidate allocations when the arena is created, stops at the first that streams
+ * at the fast level and otherwise keeps the fastest.  Reports
+ * the candidates' times in ms (0 where none was measured), how many were tried and which
+ * one was kept. */
+int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[8], int* trials, int* chosen);
+
 /* Makes a frame composited from several slab contexts (rgbdr_raymarch_shade + selection)
  * the "last ray-marched frame" of this context, so that rgbdr_fill_colors can run on it
  * (the framebuffer ReconIntegration::fillColors reads, recon_integration.cpp:283-296).

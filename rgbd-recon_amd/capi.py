@@ -177,6 +177,7 @@ SYMBOLS = {
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
     "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
     "rgbdr_raymarch_shade": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
@@ -478,6 +479,13 @@ class Context:
         depth = np.empty((height, width), dtype=np.float32)
         self._chk(lib().rgbdr_fill_colors(self._h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
+
+    def arena_probe(self):
+        """([ms per candidate placement of the LUT arena], index kept)"""
+        ms = (C.c_float * 8)()
+        n, chosen = C.c_int(), C.c_int()
+        self._chk(lib().rgbdr_get_arena_probe(self._h, ms, C.byref(n), C.byref(chosen)))
+        return [round(float(ms[i]), 4) for i in range(n.value)], chosen.value
 
     def upload_view_frame(self, color, depth):
         color = np.ascontiguousarray(color, dtype=np.float32)

@@ -440,6 +440,55 @@ __global__ __launch_bounds__(128) void k_tile_lut(const float4* __restrict__ src
   o[kTileVoxels / 4] = make_float4(v[0], v[1], v[2], v[3]);
   o[2 * (kTileVoxels / 4)] = make_float4(d[0], d[1], d[2], d[3]);
 }
+// ---------------------------------------------------------------------------
+// Arena placement probe.  The sweep time of the integrate kernel is a stable property of
+// where the driver placed the LUT arena (the same binary measures 1.06 / 1.14 / 1.19 ms on
+// different hipMalloc results; the TSDF buffer and the tile order do not matter --
+// profiles/probes_src/pair_probe.hip).  This kernel replays the LUT stream
+// of k_integrate_tiled (one 128-thread block per tile, per_tile_v4 contiguous 16-byte loads,
+// XCD-chunked order) so that rgbdr can time candidate arenas at upload and keep the fastest.
+typedef float probe_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(128) void k_arena_probe(const probe_v4* __restrict__ arena, unsigned ntiles, unsigned per_tile_v4,
+                                                     unsigned chunk, float* __restrict__ sink)
+{
+  unsigned b = blockIdx.x;
+  if (chunk) {
+    const unsigned xcd = b & 7u, slot = b >> 3, span = chunk * 8u;
+    b = (slot / chunk) * span + xcd * chunk + slot % chunk;
+  }
+  const probe_v4* q = arena + (size_t)b * per_tile_v4;
+  probe_v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (unsigned k = threadIdx.x; k < per_tile_v4; k += 128) acc += __builtin_nontemporal_load(q + k);
+  // the TSDF tile store of the real kernel (the effect only shows with the write stream present)
+  __builtin_nontemporal_store(acc, (probe_v4*)sink + (size_t)b * (kTileVoxels / 4) + threadIdx.x);
+}
+
+float probe_arena_ms(const float* arena, size_t ntiles, int N, int TX, float* sink, hipStream_t s)
+{
+  const unsigned per_tile = (unsigned)N * 3u * (kTileVoxels / 4);
+  const unsigned chunk = (TX > 0 && ntiles % (8u * (unsigned)TX) == 0) ? (unsigned)TX : 0u;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return -1.0f;
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    return -1.0f;
+  }
+  float ms = -1.0f;
+  hipLaunchKernelGGL(k_arena_probe, dim3((unsigned)ntiles), dim3(128), 0, s, (const probe_v4*)arena, (unsigned)ntiles, per_tile,
+                     chunk, sink);
+  (void)hipEventRecord(e0, s);
+  const int reps = 3;
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_arena_probe, dim3((unsigned)ntiles), dim3(128), 0, s, (const probe_v4*)arena, (unsigned)ntiles,
+                       per_tile, chunk, sink);
+  (void)hipEventRecord(e1, s);
+  if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ms /= reps;
+  else ms = -1.0f;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return ms;
+}
+
 void launch_tile_lut(const float4* src, int X, int Y, int Z, int src_z0, int TX, int TY, int tz0, int ntz, int sensor,
                      int N, float* dst, hipStream_t s)
 {

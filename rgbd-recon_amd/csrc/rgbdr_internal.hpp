@@ -171,6 +171,8 @@ void launch_untile_lut(const float* tiled, int X, int Y, int TX, int TY, int tz0
                        int N, float4* dst_rgba, hipStream_t s);
 void launch_resample_lut(const float4* src_rgba, int rx, int ry, int rz, int zoff, int X, int Y, int Z, int TX, int TY,
                          int tz0, int ntz, int sensor, int N, float* dst_tiled, hipStream_t s);
+// average time (ms) of one replay of the integrate kernel's LUT stream over `arena`; < 0 on error
+float probe_arena_ms(const float* arena, size_t ntiles, int N, int TX, float* sink, hipStream_t s);
 void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
                          hipStream_t s);
 void launch_synth_inverse(const rgbdr_pinhole& cam, int W, int H, const float bbox_min[3], const float bbox_max[3],

@@ -496,3 +496,31 @@ def test_dxt_compressed_colour_frames(pkg, orc, mode):
     check_images(ctx, ref, 2)
     assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
     ctx.close()
+
+
+def test_lut_arena_placement_probe(pkg, monkeypatch):
+    """arenas of 256 MiB and more are placed by timing candidate allocations; the choice
+    never changes a result (same TSDF with the probe off)"""
+    import os
+
+    out = []
+    for trials in ("1", None):
+        if trials:
+            monkeypatch.setenv("RGBDR_ARENA_TRIALS", trials)
+        else:
+            monkeypatch.delenv("RGBDR_ARENA_TRIALS")
+        scene, ctx, _ = build(pkg, n=2, G=256, lut_res=(32, 27, 32))         # 2 x 256^3 x 12 B = 403 MB arena
+        ms, kept = ctx.arena_probe()
+        if trials:
+            assert len(ms) == 1 and kept == 0
+        else:
+            assert 1 <= len(ms) <= 8 and 0 <= kept < len(ms) and all(m > 0 for m in ms)
+            assert ms[kept] == min(ms)
+        ctx.set_use_bricks(False)
+        ctx.step(scene.depth, scene.color)
+        out.append(ctx.readback_tsdf())
+        ctx.close()
+    assert same_bits(out[0], out[1])
+    small = build(pkg)[1]                                                     # 64^3: below the threshold
+    assert small.arena_probe() == ([0.0], 0)
+    small.close()
