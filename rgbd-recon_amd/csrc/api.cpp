@@ -95,6 +95,7 @@ struct rgbdr_ctx {
 
   // bricks
   uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
+  uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
   uint8_t* d_mask = nullptr;
   bool mask_valid = false;
 
@@ -182,6 +183,8 @@ static void free_volume(rgbdr_ctx* c)
   c->view_pixels = c->fill_floats = 0;
   c->view_w = c->view_h = 0;
   c->integrated = false;
+  (void)hipFree(c->d_tile_list);
+  c->d_tile_list = nullptr;
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
@@ -216,6 +219,7 @@ static int alloc_volume(rgbdr_ctx* ctx)
   HIPCHK(hipMalloc((void**)&ctx->d_tsdf_base, total * sizeof(float)));
   ctx->d_tsdf_owned = ctx->d_tsdf_base + ctx->layer_floats * ctx->halo;
   HIPCHK(hipMemsetAsync(ctx->d_tsdf_base, 0, total * sizeof(float), ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->d_tile_list, ((size_t)g.tiles[0] * g.tiles[1] * owned + 1) * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
@@ -966,6 +970,8 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.by = g.res_bricks[1];
   p.bz = g.res_bricks[2];
   p.tsdf = ctx->d_tsdf_owned;
+  p.tile_list = ctx->d_tile_list;
+  p.tile_count = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz;
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
   tbegin(ctx, "2integrate", ctx->stream);
   launch_integrate(p, all_tiled, ctx->stream);

@@ -188,46 +188,25 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
 // footprints of all 512 voxels are then served from LDS.  More than 4 sensors are
 // folded in two groups (the running tsd / weight stay in registers), which keeps
 // the kernel at <= ~100 VGPRs for every N.
-template <int N, bool BRICKS, int MAXG = 4, bool NT = true>
-__global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
+// One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
+template <int N, bool BRICKS, int MAXG, bool NT>
+__device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
   constexpr int G2 = N - G1;                       // second group (0 for N <= MAXG)
-  __shared__ uint2 win[G1][kWin * kWinPitch];
-  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch).
-  // Each XCD takes chunks of `order_chunk` consecutive tiles (neighbouring tiles
-  // project into overlapping frame windows -> hits in that XCD's L2), and the 8
-  // XCDs work on 8 adjacent chunks at a time so the concurrent LUT streams stay
-  // close together in memory.
-  unsigned tile = blockIdx.x;
-  if (p.order_chunk) {
-    const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
-    const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
-    tile = (chunk * 8u + xcd) * p.order_chunk + within;
-  }
   const int q = threadIdx.x;
   const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
   float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
   const float limit = p.limit;
-
   bool occ[4] = {true, true, true, true};
   if (BRICKS) {
     const int tx = tile % p.TX;
     const int ty = (tile / p.TX) % p.TY;
     const int tzl = tile / (p.TX * p.TY);
     const int vz = (p.tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx = tx * kTile + lx0;
-    bool any = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      occ[j] = voxel_occupied(p, vx + j, vy, vz);
-      any |= occ[j];
-    }
-    if (!__syncthreads_or(any)) {  // fused clear of a tile without occupied bricks
-      *out = make_float4(-limit, -limit, -limit, -limit);
-      return;
-    }
+    for (int j = 0; j < 4; ++j) occ[j] = voxel_occupied(p, vx + j, vy, vz);
   }
-
   float tsd[4] = {limit, limit, limit, limit};
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   integrate_group<G1, NT>(p, tile, q, 0, N, win, false, limit, tsd, wsum);
@@ -243,6 +222,76 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(out));
   } else
     *out = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
+}
+
+// Full sweep: one block per tile.
+template <int N, int MAXG = 4, bool NT = true>
+__global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
+{
+  constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
+  __shared__ uint2 win[G1][kWin * kWinPitch];
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch).
+  // Each XCD takes chunks of `order_chunk` consecutive tiles (neighbouring tiles
+  // project into overlapping frame windows -> hits in that XCD's L2), and the 8
+  // XCDs work on 8 adjacent chunks at a time so the concurrent LUT streams stay
+  // close together in memory.
+  unsigned tile = blockIdx.x;
+  if (p.order_chunk) {
+    const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
+    tile = (chunk * 8u + xcd) * p.order_chunk + within;
+  }
+  integrate_tile<N, false, MAXG, NT>(p, tile, win);
+}
+
+// Brick-skipping sweep, second half: persistent blocks walk the list of tiles that touch
+// an occupied brick (k_brick_clear wrote -limit everywhere else and built the list).
+template <int N>
+__global__ __launch_bounds__(128) void k_integrate_tiled_list(IntegrateParams p)
+{
+  constexpr int G1 = N <= 4 ? N : (N + 1) / 2;
+  __shared__ uint2 win[G1][kWin * kWinPitch];
+  const unsigned n = *p.tile_count;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    integrate_tile<N, true, 4, true>(p, p.tile_list[i], win);
+    __syncthreads();  // the windows are reused by the next tile
+  }
+}
+
+// Brick-skipping sweep, first half (the fused clear of recon_integration.cpp:246-249 for
+// everything integrate will not touch): a block takes 16 consecutive tiles, 16 lanes decide
+// whether their tile overlaps an occupied brick and append it to the work list, then all
+// 256 lanes stream -limit into the tiles that do not (2 KiB each, non-temporal).
+constexpr int kClearTiles = 16;
+__global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned ntiles)
+{
+  __shared__ unsigned char keep[kClearTiles];
+  const unsigned t0 = blockIdx.x * kClearTiles;
+  if (threadIdx.x < kClearTiles) {
+    const unsigned tile = t0 + threadIdx.x;
+    bool any = false;
+    if (tile < ntiles) {
+      const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, tz = p.tz0 + tile / (p.TX * p.TY);
+      // bricks overlapped by the tile's 8^3 voxel positions (voxel_occupied's predicate per brick)
+      const int bx0 = (tx * kTile) / p.bvx, bx1 = min((tx * kTile + kTile - 1) / p.bvx, p.bx - 1);
+      const int by0 = (ty * kTile) / p.bvy, by1 = min((ty * kTile + kTile - 1) / p.bvy, p.by - 1);
+      const int bz0 = (tz * kTile) / p.bvz, bz1 = min((tz * kTile + kTile - 1) / p.bvz, p.bz - 1);
+      for (int bz = bz0; bz <= bz1; ++bz)
+        for (int by = by0; by <= by1; ++by)
+          for (int bx = bx0; bx <= bx1; ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+      if (any) p.tile_list[atomicAdd(p.tile_count, 1u)] = tile;
+    }
+    keep[threadIdx.x] = any;
+  }
+  __syncthreads();
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const float l = -p.limit;
+  const v4f fill = {l, l, l, l};
+  v4f* out = reinterpret_cast<v4f*>(p.tsdf);
+  for (unsigned i = threadIdx.x; i < kClearTiles * (kTileVoxels / 4); i += 256) {
+    const unsigned t = i / (kTileVoxels / 4), tile = t0 + t;
+    if (tile < ntiles && !keep[t]) __builtin_nontemporal_store(fill, out + (size_t)tile * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
+  }
 }
 
 // Window origin of one (tile, sensor): the minimum footprint index over the
@@ -349,21 +398,25 @@ __global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
 template <int N>
 static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
 {
+  if (p.use_bricks) {
+    (void)hipMemsetAsync(p.tile_count, 0, sizeof(unsigned), s);
+    hipLaunchKernelGGL(k_brick_clear, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
+    const unsigned blocks = ntiles < 2048u ? ntiles : 2048u;  // 8 resident blocks on each of the 256 CUs
+    hipLaunchKernelGGL((k_integrate_tiled_list<N>), dim3(blocks), dim3(128), 0, s, p);
+    return;
+  }
   // developer A/B knob: RGBDR_INTEGRATE_GROUP=2 folds 3 or 4 sensors in two groups
   static const int maxg = getenv("RGBDR_INTEGRATE_GROUP") ? atoi(getenv("RGBDR_INTEGRATE_GROUP")) : 4;
-  if (maxg == 2 && (N == 3 || N == 4) && !p.use_bricks) {
-    hipLaunchKernelGGL((k_integrate_tiled<N, false, 2>), dim3(ntiles), dim3(128), 0, s, p);
+  if (maxg == 2 && (N == 3 || N == 4)) {
+    hipLaunchKernelGGL((k_integrate_tiled<N, 2>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
   // developer A/B knob: RGBDR_NT=0 uses temporal loads/stores for the LUT / TSDF streams
-  if (getenv("RGBDR_NT") && !atoi(getenv("RGBDR_NT")) && N == 4 && !p.use_bricks) {
-    hipLaunchKernelGGL((k_integrate_tiled<N, false, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
+  if (getenv("RGBDR_NT") && !atoi(getenv("RGBDR_NT")) && N == 4) {
+    hipLaunchKernelGGL((k_integrate_tiled<N, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
-  if (p.use_bricks)
-    hipLaunchKernelGGL((k_integrate_tiled<N, true>), dim3(ntiles), dim3(128), 0, s, p);
-  else
-    hipLaunchKernelGGL((k_integrate_tiled<N, false>), dim3(ntiles), dim3(128), 0, s, p);
+  hipLaunchKernelGGL((k_integrate_tiled<N>), dim3(ntiles), dim3(128), 0, s, p);
 }
 
 void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t s)

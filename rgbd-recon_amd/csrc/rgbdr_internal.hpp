@@ -79,6 +79,8 @@ struct IntegrateParams {
   int bx, by, bz;
   float* tsdf;             // first owned tile layer
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
+  unsigned* tile_list;     // brick-skipping sweep: owned tiles that overlap an occupied brick ...
+  unsigned* tile_count;    // ... and how many (device memory, rebuilt by every sweep)
 };
 
 struct InvertParams {
