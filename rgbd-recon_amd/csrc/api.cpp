@@ -96,6 +96,9 @@ struct rgbdr_ctx {
   // bricks
   uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
   uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
+  uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
+  int tile_count_parity = 0;        // which of the two list counters the next brick sweep appends to
+  uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool mask_valid = false;
 
@@ -184,7 +187,8 @@ static void free_volume(rgbdr_ctx* c)
   c->view_w = c->view_h = 0;
   c->integrated = false;
   (void)hipFree(c->d_tile_list);
-  c->d_tile_list = nullptr;
+  (void)hipFree(c->d_tile_state);
+  c->d_tile_list = c->d_tile_state = nullptr;
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
@@ -219,7 +223,12 @@ static int alloc_volume(rgbdr_ctx* ctx)
   HIPCHK(hipMalloc((void**)&ctx->d_tsdf_base, total * sizeof(float)));
   ctx->d_tsdf_owned = ctx->d_tsdf_base + ctx->layer_floats * ctx->halo;
   HIPCHK(hipMemsetAsync(ctx->d_tsdf_base, 0, total * sizeof(float), ctx->stream));
-  HIPCHK(hipMalloc((void**)&ctx->d_tile_list, ((size_t)g.tiles[0] * g.tiles[1] * owned + 1) * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void**)&ctx->d_tile_list, ((size_t)g.tiles[0] * g.tiles[1] * owned + 2) * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_tile_list + (size_t)g.tiles[0] * g.tiles[1] * owned, 0, 2 * sizeof(uint32_t), ctx->stream));
+  ctx->tile_count_parity = 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_tile_state, (size_t)g.tiles[0] * g.tiles[1] * owned * sizeof(uint32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, (size_t)g.tiles[0] * g.tiles[1] * owned * sizeof(uint32_t), ctx->stream));
+  ctx->clear_epoch = 1;
   HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
   HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
@@ -516,7 +525,10 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.4e12) break;
   }
   if (best < 0) best = 0;
-  if (got > 1) HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
+  if (got > 1) {
+    HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
+    ++ctx->clear_epoch;
+  }
   ctx->arena_trials = got;
   ctx->arena_chosen = best;
   for (int t = 0; t < got; ++t)
@@ -971,7 +983,16 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.bz = g.res_bricks[2];
   p.tsdf = ctx->d_tsdf_owned;
   p.tile_list = ctx->d_tile_list;
-  p.tile_count = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz;
+  p.tile_count = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz + ctx->tile_count_parity;
+  p.tile_count_next = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz + (1 - ctx->tile_count_parity);
+  if (bricks && all_tiled) ctx->tile_count_parity ^= 1;
+  p.tile_state = ctx->d_tile_state;
+  if (!bricks || !all_tiled) ++ctx->clear_epoch;  // sweeps that overwrite tiles without keeping tile_state
+  if (ctx->clear_epoch == 0) {                     // wrapped: forget every recorded clear
+    HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, (size_t)p.TX * p.TY * p.ntz * sizeof(uint32_t), ctx->stream));
+    ctx->clear_epoch = 1;
+  }
+  p.epoch = ctx->clear_epoch;
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
   tbegin(ctx, "2integrate", ctx->stream);
   launch_integrate(p, all_tiled, ctx->stream);
@@ -1055,6 +1076,7 @@ int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit)
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(limit > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be > 0");
   ctx->cfg.tsdf_limit = limit;
+  ++ctx->clear_epoch;  // tiles cleared to the old -limit no longer count as cleared
   return RGBDR_OK;
 }
 

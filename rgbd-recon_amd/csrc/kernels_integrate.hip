@@ -252,46 +252,55 @@ __global__ __launch_bounds__(128) void k_integrate_tiled_list(IntegrateParams p)
   constexpr int G1 = N <= 4 ? N : (N + 1) / 2;
   __shared__ uint2 win[G1][kWin * kWinPitch];
   const unsigned n = *p.tile_count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_next = 0u;  // the counter the next sweep appends to
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
     integrate_tile<N, true, 4, true>(p, p.tile_list[i], win);
     __syncthreads();  // the windows are reused by the next tile
   }
 }
 
-// Brick-skipping sweep, first half (the fused clear of recon_integration.cpp:246-249 for
-// everything integrate will not touch): a block takes 16 consecutive tiles, 16 lanes decide
-// whether their tile overlaps an occupied brick and append it to the work list, then all
-// 256 lanes stream -limit into the tiles that do not (2 KiB each, non-temporal).
-constexpr int kClearTiles = 16;
+// Brick-skipping sweep, first half (the clear of recon_integration.cpp:246-249 for everything
+// integrate will not touch).  One lane per tile: does the tile overlap an occupied brick?
+// Then it goes on the work list of k_integrate_tiled_list.  Otherwise it must hold -limit --
+// and if tile_state[tile] == epoch it still does from an earlier sweep (the host bumps the
+// epoch whenever anything else may have written the volume or the limit changed), so a
+// steady stream only rewrites the tiles the surface has just left.  Tiles that do need the
+// clear are collected per block and streamed out by all 256 lanes (2 KiB each, non-temporal).
+constexpr int kClearTiles = 256;
 __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned ntiles)
 {
-  __shared__ unsigned char keep[kClearTiles];
-  const unsigned t0 = blockIdx.x * kClearTiles;
-  if (threadIdx.x < kClearTiles) {
-    const unsigned tile = t0 + threadIdx.x;
+  __shared__ unsigned todo[kClearTiles];
+  __shared__ unsigned ntodo;
+  if (threadIdx.x == 0) ntodo = 0;
+  __syncthreads();
+  const unsigned tile = blockIdx.x * kClearTiles + threadIdx.x;
+  if (tile < ntiles) {
+    const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, tz = p.tz0 + tile / (p.TX * p.TY);
+    // bricks overlapped by the tile's 8^3 voxel positions (voxel_occupied's predicate per brick)
+    const int bx0 = (tx * kTile) / p.bvx, bx1 = min((tx * kTile + kTile - 1) / p.bvx, p.bx - 1);
+    const int by0 = (ty * kTile) / p.bvy, by1 = min((ty * kTile + kTile - 1) / p.bvy, p.by - 1);
+    const int bz0 = (tz * kTile) / p.bvz, bz1 = min((tz * kTile + kTile - 1) / p.bvz, p.bz - 1);
     bool any = false;
-    if (tile < ntiles) {
-      const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, tz = p.tz0 + tile / (p.TX * p.TY);
-      // bricks overlapped by the tile's 8^3 voxel positions (voxel_occupied's predicate per brick)
-      const int bx0 = (tx * kTile) / p.bvx, bx1 = min((tx * kTile + kTile - 1) / p.bvx, p.bx - 1);
-      const int by0 = (ty * kTile) / p.bvy, by1 = min((ty * kTile + kTile - 1) / p.bvy, p.by - 1);
-      const int bz0 = (tz * kTile) / p.bvz, bz1 = min((tz * kTile + kTile - 1) / p.bvz, p.bz - 1);
-      for (int bz = bz0; bz <= bz1; ++bz)
-        for (int by = by0; by <= by1; ++by)
-          for (int bx = bx0; bx <= bx1; ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
-      if (any) p.tile_list[atomicAdd(p.tile_count, 1u)] = tile;
+    for (int bz = bz0; bz <= bz1; ++bz)
+      for (int by = by0; by <= by1; ++by)
+        for (int bx = bx0; bx <= bx1; ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+    if (any) {
+      p.tile_list[atomicAdd(p.tile_count, 1u)] = tile;
+      p.tile_state[tile] = 0u;  // about to hold integrated values
+    } else if (p.tile_state[tile] != p.epoch) {
+      p.tile_state[tile] = p.epoch;
+      todo[atomicAdd(&ntodo, 1u)] = tile;
     }
-    keep[threadIdx.x] = any;
   }
   __syncthreads();
+  const unsigned n = ntodo;
+  if (n == 0) return;
   typedef float v4f __attribute__((ext_vector_type(4)));
   const float l = -p.limit;
   const v4f fill = {l, l, l, l};
   v4f* out = reinterpret_cast<v4f*>(p.tsdf);
-  for (unsigned i = threadIdx.x; i < kClearTiles * (kTileVoxels / 4); i += 256) {
-    const unsigned t = i / (kTileVoxels / 4), tile = t0 + t;
-    if (tile < ntiles && !keep[t]) __builtin_nontemporal_store(fill, out + (size_t)tile * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
-  }
+  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += 256)
+    __builtin_nontemporal_store(fill, out + (size_t)todo[i / (kTileVoxels / 4)] * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
 }
 
 // Window origin of one (tile, sensor): the minimum footprint index over the
@@ -399,7 +408,6 @@ template <int N>
 static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
 {
   if (p.use_bricks) {
-    (void)hipMemsetAsync(p.tile_count, 0, sizeof(unsigned), s);
     hipLaunchKernelGGL(k_brick_clear, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
     const unsigned blocks = ntiles < 2048u ? ntiles : 2048u;  // 8 resident blocks on each of the 256 CUs
     hipLaunchKernelGGL((k_integrate_tiled_list<N>), dim3(blocks), dim3(128), 0, s, p);

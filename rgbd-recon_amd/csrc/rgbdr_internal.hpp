@@ -80,7 +80,10 @@ struct IntegrateParams {
   float* tsdf;             // first owned tile layer
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
   unsigned* tile_list;     // brick-skipping sweep: owned tiles that overlap an occupied brick ...
-  unsigned* tile_count;    // ... and how many (device memory, rebuilt by every sweep)
+  unsigned* tile_count;    // ... and how many (device memory, rebuilt by every sweep; zero on entry)
+  unsigned* tile_count_next;  // the other of the two counters: zeroed by this sweep for the next one
+  unsigned* tile_state;    // == epoch: the tile holds -limit throughout since a brick sweep of this epoch
+  unsigned epoch;
 };
 
 struct InvertParams {

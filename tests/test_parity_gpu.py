@@ -524,3 +524,35 @@ def test_lut_arena_placement_probe(pkg, monkeypatch):
     small = build(pkg)[1]                                                     # 64^3: below the threshold
     assert small.arena_probe() == ([0.0], 0)
     small.close()
+
+
+def test_brick_sweep_skips_tiles_that_are_still_cleared(pkg, orc):
+    """the brick-skipping sweep rewrites -limit only where a tile does not hold it already;
+    every event that invalidates that record is followed by a correct volume"""
+    scene, ctx, inv = build(pkg, G=64)
+    scene2 = pkg.synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.6)
+
+    def expect(sc, **kw):
+        return oracle_run(orc, sc, ctx, inv, **kw)["tsdf"]
+
+    ctx.step(scene.depth, scene.color)
+    a = expect(scene)
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.step(scene.depth, scene.color)                          # steady state: nothing to clear
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.step(scene2.depth, scene2.color)                        # the surface moved: old tiles must be cleared
+    b = expect(scene2)
+    assert same_bits(ctx.readback_tsdf(), b) and not same_bits(a, b)
+    ctx.set_use_bricks(False)                                   # a full sweep writes every tile ...
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), expect(scene2, use_bricks=False))
+    ctx.set_use_bricks(True)                                    # ... so the next brick sweep clears again
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), b)
+    ctx.set_tsdf_limit(0.02)                                    # another -limit
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), expect(scene2, limit=np.float32(0.02)))
+    ctx.set_tsdf_limit(0.01)
+    ctx.step(scene.depth, scene.color)
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.close()
