@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", type=int, default=0, help="override with a cubic grid of this size")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: debugging several "
-                                                      "ranks on one GPU, halos staged through the host)")
+                                                      "ranks on one GPU)")
     ap.add_argument("--sensors", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
@@ -97,15 +97,12 @@ def main():
     halo, transport = None, None
     if world > 1:
         halo = rdist.halo_views(ctx.device_tsdf(), dev)
-        # The library enqueues on a torch stream so that the RCCL exchange can be
-        # ordered against the kernels with events instead of host syncs: the halo of
-        # step k travels on a side stream while step k+1 runs its pre_* chain; only
-        # integrate (which overwrites the layers being sent) waits for it.
+        # The library enqueues on a torch stream so that the RCCL exchange can be ordered
+        # against the kernels with events instead of host syncs (rgbd_recon_amd.dist.HaloExchanger:
+        # boundary layers are staged device-to-device, the transfer of step k overlaps step k+1).
         main = torch.cuda.Stream(dev)
-        side = torch.cuda.Stream(dev)
         torch.cuda.set_stream(main)
         ctx.set_stream(main.cuda_stream)
-        int_done, halo_done = torch.cuda.Event(), torch.cuda.Event()
         # Probe the device transport once before anything is timed.  If RCCL point-to-point
         # on these buffers fails on this node, say so in the JSON line and carry the halos
         # over a gloo group through the host instead of losing the whole scaling run.
@@ -124,25 +121,17 @@ def main():
             if int(flag[0]) == 0:
                 transport = {"kind": "gloo (host-staged; RCCL p2p failed: %s)" % (why or "on another rank"), "group": fallback}
                 sys.stderr.write("[bench rank %d] %s\n" % (rank, transport["kind"]))
+        exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, group=transport["group"],
+                                        via_host=transport["kind"] != "rccl")
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
         ctx.update_occupied_bricks()
-        if halo is not None:
-            main.wait_event(halo_done)       # no-op until the first exchange was enqueued
         ctx.integrate()
         if halo is not None:
-            int_done.record(main)
-            if transport["kind"] == "rccl":
-                with torch.cuda.stream(side):
-                    side.wait_event(int_done)
-                    rdist.exchange_halo(*halo, rank=rank, world=world)
-                    halo_done.record(side)
-            else:                            # debugging backend / fallback: stage through the host
-                int_done.synchronize()
-                rdist.exchange_halo_via_host(halo, rank=rank, world=world, group=transport["group"])
+            exchanger.exchange_async()
 
     def barrier():
         ctx.sync()

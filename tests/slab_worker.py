@@ -16,7 +16,52 @@ from __graft_entry__ import load_package  # noqa: E402
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
 
 
+def exchanger_mode(out_dir, G):
+    """three frames through integrate + HaloExchanger.exchange_async (gloo: staged through
+    the host); afterwards every rank dumps its boundary layers and its halos"""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=s, sphere_r=r) for s, r in ((1, 0.9), (2, 0.6), (3, 0.75))]
+    inv = scenes[0].inverse((G, G, G))
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=rank,
+                                        slab_count=world), 0)
+    for i in range(2):
+        ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    main = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(main)
+    ctx.set_stream(main.cuda_stream)
+    ex = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, via_host=True)
+    frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
+    torch.cuda.synchronize()
+    lo, hi, rlo, rhi = rdist.halo_views(ctx.device_tsdf(), dev)
+    history = []
+    for d, c in frames:
+        ctx.update_device(d.data_ptr(), c.data_ptr())
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        ex.exchange_async()
+        history.append((lo.clone(), hi.clone()))                  # stream-ordered snapshots, no host sync
+    ex.wait()
+    main.synchronize()
+    np.savez(os.path.join(out_dir, "halo_r%d.npz" % rank), send_lo=lo.cpu().numpy(), send_hi=hi.cpu().numpy(),
+             recv_lo=rlo.cpu().numpy(), recv_hi=rhi.cpu().numpy(), tsdf=ctx.readback_tsdf(),
+             hist_lo=torch.stack([h[0] for h in history]).cpu().numpy(),
+             hist_hi=torch.stack([h[1] for h in history]).cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] == "exchanger":
+        return exchanger_mode(sys.argv[2], int(sys.argv[3]))
     out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     load_package()

@@ -34,3 +34,40 @@ def test_slab_ranks_render_the_whole_volume(world, G, limit, tmp_path):
             got = np.load(os.path.join(str(tmp_path), "slab_r%d_v%d.npz" % (rank, n)))
             for key in ("color", "depth", "ns"):
                 assert same_bits(got[key], ref[key]), (n, rank, key)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_async_halo_exchanger(world, tmp_path, pkg):
+    """HaloExchanger: staged, stream-ordered exchange over three different frames with no
+    host synchronisation in between; the halos end up holding the neighbours' boundary
+    layers of the LAST frame, and the slabs the whole volume of that frame"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    G = 64
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), "exchanger", str(tmp_path),
+           str(G)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = [np.load(os.path.join(str(tmp_path), "halo_r%d.npz" % k)) for k in range(world)]
+    for k in range(world - 1):
+        up = [same_bits(z[k]["recv_hi"], z[k + 1]["hist_lo"][f]) for f in range(3)]
+        down = [same_bits(z[k + 1]["recv_lo"], z[k]["hist_hi"][f]) for f in range(3)]
+        assert up[2] and down[2], (k, up, down)                  # the halos hold the last frame
+        assert same_bits(z[k]["recv_hi"], z[k + 1]["send_lo"])
+        assert same_bits(z[k + 1]["recv_lo"], z[k]["send_hi"])
+        assert np.nanmax(np.abs(z[k]["send_hi"])) > 0
+    # the last frame on one context
+    capi, synth = pkg.capi, pkg.synth
+    last = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=3, sphere_r=0.75)
+    first = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=1, sphere_r=0.9)
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
+    inv = first.inverse((G, G, G))
+    for i in range(2):
+        ctx.set_calibration(i, first.xyz[i], first.lut_res, first.uv[i], first.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.step(last.depth, last.color)
+    assert same_bits(np.concatenate([zz["tsdf"] for zz in z], axis=0), ctx.readback_tsdf())
+    ctx.close()
