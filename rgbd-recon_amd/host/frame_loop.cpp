@@ -61,8 +61,8 @@ int main(int argc, char** argv)
       return 1;
     }
   }
-  if (argc != 7) {
-    std::fprintf(stderr, "usage: %s <dir> <num_sensors> <W> <H> <G> <out.tsdf>\n", argv[0]);
+  if (argc != 7 && argc != 8) {
+    std::fprintf(stderr, "usage: %s <dir> <num_sensors> <W> <H> <G> <out.tsdf> [view.bin]\n", argv[0]);
     return 2;
   }
   try {
@@ -99,6 +99,19 @@ int main(int argc, char** argv)
     std::fclose(f);
     std::printf("res %d %d %d bricks %u occupied %.4f\n", g.res_volume[0], g.res_volume[1], g.res_volume[2],
                 recon.numBricks(), recon.occupiedRatio());
+    if (argc == 8) {  // g_recons[mode]->drawF() of kinect_client.cpp: ray-march + hole filling for the given uniforms
+      rgbdr_view view;
+      FILE* vf = std::fopen(argv[7], "rb");
+      if (!vf || std::fread(&view, sizeof(view), 1, vf) != 1) return 5;
+      std::fclose(vf);
+      ReconIntegration::Frame frame;
+      recon.drawF(view, frame);
+      FILE* ff = std::fopen((std::string(argv[6]) + ".frame").c_str(), "wb");
+      if (!ff) return 3;
+      std::fwrite(frame.color.data(), sizeof(float), frame.color.size(), ff);
+      std::fwrite(frame.depth.data(), sizeof(float), frame.depth.size(), ff);
+      std::fclose(ff);
+    }
     // error behaviour mirrors the reference's exception types
     try {
       recon.setVoxelSize(-1.0f);

@@ -330,6 +330,40 @@ class ReconIntegration {
   unsigned numBricks() const { return rgbdr_num_bricks(m_be.ctx()); }
   float occupiedRatio() const { return rgbdr_occupied_ratio(m_be.ctx()); }
   float getBrickSize() const { return rgbdr_get_brick_size(m_be.ctx()); }
+  // drawing.  The reference reads its uniforms from GL state; here
+  // the caller passes them as an rgbdr_view (modelview, projection, NormalMatrix, ... as
+  // ReconIntegration::draw computes them, recon_integration.cpp:177-241).
+  void setColorFilling(bool active) { m_fill_holes = active; }
+  void setSpaceSkip(bool active) { m_skip_space = active; }
+  struct Frame {
+    int width = 0, height = 0;
+    std::vector<float> color, depth, num_samples;  // RGBA32F, gl_FragDepth, tex_num_samples
+  };
+  // draw(): depth limits when m_skip_space && use_bricks, then the ray-march (:151-159, 177-241)
+  void draw(rgbdr_view view, Frame& f) const
+  {
+    view.skip_space = m_skip_space ? 1 : 0;
+    const size_t n = (size_t)view.width * view.height;
+    f.width = view.width;
+    f.height = view.height;
+    f.color.resize(n * 4);
+    f.depth.resize(n);
+    f.num_samples.resize(n);
+    check(m_be.ctx(), rgbdr_raymarch(m_be.ctx(), &view, f.color.data(), f.depth.data(), f.num_samples.data()));
+  }
+  // drawF(): draw() and, when colour filling is on, fillColors() (:151-175)
+  void drawF(rgbdr_view const& view, Frame& f) const
+  {
+    draw(view, f);
+    if (m_fill_holes) check(m_be.ctx(), rgbdr_fill_colors(m_be.ctx(), f.color.data(), f.depth.data()));
+  }
+  // the depth-peel image of drawDepthLimits (:409-429): RGBA32F per pixel
+  std::vector<float> drawDepthLimits(rgbdr_view const& view) const
+  {
+    std::vector<float> peels((size_t)view.width * view.height * 4);
+    check(m_be.ctx(), rgbdr_draw_depth_limits(m_be.ctx(), &view, peels.data()));
+    return peels;
+  }
   // no counterpart in the reference (consumers sample texture unit 29)
   std::vector<float> readbackTsdf(rgbdr_geometry* geo_out = nullptr) const
   {
@@ -343,6 +377,7 @@ class ReconIntegration {
 
  private:
   Backend& m_be;
+  bool m_fill_holes = true, m_skip_space = true;  // defaults of recon_integration.cpp:60-63
 };
 
 // process_textures() of source/kinect_client.cpp:572-580

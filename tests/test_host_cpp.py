@@ -39,10 +39,27 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
                 f.write(scene.color[i].tobytes())
                 f.write((scene.depth[i] if k == 0 else np.zeros_like(scene.depth[i])).tobytes())
     out = os.path.join(d, "out.tsdf")
-    r = subprocess.run([EXE, d, str(n), str(W), str(H), str(G), out], capture_output=True, text=True)
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 48, 36, synth.BBOX_MIN, synth.BBOX_MAX)
+    with open(os.path.join(d, "view.bin"), "wb") as f:
+        f.write(bytes(view))
+    r = subprocess.run([EXE, d, str(n), str(W), str(H), str(G), out, os.path.join(d, "view.bin")], capture_output=True,
+                       text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("res 32 32 32 bricks 64")
     got = np.fromfile(out, dtype=np.float32).reshape(G, G, G)
+    # ReconIntegration::drawF through the C++ mirror == the same calls through the ctypes harness
+    frame = np.fromfile(out + ".frame", dtype=np.float32)
+    ctx = pkg.capi.Context(pkg.capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.step(scene.depth, scene.color)
+    view.skip_space = 1                                        # m_skip_space defaults to true
+    ctx.raymarch(view)
+    fc, fd = ctx.fill_colors(view.width, view.height)          # m_fill_holes defaults to true
+    ctx.close()
+    assert same_bits(frame[: fc.size].reshape(fc.shape), fc) and same_bits(frame[fc.size:].reshape(fd.shape), fd)
+    assert (fd < 1).mean() > 0.02
     g = pkg.capi.compute_geometry(pkg.capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G))
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
