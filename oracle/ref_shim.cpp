@@ -5,7 +5,10 @@
 // trilinear helper (framework/DataTypes.{h,cpp}).  Built by oracle/Makefile into
 // oracle/_ref/libref_shim.so *from the sources where they lie*; nothing from the
 // reference is copied into this repository.  Used by tests/test_oracle_ref.py to
-// pin the oracle's file format, record layouts and trilinear interpolation.
+// pin the oracle's file format, record layouts and trilinear interpolation, and the
+// host mirror's sensor-yml scanner and .stream reader against the reference's own
+// (framework/calibration/{calibration_files,KinectCalibrationFile}.cpp over the vendored
+// gloost math classes, framework/io/FileBuffer.cpp).
 #include <cassert>  // calibration_volume.hpp uses assert() without including it
 #include <cstdint>
 #include <cstring>
@@ -14,6 +17,11 @@
 #include <DataTypes.h>
 #include <calibration/calibration_volume.hpp>
 #include <squish.h>  // external/squish: the reference's own CPU decoder of its DXT colour frames
+#include <string>
+
+#include <FileBuffer.h>
+#include <KinectCalibrationFile.h>
+#include <calibration_files.hpp>
 
 extern "C" {
 
@@ -87,6 +95,44 @@ void ref_get_trilinear(const float* data, unsigned w, unsigned h, unsigned d, fl
 void ref_squish_decompress(unsigned char* rgba, int width, int height, const void* blocks, int mode)
 {
   squish::DecompressImage(rgba, width, height, blocks, mode == 1 ? squish::kDxt1 : squish::kDxt5);
+}
+
+// kinect::CalibrationFiles over `n` sensor yml files: out = {width, height, widthC, heightC,
+// isCompressedRGB, isCompressedDepth}, near_far = {near_0, far_0, near_1, ...}
+int ref_calibration_files(const char** paths, int n, unsigned* out, float* near_far)
+{
+  std::vector<std::string> names(paths, paths + n);
+  kinect::CalibrationFiles cf(names);
+  out[0] = cf.getWidth();
+  out[1] = cf.getHeight();
+  out[2] = cf.getWidthC();
+  out[3] = cf.getHeightC();
+  out[4] = cf.isCompressedRGB();
+  out[5] = cf.isCompressedDepth() ? 1u : 0u;
+  for (int i = 0; i < n; ++i) {
+    near_far[2 * i] = cf.getCalibs()[i].getNear();
+    near_far[2 * i + 1] = cf.getCalibs()[i].getFar();
+  }
+  return (int)cf.num();
+}
+
+// sys::FileBuffer as NetKinectArray::readFromFiles drives it (NetKinectArray.cpp:724-764):
+// open("r"), setLooping, then `frames` times read(colorsize) + read(depthsize) into dst.
+// Returns the number of bytes the reads delivered in total, -1 if the file does not open.
+long ref_stream_read(const char* path, int looping, unsigned colorsize, unsigned depthsize, int frames, unsigned char* dst)
+{
+  sys::FileBuffer fb(path);
+  if (!fb.open("r")) return -1;
+  fb.setLooping(looping != 0);
+  long total = 0;
+  for (int k = 0; k < frames; ++k) {
+    total += fb.read(dst, colorsize);
+    dst += colorsize;
+    total += fb.read(dst, depthsize);
+    dst += depthsize;
+  }
+  fb.close();
+  return total;
 }
 
 }  // extern "C"

@@ -51,8 +51,43 @@ static int run_ks(const char* ks_path, float voxel, const char* out_path)
   return 0;
 }
 
+// frame_loop --parse <sensor.yml>...            prints what parseCalibrationFiles read
+// frame_loop --stream <file> <colorsize> <depthsize> <index> <out>   writes frame `index` (colour, depth) to <out>
+static int run_tools(int argc, char** argv)
+{
+  const std::string mode = argv[1];
+  if (mode == "--parse") {
+    std::vector<std::string> names(argv + 2, argv + argc);
+    CalibrationFiles cf = parseCalibrationFiles(names);
+    std::printf("%u %u %u %u %d %d", cf.getWidth(), cf.getHeight(), cf.getWidthC(), cf.getHeightC(), cf.isCompressedRGB(),
+                cf.isCompressedDepth() ? 1 : 0);
+    for (unsigned i = 0; i < cf.num(); ++i) std::printf(" %.9g %.9g", cf.near_[i], cf.far_[i]);
+    std::printf("\n");
+    return 0;
+  }
+  if (mode == "--stream" && argc == 7) {
+    const size_t cs = (size_t)std::atoll(argv[3]), ds = (size_t)std::atoll(argv[4]);
+    std::vector<unsigned char> buf(cs + ds);
+    readStreamFrame(argv[2], cs, ds, (size_t)std::atoll(argv[5]), buf.data(), buf.data() + cs);
+    FILE* f = std::fopen(argv[6], "wb");
+    if (!f) return 3;
+    std::fwrite(buf.data(), 1, buf.size(), f);
+    std::fclose(f);
+    return 0;
+  }
+  return 2;
+}
+
 int main(int argc, char** argv)
 {
+  if (argc >= 3 && (std::string(argv[1]) == "--parse" || std::string(argv[1]) == "--stream")) {
+    try {
+      return run_tools(argc, argv);
+    } catch (const std::exception& e) {
+      std::fprintf(stderr, "frame_loop: %s\n", e.what());
+      return 1;
+    }
+  }
   if (argc == 5 && std::string(argv[1]) == "--ks") {
     try {
       return run_ks(argv[2], (float)std::atof(argv[3]), argv[4]);

@@ -274,6 +274,21 @@ class CalibVolumes {
   std::vector<std::string> m_cv_xyz_filenames, m_cv_uv_filenames;
 };
 
+// One frame of a sensor's ".stream" recording: [colorsize bytes][depthsize bytes] repeated
+// (NetKinectArray.cpp:745-763 through sys::FileBuffer::read, io/FileBuffer.cpp:108-128, with
+// looping off as the reference sets it: a read past the end is a short read).  Frame
+// `index` is what the reference's reader delivers with its (index+1)-th pair of reads.
+inline void readStreamFrame(std::string const& path, size_t colorsize, size_t depthsize, size_t index, unsigned char* color,
+                            unsigned char* depth)
+{
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("error opening " + path);
+  bool ok = std::fseek(f, (long)((colorsize + depthsize) * index), SEEK_SET) == 0 &&
+            std::fread(color, 1, colorsize, f) == colorsize && std::fread(depth, 1, depthsize, f) == depthsize;
+  std::fclose(f);
+  if (!ok) throw std::runtime_error("short read from " + path);
+}
+
 // kinect::NetKinectArray (ingest + the five pre_* passes).  The ZeroMQ reader
 // thread is transport and stays outside; frames arrive through update().
 class NetKinectArray {
@@ -299,15 +314,8 @@ class NetKinectArray {
   bool readFromFiles(std::vector<std::string> const& stream_files, size_t colorsize, size_t depthsize, size_t index = 0)
   {
     std::vector<unsigned char> color(colorsize * stream_files.size()), depth(depthsize * stream_files.size());
-    for (size_t i = 0; i < stream_files.size(); ++i) {
-      FILE* f = std::fopen(stream_files[i].c_str(), "rb");
-      if (!f) throw std::runtime_error("error opening " + stream_files[i]);
-      bool ok = std::fseek(f, (long)((colorsize + depthsize) * index), SEEK_SET) == 0 &&
-                std::fread(color.data() + i * colorsize, 1, colorsize, f) == colorsize &&
-                std::fread(depth.data() + i * depthsize, 1, depthsize, f) == depthsize;
-      std::fclose(f);
-      if (!ok) throw std::runtime_error("short read from " + stream_files[i]);
-    }
+    for (size_t i = 0; i < stream_files.size(); ++i)
+      readStreamFrame(stream_files[i], colorsize, depthsize, index, color.data() + i * colorsize, depth.data() + i * depthsize);
     return update(depth.data(), color.data());
   }
 
@@ -315,7 +323,7 @@ class NetKinectArray {
   Backend& m_be;
 };
 
-// kinect::ReconIntegration (the integrate / brick half; draw() is out of scope)
+// kinect::ReconIntegration
 class ReconIntegration {
  public:
   explicit ReconIntegration(Backend& be) : m_be(be) {}

@@ -91,3 +91,118 @@ def test_dxt_decode_matches_reference_squish(ref, orc, mode, wh):
     rgba = np.zeros((H, W, 4), np.uint8)
     ref.ref_squish_decompress(rgba.ctypes.data_as(C.c_void_p), W, H, blocks.ctypes.data_as(C.c_void_p), mode)
     assert np.array_equal(got, rgba[..., :3])
+
+
+# ---------------------------------------------------------------------------
+# The C++ host mirror's scanners against the reference's own parsers, compiled from
+# /root/reference into oracle/_ref (calibration_files.cpp + KinectCalibrationFile.cpp over
+# the vendored gloost math classes; io/FileBuffer.cpp).
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FRAME_LOOP = os.path.join(ROOT, "rgbd-recon_amd", "host", "frame_loop")
+
+RGBDEMO_BODY = """rgb_intrinsics: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 1.0553e+03, 0., 9.4198e+02, 0., 1.0537e+03, 5.3519e+02, 0., 0., 1. ]
+rgb_distortion: !!opencv-matrix
+   rows: 1
+   cols: 5
+   dt: d
+   data: [ 4.0e-02, -4.2e-02, 0., 0., 0. ]
+depth_intrinsics: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 3.6447e+02, 0., 2.5893e+02, 0., 3.6410e+02, 2.0545e+02, 0., 0., 1. ]
+depth_distortion: !!opencv-matrix
+   rows: 1
+   cols: 5
+   dt: d
+   data: [ 9.2e-02, -2.7e-01, 0., 0., 9.1e-02 ]
+R: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 1., 0., 0., 0., 1., 0., 0., 0., 1. ]
+T: !!opencv-matrix
+   rows: 3
+   cols: 1
+   dt: d
+   data: [ 5.2e-02, 0., 0. ]
+"""
+
+YML_CASES = {
+    "kinect_v2_defaults": ["%YAML:1.0\n" + RGBDEMO_BODY + "rgb_size: [ 1280, 1080 ]\ndepth_size: [ 512, 424 ]\n"] * 2,
+    "all_keys": ["%YAML:1.0\nrgb_size: [ 640, 480 ]\ndepth_size: [ 640, 480 ]\nnear_far: [ 0.5, 4.5 ]\n"
+                 "compress_rgb: [ 5, 0 ]\ncompress_depth: [ 1, 0 ]\nmin_length: [ 0.0125, 0 ]\n" + RGBDEMO_BODY,
+                 "%YAML:1.0\nrgb_size: [ 320, 240 ]\ndepth_size: [ 320, 240 ]\nnear_far: [ 0.25, 3.75 ]\n"
+                 "compress_rgb: [ 0, 0 ]\ncompress_depth: [ 0, 0 ]\n"],
+    "uncompressed": ["%YAML:1.0\nrgb_size: [ 512, 424 ]\ndepth_size: [ 512, 424 ]\nnear_far: [ 0.3, 7.0 ]\n"
+                     "compress_rgb: [ 0, 0 ]\ncompress_depth: [ 0, 0 ]\n"] * 3,
+    "keys_in_other_order": ["%YAML:1.0\ncompress_depth: [ 1, 0 ]\nnear_far: [ 1.5, 2.5 ]\ndepth_size: [ 100, 50 ]\n"
+                            + RGBDEMO_BODY + "compress_rgb: [ 1, 0 ]\nrgb_size: [ 200, 150 ]\n"],
+}
+
+
+def host_built():
+    return os.path.exists(FRAME_LOOP)
+
+
+@pytest.mark.parametrize("case", sorted(YML_CASES))
+def test_sensor_yml_scanner_matches_reference_parser(ref, tmp_path, case):
+    import subprocess
+
+    if not host_built():
+        pytest.skip("host mirror not built")
+    paths = []
+    for i, text in enumerate(YML_CASES[case]):
+        p = str(tmp_path / ("k%d.yml" % i))
+        with open(p, "w") as f:
+            f.write(text)
+        paths.append(p)
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    out = (C.c_uint * 6)()
+    nf = (C.c_float * (2 * n))()
+    ref.ref_calibration_files.restype = C.c_int
+    assert ref.ref_calibration_files(arr, n, out, nf) == n
+    r = subprocess.run([FRAME_LOOP, "--parse"] + paths, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    tok = r.stdout.split()
+    assert [int(t) for t in tok[:6]] == list(out), (tok[:6], list(out))
+    got = np.array([float(t) for t in tok[6:]], dtype=np.float32)
+    assert np.array_equal(got, np.frombuffer(nf, dtype=np.float32)), (got, list(nf))
+
+
+@pytest.mark.parametrize("colorsize,depthsize", [(96, 160), (6 * 4 * 3, 6 * 4 * 4), (1000, 24)])
+def test_stream_reader_matches_reference_filebuffer(ref, tmp_path, colorsize, depthsize):
+    """frame k of readStreamFrame == the k-th (colour, depth) pair sys::FileBuffer::read delivers"""
+    import subprocess
+
+    if not host_built():
+        pytest.skip("host mirror not built")
+    frames = 4
+    rng = np.random.default_rng(colorsize)
+    data = rng.integers(0, 256, frames * (colorsize + depthsize), dtype=np.uint8)
+    path = str(tmp_path / "k0.stream")
+    data.tofile(path)
+    want = np.zeros(frames * (colorsize + depthsize), np.uint8)
+    ref.ref_stream_read.restype = C.c_long
+    total = ref.ref_stream_read(path.encode(), 0, colorsize, depthsize, frames, want.ctypes.data_as(C.c_void_p))
+    assert total == data.size and np.array_equal(want, data)
+    for k in range(frames):
+        out = str(tmp_path / ("f%d.bin" % k))
+        r = subprocess.run([FRAME_LOOP, "--stream", path, str(colorsize), str(depthsize), str(k), out], capture_output=True,
+                           text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.fromfile(out, dtype=np.uint8)
+        assert np.array_equal(got, want[k * (colorsize + depthsize):(k + 1) * (colorsize + depthsize)])
+    # past the end: the reference's reader (looping off) comes up short, the mirror refuses
+    short = np.zeros(colorsize + depthsize, np.uint8)
+    five = np.zeros(5 * (colorsize + depthsize), np.uint8)
+    assert ref.ref_stream_read(path.encode(), 0, colorsize, depthsize, 5, five.ctypes.data_as(C.c_void_p)) == data.size
+    r = subprocess.run([FRAME_LOOP, "--stream", path, str(colorsize), str(depthsize), "4", str(tmp_path / "x.bin")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "short read" in r.stderr
+    del short
