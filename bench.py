@@ -255,6 +255,43 @@ def main():
         except capi.RgbdrError as e:           # never let the extra keys break the headline
             out["post_pass"] = {"error": str(e)}
 
+    # ---- the same step fed from HOST buffers (never part of `value`): extra keys ----
+    if world == 1:
+        try:
+            def fed(upload, steps=40):
+                ctx.set_use_bricks(False)
+                for _ in range(3):
+                    upload()
+                    ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    upload()
+                    ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+                ctx.sync()
+                return (time.perf_counter() - t0) / steps * 1e3
+
+            depth_h, color_h = np.ascontiguousarray(scene.depth), np.ascontiguousarray(scene.color)
+            pageable = fed(lambda: ctx.update(depth_h, color_h))
+
+            def mapped_fill():                                  # the producer memcpys into the page-locked back buffer
+                d, c = ctx.map_frame_buffer()
+                d[:] = depth_h.view(np.uint8).reshape(-1)
+                c[:] = color_h.reshape(-1)
+                ctx.upload_mapped_frame()
+
+            def mapped_only():                                  # the producer filled it on its own thread
+                ctx.map_frame_buffer()
+                ctx.upload_mapped_frame()
+
+            mapped_fill(); mapped_fill()
+            out["host_fed"] = {"bytes_per_frame": int(depth_h.nbytes + color_h.nbytes),
+                               "ms_per_step_pageable_upload": round(pageable, 4),
+                               "ms_per_step_mapped_buffer_incl_fill": round(fed(mapped_fill), 4),
+                               "ms_per_step_mapped_buffer": round(fed(mapped_only), 4)}
+        except capi.RgbdrError as e:
+            out["host_fed"] = {"error": str(e)}
+
     # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)

@@ -191,6 +191,15 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
  * to RGB8 with the arithmetic of the reference's own CPU decoder (squish,
  * NetKinectArray.cpp:633); host pointers, copied. */
 int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color);
+/* The double pixel-buffer of NetKinectArray (double_pixel_buffer.cpp:35-81; the reader thread
+ * memcpys each message into the mapped back PBO, update() swaps, NetKinectArray.cpp:226-238,
+ * 511-541): rgbdr_map_frame_buffer returns the BACK one of two page-locked host frame sets for
+ * the producer to fill (same layout and sizes as rgbdr_upload_frame; the sizes are returned
+ * when asked); rgbdr_upload_mapped_frame swaps and enqueues the host->device copy straight
+ * from those pages -- asynchronous, unlike a copy from pageable memory.  Mapping waits until
+ * the copy that last read that buffer has drained. */
+int rgbdr_map_frame_buffer(rgbdr_ctx* ctx, void** depth, void** color, size_t* depth_bytes, size_t* color_bytes);
+int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx);
 /* same for buffers already resident on this context's device */
 int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth_dev, const void* color_dev);
 /* ReconIntegration::clearOccupiedBricks (recon_integration.cpp:272-278) */

@@ -177,6 +177,8 @@ SYMBOLS = {
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
     "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
@@ -337,6 +339,18 @@ class Context:
         d = np.ascontiguousarray(depth)
         c = np.ascontiguousarray(color, dtype=np.uint8)   # RGB8 pixels or DXT blocks
         self._chk(lib().rgbdr_upload_frame(self._h, d.ctypes.data, c.ctypes.data))
+
+    def map_frame_buffer(self):
+        """(depth, color) numpy uint8 views of the page-locked back buffer of the double frame buffer"""
+        d, c = _P(), _P()
+        nd, nc = C.c_size_t(), C.c_size_t()
+        self._chk(lib().rgbdr_map_frame_buffer(self._h, C.byref(d), C.byref(c), C.byref(nd), C.byref(nc)))
+        depth = np.ctypeslib.as_array((C.c_uint8 * nd.value).from_address(d.value))
+        color = np.ctypeslib.as_array((C.c_uint8 * nc.value).from_address(c.value))
+        return depth, color
+
+    def upload_mapped_frame(self):
+        self._chk(lib().rgbdr_upload_mapped_frame(self._h))
 
     def update_device(self, depth_ptr, color_ptr):
         self._chk(lib().rgbdr_upload_frame_device(self._h, depth_ptr, color_ptr))

@@ -74,6 +74,13 @@ struct rgbdr_ctx {
   uint32_t inv_res[kMaxSensors][3] = {};
   float* d_lut_tiled = nullptr;       // grid-layout LUT planes of the OWNED tile layers ...
   float* d_lut_tiled_base = nullptr;  // ... inside an allocation with `halo` more layers on each side
+  // double_pbo of NetKinectArray (double_pixel_buffer.cpp:35-81): two page-locked host frame
+  // sets; the producer fills the back one, upload_mapped swaps and DMAs from the front one
+  void* h_depth[2] = {nullptr, nullptr};
+  void* h_color[2] = {nullptr, nullptr};
+  hipEvent_t ev_mapped[2] = {nullptr, nullptr};
+  bool ev_mapped_rec[2] = {false, false};
+  int mapped_back = 0;
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
   float arena_probe_ms[8] = {0};  // LUT-stream time of each candidate placement of the arena
   int arena_trials = 0, arena_chosen = 0;
@@ -389,6 +396,15 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
 
 void rgbdr_destroy(rgbdr_ctx* ctx)
 {
+  if (ctx) {
+    for (int b = 0; b < 2; ++b) {
+      if (ctx->h_depth[b]) (void)hipHostFree(ctx->h_depth[b]);
+      if (ctx->h_color[b]) (void)hipHostFree(ctx->h_color[b]);
+      if (ctx->ev_mapped[b]) (void)hipEventDestroy(ctx->ev_mapped[b]);
+      ctx->h_depth[b] = ctx->h_color[b] = nullptr;
+      ctx->ev_mapped[b] = nullptr;
+    }
+  }
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->pre_stream) (void)hipStreamSynchronize(ctx->pre_stream);
@@ -820,6 +836,42 @@ int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color)
 int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth, const void* color)
 {
   return upload_common(ctx, depth, color, hipMemcpyDeviceToDevice);
+}
+
+static size_t depth_frame_bytes_all(const rgbdr_ctx* ctx) { return npx(ctx) * (ctx->cfg.compress_depth ? 1 : 4); }
+static size_t color_frame_bytes_all(const rgbdr_ctx* ctx) { return color_frame_bytes(ctx->cfg) * (size_t)nsens(ctx); }
+
+int rgbdr_map_frame_buffer(rgbdr_ctx* ctx, void** depth, void** color, size_t* depth_bytes, size_t* color_bytes)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null output pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int b = ctx->mapped_back;
+  if (!ctx->h_depth[b]) {
+    HIPCHK(hipHostMalloc(&ctx->h_depth[b], depth_frame_bytes_all(ctx), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&ctx->h_color[b], color_frame_bytes_all(ctx), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_mapped[b], hipEventDisableTiming));
+  }
+  // the copy that last read this buffer (two uploads ago) must have drained before it is refilled
+  if (ctx->ev_mapped_rec[b]) HIPCHK(hipEventSynchronize(ctx->ev_mapped[b]));
+  *depth = ctx->h_depth[b];
+  *color = ctx->h_color[b];
+  if (depth_bytes) *depth_bytes = depth_frame_bytes_all(ctx);
+  if (color_bytes) *color_bytes = color_frame_bytes_all(ctx);
+  return RGBDR_OK;
+}
+
+int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  const int b = ctx->mapped_back;
+  if (!ctx->h_depth[b]) return ctx->fail(RGBDR_ERR_STATE, "upload_mapped_frame before map_frame_buffer");
+  int rc = upload_common(ctx, ctx->h_depth[b], ctx->h_color[b], hipMemcpyHostToDevice);  // page-locked: true async DMA
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->ev_mapped[b], ctx->pstream()));
+  ctx->ev_mapped_rec[b] = true;
+  ctx->mapped_back = 1 - b;  // swapBuffers
+  return RGBDR_OK;
 }
 
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)

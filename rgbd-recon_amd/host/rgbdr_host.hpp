@@ -311,6 +311,26 @@ class NetKinectArray {
   // NetKinectArray::readFromFiles (NetKinectArray.cpp:724-764): one ".stream" file
   // per sensor, frames of [colorsize bytes][depthsize bytes]; reads frame `index`
   // of every file into contiguous per-sensor buffers and uploads them.
+  // the mapped back PBO the reader thread memcpys each message into (NetKinectArray.cpp:
+  // 511-541) and the swap in update() (:226-238): page-locked, so the upload is a true DMA
+  struct MappedFrame {
+    unsigned char *depth = nullptr, *color = nullptr;
+    size_t depth_bytes = 0, color_bytes = 0;
+  };
+  MappedFrame mapBackBuffer()
+  {
+    MappedFrame m;
+    void *d = nullptr, *c = nullptr;
+    check(m_be.ctx(), rgbdr_map_frame_buffer(m_be.ctx(), &d, &c, &m.depth_bytes, &m.color_bytes));
+    m.depth = (unsigned char*)d;
+    m.color = (unsigned char*)c;
+    return m;
+  }
+  bool updateFromMapped()
+  {
+    check(m_be.ctx(), rgbdr_upload_mapped_frame(m_be.ctx()));
+    return true;
+  }
   bool readFromFiles(std::vector<std::string> const& stream_files, size_t colorsize, size_t depthsize, size_t index = 0)
   {
     std::vector<unsigned char> color(colorsize * stream_files.size()), depth(depthsize * stream_files.size());

@@ -556,3 +556,34 @@ def test_brick_sweep_skips_tiles_that_are_still_cleared(pkg, orc):
     ctx.step(scene.depth, scene.color)
     assert same_bits(ctx.readback_tsdf(), a)
     ctx.close()
+
+
+def test_mapped_frame_buffers_equal_plain_upload(pkg):
+    """the page-locked double frame buffer (the reference's double_pbo) feeds the same frames"""
+    scene, ctx, _ = build(pkg)
+    scene2 = pkg.synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=77, sphere_r=0.7)
+    want = []
+    for sc in (scene, scene2, scene):
+        ctx.step(sc.depth, sc.color)
+        want.append(ctx.readback_tsdf())
+    got = []
+    for sc in (scene, scene2, scene):                      # three frames: both buffers get reused
+        d, c = ctx.map_frame_buffer()
+        assert d.nbytes == sc.depth.nbytes and c.nbytes == sc.color.nbytes
+        d[:] = sc.depth.view(np.uint8).reshape(-1)
+        c[:] = sc.color.reshape(-1)
+        ctx.upload_mapped_frame()
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        got.append(ctx.readback_tsdf())
+    for a, b in zip(want, got):
+        assert same_bits(a, b)
+    assert not same_bits(want[0], want[1])
+    fresh = build(pkg)[1]
+    with pytest.raises(pkg.capi.RgbdrError) as e:
+        fresh.upload_mapped_frame()
+    assert e.value.status == pkg.capi.ERR_STATE
+    fresh.close()
+    ctx.close()
