@@ -296,6 +296,10 @@ def main():
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)
 
+    if world > 1:
+        torch.cuda.synchronize()
+        out["halo"] = {"layers_per_face": int(g.halo_tile_layers), "bytes_per_face": int(halo[0].numel() * 4),
+                       "transfer_ms_rank0": exchanger.last_transfer_ms()}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

@@ -86,6 +86,7 @@ class HaloExchanger:
         self.side = torch.cuda.Stream(device)
         self.stage = [(torch.empty_like(self.send_lo), torch.empty_like(self.send_hi)) for _ in range(2)]
         self.done = [None, None]
+        self.timing = [None, None]       # (start, end) events of the transfer that used stage[b]
         self.k = 0
 
     def exchange_async(self):
@@ -104,6 +105,8 @@ class HaloExchanger:
             staged.record(self.compute)
         with torch.cuda.stream(self.side):
             self.side.wait_event(staged)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record(self.side)
             if self.via_host:
                 host = [lo.cpu(), hi.cpu(), torch.empty(lo.shape), torch.empty(hi.shape)]   # .cpu() waits for the side stream
                 exchange_halo(*host, rank=self.rank, world=self.world, group=self.group)
@@ -113,10 +116,20 @@ class HaloExchanger:
                     self.recv_hi.copy_(host[3])
             else:
                 exchange_halo(lo, hi, self.recv_lo, self.recv_hi, rank=self.rank, world=self.world, group=self.group)
-            done = torch.cuda.Event()
+            done = torch.cuda.Event(enable_timing=True)
             done.record(self.side)
         self.done[b] = done
+        self.timing[b] = (t0, done)
         self.last = done
+
+    def last_transfer_ms(self):
+        """duration of the most recent transfer that has completed on the side stream (the
+        "halo" timer of SURVEY 8b); None before any has"""
+        for b in ((self.k - 1) & 1, self.k & 1):
+            t = self.timing[b]
+            if t is not None and t[1].query():
+                return t[0].elapsed_time(t[1])
+        return None
 
     def wait(self, stream=None):
         """make `stream` (default: the compute stream) wait for the newest halos"""
