@@ -519,7 +519,7 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) {
       (void)hipGetLastError();
       cand[t] = nullptr;
-      if (t == 0) return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed");
+      if (t == 0) return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed: out of device memory");
       break;
     }
     got = t + 1;

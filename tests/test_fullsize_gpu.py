@@ -6,6 +6,8 @@ last tile layer), and (c) properties that do not depend on the size: a second in
 reproduces the volume, the brick-skipping sweep equals the full sweep inside occupied
 bricks and -limit outside, Z slabs concatenate to the whole volume, and the slab
 ray-march composites to the single-volume frame."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,12 +127,34 @@ def test_eight_sensors_1024_slabs_with_post_pass(pkg, orc):
     orc.set_threads(16)
     dev = torch.device("cuda:0")
     free, total = torch.cuda.mem_get_info()
-    if free < 240e9:
-        pytest.skip("needs 240 GB of free HBM for the 1024^3 volume next to its eight slabs")
+    if free < 232e9:
+        pytest.skip("needs 232 GB of free HBM for the 1024^3 volume next to its eight slabs")
     scene = scene_for(pkg, 8)
     grid = (1024, 1024, 1024)
     view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 640, 360, BMIN, BMAX, shade_mode=0)
+    os.environ["RGBDR_ARENA_TRIALS"] = "1"                    # no spare HBM for candidate placements here
+    try:
+        run_1024(pkg, orc, torch, rdist, dev, scene, grid, view)
+    except pkg.capi.RgbdrError as e:
+        if "memory" in str(e).lower():
+            pytest.skip("HBM ran out next to another tenant: %s" % e)
+        raise
+    finally:
+        os.environ.pop("RGBDR_ARENA_TRIALS", None)
+
+
+def run_1024(pkg, orc, torch, rdist, dev, scene, grid, view):
+    live = []
+    try:
+        run_1024_body(pkg, orc, torch, rdist, dev, scene, grid, view, live)
+    finally:
+        for c in live:
+            c.close()
+
+
+def run_1024_body(pkg, orc, torch, rdist, dev, scene, grid, view, live):
     whole = make_ctx(pkg, scene, grid)
+    live.append(whole)
     whole.step(scene.depth, scene.color)                       # bricks on: peels available
     whole.set_use_bricks(False)
     whole.integrate()
@@ -144,6 +168,7 @@ def test_eight_sensors_1024_slabs_with_post_pass(pkg, orc):
     ctxs = []
     for rank in range(8):
         c = make_ctx(pkg, scene, grid, slab_rank=rank, slab_count=8)
+        live.append(c)
         c.step(scene.depth, scene.color)
         c.set_use_bricks(False)
         c.integrate()
@@ -180,8 +205,6 @@ def test_eight_sensors_1024_slabs_with_post_pass(pkg, orc):
         assert same_bits(color, want[skip][0]) and same_bits(depth, want[skip][1])
         ctxs[0].upload_view_frame(color, depth)
         assert frames_equal(ctxs[0].fill_colors(view.width, view.height), want[skip, "fill"])
-    for c in ctxs + [whole]:
-        c.close()
 
 
 def test_one_recorded_stream_128(pkg, orc, tmp_path):
