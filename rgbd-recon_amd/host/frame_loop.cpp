@@ -123,7 +123,16 @@ int main(int argc, char** argv)
     NetKinectArray nka(be);
     ReconIntegration recon(be);
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
-    nka.readFromFiles(streams, colorsize, depthsize, 0);
+    if (const char* msg = std::getenv("RGBDR_MESSAGE_FILE")) {  // one server message instead of the recordings
+      std::vector<unsigned char> buf((colorsize + depthsize) * (size_t)n);
+      FILE* mf = std::fopen(msg, "rb");
+      if (!mf || std::fread(buf.data(), 1, buf.size(), mf) != buf.size()) return 6;
+      std::fclose(mf);
+      nka.updateFromMessage(buf.data(), buf.size(), (unsigned)n);
+      std::fprintf(stderr, "frame time %.17g\n", nka.getCurrentFrameTime());
+    } else {
+      nka.readFromFiles(streams, colorsize, depthsize, 0);
+    }
     process_textures(nka, recon);
     recon.integrate();
     rgbdr_geometry g;

@@ -17,6 +17,7 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <memory>
@@ -308,9 +309,6 @@ class NetKinectArray {
   void useProcessedDepths(bool on) { check(m_be.ctx(), rgbdr_use_processed_depths(m_be.ctx(), on)); }
   void refineBoundary(bool on) { check(m_be.ctx(), rgbdr_refine_boundary(m_be.ctx(), on)); }
 
-  // NetKinectArray::readFromFiles (NetKinectArray.cpp:724-764): one ".stream" file
-  // per sensor, frames of [colorsize bytes][depthsize bytes]; reads frame `index`
-  // of every file into contiguous per-sensor buffers and uploads them.
   // the mapped back PBO the reader thread memcpys each message into (NetKinectArray.cpp:
   // 511-541) and the swap in update() (:226-238): page-locked, so the upload is a true DMA
   struct MappedFrame {
@@ -331,6 +329,30 @@ class NetKinectArray {
     check(m_be.ctx(), rgbdr_upload_mapped_frame(m_be.ctx()));
     return true;
   }
+  // One message of the server as the reader thread takes it apart (NetKinectArray.cpp:511-541):
+  // per sensor [colorsize bytes][depthsize bytes], K1 K2 ... KN; its first 8 bytes double as the
+  // frame time (they overlap sensor 0's colour data -- the reference reads them as a double and
+  // copies them as pixels all the same).  Scatters into the mapped back buffer and uploads.
+  bool updateFromMessage(const void* message, size_t bytes, unsigned num_sensors)
+  {
+    MappedFrame m = mapBackBuffer();
+    const size_t colorsize = m.color_bytes / num_sensors, depthsize = m.depth_bytes / num_sensors;
+    if (bytes != (colorsize + depthsize) * num_sensors) throw std::invalid_argument{"message size does not match the sensor set"};
+    const unsigned char* src = (const unsigned char*)message;
+    std::memcpy(&m_curr_frametime, src, sizeof(double));
+    for (unsigned i = 0; i < num_sensors; ++i) {
+      std::memcpy(m.color + i * colorsize, src, colorsize);
+      src += colorsize;
+      std::memcpy(m.depth + i * depthsize, src, depthsize);
+      src += depthsize;
+    }
+    return updateFromMapped();
+  }
+  double getCurrentFrameTime() const { return m_curr_frametime; }
+
+  // NetKinectArray::readFromFiles (NetKinectArray.cpp:724-764): one ".stream" file
+  // per sensor, frames of [colorsize bytes][depthsize bytes]; reads frame `index`
+  // of every file into contiguous per-sensor buffers and uploads them.
   bool readFromFiles(std::vector<std::string> const& stream_files, size_t colorsize, size_t depthsize, size_t index = 0)
   {
     std::vector<unsigned char> color(colorsize * stream_files.size()), depth(depthsize * stream_files.size());
@@ -341,6 +363,7 @@ class NetKinectArray {
 
  private:
   Backend& m_be;
+  double m_curr_frametime = 0.0;
 };
 
 // kinect::ReconIntegration

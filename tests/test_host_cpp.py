@@ -64,6 +64,19 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+    # the same frame as one server message (K1 colour, K1 depth, K2 colour, ...; NetKinectArray.cpp:511-541)
+    msg = os.path.join(d, "message.bin")
+    with open(msg, "wb") as f:
+        for i in range(n):
+            f.write(scene.color[i].tobytes())
+            f.write(scene.depth[i].tobytes())
+    out2 = os.path.join(d, "out2.tsdf")
+    r = subprocess.run([EXE, d, str(n), str(W), str(H), str(G), out2], capture_output=True, text=True,
+                       env=dict(os.environ, RGBDR_MESSAGE_FILE=msg))
+    assert r.returncode == 0, r.stderr
+    assert same_bits(np.fromfile(out2, dtype=np.float32).reshape(G, G, G), got)
+    stamp = np.frombuffer(scene.color[0].tobytes()[:8], dtype=np.float64)[0]      # the first 8 bytes double as the time
+    assert ("frame time %.17g" % stamp) in r.stderr
 
 
 @pytest.mark.gpu
