@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <map>
 #include <string>
@@ -535,10 +536,10 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     }
     // The placements fall into a few discrete levels, and consecutive allocations tend to
     // share one (slow zones are tens of GB long), so candidates are held until the choice
-    // is made.  Stop at the first candidate that streams at the fast level (>= 6.4 TB/s
-    // for LUT reads + TSDF stores; the slow levels are 5.9-6.1 TB/s).
+    // is made.  Stop at the first candidate that streams at the fastest level seen on this
+    // hardware (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s).
     const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
-    if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.4e12) break;
+    if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) break;
   }
   if (best < 0) best = 0;
   if (got > 1) {
@@ -547,8 +548,24 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   }
   ctx->arena_trials = got;
   ctx->arena_chosen = best;
+  int freed = 0;
   for (int t = 0; t < got; ++t)
-    if (t != best) (void)hipFree(cand[t]);
+    if (t != best) {
+      (void)hipFree(cand[t]);
+      ++freed;
+    }
+  // Releasing that much memory slows the device down for a moment (the kept arena measured
+  // 1.09 ms right after the frees and 1.04 ms again 0.2 s later -- the driver wipes released
+  // VRAM in the background): wait until the kept arena streams as it did when it was chosen,
+  // so that the first frames of the caller are not taken during the transient.
+  if (freed > 0 && best_ms > 0.0f) {
+    for (int k = 0; k < 40; ++k) {
+      const float ms = probe_arena_ms(cand[best] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+      if (!(ms > best_ms * 1.01f)) break;
+      struct timespec ts = {0, 50000000};
+      nanosleep(&ts, nullptr);
+    }
+  }
   ctx->d_lut_tiled_base = cand[best];
   ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
   HIPCHK(hipMalloc((void**)&ctx->d_win, ntiles * nsens(ctx) * sizeof(int32_t)));
