@@ -168,26 +168,8 @@ def main():
     # Untimed set-up: memory a previous process released is wiped by the driver in the background
     # for a while (a 6 GB free slows the sweep by 4 % for ~0.2 s).  Wait until the
     # sweep time has settled before the warm-up and the timed steps begin.
-    def settle(max_s=4.0):
-        ctx.set_use_bricks(False)
-        step(False)
-        ctx.enable_timers(True)
-        ctx.enable_timer_accumulation(True)
-        t_end, prev = time.perf_counter() + max_s, None
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                ctx.integrate()
-            ctx.sync()
-            ns, n = ctx.timer_stats("2integrate")
-            cur = ns / max(n, 1)
-            if prev is not None and abs(cur - prev) <= 0.005 * prev:
-                break
-            prev = cur
-            time.sleep(0.05)
-        ctx.enable_timer_accumulation(False)
-        ctx.enable_timers(False)
-
-    settle()
+    step(False)
+    ctx.settle(3.0)
     if world > 1:
         dist.barrier()
 

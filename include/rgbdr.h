@@ -333,12 +333,19 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the
  * driver placed that allocation (stable per allocation, several per cent apart), so the
- * library times the LUT stream on up to RGBDR_ARENA_TRIALS (environment, default 8, 1 =
- * off) candidate allocations when the arena is created, stops at the first that streams
+ * library times the LUT stream on up to RGBDR_ARENA_TRIALS (environment, default 12, at most
+ * 16, 1 = off) candidate allocations when the arena is created, stops at the first that streams
  * at the fast level and otherwise keeps the fastest.  Reports
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
-int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[8], int* trials, int* chosen);
+int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);
+/* Device memory released shortly before (by this or by an earlier process) is wiped by the
+ * driver in the background and slows every stream for a moment.  rgbdr_settle replays the
+ * integrate kernel's LUT-read + TSDF-store stream (the volume's contents are undefined
+ * afterwards, until the next integrate) until it runs at the fastest level of the hardware
+ * (>= 6.55 TB/s) or max_seconds have passed, and returns the last replay's time in ms.  For benchmarks and
+ * latency-critical start-up; never needed for correctness. */
+int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms);
 
 /* Makes a frame composited from several slab contexts (rgbdr_raymarch_shade + selection)
  * the "last ray-marched frame" of this context, so that rgbdr_fill_colors can run on it

@@ -179,6 +179,7 @@ SYMBOLS = {
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
+    "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
     "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
@@ -494,9 +495,15 @@ class Context:
         self._chk(lib().rgbdr_fill_colors(self._h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
 
+    def settle(self, max_seconds=4.0):
+        """wait until the device streams steadily (background wipe of released memory); ms of the last replay"""
+        ms = C.c_float()
+        self._chk(lib().rgbdr_settle(self._h, max_seconds, C.byref(ms)))
+        return float(ms.value)
+
     def arena_probe(self):
         """([ms per candidate placement of the LUT arena], index kept)"""
-        ms = (C.c_float * 8)()
+        ms = (C.c_float * 16)()
         n, chosen = C.c_int(), C.c_int()
         self._chk(lib().rgbdr_get_arena_probe(self._h, ms, C.byref(n), C.byref(chosen)))
         return [round(float(ms[i]), 4) for i in range(n.value)], chosen.value

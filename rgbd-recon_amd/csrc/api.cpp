@@ -83,7 +83,7 @@ struct rgbdr_ctx {
   bool ev_mapped_rec[2] = {false, false};
   int mapped_back = 0;
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
-  float arena_probe_ms[8] = {0};  // LUT-stream time of each candidate placement of the arena
+  float arena_probe_ms[16] = {0};  // LUT-stream time of each candidate placement of the arena
   int arena_trials = 0, arena_chosen = 0;
   float4* d_lut_generic[kMaxSensors] = {};
   int zoff[kMaxSensors] = {};
@@ -506,11 +506,11 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   // allocation, up to 12 % apart): time the LUT stream on a few candidate
   // placements and keep the fastest.  RGBDR_ARENA_TRIALS=1 takes the first one.
   const size_t bytes = layer * layers * sizeof(float);
-  int trials = 8;
+  int trials = 12;
   if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
-  if (trials > 8) trials = 8;
+  if (trials > 16) trials = 16;
   if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain
-  float* cand[8] = {nullptr};
+  float* cand[16] = {nullptr};
   float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too; cleared again below
   float best_ms = 0.0f;
   int best = -1, got = 0;
@@ -1601,7 +1601,36 @@ int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* 
   return RGBDR_OK;
 }
 
-int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[8], int* trials, int* chosen)
+int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->d_lut_tiled) return ctx->fail(RGBDR_ERR_STATE, "settle before the inverse LUTs were set");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
+  ++ctx->clear_epoch;  // the replay stores into the volume
+  // "steady" = the replay streams at the fastest level this hardware shows (>= 6.55 TB/s), or,
+  // for an arena at one of the slower placements, the budget is used up.  (Agreement between
+  // consecutive replays is not enough: a long wipe slows them all alike.)
+  const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
+  float cur = -1.0f;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    cur = probe_arena_ms(ctx->d_lut_tiled, ntiles, nsens(ctx), g.tiles[0], ctx->d_tsdf_owned, ctx->stream);
+    if (cur < 0.0f) return ctx->fail(RGBDR_ERR_HIP, "settle: the stream replay failed");
+    if (stream_bytes / (cur * 1e-3) >= 6.55e12) break;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > (double)max_seconds) break;
+    struct timespec ts = {0, 50000000};
+    nanosleep(&ts, nullptr);
+  }
+  if (stream_ms) *stream_ms = cur;
+  return RGBDR_OK;
+}
+
+int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ms) std::memcpy(ms, ctx->arena_probe_ms, sizeof(ctx->arena_probe_ms));
