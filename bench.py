@@ -297,6 +297,10 @@ def main():
                                "ms_per_step_pageable_upload": round(pageable, 4),
                                "ms_per_step_mapped_buffer_incl_fill": round(fed(mapped_fill), 4),
                                "ms_per_step_mapped_buffer": round(fed(mapped_only), 4)}
+            if not args.pipeline:       # RGBDR_FLAG_PIPELINE: upload + pre_* of frame k+1 overlap integrate of frame k
+                ctx.set_pipelined(True)
+                out["host_fed"]["ms_per_step_mapped_buffer_pipelined"] = round(fed(mapped_only), 4)
+                ctx.set_pipelined(False)
         except capi.RgbdrError as e:
             out["host_fed"] = {"error": str(e)}
 
