@@ -196,6 +196,17 @@ def main():
     occ = ctx.occupied_ratio()
     bint_ns, bint_n = stats_b["2integrate"]
 
+    # ---- the other schedule (extra keys): whichever of sequential / pipelined the headline did not use ----
+    other = None
+    if world == 1:
+        ctx.set_pipelined(not args.pipeline)
+        dto, stats_o = timed(False, args.steps, args.warmup)
+        ctx.set_pipelined(bool(args.pipeline))
+        oi_ns, oi_n = stats_o["2integrate"]
+        other = {"schedule": "sequential" if args.pipeline else "pipelined (pre_* of step k+1 on a second stream under integrate of step k)",
+                 "ms_per_step": round(dto / args.steps * 1e3, 4), "value": round(V_total / (dto / args.steps) / 1e6, 1),
+                 "integrate_ms": round(oi_ns / max(oi_n, 1) * 1e-6, 4)}
+
     out = {
         "metric": "Mvoxels/s TSDF integration (4 sensors, 512^3 grid) + frames/s",
         "value": round(value, 1),
@@ -227,6 +238,7 @@ def main():
                     "value": round(V_total / (dtb / bsteps) / 1e6, 1),
                     "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
                     "occupied_ratio": round(occ, 4)},
+        "other_schedule": other,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
