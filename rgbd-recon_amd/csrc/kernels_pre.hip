@@ -225,20 +225,24 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   const float scale = p.far_[l] - p.near_[l];
   const float scaled_near = scale / 255.0f;
   const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
-  // stage the (clamped) depth window once per block
+  // stage the (clamped) depth window once per block.  Taps outside [min_ds, max_ds] are skipped by
+  // the filter (pre_depth.fs:100-103); they are staged as +inf so that, for a finite centre depth,
+  // the range test |ds - depth| > dist_range_max alone rejects them (NaN taps stay NaN, as they pass
+  // all three tests in the shader).  A non-finite centre depth takes the three-test loop.
+  const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
   for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
     const int ty = i / TW, tx = i - ty * TW;
     const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
-    tile[ty][tx] = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
+    const float ds = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
+    tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? __builtin_inff() : ds;
   }
   __syncthreads();
   const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t o = (size_t)l * W * H + (size_t)py * W + px;
   const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
-  const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
   const float range = max_ds - min_ds;
-  const float depth0 = tile[threadIdx.y + R13][threadIdx.x + R13];
+  const float depth0 = pd_uncompress(depth[(size_t)py * W + px], compress, scale, scaled_near, p.near_[l]);
   const float depth_norm = (depth0 - min_ds) / range;
   const float3 pw = tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], p.xyz_res[l][2], 0, u, v, depth_norm);
   const bool in_box = pw.x >= p.bbox_min[0] && pw.y >= p.bbox_min[1] && pw.z >= p.bbox_min[2] &&
@@ -260,19 +264,35 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
     const float dist_range_max = 0.35f * (depth0 / 4.5f);
     const float dist_range_max_inv = 1.0f / dist_range_max;
     float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f;
-    for (int y = 0; y < 13; ++y) {
+    if (fabsf(depth0) <= 3.0e38f) {
+      for (int y = 0; y < 13; ++y) {
 #pragma unroll
-      for (int x = 0; x < 13; ++x) {
-        const float ds = tile[threadIdx.y + y][threadIdx.x + x];
-        const float dr = fabsf(ds - depth0);
-        if ((ds < min_ds) || (ds > max_ds) || (dr > dist_range_max)) continue;
-        const float gs = c_gauss_space[y * 13 + x];
-        const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
-        const float ws = gs * gr;
-        depth_bf += ws * ds;
-        w += ws;
-        w_range += gr;
+        for (int x = 0; x < 13; ++x) {
+          const float ds = tile[threadIdx.y + y][threadIdx.x + x];
+          const float dr = fabsf(ds - depth0);
+          if (dr > dist_range_max) continue;  // also the staged +inf of out-of-range taps
+          const float gs = c_gauss_space[y * 13 + x];
+          const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+          const float ws = gs * gr;
+          depth_bf += ws * ds;
+          w += ws;
+          w_range += gr;
+        }
       }
+    } else {  // inf / NaN centre: the shader's three tests, on the window re-read from memory
+      for (int y = 0; y < 13; ++y)
+        for (int x = 0; x < 13; ++x) {
+          const float d = depth[(size_t)clampi(py + y - R13, 0, H - 1) * W + clampi(px + x - R13, 0, W - 1)];
+          const float ds = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
+          const float dr = fabsf(ds - depth0);
+          if ((ds < min_ds) || (ds > max_ds) || (dr > dist_range_max)) continue;
+          const float gs = c_gauss_space[y * 13 + x];
+          const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+          const float ws = gs * gr;
+          depth_bf += ws * ds;
+          w += ws;
+          w_range += gr;
+        }
     }
     const float filtered = depth_bf / w;
     out = make_float2((filtered - min_ds) / range, w_range / 169.0f);
@@ -424,6 +444,8 @@ __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
     dbm = unit_outside(dbm) ? depth : dbm;
     dl = unit_outside(dl) ? depth : dl;
     dr = unit_outside(dr) ? depth : dr;
+    // (keeping the centre's eight LUT corners in registers for the neighbours, which mostly fall
+    // into the same cell, measured slower: the repeated gathers hit L1 and the compare costs more)
     const float3 wt = tex3d_xyz(lut, rx, ry, rz, 0, u, v + tsy, dt);
     const float3 wb = tex3d_xyz(lut, rx, ry, rz, 0, u, v - tsy, dbm);
     const float3 wl = tex3d_xyz(lut, rx, ry, rz, 0, u - tsx, v, dl);
@@ -460,13 +482,17 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
   const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
   for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
     const int ty = i / TW, tx = i - ty * TW;
-    tile[ty][tx] = db[((size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)) * 2];
+    // taps outside (0,1) count as border (pre_quality.fs:62-66).  They are staged as +inf: for a
+    // centre depth inside (0,1) -- the only pixels that run the loop -- |inf - depth| = inf exceeds
+    // the range limit, so the one range test below classifies them without the two bound tests.
+    const float d = db[((size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)) * 2];
+    tile[ty][tx] = unit_outside(d) ? __builtin_inff() : d;  // NaN stays NaN (it is not "outside" in the shader either)
   }
   __syncthreads();
   const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t o = (size_t)py * W + px;
-  const float depth = tile[threadIdx.y + R13][threadIdx.x + R13];
+  const float depth = db[o * 2];
   float q = 0.0f;
   if (!unit_outside(depth)) {
     const float dist_range_max = 0.35f * (depth / 1.0f);
@@ -477,7 +503,7 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
       for (int x = 0; x < 13; ++x) {
         const float ds = tile[threadIdx.y + y][threadIdx.x + x];
         const float dr = fabsf(ds - depth);
-        if (unit_outside(ds) || (dr > dist_range_max)) {
+        if (dr > dist_range_max) {
           border += 1.0f;
           continue;
         }

@@ -204,6 +204,19 @@ def test_edge_cases(pkg, orc):
     ref = oracle_run(orc, scene, ctx, inv, depth_override=d, use_bricks=False)
     check_images(ctx, ref, 2)
     assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    # (d) the same with the raw depths fed to the bilateral pass (no hole filling in front of it):
+    # non-finite centres and taps reach pre_depth / pre_quality themselves
+    rng = np.random.default_rng(3)
+    for val in (np.nan, np.inf, -np.inf, -3.0, 1e30, 0.0):
+        for _ in range(12):
+            d[rng.integers(0, 2), rng.integers(0, 53), rng.integers(0, 64)] = val
+    d[0, 20:23, 30:33] = np.nan
+    d[1, 30:32, 10:14] = np.inf
+    ctx.use_processed_depths(False)
+    ctx.step(d, scene.color)
+    ref = oracle_run(orc, scene, ctx, inv, depth_override=d, use_bricks=False)
+    check_images(ctx, ref, 2)
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
     ctx.close()
 
 
