@@ -366,8 +366,8 @@ int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns);
  * (TimerDatabase running mean, timer_database.cpp:59-121). */
 int rgbdr_enable_timer_accumulation(rgbdr_ctx* ctx, int on);
 /* 2 (default): all timers; 1: only the totals ("1preprocess", "2integrate", "bricks",
- * "draw", ...), not the five pre_* passes inside "1preprocess" -- every timer costs two
- * event records on the stream between small kernels. */
+ * "draw", ...), not the five pre_* passes inside "1preprocess"; 0: "2integrate" alone --
+ * every timer costs two event records (~4 us of stream time each) between small kernels. */
 int rgbdr_set_timer_detail(rgbdr_ctx* ctx, int detail);
 int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint32_t* count);
 

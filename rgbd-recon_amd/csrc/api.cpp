@@ -148,10 +148,17 @@ static size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->c
 // the per-pass timers sit inside "1preprocess"; every timer is two event records on
 // the stream, so a host that only wants the totals can switch them off (detail 1)
 static bool timer_is_pass(const char* n) { return n[0] == 'm' || (n[0] == 'b' && n[1] != 'r') || n[0] == 'n' || n[0] == 'q'; }
+// detail 2: every timer; 1: the totals; 0: "2integrate" alone (an event record costs ~4 us of stream time)
+static bool timer_muted(const rgbdr_ctx* c, const char* n)
+{
+  if (!c->timers) return true;
+  if (c->timer_detail < 1) return !(n[0] == '2');
+  return c->timer_detail < 2 && timer_is_pass(n);
+}
 
 static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
-  if (!c->timers || (c->timer_detail < 2 && timer_is_pass(name))) return;
+  if (timer_muted(c, name)) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -174,7 +181,7 @@ static void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 }
 static void tend(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
-  if (!c->timers || (c->timer_detail < 2 && timer_is_pass(name))) return;
+  if (timer_muted(c, name)) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
     if (!t.pending.empty()) (void)hipEventRecord(t.pending.back().second, st);
@@ -1652,7 +1659,7 @@ int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
 int rgbdr_set_timer_detail(rgbdr_ctx* ctx, int detail)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  ctx->timer_detail = detail < 2 ? 1 : 2;
+  ctx->timer_detail = detail < 1 ? 0 : (detail < 2 ? 1 : 2);
   return RGBDR_OK;
 }
 
