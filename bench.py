@@ -212,6 +212,16 @@ def main():
                  "ms_per_step": round(dto / args.steps * 1e3, 4), "value": round(V_total / (dto / args.steps) / 1e6, 1),
                  "integrate_ms": round(oi_ns / max(oi_n, 1) * 1e-6, 4)}
 
+    # ---- RGBDR_FLAG_ELIDE_STORES (extra keys): the full sweep without re-storing tiles that stay -limit ----
+    elided = None
+    if world == 1:
+        ctx.set_elide_stores(True)
+        dte, stats_e = timed(False, args.steps, args.warmup)
+        ctx.set_elide_stores(False)
+        ei_ns, ei_n = stats_e["2integrate"]
+        elided = {"ms_per_step": round(dte / args.steps * 1e3, 4), "value": round(V_total / (dte / args.steps) / 1e6, 1),
+                  "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4)}
+
     out = {
         "metric": "Mvoxels/s TSDF integration (4 sensors, 512^3 grid) + frames/s",
         "value": round(value, 1),
@@ -244,6 +254,7 @@ def main():
                     "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
                     "occupied_ratio": round(occ, 4)},
         "other_schedule": other,
+        "full_sweep_store_elision": elided,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):

@@ -58,7 +58,13 @@ enum {
    * tsdf_integration.vs:31 is static between frames) so that integrate() streams it
    * like a 1:1 LUT.  This flag keeps the file's volume resident instead and evaluates
    * the 8-tap lookup per frame (less HBM for LUTs much coarser than the grid). */
-  RGBDR_FLAG_NO_RESAMPLE = 32u
+  RGBDR_FLAG_NO_RESAMPLE = 32u,
+  /* Full sweep only (the brick-skipping sweep always works this way): a tile whose 512 voxels
+   * all come out as -limit is not stored again when it has held -limit since an earlier sweep
+   * (every voxel is still evaluated; only the store of identical bytes is left out -- 97 % of
+   * the tiles of a typical scene).  Off by default so that the benchmark's full sweep performs
+   * every store of the reference's clear + draw. */
+  RGBDR_FLAG_ELIDE_STORES = 64u
 };
 
 /* Replaces the constructor arguments of NetKinectArray (NetKinectArray.cpp:42),
@@ -221,6 +227,7 @@ int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit);
 int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size);
 int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int active);
 int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on);           /* RGBDR_FLAG_PIPELINE at run time; drains both streams */
+int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on);        /* RGBDR_FLAG_ELIDE_STORES at run time */
 int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n);
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on);         /* unlike the reference these three do not re-run */
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on);    /* processTextures() themselves (SURVEY.md A.5:   */

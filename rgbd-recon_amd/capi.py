@@ -20,6 +20,7 @@ FLAG_FILTER, FLAG_PROCESSED, FLAG_REFINE, FLAG_USE_BRICKS = 1, 2, 4, 8
 FLAGS_DEFAULT = 15
 FLAG_PIPELINE = 16
 FLAG_NO_RESAMPLE = 32
+FLAG_ELIDE_STORES = 64
 
 IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
 IMG_CHANNELS = {IMG_DEPTH_RAW: 1, IMG_DEPTH_MORPH: 1, IMG_DEPTH_RG: 2, IMG_LAB: 3, IMG_DEPTH_B_RG: 2,
@@ -158,6 +159,7 @@ SYMBOLS = {
     "rgbdr_set_brick_size": (C.c_int, [_P, C.c_float]),
     "rgbdr_set_use_bricks": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_pipelined": (C.c_int, [_P, C.c_int]),
+    "rgbdr_set_elide_stores": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
     "rgbdr_filter_textures": (C.c_int, [_P, C.c_int]),
     "rgbdr_use_processed_depths": (C.c_int, [_P, C.c_int]),
@@ -402,6 +404,10 @@ class Context:
     def set_pipelined(self, on):
         self._chk(lib().rgbdr_set_pipelined(self._h, int(on)))
         self._flag(FLAG_PIPELINE, on)
+
+    def set_elide_stores(self, on):
+        self._chk(lib().rgbdr_set_elide_stores(self._h, int(on)))
+        self._flag(FLAG_ELIDE_STORES, on)
 
     def set_min_voxels_per_brick(self, n):
         self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))

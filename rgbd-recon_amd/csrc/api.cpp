@@ -1063,7 +1063,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.tile_count_next = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz + (1 - ctx->tile_count_parity);
   if (bricks && all_tiled) ctx->tile_count_parity ^= 1;
   p.tile_state = ctx->d_tile_state;
-  if (!bricks || !all_tiled) ++ctx->clear_epoch;  // sweeps that overwrite tiles without keeping tile_state
+  const bool elide = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_ELIDE_STORES) != 0;
+  p.elide_stores = elide ? 1 : 0;
+  if ((!bricks && !elide) || !all_tiled) ++ctx->clear_epoch;  // sweeps that overwrite tiles without keeping tile_state
   if (ctx->clear_epoch == 0) {                     // wrapped: forget every recorded clear
     HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, (size_t)p.TX * p.TY * p.ntz * sizeof(uint32_t), ctx->stream));
     ctx->clear_epoch = 1;
@@ -1175,6 +1177,7 @@ int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
   ctx->ev_pre_rec[0] = ctx->ev_pre_rec[1] = ctx->ev_int_rec[0] = ctx->ev_int_rec[1] = false;
   return set_flag(ctx, RGBDR_FLAG_PIPELINE, on);
 }
+int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_ELIDE_STORES, on); }
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_PROCESSED, on); }
 int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }

@@ -189,7 +189,7 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
 // folded in two groups (the running tsd / weight stay in registers), which keeps
 // the kernel at <= ~100 VGPRs for every N.
 // One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
-template <int N, bool BRICKS, int MAXG, bool NT>
+template <int N, bool BRICKS, int MAXG, bool NT, bool ELIDE = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
@@ -216,6 +216,16 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
     for (int j = 0; j < 4; ++j)
       if (!occ[j]) tsd[j] = -limit;
   }
+  if (ELIDE) {
+    // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
+    // of this epoch (tile_state, see k_brick_clear) need not be written again
+    const float ml = -limit;
+    const bool mine = tsd[0] == ml && tsd[1] == ml && tsd[2] == ml && tsd[3] == ml;
+    const unsigned st = p.tile_state[tile];  // read before the barrier: lane 0 rewrites it after
+    const bool all_clear = __syncthreads_and(mine) != 0;
+    if (all_clear && st == p.epoch) return;
+    if (q == 0) p.tile_state[tile] = all_clear ? p.epoch : 0u;
+  }
   if (NT) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     v4f r = {tsd[0], tsd[1], tsd[2], tsd[3]};
@@ -225,7 +235,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
 }
 
 // Full sweep: one block per tile.
-template <int N, int MAXG = 4, bool NT = true>
+template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
     tile = (chunk * 8u + xcd) * p.order_chunk + within;
   }
-  integrate_tile<N, false, MAXG, NT>(p, tile, win);
+  integrate_tile<N, false, MAXG, NT, ELIDE>(p, tile, win);
 }
 
 // Brick-skipping sweep, second half: persistent blocks walk the list of tiles that touch
@@ -424,7 +434,10 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
-  hipLaunchKernelGGL((k_integrate_tiled<N>), dim3(ntiles), dim3(128), 0, s, p);
+  if (p.elide_stores)
+    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
+  else
+    hipLaunchKernelGGL((k_integrate_tiled<N>), dim3(ntiles), dim3(128), 0, s, p);
 }
 
 void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t s)

@@ -84,6 +84,7 @@ struct IntegrateParams {
   unsigned* tile_count_next;  // the other of the two counters: zeroed by this sweep for the next one
   unsigned* tile_state;    // == epoch: the tile holds -limit throughout since a brick sweep of this epoch
   unsigned epoch;
+  int elide_stores;        // full sweep: skip the store of an all -limit tile that tile_state says is already -limit
 };
 
 struct InvertParams {

@@ -618,3 +618,38 @@ def test_settle_leaves_a_usable_context(pkg, orc):
     ctx.integrate()
     assert same_bits(ctx.readback_tsdf(), full)
     ctx.close()
+
+
+def test_full_sweep_store_elision(pkg, orc):
+    """RGBDR_FLAG_ELIDE_STORES: identical volumes, through every event that changes which
+    tiles hold -limit (another frame, the brick sweep in between, another limit, settle)"""
+    scene, ctx, inv = build(pkg, G=64)
+    scene2 = pkg.synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.6)
+    ctx.set_use_bricks(False)
+
+    def expect(sc, **kw):
+        return oracle_run(orc, sc, ctx, inv, use_bricks=False, **kw)["tsdf"]
+
+    a, b = expect(scene), expect(scene2)
+    ctx.set_elide_stores(True)
+    for sc, want in ((scene, a), (scene, a), (scene2, b), (scene, a)):
+        ctx.step(sc.depth, sc.color)
+        assert same_bits(ctx.readback_tsdf(), want)
+    ctx.set_use_bricks(True)                                    # brick sweep in between shares tile_state
+    ctx.step(scene2.depth, scene2.color)
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.set_tsdf_limit(0.02)
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), expect(scene, limit=np.float32(0.02)))
+    ctx.set_tsdf_limit(0.01)
+    ctx.settle(0.1)                                             # scribbles over the volume
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.set_elide_stores(False)
+    ctx.integrate()
+    ctx.set_elide_stores(True)
+    ctx.integrate()
+    assert same_bits(ctx.readback_tsdf(), a)
+    ctx.close()
