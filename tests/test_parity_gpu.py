@@ -653,3 +653,52 @@ def test_full_sweep_store_elision(pkg, orc):
     ctx.integrate()
     assert same_bits(ctx.readback_tsdf(), a)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_call_sequences(pkg, orc, seed):
+    """state machine check: random interleavings of the setters, both sweeps, both schedules,
+    store elision, settle and two different frames -- after every frame the volume, the images
+    and the brick table equal the oracle run with the settings in force"""
+    rng = np.random.default_rng(seed)
+    scene, ctx, inv = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
+    scenes = [scene, pkg.synth.Scene(2, 64, 53, lut_res=(16, 13, 16), seed=99, sphere_r=0.7)]
+    state = dict(limit=np.float32(0.01), bricks=True, filt=True, proc=True, refine=True, min_voxels=10)
+    cur = 0
+    for step_no in range(28):
+        op = rng.integers(0, 12)
+        if op == 0:
+            state["bricks"] = not state["bricks"]
+            ctx.set_use_bricks(state["bricks"])
+        elif op == 1:
+            ctx.set_elide_stores(bool(rng.integers(0, 2)))
+        elif op == 2:
+            state["limit"] = np.float32(rng.choice([0.01, 0.02, 0.035]))
+            ctx.set_tsdf_limit(float(state["limit"]))
+        elif op == 3:
+            ctx.set_pipelined(bool(rng.integers(0, 2)))
+        elif op == 4:
+            state["filt"] = not state["filt"]
+            ctx.filter_textures(state["filt"])
+        elif op == 5:
+            state["proc"] = not state["proc"]
+            ctx.use_processed_depths(state["proc"])
+        elif op == 6:
+            state["refine"] = not state["refine"]
+            ctx.refine_boundary(state["refine"])
+        elif op == 7:
+            state["min_voxels"] = int(rng.choice([1, 10, 40]))
+            ctx.set_min_voxels_per_brick(state["min_voxels"])
+        elif op == 8:
+            ctx.settle(0.05)
+        else:
+            cur = int(rng.integers(0, 2))
+        sc = scenes[cur]
+        ctx.step(sc.depth, sc.color)
+        ref = oracle_run(orc, sc, ctx, inv, limit=state["limit"], use_bricks=state["bricks"], filter_textures=state["filt"],
+                         processed=state["proc"], refine=state["refine"], min_voxels=state["min_voxels"])
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (seed, step_no, int(op), state)
+        if step_no % 7 == 0:
+            check_images(ctx, ref, 2)
+            assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+    ctx.close()
