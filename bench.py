@@ -122,13 +122,15 @@ def main():
                 transport = {"kind": "gloo (host-staged; RCCL p2p failed: %s)" % (why or "on another rank"), "group": fallback}
                 sys.stderr.write("[bench rank %d] %s\n" % (rank, transport["kind"]))
         exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, group=transport["group"],
-                                        via_host=transport["kind"] != "rccl")
+                                        via_host=transport["kind"] != "rccl", ctx=ctx)
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
         ctx.update_occupied_bricks()
+        if halo is not None:
+            exchanger.begin_step()           # the sweep stores its boundary layers into a staging set
         ctx.integrate()
         if halo is not None:
             exchanger.exchange_async()

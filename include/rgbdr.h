@@ -270,6 +270,17 @@ typedef struct {
   int32_t halo_layers;    /* rgbdr_geometry.halo_tile_layers on each side */
 } rgbdr_tsdf_device_view;
 int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
+/* Halo staging for Z slabs.  The boundary tile layers a slab sends to its neighbours are the
+ * ones the next integrate overwrites, and at 1024^3 / 8 GPUs a face is 64 MiB -- a transfer as
+ * long as a frame.  rgbdr_halo_staging returns two device buffers (lower face, upper face:
+ * halo_tile_layers tile layers each, `bytes` long, tile-linear like the volume) of staging set
+ * 0 or 1; after rgbdr_set_halo_staging(ctx, b) every rgbdr_integrate leaves a copy of its first /
+ * last halo_tile_layers owned layers in set b (the full sweep stores them from the kernel
+ * itself, the other sweeps copy them afterwards; a face without a neighbour is skipped), so
+ * the transfer can run from there while later frames are integrated.  -1 switches it off.
+ * The host alternates the two sets (rgbd-recon_amd/dist.py:HaloExchanger). */
+int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t* bytes);
+int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);

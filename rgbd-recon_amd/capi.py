@@ -181,6 +181,8 @@ SYMBOLS = {
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
+    "rgbdr_halo_staging": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    "rgbdr_set_halo_staging": (C.c_int, [_P, C.c_int]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
@@ -500,6 +502,15 @@ class Context:
         depth = np.empty((height, width), dtype=np.float32)
         self._chk(lib().rgbdr_fill_colors(self._h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
+
+    def halo_staging(self, buffer):
+        """(lo_ptr, hi_ptr, bytes) of halo staging set `buffer` (0 / 1)"""
+        lo, hi, n = _P(), _P(), C.c_size_t()
+        self._chk(lib().rgbdr_halo_staging(self._h, buffer, C.byref(lo), C.byref(hi), C.byref(n)))
+        return lo.value, hi.value, n.value
+
+    def set_halo_staging(self, buffer):
+        self._chk(lib().rgbdr_set_halo_staging(self._h, buffer))
 
     def settle(self, max_seconds=4.0):
         """wait until the device streams steadily (background wipe of released memory); ms of the last replay"""

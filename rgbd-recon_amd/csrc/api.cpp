@@ -106,6 +106,9 @@ struct rgbdr_ctx {
   uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
   uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
   int tile_count_parity = 0;        // which of the two list counters the next brick sweep appends to
+  // halo staging for Z slabs: two sets of (lower face, upper face) buffers of `halo` tile layers
+  float* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int stage_target = -1;            // set the next integrate fills (-1: none)
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool mask_valid = false;
@@ -201,6 +204,12 @@ static void free_volume(rgbdr_ctx* c)
   c->view_pixels = c->fill_floats = 0;
   c->view_w = c->view_h = 0;
   c->integrated = false;
+  for (int b = 0; b < 2; ++b)
+    for (int f = 0; f < 2; ++f) {
+      (void)hipFree(c->d_stage[b][f]);
+      c->d_stage[b][f] = nullptr;
+    }
+  c->stage_target = -1;
   (void)hipFree(c->d_tile_list);
   (void)hipFree(c->d_tile_state);
   c->d_tile_list = c->d_tile_state = nullptr;
@@ -1071,11 +1080,33 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
     ctx->clear_epoch = 1;
   }
   p.epoch = ctx->clear_epoch;
+  const int sb = ctx->stage_target;
+  const size_t face_floats = ctx->layer_floats * (size_t)ctx->halo;
+  bool copy_faces = false;
+  if (sb >= 0 && ctx->halo > 0) {
+    float* lo = ctx->cfg.slab_rank > 0 ? ctx->d_stage[sb][0] : nullptr;
+    float* hi = ctx->cfg.slab_rank < ctx->cfg.slab_count - 1 ? ctx->d_stage[sb][1] : nullptr;
+    p.stage_layers = ctx->halo;
+    if (integrate_stages_halo(p, all_tiled)) {
+      p.stage_lo = lo;
+      p.stage_hi = hi;
+    } else {
+      copy_faces = true;
+    }
+  }
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
   tbegin(ctx, "2integrate", ctx->stream);
   launch_integrate(p, all_tiled, ctx->stream);
   tend(ctx, "2integrate", ctx->stream);
   LAUNCHCHK("integrate");
+  if (copy_faces) {  // sweeps that do not stage by themselves: copy the boundary layers after them
+    const int owned = g.slab_tile_z1 - g.slab_tile_z0;
+    if (ctx->cfg.slab_rank > 0)
+      HIPCHK(hipMemcpyAsync(ctx->d_stage[sb][0], ctx->d_tsdf_owned, face_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->cfg.slab_rank < ctx->cfg.slab_count - 1)
+      HIPCHK(hipMemcpyAsync(ctx->d_stage[sb][1], ctx->d_tsdf_owned + ctx->layer_floats * (size_t)(owned - ctx->halo),
+                            face_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  }
   ctx->integrated = true;
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
@@ -1646,6 +1677,34 @@ int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* 
   if (ms) std::memcpy(ms, ctx->arena_probe_ms, sizeof(ctx->arena_probe_ms));
   if (trials) *trials = ctx->arena_trials;
   if (chosen) *chosen = ctx->arena_chosen;
+  return RGBDR_OK;
+}
+
+int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t* bytes)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (buffer < 0 || buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0 or 1");
+  if (ctx->halo <= 0) return ctx->fail(RGBDR_ERR_STATE, "halo staging needs a Z-slab context (slab_count > 1)");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t face = ctx->layer_floats * (size_t)ctx->halo * sizeof(float);
+  for (int f = 0; f < 2; ++f)
+    if (!ctx->d_stage[buffer][f]) {
+      HIPCHK(hipMalloc((void**)&ctx->d_stage[buffer][f], face));
+      HIPCHK(hipMemsetAsync(ctx->d_stage[buffer][f], 0, face, ctx->stream));
+    }
+  if (lo) *lo = ctx->d_stage[buffer][0];
+  if (hi) *hi = ctx->d_stage[buffer][1];
+  if (bytes) *bytes = face;
+  return RGBDR_OK;
+}
+
+int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0, 1 or -1");
+  if (buffer >= 0 && (!ctx->d_stage[buffer][0] || !ctx->d_stage[buffer][1]))
+    return ctx->fail(RGBDR_ERR_STATE, "set_halo_staging before rgbdr_halo_staging of that buffer");
+  ctx->stage_target = buffer < 0 ? -1 : buffer;
   return RGBDR_OK;
 }
 

@@ -189,7 +189,7 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
 // folded in two groups (the running tsd / weight stay in registers), which keeps
 // the kernel at <= ~100 VGPRs for every N.
 // One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
-template <int N, bool BRICKS, int MAXG, bool NT, bool ELIDE = false>
+template <int N, bool BRICKS, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
@@ -232,10 +232,18 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
     __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(out));
   } else
     *out = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
+  if (STAGE) {  // boundary tile layers of a Z slab go to the halo staging buffers as well
+    const unsigned per_layer = (unsigned)(p.TX * p.TY), layer = tile / per_layer;
+    const float4 r4 = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
+    if (p.stage_lo && layer < (unsigned)p.stage_layers) reinterpret_cast<float4*>(p.stage_lo + (size_t)tile * kTileVoxels)[q] = r4;
+    const unsigned first_hi = (unsigned)(p.ntz - p.stage_layers);
+    if (p.stage_hi && layer >= first_hi)
+      reinterpret_cast<float4*>(p.stage_hi + (size_t)(tile - first_hi * per_layer) * kTileVoxels)[q] = r4;
+  }
 }
 
 // Full sweep: one block per tile.
-template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false>
+template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
     tile = (chunk * 8u + xcd) * p.order_chunk + within;
   }
-  integrate_tile<N, false, MAXG, NT, ELIDE>(p, tile, win);
+  integrate_tile<N, false, MAXG, NT, ELIDE, STAGE>(p, tile, win);
 }
 
 // Brick-skipping sweep, second half: persistent blocks walk the list of tiles that touch
@@ -436,8 +444,19 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
   }
   if (p.elide_stores)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
+  else if (p.stage_lo || p.stage_hi)
+    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);
   else
     hipLaunchKernelGGL((k_integrate_tiled<N>), dim3(ntiles), dim3(128), 0, s, p);
+}
+
+// true when launch_integrate's kernel itself fills the halo staging buffers (plain full sweep of a
+// 1:1 / resampled LUT); for every other sweep the caller copies the layers afterwards
+bool integrate_stages_halo(const IntegrateParams& p, bool one_to_one)
+{
+  if (!one_to_one || p.use_bricks || p.elide_stores) return false;
+  static const bool knobs = getenv("RGBDR_INTEGRATE_GROUP") || getenv("RGBDR_NT");
+  return !knobs;
 }
 
 void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t s)

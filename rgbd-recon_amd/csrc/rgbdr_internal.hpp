@@ -85,6 +85,12 @@ struct IntegrateParams {
   unsigned* tile_state;    // == epoch: the tile holds -limit throughout since a brick sweep of this epoch
   unsigned epoch;
   int elide_stores;        // full sweep: skip the store of an all -limit tile that tile_state says is already -limit
+  // halo staging (Z slabs): the sweep also stores the tiles of its first / last `stage_layers` owned
+  // tile layers into these buffers (null: that face has no neighbour), so that the transfer to the
+  // neighbours need not read the volume while the next sweep overwrites it
+  float* stage_lo;
+  float* stage_hi;
+  int stage_layers;
 };
 
 struct InvertParams {
@@ -169,6 +175,7 @@ void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_v
                             uint32_t* count, hipStream_t s);
 void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);
 void launch_integrate(const IntegrateParams& p, bool one_to_one, hipStream_t s);
+bool integrate_stages_halo(const IntegrateParams& p, bool one_to_one);
 void launch_detile(const float* tiled, float* linear, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
                    hipStream_t s);
 void launch_tile_lut(const float4* src_rgba, int X, int Y, int Z, int src_z0, int TX, int TY, int tz0, int ntz,

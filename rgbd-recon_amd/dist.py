@@ -64,11 +64,16 @@ class HaloExchanger:
     At 1024^3 on 8 GPUs a slab face is 2 tile layers = 64 MiB per neighbour, about 1 ms on
     one xGMI link -- as long as a whole step.  Sending straight from the volume would make
     the next integrate (which overwrites those layers) wait for the transfer, so the
-    boundary layers are first copied into one of two staging buffers on the compute stream
-    (device-to-device, ~30 us) and the transfer runs from there on a side stream while the
-    next frame is processed.  Order per step k (b = k mod 2):
-        compute stream: [wait: transfer k-2 done]  stage[b] <- boundary layers   record staged_k
-        side stream   : wait staged_k   send stage[b] / receive into the halo layers   record done_k
+    boundary layers go through one of two staging sets and the transfer runs from there on a
+    side stream while the next frames are processed.  With `ctx` the staging sets are the
+    library's (rgbdr_halo_staging): the integrate sweep stores its boundary tiles there
+    itself, no copy at all.  Without, they are torch buffers filled by a device-to-device
+    copy after the sweep.  Per step k (b = k mod 2):
+        begin_step()      compute stream: [wait: transfer k-2 done]; the sweep will fill set b
+        ... ctx.integrate() ...
+        exchange_async()  compute stream: record staged_k
+                          side stream   : wait staged_k, send set b / receive into the halo layers,
+                                          record done_k
     A consumer that samples across slab faces calls wait(stream) first.
 
     `ctx` must enqueue on `compute_stream` (ctx.set_stream(compute_stream.cuda_stream)).
@@ -76,7 +81,7 @@ class HaloExchanger:
     writes device pointers from the host with no regard for streams): the staged layers
     travel through host tensors, with host synchronisation."""
 
-    def __init__(self, tsdf_view, device, compute_stream, rank=None, world=None, group=None, via_host=False):
+    def __init__(self, tsdf_view, device, compute_stream, rank=None, world=None, group=None, via_host=False, ctx=None):
         self.via_host = via_host
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
@@ -84,23 +89,45 @@ class HaloExchanger:
         self.send_lo, self.send_hi, self.recv_lo, self.recv_hi = halo_views(tsdf_view, device)
         self.compute = compute_stream
         self.side = torch.cuda.Stream(device)
-        self.stage = [(torch.empty_like(self.send_lo), torch.empty_like(self.send_hi)) for _ in range(2)]
+        self.ctx = ctx
+        if ctx is not None:
+            self.stage = []
+            for b in range(2):
+                lo, hi, nbytes = ctx.halo_staging(b)
+                assert nbytes == self.send_lo.numel() * 4
+                self.stage.append((wrap_device_floats(lo, nbytes // 4, device), wrap_device_floats(hi, nbytes // 4, device)))
+        else:
+            self.stage = [(torch.empty_like(self.send_lo), torch.empty_like(self.send_hi)) for _ in range(2)]
         self.done = [None, None]
         self.timing = [None, None]       # (start, end) events of the transfer that used stage[b]
         self.k = 0
+        self.begun = False
+
+    def begin_step(self):
+        """before integrate(): claims the staging set of this step"""
+        b = self.k & 1
+        if self.done[b] is not None:
+            self.compute.wait_event(self.done[b])        # the transfer that last read stage[b]
+        if self.ctx is not None:
+            self.ctx.set_halo_staging(b)
+        self.begun = True
 
     def exchange_async(self):
-        """call after integrate() has been enqueued on the compute stream"""
+        """after integrate() has been enqueued on the compute stream"""
+        if not self.begun:
+            if self.ctx is not None:
+                raise RuntimeError("HaloExchanger(ctx=...): call begin_step() before integrate()")
+            self.begin_step()
+        self.begun = False
         b = self.k & 1
         self.k += 1
         lo, hi = self.stage[b]
-        if self.done[b] is not None:
-            self.compute.wait_event(self.done[b])        # the transfer that last read stage[b]
         with torch.cuda.stream(self.compute):
-            if self.rank > 0:
-                lo.copy_(self.send_lo, non_blocking=True)
-            if self.rank < self.world - 1:
-                hi.copy_(self.send_hi, non_blocking=True)
+            if self.ctx is None:
+                if self.rank > 0:
+                    lo.copy_(self.send_lo, non_blocking=True)
+                if self.rank < self.world - 1:
+                    hi.copy_(self.send_hi, non_blocking=True)
             staged = torch.cuda.Event()
             staged.record(self.compute)
         with torch.cuda.stream(self.side):

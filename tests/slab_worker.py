@@ -16,7 +16,7 @@ from __graft_entry__ import load_package  # noqa: E402
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
 
 
-def exchanger_mode(out_dir, G):
+def exchanger_mode(out_dir, G, library_staging=False):
     """three frames through integrate + HaloExchanger.exchange_async (gloo: staged through
     the host); afterwards every rank dumps its boundary layers and its halos"""
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -36,16 +36,20 @@ def exchanger_mode(out_dir, G):
     main = torch.cuda.Stream(dev)
     torch.cuda.set_stream(main)
     ctx.set_stream(main.cuda_stream)
-    ex = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, via_host=True)
+    ex = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, via_host=True,
+                             ctx=ctx if library_staging else None)
     frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
     torch.cuda.synchronize()
     lo, hi, rlo, rhi = rdist.halo_views(ctx.device_tsdf(), dev)
     history = []
-    for d, c in frames:
+    for n, (d, c) in enumerate(frames):
         ctx.update_device(d.data_ptr(), c.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
         ctx.update_occupied_bricks()
+        if library_staging:
+            ctx.set_use_bricks(n != 1)                                # frame 1: full sweep (stages in the kernel)
+            ex.begin_step()
         ctx.integrate()
         ex.exchange_async()
         history.append((lo.clone(), hi.clone()))                  # stream-ordered snapshots, no host sync
@@ -60,8 +64,8 @@ def exchanger_mode(out_dir, G):
 
 
 def main():
-    if sys.argv[1] == "exchanger":
-        return exchanger_mode(sys.argv[2], int(sys.argv[3]))
+    if sys.argv[1] in ("exchanger", "exchanger_lib"):
+        return exchanger_mode(sys.argv[2], int(sys.argv[3]), library_staging=sys.argv[1] == "exchanger_lib")
     out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     load_package()

@@ -36,8 +36,9 @@ def test_slab_ranks_render_the_whole_volume(world, G, limit, tmp_path):
                 assert same_bits(got[key], ref[key]), (n, rank, key)
 
 
+@pytest.mark.parametrize("mode", ["exchanger", "exchanger_lib"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_async_halo_exchanger(world, tmp_path, pkg):
+def test_async_halo_exchanger(world, mode, tmp_path, pkg):
     """HaloExchanger: staged, stream-ordered exchange over three different frames with no
     host synchronisation in between; the halos end up holding the neighbours' boundary
     layers of the LAST frame, and the slabs the whole volume of that frame"""
@@ -47,7 +48,7 @@ def test_async_halo_exchanger(world, tmp_path, pkg):
     s.close()
     G = 64
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), "exchanger", str(tmp_path),
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), mode, str(tmp_path),
            str(G)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -702,3 +702,49 @@ def test_random_call_sequences(pkg, orc, seed):
             check_images(ctx, ref, 2)
             assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
     ctx.close()
+
+
+@pytest.mark.parametrize("rank,count", [(0, 2), (1, 2), (1, 3)])
+def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
+    """rgbdr_set_halo_staging: after integrate the staging set holds the slab's first / last halo
+    layers -- written by the full-sweep kernel itself, copied after the other sweeps"""
+    import torch
+
+    from rgbd_recon_amd import dist as rdist
+
+    dev = torch.device("cuda:0")
+    scene, ctx, _ = build(pkg, G=64, tsdf_limit=0.1, slab_rank=rank, slab_count=count)      # 2 halo layers
+    assert ctx.geo.halo_tile_layers == 2
+    with pytest.raises(pkg.capi.RgbdrError):
+        ctx.set_halo_staging(0)                                   # not allocated yet
+    sets = []
+    for b in range(2):
+        lo, hi, n = ctx.halo_staging(b)
+        sets.append((rdist.wrap_device_floats(lo, n // 4, dev), rdist.wrap_device_floats(hi, n // 4, dev)))
+    send_lo, send_hi, _, _ = rdist.halo_views(ctx.device_tsdf(), dev)
+    assert send_lo.numel() * 4 == n
+    for k, (bricks, elide) in enumerate([(False, False), (True, False), (False, True), (False, False)]):
+        b = k & 1
+        ctx.set_use_bricks(bricks)
+        ctx.set_elide_stores(elide)
+        sets[b][0].fill_(7.0)
+        sets[b][1].fill_(7.0)
+        torch.cuda.synchronize()
+        ctx.set_halo_staging(b)
+        ctx.step(scene.depth, scene.color)
+        ctx.sync()
+        has_lo, has_hi = rank > 0, rank < count - 1
+        assert torch.equal(sets[b][0].view(torch.int32), send_lo.view(torch.int32)) == has_lo
+        assert torch.equal(sets[b][1].view(torch.int32), send_hi.view(torch.int32)) == has_hi
+        if not has_lo:
+            assert bool((sets[b][0] == 7.0).all())                # a face without a neighbour is left alone
+    ctx.set_halo_staging(-1)
+    sets[0][1].fill_(7.0)
+    ctx.step(scene.depth, scene.color)
+    ctx.sync()
+    assert bool((sets[0][1] == 7.0).all())
+    whole = build(pkg, G=64)[1]
+    with pytest.raises(pkg.capi.RgbdrError):
+        whole.halo_staging(0)                                     # not a slab context
+    whole.close()
+    ctx.close()
