@@ -263,6 +263,27 @@ class CalibVolumes {
     for (unsigned i = 0; i < m_cv_xyz_filenames.size(); ++i)
       check(m_be.ctx(), rgbdr_compute_inverse_calibration(m_be.ctx(), (int)i, window));
   }
+  // CalibrationInverter::calculateInverseVolumes + writeInverseVolumes (calibration_inverter.cpp:
+  // 29-36, 99-155) on the device: a volume of `res` texels per sensor, written as
+  // "<path><basename>.cv_xyz_inv" in the calibration-volume format (uvec3 res, the fixed
+  // depth limits (0.5, 4.5) the tool stores, then RGBA32F records x-fastest).
+  void writeInverseCalibs(std::string const& path, const uint32_t res[3], int window = 2) const
+  {
+    const size_t n = (size_t)res[0] * res[1] * res[2];
+    std::vector<float> vol(n * 4);
+    for (unsigned i = 0; i < m_cv_xyz_filenames.size(); ++i) {
+      check(m_be.ctx(), rgbdr_generate_inverse_lut(m_be.ctx(), (int)i, res, window, vol.data()));
+      const std::string& s = m_cv_xyz_filenames[i];
+      const std::string out = path + s.substr(s.find_last_of("/\\") + 1) + "_inv";
+      FILE* f = std::fopen(out.c_str(), "wb");
+      if (!f) throw std::runtime_error("cannot write " + out);
+      const float limits[2] = {0.5f, 4.5f};
+      const bool ok = std::fwrite(res, sizeof(uint32_t), 3, f) == 3 && std::fwrite(limits, sizeof(float), 2, f) == 2 &&
+                      std::fwrite(vol.data(), sizeof(float), vol.size(), f) == vol.size();
+      std::fclose(f);
+      if (!ok) throw std::runtime_error("short write to " + out);
+    }
+  }
   std::vector<std::array<float, 3>> getCameraPositions() const
   {
     std::vector<std::array<float, 3>> out(m_cv_xyz_filenames.size());

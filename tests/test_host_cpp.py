@@ -128,3 +128,39 @@ def test_frame_loop_from_ks_scene_with_reference_defaults(pkg, orc, tmp_path):
                            res_bricks=tuple(g.res_bricks))
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
     assert np.sum(np.abs(got) < 0.01) > 1000
+
+
+@pytest.mark.gpu
+def test_calib_inverter_tool(pkg, orc, tmp_path):
+    """the reference's offline tool `calib_inverter <scene.ks> -s <voxel>` over the C ABI: same
+    command line, file names and file format; the volumes equal rgbdr_generate_inverse_lut"""
+    synth = pkg.synth
+    n, W, H = 2, 64, 52
+    scene = synth.Scene(n, W, H, lut_res=(16, 13, 16), seed=5, make_frames=False)
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "calib"))
+    with open(os.path.join(d, "scene.ks"), "w") as f:
+        for i in range(n):
+            f.write("kinect calib/k%d.yml\n" % i)
+        f.write("bbx -1.0 0.0 -1.0 1.0 2.2 1.0\n")
+    for i in range(n):
+        with open(os.path.join(d, "calib", "k%d.yml" % i), "w") as f:
+            f.write("%%YAML:1.0\nrgb_size: [ %d, %d ]\ndepth_size: [ %d, %d ]\nnear_far: [ 0.5, 4.5 ]\n" % (W, H, W, H))
+        assert orc.lut_write(os.path.join(d, "calib", "k%d.cv_xyz" % i), scene.xyz[i], 3) == 0
+        assert orc.lut_write(os.path.join(d, "calib", "k%d.cv_uv" % i), scene.uv[i], 2) == 0
+    exe = os.path.join(ROOT, "rgbd-recon_amd", "host", "calib_inverter")
+    r = subprocess.run([exe, os.path.join(d, "scene.ks"), "-s", "0.05"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    res = (40, 44, 40)                                         # ceil((2, 2.2, 2) / 0.05)
+    assert "using resolution 40, 44, 40" in r.stdout
+    ctx = pkg.capi.Context(pkg.capi.make_config(n, (W, H), bbox_min=(-1.0, 0.0, -1.0), bbox_max=(1.0, 2.2, 1.0),
+                                                voxel_size=2.2 / 32, brick_size=2.2 / 4), 0)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        got, limits = orc.lut_read(os.path.join(d, "k%d.cv_xyz_inv" % i), 4)
+        assert got.shape == (res[2], res[1], res[0], 4) and tuple(limits) == (0.5, 4.5)
+        want = ctx.generate_inverse_lut(i, res)
+        assert same_bits(got, want)
+        assert 0.02 < (got[..., 3] == 1.0).mean() < 0.98       # inside / outside the frustum
+    ctx.close()
+    assert subprocess.run([exe, os.path.join(d, "scene.txt")], capture_output=True).returncode == 1   # "No .ks file specified"
