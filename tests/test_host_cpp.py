@@ -19,6 +19,9 @@ def test_frame_loop_is_built_and_linked_against_the_c_abi():
     out = subprocess.run(["ldd", EXE], capture_output=True, text=True).stdout
     assert "librgbdr_hip.so" in out and "not found" not in out
     assert subprocess.run([EXE], capture_output=True).returncode == 2      # usage
+    inv = os.path.join(ROOT, "rgbd-recon_amd", "host", "calib_inverter")
+    assert os.path.exists(inv), "run __graft_entry__.build()"
+    assert subprocess.run([inv], capture_output=True).returncode == 2      # usage
 
 
 @pytest.mark.gpu
