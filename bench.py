@@ -244,7 +244,7 @@ def main():
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": "zslab%d" % world if world > 1 else "single",
                    "halo_transport": transport["kind"] if world > 1 else None},
-        "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false>" % N,
+        "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, false>" % N,
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
