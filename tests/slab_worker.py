@@ -67,13 +67,18 @@ def main():
     if sys.argv[1] in ("exchanger", "exchanger_lib"):
         return exchanger_mode(sys.argv[2], int(sys.argv[3]), library_staging=sys.argv[1] == "exchanger_lib")
     out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])
+    backend = sys.argv[4] if len(sys.argv) > 4 else "gloo"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     load_package()
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32))
     inv = scene.inverse((G, G, G))
 
@@ -87,14 +92,16 @@ def main():
         return ctx
 
     ctx = make(slab_rank=rank, slab_count=world)
-    rdist.exchange_halo_via_host(rdist.halo_views(ctx.device_tsdf(), dev), rank=rank, world=world)
+    if world > 1:
+        rdist.exchange_halo_via_host(rdist.halo_views(ctx.device_tsdf(), dev), rank=rank, world=world)
     torch.cuda.synchronize()
     whole = make() if rank == 0 else None
     for n, (shade_mode, eye, skip) in enumerate([(0, (2.2, 1.6, 1.9), 0), (1, (0.85, 1.7, 0.8), 1)]):
         view = capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=shade_mode)
         view.skip_space = skip
-        col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=True)
-        np.savez(os.path.join(out_dir, "slab_r%d_v%d.npz" % (rank, n)), color=col.numpy(), depth=dep.numpy(), ns=ns.numpy())
+        col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=backend != "nccl")
+        np.savez(os.path.join(out_dir, "slab_r%d_v%d.npz" % (rank, n)), color=col.cpu().numpy(), depth=dep.cpu().numpy(),
+                 ns=ns.cpu().numpy())
         if whole is not None:
             c, d, s = whole.raymarch(view)
             np.savez(os.path.join(out_dir, "whole_v%d.npz" % n), color=c, depth=d, ns=s)

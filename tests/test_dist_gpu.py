@@ -16,15 +16,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,G,limit", [(2, 64, 0.03), (3, 96, 0.05)])
-def test_slab_ranks_render_the_whole_volume(world, G, limit, tmp_path):
+@pytest.mark.parametrize("world,G,limit,backend", [(2, 64, 0.03, "gloo"), (3, 96, 0.05, "gloo"), (1, 64, 0.03, "nccl")])
+def test_slab_ranks_render_the_whole_volume(world, G, limit, backend, tmp_path):
+    """(the nccl case has one rank -- the box has one GPU -- but sends the library's device
+    buffers, wrapped without a copy, through RCCL's all-reduce MIN / SUM)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), str(tmp_path), str(G),
-           str(limit)]
+           str(limit), backend]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     for n in range(2):
