@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--pipeline", action="store_true",
                     help="RGBDR_FLAG_PIPELINE: the pre_* chain of step k+1 overlaps integrate of step k on a second stream "
                          "(measured slower for the full sweep: integrate already saturates HBM and the CUs)")
+    ap.add_argument("--loopback", action="store_true",
+                    help="one GPU, real RCCL: run an inner Z slab (rank 1 of 4) whose two neighbours are this process "
+                         "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="bound the CPU baseline to this many z rows of the volume (0 = the whole volume, about 10 s)")
     args = ap.parse_args()
@@ -66,7 +69,12 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    loop = bool(args.loopback) and world == 1
+    multi = world > 1 or loop
+    if loop:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -80,11 +88,14 @@ def main():
     N = args.sensors
     W, H = 512, 424
     grid = (args.grid,) * 3 if args.grid else GRID_FOR_GPUS.get(world, (512, 512, 512))
+    if loop:
+        grid = (512, 512, 2048)          # four slabs of 512^3; this process is an inner one
+    slab_rank, slab_count = (1, 4) if loop else (rank, world)
     G = grid[0]
     scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
     flags = capi.FLAGS_DEFAULT | (capi.FLAG_PIPELINE if args.pipeline else 0)
     cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags,
-                           res_override=grid, slab_rank=rank, slab_count=world)
+                           res_override=grid, slab_rank=slab_rank, slab_count=slab_count)
     ctx = capi.Context(cfg, local_rank)
     g = ctx.geo
     for i in range(N):
@@ -95,7 +106,7 @@ def main():
     torch.cuda.synchronize()
 
     halo, transport = None, None
-    if world > 1:
+    if multi:
         halo = rdist.halo_views(ctx.device_tsdf(), dev)
         # The library enqueues on a torch stream so that the RCCL exchange can be ordered
         # against the kernels with events instead of host syncs (rgbd_recon_amd.dist.HaloExchanger:
@@ -112,7 +123,7 @@ def main():
             ok, why = 1, ""
             try:
                 ctx.sync()
-                rdist.exchange_halo(*halo, rank=rank, world=world)
+                rdist.exchange_halo(*halo, rank=rank, world=world, loopback=loop)
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001 -- reported, not swallowed
                 ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
@@ -121,8 +132,8 @@ def main():
             if int(flag[0]) == 0:
                 transport = {"kind": "gloo (host-staged; RCCL p2p failed: %s)" % (why or "on another rank"), "group": fallback}
                 sys.stderr.write("[bench rank %d] %s\n" % (rank, transport["kind"]))
-        exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=rank, world=world, group=transport["group"],
-                                        via_host=transport["kind"] != "rccl", ctx=ctx)
+        exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
+                                        via_host=transport["kind"] != "rccl", ctx=ctx, loopback=loop)
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
@@ -138,7 +149,7 @@ def main():
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +173,7 @@ def main():
         stats = {n: ctx.timer_stats(n) for n in names}
         ctx.enable_timer_accumulation(False)
         ctx.enable_timers(False)
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -173,13 +184,13 @@ def main():
     # sweep time has settled before the warm-up and the timed steps begin.
     step(False)
     ctx.settle(3.0)
-    if world > 1:
+    if multi:
         dist.barrier()
 
     # ---- headline: full sweep ------------------------------------------------
     dt, stats = timed(False, args.steps, args.warmup)
     V_local = g.res_volume[0] * g.res_volume[1] * (g.slab_voxel_z1 - g.slab_voxel_z0)
-    V_total = g.res_volume[0] * g.res_volume[1] * g.res_volume[2]
+    V_total = g.res_volume[0] * g.res_volume[1] * g.res_volume[2] if not loop else V_local   # loopback: this slab only
     ms_per_step = dt / args.steps * 1e3
     value = V_total / (dt / args.steps) / 1e6
     int_ns, int_n = stats["2integrate"]
@@ -205,7 +216,7 @@ def main():
 
     # ---- the other schedule (extra keys): whichever of sequential / pipelined the headline did not use ----
     other = None
-    if world == 1:
+    if world == 1 and not loop:
         ctx.set_pipelined(not args.pipeline)
         dto, stats_o = timed(False, args.steps, args.warmup)
         ctx.set_pipelined(bool(args.pipeline))
@@ -216,7 +227,7 @@ def main():
 
     # ---- RGBDR_FLAG_ELIDE_STORES (extra keys): the full sweep without re-storing tiles that stay -limit ----
     elided = None
-    if world == 1:
+    if world == 1 and not loop:
         ctx.set_elide_stores(True)
         dte, stats_e = timed(False, args.steps, args.warmup)
         ctx.set_elide_stores(False)
@@ -242,8 +253,8 @@ def main():
                                "inverse LUT" % ((N,) + tuple(g.res_volume)),
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
-                   "parallelism": "zslab%d" % world if world > 1 else "single",
-                   "halo_transport": transport["kind"] if world > 1 else None},
+                   "parallelism": ("zslab%d" % world if world > 1 else "single") + (" (loopback: an inner slab of 4)" if loop else ""),
+                   "halo_transport": transport["kind"] if multi else None},
         "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, false>" % N,
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
@@ -269,7 +280,7 @@ def main():
             pass
 
     # ---- consumer of the volume (BASELINE config 5 names the post-pass): extra keys ----
-    if world == 1:
+    if world == 1 and not loop:
         try:
             ctx.set_use_bricks(False)
             ctx.integrate()
@@ -294,7 +305,7 @@ def main():
             out["post_pass"] = {"error": str(e)}
 
     # ---- the same step fed from HOST buffers (never part of `value`): extra keys ----
-    if world == 1:
+    if world == 1 and not loop:
         try:
             def fed(upload, steps=40):
                 ctx.set_use_bricks(False)
@@ -335,17 +346,17 @@ def main():
             out["host_fed"] = {"error": str(e)}
 
     # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and not loop and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)
 
-    if world > 1:
+    if multi:
         torch.cuda.synchronize()
         out["halo"] = {"layers_per_face": int(g.halo_tile_layers), "bytes_per_face": int(halo[0].numel() * 4),
                        "transfer_ms_rank0": exchanger.last_transfer_ms()}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -40,10 +40,20 @@ def halo_views(view, device):
             wrap_device_floats(base, n, device), wrap_device_floats(hi_halo, n, device))
 
 
-def exchange_halo(send_lo, send_hi, recv_lo, recv_hi, rank=None, world=None, group=None):
+def exchange_halo(send_lo, send_hi, recv_lo, recv_hi, rank=None, world=None, group=None, loopback=False):
     """Neighbour exchange of one tile layer per slab face.  Slab r's lowest layer
     goes to r-1's upper halo, its highest layer to r+1's lower halo.  The same
-    function runs on CUDA tensors (RCCL) and CPU tensors (gloo)."""
+    function runs on CUDA tensors (RCCL) and CPU tensors (gloo).
+    `loopback` (tests on a single GPU): both neighbours are this process itself -- the
+    lower face lands in the own upper halo and the upper face in the own lower halo,
+    through the same send/recv pairs."""
+    if loopback:
+        me = dist.get_rank(group)
+        ops = [dist.P2POp(dist.isend, send_lo, me, group), dist.P2POp(dist.irecv, recv_hi, me, group),
+               dist.P2POp(dist.isend, send_hi, me, group), dist.P2POp(dist.irecv, recv_lo, me, group)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        return
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
     ops = []
@@ -81,8 +91,10 @@ class HaloExchanger:
     writes device pointers from the host with no regard for streams): the staged layers
     travel through host tensors, with host synchronisation."""
 
-    def __init__(self, tsdf_view, device, compute_stream, rank=None, world=None, group=None, via_host=False, ctx=None):
+    def __init__(self, tsdf_view, device, compute_stream, rank=None, world=None, group=None, via_host=False, ctx=None,
+                 loopback=False):
         self.via_host = via_host
+        self.loopback = loopback        # tests: see exchange_halo
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group
@@ -142,7 +154,8 @@ class HaloExchanger:
                 if self.rank < self.world - 1:
                     self.recv_hi.copy_(host[3])
             else:
-                exchange_halo(lo, hi, self.recv_lo, self.recv_hi, rank=self.rank, world=self.world, group=self.group)
+                exchange_halo(lo, hi, self.recv_lo, self.recv_hi, rank=self.rank, world=self.world, group=self.group,
+                              loopback=self.loopback)
             done = torch.cuda.Event(enable_timing=True)
             done.record(self.side)
         self.done[b] = done

@@ -16,6 +16,51 @@ from __graft_entry__ import load_package  # noqa: E402
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
 
 
+def loopback_mode(out_dir, G):
+    """One process, one GPU, real RCCL: a middle slab (rank 1 of 3) whose two neighbours are
+    the process itself.  Four different frames go through integrate + the asynchronous,
+    stream-ordered HaloExchanger with the library's staging sets and no host synchronisation;
+    afterwards the halos must hold the own boundary layers of the LAST frame."""
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=s, sphere_r=r)
+              for s, r in ((1, 0.9), (2, 0.6), (3, 0.75), (4, 0.85))]
+    inv = scenes[0].inverse((G, G, G))
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=1, slab_count=3), 0)
+    for i in range(2):
+        ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    main = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(main)
+    ctx.set_stream(main.cuda_stream)
+    ex = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=1, world=3, ctx=ctx, loopback=True)
+    frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
+    lo, hi, rlo, rhi = rdist.halo_views(ctx.device_tsdf(), dev)
+    torch.cuda.synchronize()
+    history = []
+    for n, (d, c) in enumerate(frames):
+        ctx.update_device(d.data_ptr(), c.data_ptr())
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.set_use_bricks(n % 2 == 0)                                # both staging paths
+        ex.begin_step()
+        ctx.integrate()
+        ex.exchange_async()
+        history.append((lo.clone(), hi.clone()))
+    ex.wait()
+    main.synchronize()
+    np.savez(os.path.join(out_dir, "loopback.npz"), recv_lo=rlo.cpu().numpy(), recv_hi=rhi.cpu().numpy(),
+             hist_lo=torch.stack([h[0] for h in history]).cpu().numpy(),
+             hist_hi=torch.stack([h[1] for h in history]).cpu().numpy(), ms=ex.last_transfer_ms() or -1.0)
+    dist.destroy_process_group()
+
+
 def exchanger_mode(out_dir, G, library_staging=False):
     """three frames through integrate + HaloExchanger.exchange_async (gloo: staged through
     the host); afterwards every rank dumps its boundary layers and its halos"""
@@ -64,6 +109,8 @@ def exchanger_mode(out_dir, G, library_staging=False):
 
 
 def main():
+    if sys.argv[1] == "loopback":
+        return loopback_mode(sys.argv[2], int(sys.argv[3]))
     if sys.argv[1] in ("exchanger", "exchanger_lib"):
         return exchanger_mode(sys.argv[2], int(sys.argv[3]), library_staging=sys.argv[1] == "exchanger_lib")
     out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])

@@ -74,3 +74,23 @@ def test_async_halo_exchanger(world, mode, tmp_path, pkg):
     ctx.step(last.depth, last.color)
     assert same_bits(np.concatenate([zz["tsdf"] for zz in z], axis=0), ctx.readback_tsdf())
     ctx.close()
+
+
+def test_async_halo_exchanger_over_rccl_loopback(tmp_path):
+    """the stream-ordered path as it runs on a multi-GPU node -- RCCL send/recv on the library's
+    staging sets, side stream, events, no host synchronisation between four frames -- with
+    the one process as its own two neighbours"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), "loopback", str(tmp_path), "96"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = np.load(os.path.join(str(tmp_path), "loopback.npz"))
+    lo_matches = [same_bits(z["recv_hi"], z["hist_lo"][f]) for f in range(4)]      # lower face -> own upper halo
+    hi_matches = [same_bits(z["recv_lo"], z["hist_hi"][f]) for f in range(4)]
+    assert lo_matches[3] and hi_matches[3], (lo_matches, hi_matches)
+    assert not same_bits(z["hist_lo"][2], z["hist_lo"][3])                          # the frames differ at the faces
+    assert float(z["ms"]) > 0
