@@ -258,7 +258,9 @@ int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst);
 /* m_bricks_occupied (ascending ids) and m_ratio_occupied */
 int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* count, float* ratio);
 
-/* Zero-copy consumers: device pointer of the tile-linear TSDF slab.
+/* Zero-copy consumers: device pointer of the tile-linear TSDF slab.  The owned layers are
+ * read-only for the caller (the library remembers which tiles already hold -limit and does
+ * not store those again); the halo layers are the caller's to fill (neighbour exchange).
  * Layout: tile (tx,ty,tz_local) at ((tz_local*tiles[1] + ty)*tiles[0] + tx)*512 floats,
  * voxel (x,y,z) inside it at (z&7)*64 + (y&7)*8 + (x&7).  `halo_layers` tile layers
  * precede and follow the owned layers when slab_count > 1. */
