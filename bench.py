@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--sensors", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
-                    help="RGBDR_FLAG_PIPELINE: the pre_* chain of step k+1 overlaps integrate of step k on a second stream "
-                         "(measured slower for the full sweep: integrate already saturates HBM and the CUs)")
+                    help="RGBDR_FLAG_PIPELINE for the headline: the pre_* chain of step k+1 overlaps integrate of step k on a "
+                         "second stream (2-3 %% more frames/s, but the integrate launches it is measured on run 4 %% longer "
+                         "under the overlap; the other schedule is always reported under 'other_schedule')")
     ap.add_argument("--loopback", action="store_true",
                     help="one GPU, real RCCL: run an inner Z slab (rank 1 of 4) whose two neighbours are this process "
                          "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
