@@ -18,7 +18,11 @@
  *   - the record layouts (kinect::xyz 12 B, kinect::uv 8 B, framework/DataTypes.h:12-35),
  *   - trilinear interpolation versus kinect::getTrilinear
  *     (framework/DataTypes.cpp:115-163) to a few ulp (different but equivalent
- *     association of the lerps).
+ *     association of the lerps),
+ *   - DXT1 / DXT5 colour decoding (orc_decode_dxt) bit for bit versus squish::DecompressImage
+ *     (external/squish, the decoder of NetKinectArray.cpp:633).
+ * The same shim also pins the C++ host mirror's sensor-yml scanner and .stream reader against
+ * kinect::CalibrationFiles / sys::FileBuffer (tests/test_oracle_ref.py).
  *
  * NUMERIC CONVENTIONS (decisions where GLSL / GL leave the result to the driver):
  *   - all arithmetic is IEEE-754 binary32, no FMA contraction (-ffp-contract=off),
