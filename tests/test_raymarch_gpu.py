@@ -152,7 +152,7 @@ def oracle_images_skip(orc, ctx, scene, inv, view, peels):
     return orc.raymarch(bytes(view), tsdf, inv, scene.uv, [scene.color[i] for i in range(2)], db, q, peels=peels)
 
 
-@pytest.mark.parametrize("count,G,tsdf_limit", [(2, 64, 0.03), (3, 64, 0.03), (4, 128, 0.03), (2, 96, 0.1)])
+@pytest.mark.parametrize("count,G,tsdf_limit", [(2, 64, 0.03), (3, 64, 0.03), (4, 128, 0.03), (2, 96, 0.1), (3, 50, 0.03), (2, 100, 0.05)])
 @pytest.mark.parametrize("skip", [0, 1])
 def test_slab_raymarch_equals_whole_volume(pkg, orc, count, G, tsdf_limit, skip):
     """Z slabs: find -> element-wise MIN of the first-hit indices -> shade -> select.
