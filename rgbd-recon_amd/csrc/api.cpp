@@ -103,6 +103,7 @@ struct rgbdr_ctx {
 
   // bricks
   uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
+  bool clear_pending = false;       // clearOccupiedBricks was called; the zeroing rides on the next k_morph
   uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
   uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
   int tile_count_parity = 0;        // which of the two list counters the next brick sweep appends to
@@ -842,6 +843,12 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
+  if (kind == hipMemcpyDeviceToDevice && !ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
+      launch_copy_frames(depth, ctx->d_depth_raw, n * 4, color, ctx->d_color, ncol, ps)) {
+    LAUNCHCHK("copy_frames");
+    ctx->frame_uploaded = true;
+    return RGBDR_OK;
+  }
   if (ctx->cfg.compress_depth) {
     HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
     launch_u8_to_unit(ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
@@ -910,8 +917,17 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  ctx->clear_pending = true;  // performed by the first kernel of process_textures, or by whoever reads the counters first
+  return RGBDR_OK;
+}
+
+// clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
+static int flush_clear(rgbdr_ctx* ctx)
+{
+  if (!ctx->clear_pending) return RGBDR_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->pstream()));
+  ctx->clear_pending = false;
   return RGBDR_OK;
 }
 
@@ -969,7 +985,9 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
   tbegin(ctx, "1preprocess", ps);
   tbegin(ctx, "morph", ps);
-  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ps);
+  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->clear_pending ? ctx->d_counters : nullptr,
+               (unsigned)ctx->geo.num_bricks, ps);
+  ctx->clear_pending = false;
   tend(ctx, "morph", ps);
   tbegin(ctx, "bilateral", ps);
   launch_pre_depth(p, ps);
@@ -998,6 +1016,7 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   hipStream_t ps = ctx->pstream();
   const int w = ctx->rbuf;  // belongs to the frame process_textures just wrote
   tbegin(ctx, "bricks", ps);
@@ -1346,6 +1365,7 @@ int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst)
 
 int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
 {
+  if (ctx) { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
@@ -1418,6 +1438,7 @@ static void mat4_product(const float* a, const float* b, float* o)  // glm assoc
 // ReconIntegration::drawDepthLimits into the peel image of the view buffers
 static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
 {
+  { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "depth limits before update_occupied_bricks");
   PeelParams p{};
   mat4_product(v->projection, v->modelview, p.pmv);

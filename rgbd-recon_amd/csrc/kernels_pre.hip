@@ -41,6 +41,33 @@ void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s)
   hipLaunchKernelGGL(k_u8_to_unit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
 }
 
+// NetKinectArray::update for frames already on the device: the depth and the colour set in one
+// launch (two blit launches cost ~10 us of stream time, more than moving the 6 MB)
+__global__ __launch_bounds__(256) void k_copy_frames(const uint4* __restrict__ a_src, uint4* __restrict__ a_dst, size_t a_n16,
+                                                     const uint4* __restrict__ b_src, uint4* __restrict__ b_dst, size_t b_n16,
+                                                     const uint8_t* a_tail_src, uint8_t* a_tail_dst, int a_tail,
+                                                     const uint8_t* b_tail_src, uint8_t* b_tail_dst, int b_tail)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a_n16) a_dst[i] = a_src[i];
+  else if (i < a_n16 + b_n16) b_dst[i - a_n16] = b_src[i - a_n16];
+  if (i < (size_t)a_tail) a_tail_dst[i] = a_tail_src[i];
+  if (i < (size_t)b_tail) b_tail_dst[i] = b_tail_src[i];
+}
+bool launch_copy_frames(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
+                        hipStream_t s)
+{
+  // 16-byte vectors need aligned pointers; otherwise the caller falls back to two memcpys
+  if ((((uintptr_t)a_src | (uintptr_t)a_dst | (uintptr_t)b_src | (uintptr_t)b_dst) & 15u) != 0) return false;
+  const size_t a16 = a_bytes / 16, b16 = b_bytes / 16;
+  const size_t n = a16 + b16 > 16 ? a16 + b16 : 16;
+  hipLaunchKernelGGL(k_copy_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)a_src, (uint4*)a_dst, a16,
+                     (const uint4*)b_src, (uint4*)b_dst, b16, (const uint8_t*)a_src + a16 * 16, (uint8_t*)a_dst + a16 * 16,
+                     (int)(a_bytes - a16 * 16), (const uint8_t*)b_src + b16 * 16, (uint8_t*)b_dst + b16 * 16,
+                     (int)(b_bytes - b16 * 16));
+  return true;
+}
+
 __global__ void k_repack_xyz(const float* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,8 +144,15 @@ void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, siz
 __device__ __forceinline__ bool morph_valid(float d) { return d > 0.5f && d < 4.5f; }
 
 __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_all, float* __restrict__ out_all, int W,
-                                                  int H)
+                                                  int H, uint32_t* __restrict__ zero, unsigned nzero)
 {
+  // clearOccupiedBricks rides along (a separate fill launch costs more stream time than
+  // zeroing the 1 MiB): the counters are next touched by k_normal, three launches later
+  if (zero) {
+    const unsigned nthreads = gridDim.x * gridDim.y * gridDim.z * (BX * BY);
+    const unsigned tid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
+    for (unsigned i = tid; i < nzero; i += nthreads) zero[i] = 0u;
+  }
   const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const float* in = in_all + (size_t)blockIdx.z * W * H;
@@ -163,10 +197,10 @@ __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_a
   out[(size_t)py * W + px] = res;
 }
 
-void launch_morph(const PreParams& p, const float* in, float* out, hipStream_t s)
+void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s)
 {
   dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_morph, grid, dim3(BX, BY), 0, s, in, out, p.W, p.H);
+  hipLaunchKernelGGL(k_morph, grid, dim3(BX, BY), 0, s, in, out, p.W, p.H, zero, nzero);
 }
 
 // ---------------------------------------------------------------------------

@@ -748,3 +748,26 @@ def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
         whole.halo_staging(0)                                     # not a slab context
     whole.close()
     ctx.close()
+
+
+def test_deferred_counter_clear(pkg):
+    """clearOccupiedBricks is performed by the next process_textures -- or by whoever reads the
+    counters first"""
+    scene, ctx, _ = build(pkg)
+    ctx.step(scene.depth, scene.color)
+    c1 = ctx.readback_brick_counters()
+    assert c1.sum() > 0
+    ctx.clear_occupied_bricks()
+    assert ctx.readback_brick_counters().sum() == 0            # flushed by the reader
+    ctx.process_textures()
+    assert np.array_equal(ctx.readback_brick_counters(), c1)
+    ctx.process_textures()                                      # no clear in between: the reference double counts too
+    assert np.array_equal(ctx.readback_brick_counters(), 2 * c1)
+    ctx.clear_occupied_bricks()
+    ctx.update_occupied_bricks()                                # flushed by the occupied update
+    assert len(ctx.get_occupied()[0]) == 0
+    ctx.clear_occupied_bricks()
+    ctx.process_textures()
+    ctx.update_occupied_bricks()
+    assert np.array_equal(ctx.readback_brick_counters(), c1) and len(ctx.get_occupied()[0]) > 0
+    ctx.close()
