@@ -400,7 +400,7 @@ def test_calibration_files_round_trip(pkg, orc, tmp_path):
     ctx2.close()
 
 
-def test_timers_report_each_pass(pkg):
+def test_timers_report_each_pass(pkg, orc):
     scene, ctx, inv = build(pkg)
     ctx.enable_timers(True)
     ctx.step(scene.depth, scene.color)
@@ -409,6 +409,15 @@ def test_timers_report_each_pass(pkg):
     t = {n: ctx.timer_ns(n) for n in names}
     assert all(v > 0 for v in t.values())
     assert t["1preprocess"] >= t["bilateral"]
+    # the timers never change a result, whatever their level of detail
+    ref = oracle_run(orc, scene, ctx, inv)
+    for detail in (2, 1):
+        ctx.set_timer_detail(detail)
+        ctx.step(scene.depth, scene.color)
+        check_images(ctx, ref, 2)
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    ctx.set_timer_detail(2)
     with pytest.raises(pkg.capi.RgbdrError):
         ctx.timer_ns("nope")
     ctx.close()
