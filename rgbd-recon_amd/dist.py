@@ -118,8 +118,8 @@ class HaloExchanger:
     def begin_step(self):
         """before integrate(): claims the staging set of this step"""
         b = self.k & 1
-        if self.done[b] is not None:
-            self.compute.wait_event(self.done[b])        # the transfer that last read stage[b]
+        if self.done[b] is not None and not self.done[b].query():
+            self.compute.wait_event(self.done[b])        # the transfer that last read stage[b] (skipped once it has completed)
         if self.ctx is not None:
             self.ctx.set_halo_staging(b)
         self.begun = True
