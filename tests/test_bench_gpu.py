@@ -1,0 +1,48 @@
+"""bench.py keeps its contract: one JSON line with the driver's fields, the roofline block of
+the integrate kernel and the CPU baseline (with the full-size parity check inside it)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    j = run_bench("--steps", "6", "--warmup", "2", "--cpu-rows", "64")
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+        assert isinstance(j[key], typ), key
+    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2 and j["higher_is_better"] is True
+    assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["unit"] == "Mvoxels/s" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.5 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["bytes_per_launch"] == 512 ** 3 * (4 + 12 * 4) + 4 * 512 * 424 * 8
+    assert r["traffic"] is None or 0.9 * r["bytes_per_launch"] < r["traffic"] < 1.2 * r["bytes_per_launch"]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mvoxels/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["parity_rows_bit_exact"] is True and c["parity_rows"] == 64
+    assert j["bricked"]["ms_per_step"] < j["ms_per_step"]
+    assert j["full_sweep_store_elision"]["ms_per_step"] < 1.02 * j["ms_per_step"]
+
+
+def test_bench_loopback_runs_the_multi_gpu_path():
+    j = run_bench("--loopback", "--steps", "6", "--warmup", "2")
+    assert j["config"]["halo_transport"] == "rccl" and "loopback" in j["config"]["parallelism"]
+    assert j["halo"]["bytes_per_face"] > 0 and j["halo"]["transfer_ms_rank0"] > 0
+    assert "cpu_baseline" not in j and j["other_schedule"] is None
