@@ -664,7 +664,7 @@ def test_full_sweep_store_elision(pkg, orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", list(range(1, 7 + int(__import__("os").environ.get("RGBDR_EXTRA_SEEDS", "0")))))
 def test_random_call_sequences(pkg, orc, seed):
     """state machine check: random interleavings of the setters, both sweeps, both schedules,
     store elision, settle and two different frames -- after every frame the volume, the images
