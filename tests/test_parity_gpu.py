@@ -666,11 +666,25 @@ def test_full_sweep_store_elision(pkg, orc):
 
 @pytest.mark.parametrize("seed", list(range(1, 7 + int(__import__("os").environ.get("RGBDR_EXTRA_SEEDS", "0")))))
 def test_random_call_sequences(pkg, orc, seed):
+    run_random_sequence(pkg, orc, seed, None)
+
+
+@pytest.mark.parametrize("seed,slab", [(11, (0, 2)), (12, (1, 2)), (13, (1, 3)), (14, (2, 3))])
+def test_random_call_sequences_on_a_slab(pkg, orc, seed, slab):
+    run_random_sequence(pkg, orc, seed, slab)
+
+
+def run_random_sequence(pkg, orc, seed, slab):
     """state machine check: random interleavings of the setters, both sweeps, both schedules,
     store elision, settle and two different frames -- after every frame the volume, the images
     and the brick table equal the oracle run with the settings in force"""
     rng = np.random.default_rng(seed)
-    scene, ctx, inv = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
+    kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
+    scene, ctx, inv = build(pkg, wh=(64, 53), G=48 if slab else 32, lut_res=(16, 13, 16), **kw)
+    z0, z1 = ctx.geo.slab_voxel_z0, ctx.geo.slab_voxel_z1
+    if slab:
+        for b in range(2):
+            ctx.halo_staging(b)
     scenes = [scene, pkg.synth.Scene(2, 64, 53, lut_res=(16, 13, 16), seed=99, sphere_r=0.7)]
     state = dict(limit=np.float32(0.01), bricks=True, filt=True, proc=True, refine=True, min_voxels=10)
     cur = 0
@@ -700,13 +714,15 @@ def test_random_call_sequences(pkg, orc, seed):
             ctx.set_min_voxels_per_brick(state["min_voxels"])
         elif op == 8:
             ctx.settle(0.05)
+        elif op == 9 and slab:
+            ctx.set_halo_staging(int(rng.integers(-1, 2)))
         else:
             cur = int(rng.integers(0, 2))
         sc = scenes[cur]
         ctx.step(sc.depth, sc.color)
         ref = oracle_run(orc, sc, ctx, inv, limit=state["limit"], use_bricks=state["bricks"], filter_textures=state["filt"],
                          processed=state["proc"], refine=state["refine"], min_voxels=state["min_voxels"])
-        assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (seed, step_no, int(op), state)
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"][z0:z1]), (seed, step_no, int(op), state)
         if step_no % 7 == 0:
             check_images(ctx, ref, 2)
             assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
