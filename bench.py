@@ -346,6 +346,47 @@ def main():
         except capi.RgbdrError as e:
             out["host_fed"] = {"error": str(e)}
 
+    # ---- the reference's own default operating point (extra keys) ----------------------------
+    # voxel 0.01 m over (-1,0,-1)-(1,2.2,1) -> 200 x 221 x 200, bricks of 0.1 m (10 voxels), inverse LUTs at
+    # the calib_inverter default spacing 0.007 m (286 x 315 x 286, generated on the device, resampled to the
+    # grid at upload), DXT1 colour frames, 1280 x 1080 colour next to 512 x 424 depth, brick-skipping sweep
+    if world == 1 and not loop:
+        try:
+            bmax = (1.0, 2.2, 1.0)
+            sc = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234, color_wh=(1280, 1080))
+            rc = capi.Context(capi.make_config(N, (W, H), color_wh=(1280, 1080), bbox_max=bmax, voxel_size=0.01, brick_size=0.1,
+                                               compress_rgb=1), local_rank)
+            t0 = time.perf_counter()
+            for i in range(N):
+                rc.set_calibration(i, sc.xyz[i], sc.lut_res, sc.uv[i], sc.lut_res, (0.5, 4.5))
+                rc.set_inverse_calibration(i, rc.generate_inverse_lut(i, (286, 315, 286)), (286, 315, 286))
+            rc.sync()
+            t_lut = time.perf_counter() - t0
+            blocks = np.stack([synth.encode_dxt(sc.color[i], 1) for i in range(N)])
+            d_b = torch.from_numpy(np.ascontiguousarray(blocks)).to(dev)
+            d_d = torch.from_numpy(sc.depth).to(dev)
+            torch.cuda.synchronize()
+
+            def rstep():
+                rc.update_device(d_d.data_ptr(), d_b.data_ptr())
+                rc.clear_occupied_bricks(); rc.process_textures(); rc.update_occupied_bricks(); rc.integrate()
+            for _ in range(5):
+                rstep()
+            rc.sync()
+            t0 = time.perf_counter()
+            for _ in range(100):
+                rstep()
+            rc.sync()
+            ms = (time.perf_counter() - t0) / 100 * 1e3
+            out["reference_defaults"] = {"grid": list(rc.geo.res_volume), "brick_voxels": int(rc.geo.brick_voxels),
+                                         "inverse_lut": [286, 315, 286], "colour": "DXT1 1280x1080",
+                                         "ms_per_frame": round(ms, 4), "frames_per_s": round(1e3 / ms, 1),
+                                         "occupied_ratio": round(rc.occupied_ratio(), 4),
+                                         "inverse_luts_generated_and_resampled_s": round(t_lut, 3)}
+            rc.close()
+        except (capi.RgbdrError, TypeError, ValueError) as e:
+            out["reference_defaults"] = {"error": str(e)}
+
     # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
     if world == 1 and not loop and rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, scene, capi, synth, G, N, W, H, args.cpu_rows, V_total)
