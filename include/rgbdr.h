@@ -104,7 +104,7 @@ typedef struct {
  * :474-484). */
 typedef struct {
   int32_t res_volume[3];   /* m_res_volume */
-  int32_t res_bricks[3];   /* m_res_bricks */
+  int32_t res_bricks[3];   /* m_res_bricks: the float-accumulating loops of divideBox (recon_integration.cpp:366-388) */
   float brick_size;        /* adjusted: voxel * round(size / voxel) */
   int32_t brick_voxels;    /* voxels per brick edge: round(brick_size / voxel_size) (x axis) */
   int32_t brick_voxels_axis[3]; /* per axis; differs from brick_voxels only for res_override grids with anisotropic voxels */
@@ -154,6 +154,13 @@ const char* rgbdr_version(void);
 
 /* host-only: geometry of a config (no device touched) */
 int rgbdr_compute_geometry(const rgbdr_config* cfg, rgbdr_geometry* out);
+/* host-only: the voxel indices [first, last] brick `brick` of `axis` (0 x, 1 y, 2 z) holds, exactly as
+ * divideBox + VolumeSampler::containedVoxels build the per-brick index lists (recon_integration.cpp:
+ * 366-375, framework/rendering/volume_sampler.cpp:50-62: binary32 pos/step truncated to unsigned, float
+ * upper bound) -- neighbouring bricks share a voxel row where the quotients round up, and `last` of the
+ * final brick may exceed res - 1 (those indices alias other voxels through z*X*Y + y*X + x; the
+ * brick-skipping sweep reproduces that).  A voxel held by no occupied brick keeps -limit. */
+int rgbdr_brick_voxel_range(const rgbdr_config* cfg, int axis, int brick, int32_t* first, int32_t* last);
 /* host-only: tile layers [t0,t1) of slab `rank` out of `count` over `tiles_z` layers */
 int rgbdr_slab_range(int tiles_z, int count, int rank, int* t0, int* t1);
 /* host-only: Frustum::getCameraPos of a cv_xyz volume (frustum.cpp:21-33, CalibVolumes.cpp:98-113) */
@@ -214,6 +221,10 @@ int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx);
 int rgbdr_process_textures(rgbdr_ctx* ctx);
 /* ReconIntegration::updateOccupiedBricks (recon_integration.cpp:431-446), device side, no readback */
 int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx);
+/* Replaces m_bricks_occupied (recon_integration.cpp:434-441) with the caller's own list of brick ids
+ * (divideBox order, x fastest) -- for a host that filters the counters itself, as the reference does on
+ * the CPU.  Valid until the next rgbdr_update_occupied_bricks. */
+int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count);
 /* ReconIntegration::integrate (recon_integration.cpp:243-270) */
 int rgbdr_integrate(rgbdr_ctx* ctx);
 /* process_textures() + integrate() of kinect_client.cpp:572-602 in one call */

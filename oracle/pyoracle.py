@@ -32,7 +32,7 @@ class NormalParams(C.Structure):
 
 class IntegrateParams(C.Structure):
     _fields_ = [("num_sensors", C.c_int), ("W", C.c_int), ("H", C.c_int), ("res", C.c_int * 3),
-                ("limit", C.c_float), ("bv", C.c_int * 3), ("res_bricks", C.c_int * 3)]
+                ("limit", C.c_float)]
 
 
 class View(C.Structure):
@@ -75,6 +75,9 @@ def lib():
         l.orc_axis_nearest.argtypes = [C.c_float, C.c_int]
         l.orc_volume_res.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         l.orc_divide_box.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        l.orc_brick_voxel_mask.restype = C.c_size_t
+        l.orc_brick_voxel_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p]
         l.orc_update_occupied.restype = C.c_uint32
         l.orc_update_occupied.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib = l
@@ -205,10 +208,30 @@ def camera_pos(cv_xyz):
     return out
 
 
-def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, bv=8, res_bricks=(1, 1, 1),
-              z_range=None, out=None):
+def brick_voxel_mask(bbox_min, bbox_max, brick_size, res, occupied_mask, z_range=None):
+    """The voxels the reference draws in brick mode: divideBox + containedVoxels, literally.
+    Returns (mask [z1-z0, Y, X] u8, res_bricks, number of listed index triples outside the volume)."""
+    X, Y, Z = res
+    z0, z1 = (0, Z) if z_range is None else z_range
+    occ = np.ascontiguousarray(occupied_mask, dtype=np.uint8)
+    rb = divide_box(bbox_min, bbox_max, brick_size)
+    assert occ.size == rb[0] * rb[1] * rb[2], "occupied mask has %d bricks, divideBox makes %s" % (occ.size, rb)
+    out = np.empty((z1 - z0, Y, X), dtype=np.uint8)
+    d = (C.c_int * 3)(X, Y, Z)
+    rbo = (C.c_int * 3)()
+    outside = lib().orc_brick_voxel_mask(_p(f32(bbox_min)), _p(f32(bbox_max)), C.c_float(brick_size), d, _p(occ), z0, z1,
+                                         _p(out), rbo)
+    assert tuple(rbo) == rb
+    return out, rb, int(outside)
+
+
+def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, bv=None, res_bricks=None,
+              z_range=None, out=None, bbox=None, brick_size=None):
     """inv_luts: list of [Iz,Iy,Ix,4]; images: lists of [H,W(,2)]; res = (X,Y,Z).
-    Returns the full [Z,Y,X] volume (only z_range written when given)."""
+    Returns the full [Z,Y,X] volume (only z_range written when given).
+    occupied_mask (one byte per brick, divideBox order) selects brick mode: the voxels drawn
+    are those of brick_voxel_mask(bbox[0], bbox[1], brick_size, ...); `res_bricks`, if given
+    (e.g. the product's geometry), must equal the oracle's own divideBox; `bv` is ignored."""
     n = len(inv_luts)
     inv = [f32(a) for a in inv_luts]
     sil = [f32(a) for a in sils]
@@ -219,8 +242,6 @@ def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, b
     p.num_sensors, p.W, p.H = n, w, h
     p.res[:] = list(res)
     p.limit = limit
-    p.bv[:] = [bv] * 3 if np.isscalar(bv) else list(bv)
-    p.res_bricks[:] = list(res_bricks)
     arr = lambda xs: (C.c_void_p * n)(*[x.ctypes.data for x in xs])
     inv_res = (C.c_int * (3 * n))()
     for i, a in enumerate(inv):
@@ -229,11 +250,14 @@ def integrate(inv_luts, sils, depth_bs, quals, res, limit, occupied_mask=None, b
     if out is None:
         out = np.full((Z, Y, X), np.nan, dtype=np.float32)
     z0, z1 = (0, Z) if z_range is None else z_range
-    mask = None
+    vmask = None
     if occupied_mask is not None:
-        mask = np.ascontiguousarray(occupied_mask, dtype=np.uint8)
+        assert bbox is not None and brick_size is not None, "brick mode needs bbox=(min, max) and brick_size"
+        vmask, rb, _ = brick_voxel_mask(bbox[0], bbox[1], brick_size, res, occupied_mask, (z0, z1))
+        if res_bricks is not None:
+            assert tuple(res_bricks) == rb, "res_bricks %s differs from divideBox %s" % (tuple(res_bricks), rb)
     lib().orc_integrate(C.byref(p), arr(inv), inv_res, arr(sil), arr(db), arr(q),
-                        _p(mask) if mask is not None else None, z0, z1, _p(out))
+                        _p(vmask) if vmask is not None else None, z0, z1, _p(out))
     return out
 
 
@@ -404,11 +428,14 @@ def run_pipeline(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_siz
                  compress=False, depth_override=None, limits=(0.5, 4.5)):
     """Whole frame through the oracle, in the reference's call order
     (source/kinect_client.cpp:572-602).  Returns a dict of per-sensor images,
-    brick counters, occupied ids and the TSDF volume."""
+    brick counters, occupied ids and the TSDF volume.  `bv` is ignored (brick membership is
+    the reference's containedVoxels, see brick_voxel_mask)."""
     n = scene.N
-    if res_bricks is None:
-        bva = [bv] * 3 if np.isscalar(bv) else list(bv)
-        res_bricks = tuple((r + b - 1) // b for r, b in zip(res, bva))
+    # m_res_bricks comes from the oracle's own divideBox; a caller passing the product's geometry gets it checked
+    rb = divide_box(bbox_min, bbox_max, brick_size)
+    if res_bricks is not None:
+        assert tuple(res_bricks) == rb, "res_bricks %s differs from divideBox %s" % (tuple(res_bricks), rb)
+    res_bricks = rb
     nb = res_bricks[0] * res_bricks[1] * res_bricks[2]
     counters = np.zeros(nb, dtype=np.uint32)
     out = {k: [] for k in ("raw", "morph", "depth_rg", "lab", "depth_b", "sil", "normal", "quality")}
@@ -431,5 +458,5 @@ def run_pipeline(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_siz
     out["counters"], out["occupied"], out["ratio"], out["mask"] = counters, ids, ratio, mask
     if inv_luts is not None:
         out["tsdf"] = integrate(inv_luts, out["sil"], out["depth_b"], out["quality"], res, limit,
-                                mask if use_bricks else None, bv, res_bricks)
+                                mask if use_bricks else None, bbox=(bbox_min, bbox_max), brick_size=brick_size)
     return out

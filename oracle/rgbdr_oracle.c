@@ -631,9 +631,9 @@ ORC_API void orc_quality(const float* depth_b_rg, const float* normals, const fl
 /* ------------------------------------------------------------------------- */
 /* tsdf_integration.vs (a9) + VolumeSampler voxel positions (a8)              */
 /* Writes voxels z in [z0, z1) of an X*Y*Z x-fastest volume (whole-volume     */
-/* pointer).  `occupied_voxel_mask`, if not NULL, is one byte per brick       */
-/* (brick = bv[axis] voxels per axis, bricks x-fastest, res_bricks given): voxels    */
-/* of unoccupied bricks keep the clear value -limit                           */
+/* pointer).  `voxel_mask`, if not NULL, is one byte per voxel of rows         */
+/* [z0, z1) (orc_brick_voxel_mask below: the voxels in the index list of an    */
+/* occupied brick); the others keep the clear value -limit                     */
 /* (framework/reconstruction/recon_integration.cpp:243-270).                  */
 
 typedef struct {
@@ -641,14 +641,71 @@ typedef struct {
   int W, H;
   int res[3];          /* TSDF resolution m_res_volume */
   float limit;
-  int bv[3];           /* voxels per brick edge, per axis */
-  int res_bricks[3];
 } orc_integrate_params;
+
+/* The voxels the reference draws in brick mode (recon_integration.cpp:255-259:
+ * for every occupied brick, m_sampler.sample(m_bricks[index].indices)): the three
+ * nested while loops of divideBox (:366-388, brick id = emplace order, x fastest)
+ * and, per brick, the index list of VolumeSampler::containedVoxels
+ * (volume_sampler.cpp:50-62) -- binary32 pos / step truncated to unsigned, float
+ * upper bounds, linear index z*X*Y + y*X + x.  An index triple past the x or y end
+ * of the volume therefore aliases a voxel of the next row / slice; an index beyond
+ * X*Y*Z leaves the vertex buffer (undefined in GL) and is dropped here.
+ * out: one byte per voxel of rows [z0, z1), set to 1 where some occupied brick
+ * lists the voxel.  res_bricks receives m_res_bricks.  Returns the number of listed
+ * index triples that lie outside the volume on some axis (aliased or dropped). */
+ORC_API size_t orc_brick_voxel_mask(const float* bbox_min, const float* bbox_max, float brick_size, const int* dims,
+                                    const uint8_t* occupied_brick_mask, int z0, int z1, uint8_t* out, int* res_bricks)
+{
+  const float size[3] = {bbox_max[0] - bbox_min[0], bbox_max[1] - bbox_min[1], bbox_max[2] - bbox_min[2]};
+  const float stepv[3] = {1.0f / (float)dims[0], 1.0f / (float)dims[1], 1.0f / (float)dims[2]};
+  const size_t XY = (size_t)dims[0] * dims[1], total = XY * (size_t)dims[2];
+  memset(out, 0, XY * (size_t)(z1 - z0));
+  size_t brick = 0, outside = 0;
+  int rb[3] = {0, 0, 0};
+  float start[3] = {bbox_min[0], bbox_min[1], bbox_min[2]};
+  while (size[2] - start[2] + bbox_min[2] > 0.0f) {
+    while (size[1] - start[1] + bbox_min[1] > 0.0f) {
+      while (size[0] - start[0] + bbox_min[0] > 0.0f) {
+        float pos[3], bs[3];
+        for (int a = 0; a < 3; ++a) {
+          bs[a] = fminf(brick_size, size[a] - start[a] + bbox_min[a]) / size[a];
+          pos[a] = (start[a] - bbox_min[a]) / size[a];
+        }
+        if (occupied_brick_mask[brick]) {
+          for (unsigned y = (unsigned)(pos[1] / stepv[1]); (float)y < (pos[1] + bs[1]) / stepv[1]; ++y)
+            for (unsigned x = (unsigned)(pos[0] / stepv[0]); (float)x < (pos[0] + bs[0]) / stepv[0]; ++x)
+              for (unsigned z = (unsigned)(pos[2] / stepv[2]); (float)z < (pos[2] + bs[2]) / stepv[2]; ++z) {
+                const size_t id = (size_t)z * XY + (size_t)y * (unsigned)dims[0] + x;
+                if (x >= (unsigned)dims[0] || y >= (unsigned)dims[1] || z >= (unsigned)dims[2]) ++outside;
+                if (id >= total) continue;
+                if (id >= (size_t)z0 * XY && id < (size_t)z1 * XY) out[id - (size_t)z0 * XY] = 1;
+              }
+        }
+        ++brick;
+        start[0] += brick_size;
+        if (rb[2] == 0 && rb[1] == 0) ++rb[0];
+      }
+      start[0] = bbox_min[0];
+      start[1] += brick_size;
+      if (rb[2] == 0) ++rb[1];
+    }
+    start[1] = bbox_min[1];
+    start[2] += brick_size;
+    ++rb[2];
+  }
+  if (res_bricks) {
+    res_bricks[0] = rb[0];
+    res_bricks[1] = rb[1];
+    res_bricks[2] = rb[2];
+  }
+  return outside;
+}
 
 ORC_API void orc_integrate(const orc_integrate_params* p, const float* const* cv_xyz_inv /* RGBA */,
                            const int* inv_res /* 3 per sensor */, const float* const* silhouette,
                            const float* const* depth_b_rg, const float* const* quality,
-                           const uint8_t* occupied_brick_mask, int z0, int z1, float* tsdf)
+                           const uint8_t* voxel_mask, int z0, int z1, float* tsdf)
 {
   const int X = p->res[0], Y = p->res[1], Z = p->res[2];
   const float stepX = 1.0f / (float)X, stepY = 1.0f / (float)Y, stepZ = 1.0f / (float)Z;
@@ -659,12 +716,9 @@ ORC_API void orc_integrate(const orc_integrate_params* p, const float* const* cv
     for (int y = 0; y < Y; ++y) {
       for (int x = 0; x < X; ++x) {
         const size_t o = (size_t)z * X * Y + (size_t)y * X + x;
-        if (occupied_brick_mask) {
-          size_t b = ((size_t)(z / p->bv[2]) * p->res_bricks[1] + (size_t)(y / p->bv[1])) * p->res_bricks[0] + (size_t)(x / p->bv[0]);
-          if (!occupied_brick_mask[b]) {
-            tsdf[o] = -limit;
-            continue;
-          }
+        if (voxel_mask && !voxel_mask[o - (size_t)z0 * X * Y]) { /* not drawn: keeps the clear value */
+          tsdf[o] = -limit;
+          continue;
         }
         /* framework/rendering/volume_sampler.cpp:36-42 */
         const float pos[3] = {((float)x + 0.5f) * stepX, ((float)y + 0.5f) * stepY, ((float)z + 0.5f) * stepZ};

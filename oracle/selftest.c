@@ -87,7 +87,7 @@ int main(void)
   float* q = malloc(sizeof(float) * W * H);
   orc_quality(db, nrm, xyz, res, cam, W, H, q);
   printf("quality %.6f cam %.4f %.4f %.4f\n", checksum(q, W * H), cam[0], cam[1], cam[2]);
-  orc_integrate_params ip = {N, W, H, {G, G, G}, 0.01f, {8, 8, 8}, {2, 2, 2}};
+  orc_integrate_params ip = {N, W, H, {G, G, G}, 0.01f};
   const float* invs[N] = {inv, inv};
   const int inv_res[6] = {G, G, G, G, G, G};
   const float* sils[N] = {sil, sil};
@@ -95,7 +95,25 @@ int main(void)
   const float* qs[N] = {q, q};
   uint8_t mask[8] = {1, 0, 1, 1, 0, 1, 1, 1};
   float* tsdf = malloc(sizeof(float) * G * G * G);
-  orc_integrate(&ip, invs, inv_res, sils, dbs, qs, mask, 0, G, tsdf);
+  /* brick mode: the voxels divideBox + containedVoxels list for the occupied bricks (a box whose last
+   * bricks reach one index past the x and y ends: the aliasing / out-of-buffer paths run too) */
+  uint8_t* vmask = (uint8_t*)malloc((size_t)G * G * G);
+  int vrb[3];
+  const float vbmin[3] = {-1, 0, -1}, vbmax[3] = {1, 2, 1};
+  orc_brick_voxel_mask(vbmin, vbmax, 1.0f, (int[3]){G, G, G}, mask, 0, G, vmask, vrb);
+  orc_integrate(&ip, invs, inv_res, sils, dbs, qs, vmask, 0, G, tsdf);
+  {
+    const float omin[3] = {-1.0f, 0.0f, -1.0f}, omax[3] = {1.4f, 2.4f, 1.0f};
+    int od[3] = {121, 121, 100}, orb[3];
+    uint8_t* occ = (uint8_t*)malloc(24 * 25 * 20);
+    uint8_t* om = (uint8_t*)malloc((size_t)121 * 121 * 100);
+    memset(occ, 1, 24 * 25 * 20);
+    size_t outside = orc_brick_voxel_mask(omin, omax, 0.02f * roundf(0.1f / 0.02f), od, occ, 0, 100, om, orb);
+    printf("overflow box: bricks %d %d %d, %zu index triples outside\n", orb[0], orb[1], orb[2], outside);
+    free(occ);
+    free(om);
+  }
+  free(vmask);
   printf("integrate %.6f\n", checksum(tsdf, G * G * G));
   uint32_t ids[512];
   float ratio;

@@ -138,6 +138,7 @@ SYMBOLS = {
     "rgbdr_status_string": (C.c_char_p, [C.c_int]),
     "rgbdr_version": (C.c_char_p, []),
     "rgbdr_compute_geometry": (C.c_int, [_CFG, _GEO]),
+    "rgbdr_brick_voxel_range": (C.c_int, [_CFG, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rgbdr_slab_range": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_camera_position": (C.c_int, [_LUT, _F]),
     "rgbdr_set_calibration": (C.c_int, [_P, C.c_int, _LUT, _LUT]),
@@ -151,6 +152,7 @@ SYMBOLS = {
     "rgbdr_clear_occupied_bricks": (C.c_int, [_P]),
     "rgbdr_process_textures": (C.c_int, [_P]),
     "rgbdr_update_occupied_bricks": (C.c_int, [_P]),
+    "rgbdr_set_occupied_bricks": (C.c_int, [_P, _U32, C.c_size_t]),
     "rgbdr_integrate": (C.c_int, [_P]),
     "rgbdr_step": (C.c_int, [_P, _P, _P]),
     "rgbdr_sync": (C.c_int, [_P]),
@@ -277,6 +279,15 @@ def compute_geometry(cfg):
     return g
 
 
+def brick_voxel_range(cfg, axis, brick):
+    """(first, last) voxel index of `brick` on `axis` as the reference's containedVoxels builds it"""
+    a, b = C.c_int32(), C.c_int32()
+    rc = lib().rgbdr_brick_voxel_range(C.byref(cfg), axis, brick, C.byref(a), C.byref(b))
+    if rc != OK:
+        raise RgbdrError(rc, lib().rgbdr_last_error(None).decode())
+    return a.value, b.value
+
+
 class Context:
     """Thin RAII wrapper; method names follow the reference's
     (NetKinectArray::update/processTextures, ReconIntegration::integrate ...)."""
@@ -368,6 +379,10 @@ class Context:
 
     def update_occupied_bricks(self):
         self._chk(lib().rgbdr_update_occupied_bricks(self._h))
+
+    def set_occupied_bricks(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        self._chk(lib().rgbdr_set_occupied_bricks(self._h, a.ctypes.data_as(_U32), a.size))
 
     def integrate(self):
         self._chk(lib().rgbdr_integrate(self._h))

@@ -113,6 +113,10 @@ struct rgbdr_ctx {
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool mask_valid = false;
+  // brick -> voxel membership of divideBox / containedVoxels (geometry.cpp compute_brick_tables):
+  // device copy of vox[x] | vox[y] | vox[z] | tile[x] | tile[y] | tile[z]
+  BrickTables bt;
+  uint32_t* d_brick_tab = nullptr;
 
   bool timers = false, accumulate = false;
   int timer_detail = 2;  // 1: only "1preprocess" / "2integrate" / "bricks" ...; 2: also the five pre_* passes
@@ -217,6 +221,8 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
   (void)hipFree(c->d_mask);
+  (void)hipFree(c->d_brick_tab);
+  c->d_brick_tab = nullptr;
   (void)hipFree(c->d_lut_tiled_base);
   c->d_lut_tiled_base = nullptr;
   (void)hipFree(c->d_win);
@@ -231,6 +237,45 @@ static void free_volume(rgbdr_ctx* c)
     c->d_lut_generic[i] = nullptr;
     c->inv_set[i] = c->inv_tiled[i] = c->inv_resampled[i] = false;
   }
+}
+
+// brick table of `g`: counters, id list, two occupied masks and the membership tables.  The new
+// buffers are allocated before the old ones are released, so a failure leaves the context as it was.
+static int alloc_brick_table(rgbdr_ctx* ctx, const rgbdr_config& cfg, const rgbdr_geometry& g)
+{
+  BrickTables bt;
+  std::string e;
+  int rc = compute_brick_tables(cfg, g, &bt, &e);
+  if (rc != RGBDR_OK) return ctx->fail(rc, e);
+  std::vector<uint32_t> host;
+  for (int a = 0; a < 3; ++a) host.insert(host.end(), bt.vox[a].begin(), bt.vox[a].end());
+  for (int a = 0; a < 3; ++a) host.insert(host.end(), bt.tile[a].begin(), bt.tile[a].end());
+  uint32_t *counters = nullptr, *ids = nullptr, *tab = nullptr;
+  uint8_t* mask = nullptr;
+  const size_t nb = (size_t)g.num_bricks;
+  if (hipMalloc((void**)&counters, nb * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&ids, nb * sizeof(uint32_t)) != hipSuccess ||
+      hipMalloc((void**)&mask, nb * 2) != hipSuccess || hipMalloc((void**)&tab, host.size() * sizeof(uint32_t)) != hipSuccess ||
+      hipMemcpy(tab, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemsetAsync(counters, 0, nb * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+      hipMemsetAsync(mask, 0, nb * 2, ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(counters);
+    (void)hipFree(ids);
+    (void)hipFree(mask);
+    (void)hipFree(tab);
+    return ctx->fail(RGBDR_ERR_HIP, "allocation of the brick table failed");
+  }
+  (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_ids);
+  (void)hipFree(ctx->d_mask);
+  (void)hipFree(ctx->d_brick_tab);
+  ctx->d_counters = counters;
+  ctx->d_ids = ids;
+  ctx->d_mask = mask;
+  ctx->d_brick_tab = tab;
+  ctx->bt = std::move(bt);
+  ctx->mask_valid = false;
+  return RGBDR_OK;
 }
 
 // setVoxelSize / setBrickSize: (re)allocate TSDF slab + brick table
@@ -254,13 +299,7 @@ static int alloc_volume(rgbdr_ctx* ctx)
   HIPCHK(hipMalloc((void**)&ctx->d_tile_state, (size_t)g.tiles[0] * g.tiles[1] * owned * sizeof(uint32_t)));
   HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, (size_t)g.tiles[0] * g.tiles[1] * owned * sizeof(uint32_t), ctx->stream));
   ctx->clear_epoch = 1;
-  HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
-  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks * 2, ctx->stream));
-  ctx->mask_valid = false;
-  return RGBDR_OK;
+  return alloc_brick_table(ctx, ctx->cfg, g);
 }
 
 // drain both streams (readbacks, setters, resizes)
@@ -296,6 +335,21 @@ int rgbdr_compute_geometry(const rgbdr_config* cfg, rgbdr_geometry* out)
 {
   if (!cfg || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   return compute_geometry(*cfg, out, &g_create_error);
+}
+
+int rgbdr_brick_voxel_range(const rgbdr_config* cfg, int axis, int brick, int32_t* first, int32_t* last)
+{
+  if (!cfg || !first || !last || axis < 0 || axis > 2) return RGBDR_ERR_INVALID_ARGUMENT;
+  rgbdr_geometry g;
+  int rc = compute_geometry(*cfg, &g, &g_create_error);
+  if (rc != RGBDR_OK) return rc;
+  BrickTables bt;
+  rc = compute_brick_tables(*cfg, g, &bt, &g_create_error);
+  if (rc != RGBDR_OK) return rc;
+  if (brick < 0 || brick >= (int)bt.first[axis].size()) return RGBDR_ERR_OUT_OF_RANGE;
+  *first = bt.first[axis][brick];
+  *last = bt.last[axis][brick];
+  return RGBDR_OK;
 }
 
 int rgbdr_slab_range(int tiles_z, int count, int rank, int* t0, int* t1)
@@ -1032,6 +1086,22 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
   return RGBDR_OK;
 }
 
+int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ids && count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null id list");
+  const size_t nb = (size_t)ctx->geo.num_bricks;
+  std::vector<uint8_t> mask(nb, 0);
+  for (size_t i = 0; i < count; ++i) {
+    if (ids[i] >= nb) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "brick id out of range");
+    mask[ids[i]] = 1;
+  }
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  HIPCHK(hipMemcpy(ctx->mask_buf(ctx->rbuf), mask.data(), nb, hipMemcpyHostToDevice));
+  ctx->mask_valid = true;
+  return RGBDR_OK;
+}
+
 int rgbdr_integrate(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
@@ -1079,9 +1149,14 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.win = ctx->d_win;
   p.use_bricks = bricks ? 1 : 0;
   p.brick_mask = ctx->mask_buf(ctx->rbuf);
-  p.bvx = g.brick_voxels_axis[0];
-  p.bvy = g.brick_voxels_axis[1];
-  p.bvz = g.brick_voxels_axis[2];
+  p.vbx = ctx->d_brick_tab;
+  p.vby = p.vbx + g.res_volume[0];
+  p.vbz = p.vby + g.res_volume[1];
+  p.tbx = p.vbz + g.res_volume[2];
+  p.tby = p.tbx + g.tiles[0];
+  p.tbz = p.tby + g.tiles[1];
+  p.ovx = ctx->bt.overflow[0];
+  p.ovy = ctx->bt.overflow[1];
   p.bx = g.res_bricks[0];
   p.by = g.res_bricks[1];
   p.bz = g.res_bricks[2];
@@ -1181,21 +1256,12 @@ int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
   std::string e;
   int rc = compute_geometry(trial, &g, &e);
   if (rc != RGBDR_OK) return ctx->fail(rc, e);
+  // only the brick table changes; the volume and the LUTs stay
+  rc = alloc_brick_table(ctx, trial, g);
+  if (rc != RGBDR_OK) return rc;  // the old table is still in place
   ctx->cfg = trial;
   ctx->geo = g;
-  // only the brick table changes; the volume and the LUTs stay
-  (void)hipFree(ctx->d_counters);
-  (void)hipFree(ctx->d_ids);
-  (void)hipFree(ctx->d_mask);
-  ctx->d_counters = ctx->d_ids = nullptr;
-  ctx->d_mask = nullptr;
-  HIPCHK(hipMalloc((void**)&ctx->d_counters, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_ids, (size_t)g.num_bricks * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void**)&ctx->d_mask, (size_t)g.num_bricks * 2));
-  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)g.num_bricks * sizeof(uint32_t), ctx->stream));
-  HIPCHK(hipMemsetAsync(ctx->d_mask, 0, (size_t)g.num_bricks * 2, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->mask_valid = false;
   return RGBDR_OK;
 }
 

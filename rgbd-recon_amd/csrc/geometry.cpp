@@ -55,8 +55,11 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
       g->brick_voxels_axis[a] = r < 1.0f ? 1 : (int)r;
     }
   }
-  // divideBox: count bricks per axis with the reference's accumulating loop; a
-  // rounding residue can add a sliver brick, never lose one that holds voxels
+  // divideBox: bricks per axis from the reference's float-accumulating loop alone
+  // (recon_integration.cpp:366-388) -- m_res_bricks, the divisor of occupiedRatio and the
+  // clamp of mark_brick.  Voxels past the last brick belong to no brick (they stay -limit
+  // in the brick-skipping sweep, as in the reference); which voxels a brick holds is
+  // compute_brick_tables() below.
   for (int a = 0; a < 3; ++a) {
     const float mn = cfg.bbox_min[a];
     const float size = cfg.bbox_max[a] - mn;
@@ -65,10 +68,9 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
     while (size - start + mn > 0.0f) {
       start += g->brick_size;
       ++n;
-      if (n > (1 << 20)) return fail("brick grid too fine");
+      if (n > 65535) return fail("brick grid too fine");
     }
-    const int need = (g->res_volume[a] + g->brick_voxels_axis[a] - 1) / g->brick_voxels_axis[a];
-    g->res_bricks[a] = n > need ? n : need;
+    g->res_bricks[a] = n;
   }
   const long long nb = (long long)g->res_bricks[0] * g->res_bricks[1] * g->res_bricks[2];
   if (nb > (1ll << 30)) return fail("too many bricks");
@@ -88,6 +90,91 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
     const int rows = (int)std::ceil(cfg.tsdf_limit * (float)g->res_volume[2]) + 2;
     g->halo_tile_layers = rows <= kTile ? 1 : (rows + kTile - 1) / kTile;
     if (g->slab_tile_z1 - g->slab_tile_z0 < g->halo_tile_layers) return fail("slab thinner than its halo");
+  }
+  return RGBDR_OK;
+}
+
+// Which voxels a brick holds, exactly as divideBox + VolumeSampler::containedVoxels build the
+// per-brick index lists (recon_integration.cpp:366-375, volume_sampler.cpp:50-62): per axis,
+//   pos_n = (start - min) / size, size_n = min(brick_size, size - start + min) / size, step = 1 / res,
+//   for (unsigned v = pos_n / step; v < (pos_n + size_n) / step; ++v)
+// in binary32, `start` accumulated by += brick_size.  The float -> unsigned truncation and the
+// float upper bound make neighbouring bricks share a voxel row wherever the quotients round up
+// (at the reference's default 200 x 221 x 200 grid with 0.1 m bricks almost every brick also holds
+// the first row of the next one), and the last brick can reach one index past the axis end.
+int compute_brick_tables(const rgbdr_config& cfg, const rgbdr_geometry& g, BrickTables* t, std::string* err)
+{
+  for (int a = 0; a < 3; ++a) {
+    const int res = g.res_volume[a];
+    const float mn = cfg.bbox_min[a];
+    const float size = cfg.bbox_max[a] - mn;
+    const float step = 1.0f / (float)res;
+    float start = mn;
+    t->first[a].clear();
+    t->last[a].clear();
+    while (size - start + mn > 0.0f) {
+      const float rest = size - start + mn;
+      const float bsz = g.brick_size < rest ? g.brick_size : rest;  // glm::min(fvec3{m_brick_size}, size - start + min)
+      const float pos_n = (start - mn) / size;
+      const float size_n = bsz / size;
+      const unsigned lo = (unsigned)(pos_n / step);
+      const float bound = (pos_n + size_n) / step;
+      long long hi = (long long)lo - 1;
+      for (unsigned v = lo; (float)v < bound; ++v) {
+        hi = v;
+        if (v > lo + (1u << 22)) break;
+      }
+      t->first[a].push_back((int32_t)lo);
+      t->last[a].push_back((int32_t)hi);
+      start += g.brick_size;
+      if ((int)t->first[a].size() > 65535) {
+        if (err) *err = "brick grid too fine";
+        return RGBDR_ERR_INVALID_ARGUMENT;
+      }
+    }
+    const int nb = (int)t->first[a].size();
+    t->vox[a].assign((size_t)res, 0x0000ffffu);  // lo = 0xffff, hi = 0: no brick
+    t->overflow[a] = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int lo = t->first[a][b], hi = t->last[a][b];
+      if (hi >= res) {
+        // indices past the axis end alias other voxels through the linear index
+        // z*X*Y + y*X + x (integrate kernel: voxel_occupied); only the last brick can do that
+        if (b != nb - 1) {
+          if (err) *err = "a brick other than the last one reaches past the volume";
+          return RGBDR_ERR_INVALID_ARGUMENT;
+        }
+        t->overflow[a] = hi - (res - 1);
+      }
+      for (int v = lo; v <= hi && v < res; ++v) {
+        uint32_t e = t->vox[a][v];
+        uint32_t l = e & 0xffffu, h = e >> 16;
+        if (l > h) {  // first brick holding v
+          l = (uint32_t)b;
+          h = (uint32_t)b;
+        } else {
+          if ((uint32_t)b < l) l = (uint32_t)b;
+          if ((uint32_t)b > h) h = (uint32_t)b;
+        }
+        t->vox[a][v] = l | (h << 16);
+      }
+    }
+    const int ntile = (res + kTile - 1) / kTile;
+    t->tile[a].assign((size_t)ntile, 0x0000ffffu);
+    for (int v = 0; v < res; ++v) {
+      const uint32_t e = t->vox[a][v];
+      if ((e & 0xffffu) > (e >> 16)) continue;
+      uint32_t& d = t->tile[a][v / kTile];
+      uint32_t l = d & 0xffffu, h = d >> 16;
+      if (l > h) {
+        l = e & 0xffffu;
+        h = e >> 16;
+      } else {
+        if ((e & 0xffffu) < l) l = e & 0xffffu;
+        if ((e >> 16) > h) h = e >> 16;
+      }
+      d = l | (h << 16);
+    }
   }
   return RGBDR_OK;
 }

@@ -117,11 +117,41 @@ __device__ __forceinline__ void fold_voxel_window(const uint2* win, int wx0, int
   fold_taps(p00, p10, p01, p11, ax, ay, pcz, limit, tsd, wsum);
 }
 
+// Any occupied brick among those that hold the index triple (xs, ys, zs) of
+// VolumeSampler::containedVoxels (volume_sampler.cpp:53-55).  Membership is separable per
+// axis (BrickTables, geometry.cpp); an index past the x / y end lies in the last brick there.
+__device__ __forceinline__ bool bricks_any(const IntegrateParams& p, int xs, int ys, int zs)
+{
+  const uint32_t ex = xs < p.X ? p.vbx[xs] : (uint32_t)(p.bx - 1) * 0x10001u;
+  const uint32_t ey = ys < p.Y ? p.vby[ys] : (uint32_t)(p.by - 1) * 0x10001u;
+  const uint32_t ez = p.vbz[zs];
+  bool any = false;
+  for (uint32_t bz = ez & 0xffffu; bz <= (ez >> 16); ++bz)
+    for (uint32_t by = ey & 0xffffu; by <= (ey >> 16); ++by)
+      for (uint32_t bx = ex & 0xffffu; bx <= (ex >> 16); ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+  return any;
+}
+
+// Is voxel (vx, vy, vz) in the index list of an occupied brick (recon_integration.cpp:255-259)?
+// The lists hold linear indices z*X*Y + y*X + x (volume_sampler.cpp:57); where the last brick of
+// the x or y axis reaches `ovx` / `ovy` indices past the axis end, those indices alias voxels of
+// the next row / slice, so up to four index triples produce this voxel's linear index.  Indices
+// past the z end leave the vertex buffer and are dropped.
 __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx, int vy, int vz)
 {
-  const int bx = vx / p.bvx, by = vy / p.bvy, bz = vz / p.bvz;
-  if (bx >= p.bx || by >= p.by || bz >= p.bz) return false;
-  return p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+  if (vx >= p.X || vy >= p.Y || vz >= p.Z) return false;  // padding voxel of a partial tile
+  bool any = bricks_any(p, vx, vy, vz);
+  if (__builtin_expect((p.ovx | p.ovy) != 0, 0)) {
+    for (int kx = 0; kx < 2; ++kx) {
+      if (kx == 1 && vx >= p.ovx) break;
+      const int m = vz * p.Y + vy - kx;  // ys + zs * Y of the source triple
+      if (m < 0) continue;
+      const int zs = m / p.Y, ys = m - zs * p.Y;
+      if (kx == 1) any |= bricks_any(p, vx + p.X, ys, zs);
+      if (ys < p.ovy && zs >= 1) any |= bricks_any(p, vx + kx * p.X, ys + p.Y, zs - 1);
+    }
+  }
+  return any;
 }
 
 // ---------------------------------------------------------------------------
@@ -294,14 +324,17 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
   const unsigned tile = blockIdx.x * kClearTiles + threadIdx.x;
   if (tile < ntiles) {
     const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, tz = p.tz0 + tile / (p.TX * p.TY);
-    // bricks overlapped by the tile's 8^3 voxel positions (voxel_occupied's predicate per brick)
-    const int bx0 = (tx * kTile) / p.bvx, bx1 = min((tx * kTile + kTile - 1) / p.bvx, p.bx - 1);
-    const int by0 = (ty * kTile) / p.bvy, by1 = min((ty * kTile + kTile - 1) / p.bvy, p.by - 1);
-    const int bz0 = (tz * kTile) / p.bvz, bz1 = min((tz * kTile + kTile - 1) / p.bvz, p.bz - 1);
+    // bricks that hold any of the tile's voxels (union of the per-coordinate brick ranges); a superset
+    // of the tiles with an occupied voxel is enough here -- integrate_tile decides per voxel
+    // (BrickTables::tile: the same lo | hi << 16 ranges per storage tile, built on the host)
+    const uint32_t ex = p.tbx[tx], ey = p.tby[ty], ez = p.tbz[tz];
+    const uint32_t lo[3] = {ex & 0xffffu, ey & 0xffffu, ez & 0xffffu}, hi[3] = {ex >> 16, ey >> 16, ez >> 16};
     bool any = false;
-    for (int bz = bz0; bz <= bz1; ++bz)
-      for (int by = by0; by <= by1; ++by)
-        for (int bx = bx0; bx <= bx1; ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+    for (uint32_t bz = lo[2]; bz <= hi[2]; ++bz)
+      for (uint32_t by = lo[1]; by <= hi[1]; ++by)
+        for (uint32_t bx = lo[0]; bx <= hi[0]; ++bx) any |= p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+    // voxels that indices past the x / y end of the last brick alias (voxel_occupied): x < ovx or y < ovy
+    any |= (p.ovx && tx * kTile < p.ovx) || (p.ovy && ty * kTile < p.ovy);
     if (any) {
       p.tile_list[atomicAdd(p.tile_count, 1u)] = tile;
       p.tile_state[tile] = 0u;  // about to hold integrated values

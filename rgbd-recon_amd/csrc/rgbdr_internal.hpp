@@ -17,6 +17,17 @@ constexpr int kMaxSensors = RGBDR_MAX_SENSORS;
 // ---- host-only geometry (geometry.cpp) -------------------------------------
 int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err);
 int slab_range(int tiles_z, int count, int rank, int* t0, int* t1);
+// Brick -> voxel membership of divideBox + VolumeSampler::containedVoxels, per axis (it is
+// separable): brick b holds voxel indices [first[a][b], last[a][b]]; vox[a][v] = lo | hi << 16 is
+// the range of bricks holding coordinate v (lo > hi: none); overflow[a] = how far the last
+// brick reaches past res - 1 (the reference then aliases other voxels through the linear index).
+struct BrickTables {
+  std::vector<int32_t> first[3], last[3];
+  std::vector<uint32_t> vox[3];
+  std::vector<uint32_t> tile[3];  // the union of vox[a] over the 8 coordinates of a storage tile, same packing
+  int overflow[3] = {0, 0, 0};
+};
+int compute_brick_tables(const rgbdr_config& cfg, const rgbdr_geometry& g, BrickTables* t, std::string* err);
 void camera_position(const float* cv_xyz, const uint32_t res[3], float out[3]);
 // Frustum::getPlanes of the 8 corner samples of cv_xyz (frustum.cpp:113-177)
 void frustum_planes(const float* cv_xyz, const uint32_t res[3], float planes[6][4]);
@@ -75,8 +86,15 @@ struct IntegrateParams {
   // bricks
   int use_bricks;
   const uint8_t* brick_mask;
-  int bvx, bvy, bvz;       // voxels per brick edge, per axis
-  int bx, by, bz;
+  int bx, by, bz;          // m_res_bricks
+  // per voxel coordinate the range of bricks holding it (BrickTables::vox), on the device
+  const uint32_t* vbx;
+  const uint32_t* vby;
+  const uint32_t* vbz;
+  const uint32_t* tbx;     // the same per storage tile (BrickTables::tile)
+  const uint32_t* tby;
+  const uint32_t* tbz;
+  int ovx, ovy;            // BrickTables::overflow of x and y (indices past the z end leave the VBO: dropped)
   float* tsdf;             // first owned tile layer
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
   unsigned* tile_list;     // brick-skipping sweep: owned tiles that overlap an occupied brick ...

@@ -73,9 +73,7 @@ def test_geometry_matches_oracle(pkg, orc, bmax, voxel, brick):
     bs = orc.adjust_brick_size(brick, voxel)
     assert g.brick_size == np.float32(bs)
     assert g.brick_voxels == int(round(brick / voxel))
-    ref_rb = orc.divide_box(bmin, bmax, bs)
-    need = tuple(-(-r // g.brick_voxels) for r in g.res_volume)
-    assert tuple(g.res_bricks) == tuple(max(a, b) for a, b in zip(ref_rb, need))
+    assert tuple(g.res_bricks) == orc.divide_box(bmin, bmax, bs)       # m_res_bricks: the divideBox loops alone
     assert g.num_bricks == g.res_bricks[0] * g.res_bricks[1] * g.res_bricks[2]
     assert tuple(g.tiles) == tuple(-(-r // 8) for r in g.res_volume)
     assert (g.slab_tile_z0, g.slab_tile_z1) == (0, g.tiles[2])

@@ -46,7 +46,8 @@ def _worker(rank, world, port, tmp):
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), None, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
     vol = orc.integrate(inv, ref["sil"], ref["depth_b"], ref["quality"], (G, G, G), 0.01, ref["mask"],
-                        g.brick_voxels, tuple(g.res_bricks), z_range=(g.slab_voxel_z0, g.slab_voxel_z1))
+                        res_bricks=tuple(g.res_bricks), z_range=(g.slab_voxel_z0, g.slab_voxel_z1),
+                        bbox=(synth.BBOX_MIN, synth.BBOX_MAX), brick_size=g.brick_size)
     own = tile_layers(vol, g.slab_tile_z0, g.slab_tile_z1)
     layer = own.shape[1]
     slab = torch.full((own.shape[0] + 2, layer), float("nan"))       # [halo_lo | owned | halo_hi]

@@ -210,7 +210,8 @@ def test_bricks_mask_restricts_integration(orc):
     full = orc.integrate([inv], [sil], [db], [q], (G, G, G), LIMIT)
     mask = np.zeros(8, np.uint8)
     mask[3] = 1                           # brick (1,1,0)
-    part = orc.integrate([inv], [sil], [db], [q], (G, G, G), LIMIT, mask, bv, (2, 2, 2))
+    part = orc.integrate([inv], [sil], [db], [q], (G, G, G), LIMIT, mask, res_bricks=(2, 2, 2),
+                         bbox=((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), brick_size=0.5)
     assert np.array_equal(part[0:8, 8:16, 8:16], full[0:8, 8:16, 8:16])
     part[0:8, 8:16, 8:16] = -LIMIT
     assert np.all(part == np.float32(-LIMIT))

@@ -124,12 +124,72 @@ def test_reference_default_grid(pkg, orc):
         ctx.set_calibration(i, scene.xyz[i], (16, 13, 16), scene.uv[i], (16, 13, 16), (0.5, 4.5))
         ctx.set_inverse_calibration(i, inv[i], inv_res)
     ctx.step(scene.depth, scene.color)
+    assert tuple(g.res_bricks) == (20, 22, 20)           # divideBox: 22 bricks on y, not ceil(221 / 10)
     ref = orc.run_pipeline(scene, BMIN, bmax, tuple(g.res_volume), inv, limit=0.01, brick_size=g.brick_size,
-                           bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
+                           res_bricks=tuple(g.res_bricks))
     assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+    ids, ratio = ctx.get_occupied()
+    assert np.array_equal(ids, ref["occupied"]) and ratio == np.float32(len(ids)) / np.float32(8800)
     got = ctx.readback_tsdf()
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
     assert np.sum(np.abs(got) < 0.01) > 1000 and ref["counters"].sum() > 100
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["default", "default-generic-kernel", "overflow", "overflow-generic-kernel"])
+def test_brick_sweep_draws_the_reference_index_lists(pkg, orc, case):
+    """Brick mode against the reference's own brick -> voxel lists (divideBox + containedVoxels, run
+    literally by the oracle) for random sets of occupied bricks.  `default`: the reference's operating
+    point, where most bricks also list the first voxel row of the next brick; `overflow`: a box whose last
+    x and y bricks list one index past the axis end, which aliases voxels of the next row / slice
+    through z*X*Y + y*X + x."""
+    capi, synth = pkg.capi, pkg.synth
+    over = case.startswith("overflow")
+    bmin = (-1.0, 0.0, -1.0)
+    bmax = (1.4, 2.4, 1.0) if over else (1.0, 2.2, 1.0)
+    voxel = 0.02 if over else 0.01
+    flags = capi.FLAGS_DEFAULT | (capi.FLAG_NO_RESAMPLE if case.endswith("generic-kernel") else 0)
+    scene = synth.Scene(2, 64, 53, lut_res=(16, 13, 16))
+    ctx = capi.Context(capi.make_config(2, (64, 53), bbox_min=bmin, bbox_max=bmax, voxel_size=voxel, brick_size=0.1,
+                                        flags=flags), 0)
+    g = ctx.geo
+    res = tuple(g.res_volume)
+    assert res == ((121, 121, 100) if over else (200, 221, 200))
+    inv_res = (61, 57, 49) if over else (70, 77, 70)
+    inv = [synth.inverse_lut(s, inv_res, bmin, bmax) for s in scene.sensors]
+    for i in range(2):
+        ctx.set_calibration(i, scene.xyz[i], (16, 13, 16), scene.uv[i], (16, 13, 16), (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    ctx.step(scene.depth, scene.color)
+    ref = orc.run_pipeline(scene, bmin, bmax, res, None, brick_size=g.brick_size, res_bricks=tuple(g.res_bricks))
+    assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+    ctx.set_use_bricks(False)
+    ctx.integrate()
+    full = ctx.readback_tsdf()
+    ctx.set_use_bricks(True)
+    rng = np.random.default_rng(11)
+    bv = g.brick_voxels
+    differs_from_partition = 0
+    for density in (0.03, 0.4):
+        occ = (rng.random(g.num_bricks) < density).astype(np.uint8)
+        occ[-1] = 1                          # the corner brick: the one whose lists overflow
+        ctx.set_occupied_bricks(np.nonzero(occ)[0])
+        ctx.integrate()
+        got = ctx.readback_tsdf()
+        want = orc.integrate(inv, ref["sil"], ref["depth_b"], ref["quality"], res, 0.01, occ, res_bricks=tuple(g.res_bricks),
+                             bbox=(bmin, bmax), brick_size=g.brick_size)
+        assert same_bits(got, want), "%d voxels differ" % count_diff(got, want)
+        # the voxels drawn are the full sweep's values, everything else the clear value
+        drawn, _, outside = orc.brick_voxel_mask(bmin, bmax, g.brick_size, res, occ)
+        drawn = drawn.astype(bool)
+        assert same_bits(got[drawn], full[drawn]) and np.all(got[~drawn] == np.float32(-0.01))
+        assert (outside > 0) == over
+        # ... and NOT what an integer partition voxel // brick_voxels would draw (round 1's membership)
+        rb = g.res_bricks
+        part = np.kron(np.pad(occ.reshape(rb[2], rb[1], rb[0]), ((0, 1), (0, 1), (0, 1))), np.ones((bv,) * 3, np.uint8))
+        part = part[:res[2], :res[1], :res[0]].astype(bool)
+        differs_from_partition += int(np.sum(part != drawn))
+    assert differs_from_partition > 1000
     ctx.close()
 
 
