@@ -8,12 +8,17 @@ updateOccupiedBricks and a FULL-SWEEP integrate() of every voxel
 (source/kinect_client.cpp:572-602).  The brick-skipping mode the reference
 defaults to is timed separately and reported under "bricked".
 
-N = 1: BASELINE.json config "4 sensors, 512^3 TSDF, full pre_* chain".
+N = 1: BASELINE.json configs[2] "4 sensors, 512^3 TSDF, full pre_* chain".
 N > 1: one process per GPU, the volume is split into Z slabs of storage-tile
 layers (no data-path collective for integration; the one exchange per step is the
-one-tile-layer halo to the Z neighbours over RCCL), weak scaling: grids
-512^3 / 512x512x1024 / 512x1024x1024 / 1024^3 over the same 2 m box for 1 / 2 / 4 / 8
-GPUs, i.e. 134 M voxels per GPU (each slab is 2^27 voxels).
+halo tile layers to the Z neighbours over RCCL):
+  --gpus 2 / 4: BASELINE.json configs[3], "8 sensors, 512^3 TSDF, Z-slab split" (strong split
+                of the same volume; configs[3] names 4 GPUs, 2 is the same workload on 2);
+  --gpus 8:     BASELINE.json configs[4], "8 sensors, 1024^3 TSDF across 8 MI355X +
+                tsdf_colorfill/inpaint post-pass" (the slab ray-march + hole filling is timed
+                and reported under "post_pass", outside `value`);
+  --weak:       the weak-scaling grids instead (4 sensors; 512^3 / 512x512x1024 / 512x1024x1024 /
+                1024^3 for 1 / 2 / 4 / 8 GPUs, 134 M voxels per GPU).
 """
 import argparse
 import json
@@ -41,7 +46,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0, help="override with a cubic grid of this size")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: debugging several "
                                                       "ranks on one GPU)")
-    ap.add_argument("--sensors", type=int, default=4)
+    ap.add_argument("--sensors", type=int, default=0, help="0 = what the BASELINE config of --gpus names (4 at 1 GPU, 8 above)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak-scaling grids with 4 sensors instead of BASELINE configs[3]/[4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="RGBDR_FLAG_PIPELINE for the headline: the pre_* chain of step k+1 overlaps integrate of step k on a "
@@ -86,9 +92,26 @@ def main():
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
 
-    N = args.sensors
     W, H = 512, 424
-    grid = (args.grid,) * 3 if args.grid else GRID_FOR_GPUS.get(world, (512, 512, 512))
+    # which BASELINE.json config this run is
+    if world == 1 or loop or args.weak:
+        N = args.sensors or 4
+        grid = GRID_FOR_GPUS.get(world, (512, 512, 512))
+        baseline_config = "configs[2]: 4 sensors, 512^3 TSDF, full pre_* depth-filter chain on 1 MI355X" if world == 1 and not loop \
+            else "weak-scaling grid (not a BASELINE config)"
+        scaling = "weak"
+    elif world == 8:
+        N = args.sensors or 8
+        grid = (1024, 1024, 1024)
+        baseline_config = "configs[4]: 8 sensors, 1024^3 TSDF across 8 MI355X + tsdf_colorfill/inpaint post-pass"
+        scaling = "weak"                 # 134 M voxels per GPU, like the 512^3 of one GPU
+    else:
+        N = args.sensors or 8
+        grid = (512, 512, 512)
+        baseline_config = "configs[3]: 8 sensors, 512^3 TSDF, Z-slab split across %d MI355X with RCCL brick-halo over xGMI" % world
+        scaling = "strong"
+    if args.grid:
+        grid = (args.grid,) * 3
     if loop:
         grid = (512, 512, 2048)          # four slabs of 512^3; this process is an inner one
     slab_rank, slab_count = (1, 4) if loop else (rank, world)
@@ -131,8 +154,16 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fallback)
             if int(flag[0]) == 0:
-                transport = {"kind": "gloo (host-staged; RCCL p2p failed: %s)" % (why or "on another rank"), "group": fallback}
-                sys.stderr.write("[bench rank %d] %s\n" % (rank, transport["kind"]))
+                # a run whose halos go through host memory would measure PCIe, not xGMI: never time it
+                # (--backend gloo asks for that path explicitly, for debugging several ranks on one GPU)
+                sys.stderr.write("[bench rank %d] RCCL point-to-point failed (%s); refusing to time a host-staged "
+                                 "fallback\n" % (rank, why or "on another rank"))
+                if rank == 0:
+                    print(json.dumps({"error": "RCCL point-to-point halo exchange failed: %s" % (why or "on another rank"),
+                                      "n_gpus": world}))
+                ctx.close()
+                dist.destroy_process_group()
+                sys.exit(3)
         exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
                                         via_host=transport["kind"] != "rccl", ctx=ctx, loopback=loop)
 
@@ -174,6 +205,7 @@ def main():
         stats = {n: ctx.timer_stats(n) for n in names}
         ctx.enable_timer_accumulation(False)
         ctx.enable_timers(False)
+        ctx.set_timer_detail(2)          # the library's default again (detail 0 mutes every timer but "2integrate")
         if multi:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -201,6 +233,14 @@ def main():
     # repacked, xyz-only 1:1 LUT) + the packed 8-B frame texels read once
     bytes_launch = V_local * (4 + 12 * N) + N * W * H * 8
     achieved = bytes_launch / int_s if int_s > 0 else 0.0
+    # Box calibration, right after the timed steps: one replay of the kernel's own memory streams with no
+    # arithmetic (k_arena_probe: non-temporal 16-B loads of every LUT plane of the kept arena + the
+    # non-temporal TSDF tile stores, same block -> tile order).  MI355X boxes of the pool stream this at
+    # 5.9-6.7 TB/s depending on the box; kernel rate / replay rate says how close the kernel is to what THIS
+    # box moves, whatever its level.
+    replay_ms = ctx.settle(0.0)
+    box_stream = V_local * (4 + 12 * N) / (replay_ms * 1e-3) if replay_ms > 0 else 0.0
+    box = gpu_state()
 
     # breakdown, not part of the headline timing: the totals from a run with the three total timers,
     # the five passes from a run with every timer (their event records inflate the totals)
@@ -237,7 +277,8 @@ def main():
                   "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4)}
 
     out = {
-        "metric": "Mvoxels/s TSDF integration (4 sensors, 512^3 grid) + frames/s",
+        "metric": "Mvoxels/s TSDF integration (%d sensors, %s grid) + frames/s" % (
+            N, "%d^3" % grid[0] if grid[0] == grid[1] == grid[2] else "%dx%dx%d" % grid),
         "value": round(value, 1),
         "unit": "Mvoxels/s",
         "n_gpus": world,
@@ -246,12 +287,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "frames_per_s": round(args.steps / dt, 2),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "voxel_sensor_updates_per_s": round(V_total * N / (dt / args.steps), 1),
         "config": {"workload": "%d sensors 512x424 -> %dx%dx%d TSDF, full pre_* chain + full-sweep integrate, 1:1 "
                                "inverse LUT" % ((N,) + tuple(g.res_volume)),
+                   "baseline_config": baseline_config,
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": ("zslab%d" % world if world > 1 else "single") + (" (loopback: an inner slab of 4)" if loop else ""),
@@ -261,6 +304,9 @@ def main():
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
                      "launches_timed": int_n,
+                     "box_stream_GBps": round(box_stream / 1e9, 1), "box_stream_replay_ms": round(replay_ms, 4),
+                     "frac_of_box_stream": round(achieved / box_stream, 4) if box_stream > 0 else None,
+                     "box": box,
                      "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1]},
         "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
         "bricked": {"ms_per_step": round(dtb / bsteps * 1e3, 4),
@@ -285,6 +331,7 @@ def main():
         try:
             ctx.set_use_bricks(False)
             ctx.integrate()
+            ctx.set_timer_detail(2)
             ctx.enable_timers(True)
             view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
                                   synth.BBOX_MAX)
@@ -395,11 +442,58 @@ def main():
         torch.cuda.synchronize()
         out["halo"] = {"layers_per_face": int(g.halo_tile_layers), "bytes_per_face": int(halo[0].numel() * 4),
                        "transfer_ms_rank0": exchanger.last_transfer_ms()}
+    # ---- post-pass across the slabs (BASELINE configs[4]): slab ray-march (find, all-reduce MIN, shade,
+    # composite) + tsdf_inpaint / tsdf_colorfill of the composited frame; outside `value` ----
+    if world > 1:
+        try:
+            ctx.set_use_bricks(False)
+            step(False)
+            exchanger.wait()
+            barrier()
+            view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
+                                  synth.BBOX_MAX)
+            vh = transport["kind"] != "rccl"
+            rdist.raymarch_slabs(ctx, view, dev, group=transport["group"], via_host=vh)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                col, dep, _ = rdist.raymarch_slabs(ctx, view, dev, group=transport["group"], via_host=vh)
+            barrier()
+            t_march = (time.perf_counter() - t0) / 3 * 1e3
+            ctx.set_timer_detail(2)
+            ctx.enable_timers(True)
+            ctx.upload_view_frame(col.cpu().numpy(), dep.cpu().numpy())
+            ctx.fill_colors(1280, 720)
+            ctx.fill_colors(1280, 720)
+            out["post_pass"] = {"viewport": [1280, 720], "slab_raymarch_composited_ms": round(t_march, 4),
+                                "holefill_ms": round(ctx.timer_ns("holefill") * 1e-6, 4),
+                                "surface_pixels": round(float((dep < 1).float().mean()), 4)}
+            ctx.enable_timers(False)
+        except capi.RgbdrError as e:
+            out["post_pass"] = {"error": str(e)}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
     if multi:
         dist.destroy_process_group()
+
+
+def gpu_state():
+    """power / clocks of device 0 as rocm-smi reports them right after the timed steps (a box that shows
+    hundreds of watts with this process idle is shared); {} when rocm-smi is unavailable"""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=30)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if "power" in kl or kl.startswith("sclk") or kl.startswith("mclk") or kl.startswith("fclk") or "performance" in kl:
+                keep[k] = v
+        return keep
+    except Exception as e:  # noqa: BLE001 -- diagnostic only
+        return {"unavailable": type(e).__name__}
 
 
 def available_cpus():

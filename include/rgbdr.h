@@ -127,7 +127,9 @@ typedef enum {
   RGBDR_IMG_DEPTH_B_RG = 4,  /* m_textures_depth_b (2) */
   RGBDR_IMG_SILHOUETTE = 5,  /* m_textures_silhouette (1) */
   RGBDR_IMG_NORMAL = 6,      /* m_textures_normal (3) */
-  RGBDR_IMG_QUALITY = 7      /* m_textures_quality (1) */
+  RGBDR_IMG_QUALITY = 7,     /* m_textures_quality (1) */
+  RGBDR_IMG_COLOR = 8        /* m_colorArray as sampled: RGB8 (3 x u8), decoded when the frames are DXT; only through
+                                rgbdr_device_image (rgbdr_readback_color returns it to the host) */
 } rgbdr_image;
 
 /* Pinhole description for the device-side synthetic inverse-LUT generator
@@ -283,6 +285,22 @@ typedef struct {
   int32_t halo_layers;    /* rgbdr_geometry.halo_tile_layers on each side */
 } rgbdr_tsdf_device_view;
 int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
+/* Zero-copy access to the per-sensor images for consumers that stay on the device -- what the other
+ * Reconstructions of the reference sample from texture units 1-7 (ReconTrigrid:
+ * framework/reconstruction/recon_trigrid.cpp:30-33 binds depth_b / quality / normals / colour; SURVEY.md
+ * A.4).  `ptr` is the dense row-major image of `sensor` ([height][width][channels], f32, or u8 for
+ * RGBDR_IMG_COLOR) inside the context's allocation: the same memory rgbdr_readback_image copies from,
+ * valid until the context is destroyed, rewritten by every rgbdr_process_textures (colour / raw depth:
+ * by every upload).  The passes that write it run on `stream` (hipStream_t: the context's stream, or its
+ * internal second stream under RGBDR_FLAG_PIPELINE): order a consumer after them with an event recorded
+ * on that stream, or call rgbdr_sync. */
+typedef struct {
+  void* ptr;
+  int32_t width, height, channels;
+  int32_t element_bytes;  /* 4 (f32) or 1 (u8) */
+  void* stream;
+} rgbdr_image_device_view;
+int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device_view* out);
 /* Halo staging for Z slabs.  The boundary tile layers a slab sends to its neighbours are the
  * ones the next integrate overwrites, and at 1024^3 / 8 GPUs a face is 64 MiB -- a transfer as
  * long as a frame.  rgbdr_halo_staging returns two device buffers (lower face, upper face:

@@ -23,6 +23,7 @@ FLAG_NO_RESAMPLE = 32
 FLAG_ELIDE_STORES = 64
 
 IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
+IMG_COLOR = 8
 IMG_CHANNELS = {IMG_DEPTH_RAW: 1, IMG_DEPTH_MORPH: 1, IMG_DEPTH_RG: 2, IMG_LAB: 3, IMG_DEPTH_B_RG: 2,
                 IMG_SILHOUETTE: 1, IMG_NORMAL: 3, IMG_QUALITY: 1}
 
@@ -127,6 +128,11 @@ class TsdfDeviceView(C.Structure):
                 ("owned_layers", C.c_int32), ("halo_layers", C.c_int32)]
 
 
+class ImageDeviceView(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("element_bytes", C.c_int32), ("stream", C.c_void_p)]
+
+
 # every symbol include/rgbdr.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _CFG, _GEO, _LUT = C.POINTER(Config), C.POINTER(Geometry), C.POINTER(Lut)
@@ -179,6 +185,7 @@ SYMBOLS = {
     "rgbdr_get_occupied": (C.c_int, [_P, _U32, C.c_size_t, C.POINTER(C.c_size_t), _F]),
     "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "rgbdr_device_image": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(ImageDeviceView)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -546,6 +553,11 @@ class Context:
         h, w = depth.shape
         assert color.shape == (h, w, 4)
         self._chk(lib().rgbdr_upload_view_frame(self._h, w, h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
+
+    def device_image(self, which, sensor):
+        v = ImageDeviceView()
+        self._chk(lib().rgbdr_device_image(self._h, which, sensor, C.byref(v)))
+        return v
 
     def device_tsdf(self):
         v = TsdfDeviceView()

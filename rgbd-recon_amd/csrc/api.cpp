@@ -142,6 +142,26 @@ struct rgbdr_ctx {
     if (e_ != hipSuccess) return ctx->fail(RGBDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// device scratch that is released on every return path (HIPCHK / LAUNCHCHK return early)
+struct DevScratch {
+  void* p = nullptr;
+  ~DevScratch() { (void)hipFree(p); }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+// Whatever writes the volume without keeping tile_state (full sweep, generic-LUT sweep, stream
+// replay) or changes -limit invalidates every recorded "this tile already holds -limit".
+static int bump_clear_epoch(rgbdr_ctx* ctx)
+{
+  if (++ctx->clear_epoch == 0) {  // wrapped: forget every recorded clear
+    const rgbdr_geometry& g = ctx->geo;
+    const size_t n = (size_t)g.tiles[0] * g.tiles[1] * (size_t)(g.slab_tile_z1 - g.slab_tile_z0);
+    if (ctx->d_tile_state) HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, n * sizeof(uint32_t), ctx->stream));
+    ctx->clear_epoch = 1;
+  }
+  return RGBDR_OK;
+}
+
 static int nsens(const rgbdr_ctx* c) { return c->cfg.num_sensors; }
 // bytes of one sensor's colour frame as the caller hands it over (NetKinectArray.cpp:120-131)
 static size_t color_frame_bytes(const rgbdr_config& c)
@@ -525,16 +545,16 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, cons
   (void)hipFree(ctx->d_cv_uv[sensor]);
   ctx->d_cv_xyz[sensor] = nullptr;
   ctx->d_cv_uv[sensor] = nullptr;
-  float* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, nx * 12));
+  ctx->have_calib[sensor] = false;
+  DevScratch tmp;
+  HIPCHK(hipMalloc(&tmp.p, nx * 12));
   HIPCHK(hipMalloc((void**)&ctx->d_cv_xyz[sensor], nx * 16));
   HIPCHK(hipMalloc((void**)&ctx->d_cv_uv[sensor], nu * 8));
-  HIPCHK(hipMemcpyAsync(tmp, xyz->data, nx * 12, hipMemcpyHostToDevice, ctx->stream));
-  launch_repack_xyz(tmp, ctx->d_cv_xyz[sensor], nx, ctx->stream);
+  HIPCHK(hipMemcpyAsync(tmp.p, xyz->data, nx * 12, hipMemcpyHostToDevice, ctx->stream));
+  launch_repack_xyz(tmp.as<float>(), ctx->d_cv_xyz[sensor], nx, ctx->stream);
   LAUNCHCHK("repack_xyz");
   HIPCHK(hipMemcpyAsync(ctx->d_cv_uv[sensor], uv->data, nu * 8, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  HIPCHK(hipFree(tmp));
   for (int a = 0; a < 3; ++a) {
     ctx->xyz_res[sensor][a] = xyz->res[a];
     ctx->uv_res[sensor][a] = uv->res[a];
@@ -573,18 +593,24 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
   const size_t layer = (size_t)g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
   const size_t layers = (size_t)(g.slab_tile_z1 - g.slab_tile_z0) + 2 * (size_t)ctx->halo;
-  // Where the driver places this arena decides the sweep time of integrate (stable per
-  // allocation, up to 12 % apart): time the LUT stream on a few candidate
-  // placements and keep the fastest.  RGBDR_ARENA_TRIALS=1 takes the first one.
   const size_t bytes = layer * layers * sizeof(float);
-  int trials = 12;
+  // Where the driver places this arena shifts the sweep time of integrate by a few per cent on some
+  // boxes (stable per allocation).  OPT-IN (RGBDR_ARENA_TRIALS=n, 2..16; default 1 = take
+  // the first allocation, no probing): time the kernel's memory streams on up to n candidate
+  // placements, keep the fastest.  Candidates are held while probing (otherwise the next hipMalloc
+  // returns the same place), so this transiently needs up to n x the arena; it stops at the first
+  // candidate at the fast level, when less than arena + 4 GiB is free, or after ~1 s.
+  int trials = 1;
   if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
   if (trials > 16) trials = 16;
   if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain
   float* cand[16] = {nullptr};
-  float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too; cleared again below
+  float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too: the volume is invalidated below
   float best_ms = 0.0f;
   int best = -1, got = 0;
+  bool probed = false;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int t = 0; t < trials; ++t) {
     size_t free_b = 0, total_b = 0;
     if (t > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)4 << 30))) break;
@@ -600,23 +626,20 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
       break;
     }
     const float ms = probe_arena_ms(cand[t] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+    probed = true;
     ctx->arena_probe_ms[t] = ms;
     if (ms > 0.0f && (best < 0 || ms < best_ms)) {
       best = t;
       best_ms = ms;
     }
-    // The placements fall into a few discrete levels, and consecutive allocations tend to
-    // share one (slow zones are tens of GB long), so candidates are held until the choice
-    // is made.  Stop at the first candidate that streams at the fastest level seen on this
-    // hardware (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s).
+    // stop at the first candidate that streams at the fastest level seen on this hardware
+    // (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s)
     const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
     if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) break;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > 1.0) break;
   }
   if (best < 0) best = 0;
-  if (got > 1) {
-    HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
-    ++ctx->clear_epoch;
-  }
   ctx->arena_trials = got;
   ctx->arena_chosen = best;
   int freed = 0;
@@ -625,10 +648,8 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
       (void)hipFree(cand[t]);
       ++freed;
     }
-  // Releasing that much memory slows the device down for a moment (the kept arena measured
-  // 1.09 ms right after the frees and 1.04 ms again 0.2 s later -- the driver wipes released
-  // VRAM in the background): wait until the kept arena streams as it did when it was chosen,
-  // so that the first frames of the caller are not taken during the transient.
+  // Releasing that much memory slows the device down for a moment (the driver wipes released VRAM
+  // in the background): wait, at most 2 s, until the kept arena streams as it did when it was chosen.
   if (freed > 0 && best_ms > 0.0f) {
     for (int k = 0; k < 40; ++k) {
       const float ms = probe_arena_ms(cand[best] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
@@ -639,6 +660,11 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   }
   ctx->d_lut_tiled_base = cand[best];
   ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
+  if (probed) {  // the replay stored into the volume: clear it again, forget recorded clears, nothing is integrated
+    HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
+    { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }
+    ctx->integrated = false;
+  }
   HIPCHK(hipMalloc((void**)&ctx->d_win, ntiles * nsens(ctx) * sizeof(int32_t)));
   HIPCHK(hipMemsetAsync(ctx->d_win, 0, ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
   return RGBDR_OK;
@@ -660,29 +686,42 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
   ctx->inv_set[sensor] = false;
   ctx->inv_resampled[sensor] = false;
   for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = inv->res[a];
-  if (lut_is_one_to_one(inv->res, g.res_volume)) {
-    int rc = ensure_tiled_lut(ctx);
-    if (rc != RGBDR_OK) return rc;
+  // Every sensor of a context is resident in the same layout, so LUTs of any mix of resolutions work
+  // together: the grid layout (a 1:1 LUT re-tiled, any other resolution resampled at the voxel centres
+  // once -- the lookup of tsdf_integration.vs:31 is static between frames) unless RGBDR_FLAG_NO_RESAMPLE
+  // asks for the file layout, or the arena did not fit when the first sensor was set.
+  bool others_tiled = false, others_file = false;
+  for (int i = 0; i < nsens(ctx); ++i) {
+    if (i == sensor || !ctx->inv_set[i]) continue;
+    others_tiled = others_tiled || ctx->inv_tiled[i];
+    others_file = others_file || !ctx->inv_tiled[i];
+  }
+  bool grid_layout = !(ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE) && !others_file;
+  if (grid_layout && ensure_tiled_lut(ctx) != RGBDR_OK) {
+    (void)hipGetLastError();
+    if (others_tiled) return RGBDR_ERR_HIP;  // message set by ensure_tiled_lut; cannot happen: the arena exists already
+    grid_layout = false;                     // the arena does not fit: keep the file's volume, sample per frame
+  }
+  const size_t row = (size_t)X * Y;
+  if (grid_layout && lut_is_one_to_one(inv->res, g.res_volume)) {
     // stage whole tile layers through a bounded scratch buffer
     const int chunk_layers = 8;
-    float4* tmp = nullptr;
-    const size_t row = (size_t)X * Y;
-    HIPCHK(hipMalloc((void**)&tmp, row * kTile * chunk_layers * sizeof(float4)));
+    DevScratch tmp;
+    HIPCHK(hipMalloc(&tmp.p, row * kTile * chunk_layers * sizeof(float4)));
     const LutExtent ext = lut_extent(ctx);
     for (int tz = ext.t0; tz < ext.t1; tz += chunk_layers) {
       const int tz_end = tz + chunk_layers < ext.t1 ? tz + chunk_layers : ext.t1;
       const int vz0 = tz * kTile;
       int vz1 = tz_end * kTile;
       if (vz1 > Z) vz1 = Z;
-      HIPCHK(hipMemcpyAsync(tmp, host + row * vz0, row * (size_t)(vz1 - vz0) * sizeof(float4), hipMemcpyHostToDevice,
+      HIPCHK(hipMemcpyAsync(tmp.p, host + row * vz0, row * (size_t)(vz1 - vz0) * sizeof(float4), hipMemcpyHostToDevice,
                             ctx->stream));
       float* dst = ext.dst + (size_t)(tz - ext.t0) * g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
-      launch_tile_lut(tmp, X, Y, Z, vz0, g.tiles[0], g.tiles[1], tz, tz_end - tz, sensor, nsens(ctx), dst,
+      launch_tile_lut(tmp.as<float4>(), X, Y, Z, vz0, g.tiles[0], g.tiles[1], tz, tz_end - tz, sensor, nsens(ctx), dst,
                       ctx->stream);
       LAUNCHCHK("tile_lut");
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
-    HIPCHK(hipFree(tmp));
     launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
                         g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                         ctx->stream);
@@ -692,7 +731,6 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
     int lo, hi;
     const LutExtent ext = lut_extent(ctx);
     lut_z_range(Z, g.res_volume[2], ext.vz0, ext.vz1, &lo, &hi);
-    const size_t row = (size_t)X * Y;
     const size_t cnt = row * (size_t)(hi - lo + 1);
     HIPCHK(hipMalloc((void**)&ctx->d_lut_generic[sensor], cnt * sizeof(float4)));
     HIPCHK(hipMemcpyAsync(ctx->d_lut_generic[sensor], host + row * lo, cnt * sizeof(float4), hipMemcpyHostToDevice,
@@ -700,29 +738,19 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->zoff[sensor] = lo;
     ctx->inv_tiled[sensor] = false;
-    // Resample the LUT at the voxel centres once, into the grid layout the tiled
-    // kernel streams (the lookup is static between frames).  Falls back to the
-    // per-frame 8-tap kernel when the flag forbids it or HBM is too small.
-    if (!(ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE)) {
-      bool other_generic = false;
-      for (int i = 0; i < nsens(ctx); ++i) other_generic = other_generic || (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i]);
-      if (!other_generic && ensure_tiled_lut(ctx) == RGBDR_OK) {
-        const LutExtent ex2 = lut_extent(ctx);
-        launch_resample_lut(ctx->d_lut_generic[sensor], X, Y, Z, lo, g.res_volume[0], g.res_volume[1], g.res_volume[2],
-                            g.tiles[0], g.tiles[1], ex2.t0, ex2.t1 - ex2.t0, sensor, nsens(ctx), ex2.dst, ctx->stream);
-        LAUNCHCHK("resample_lut");
-        launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
-                            g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
-                            ctx->stream);
-        LAUNCHCHK("tile_windows");
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(ctx->d_lut_generic[sensor]);
-        ctx->d_lut_generic[sensor] = nullptr;
-        ctx->inv_tiled[sensor] = true;
-        ctx->inv_resampled[sensor] = true;
-      } else {
-        (void)hipGetLastError();  // a failed allocation is not an error here: keep the generic copy
-      }
+    if (grid_layout) {
+      launch_resample_lut(ctx->d_lut_generic[sensor], X, Y, Z, lo, g.res_volume[0], g.res_volume[1], g.res_volume[2],
+                          g.tiles[0], g.tiles[1], ext.t0, ext.t1 - ext.t0, sensor, nsens(ctx), ext.dst, ctx->stream);
+      LAUNCHCHK("resample_lut");
+      launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                          g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                          ctx->stream);
+      LAUNCHCHK("tile_windows");
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->d_lut_generic[sensor]);
+      ctx->d_lut_generic[sensor] = nullptr;
+      ctx->inv_tiled[sensor] = true;
+      ctx->inv_resampled[sensor] = true;
     }
   }
   ctx->inv_set[sensor] = true;
@@ -872,19 +900,18 @@ int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3]
   fill_invert_params(ctx, sensor, vr, window, &p);
   const size_t row = (size_t)res[0] * res[1];
   const int chunk = 64;
-  float4* tmp = nullptr;
-  HIPCHK(hipMalloc((void**)&tmp, row * chunk * sizeof(float4)));
+  DevScratch tmp;
+  HIPCHK(hipMalloc(&tmp.p, row * chunk * sizeof(float4)));
   for (int z = 0; z < (int)res[2]; z += chunk) {
     p.z0 = z;
     p.nz = z + chunk <= (int)res[2] ? chunk : (int)res[2] - z;
-    p.out_linear = tmp;
+    p.out_linear = tmp.as<float4>();
     launch_invert_lut(p, ctx->stream);
     LAUNCHCHK("invert_lut");
-    HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
+    HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp.p, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  HIPCHK(hipFree(tmp));
   return RGBDR_OK;
 }
 
@@ -1168,10 +1195,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.tile_state = ctx->d_tile_state;
   const bool elide = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_ELIDE_STORES) != 0;
   p.elide_stores = elide ? 1 : 0;
-  if ((!bricks && !elide) || !all_tiled) ++ctx->clear_epoch;  // sweeps that overwrite tiles without keeping tile_state
-  if (ctx->clear_epoch == 0) {                     // wrapped: forget every recorded clear
-    HIPCHK(hipMemsetAsync(ctx->d_tile_state, 0, (size_t)p.TX * p.TY * p.ntz * sizeof(uint32_t), ctx->stream));
-    ctx->clear_epoch = 1;
+  if ((!bricks && !elide) || !all_tiled) {  // sweeps that overwrite tiles without keeping tile_state
+    int rc_ = bump_clear_epoch(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
   }
   p.epoch = ctx->clear_epoch;
   const int sb = ctx->stage_target;
@@ -1270,8 +1296,7 @@ int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit)
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(limit > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be > 0");
   ctx->cfg.tsdf_limit = limit;
-  ++ctx->clear_epoch;  // tiles cleared to the old -limit no longer count as cleared
-  return RGBDR_OK;
+  return bump_clear_epoch(ctx);  // tiles cleared to the old -limit no longer count as cleared
 }
 
 static int set_flag(rgbdr_ctx* ctx, uint32_t flag, int on)
@@ -1382,6 +1407,42 @@ int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst)
   return RGBDR_OK;
 }
 
+int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device_view* out)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!out) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null view");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  const size_t px = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h;
+  rgbdr_image_device_view v{};
+  v.width = ctx->cfg.depth_w;
+  v.height = ctx->cfg.depth_h;
+  v.channels = 1;
+  v.element_bytes = 4;
+  const float* f = nullptr;
+  switch (which) {
+    case RGBDR_IMG_DEPTH_RAW: f = ctx->d_depth_raw; break;
+    case RGBDR_IMG_DEPTH_MORPH: f = ctx->d_depth_morph; break;
+    case RGBDR_IMG_DEPTH_RG: f = ctx->d_depth_rg; v.channels = 2; break;
+    case RGBDR_IMG_LAB: f = ctx->d_lab; v.channels = 3; break;
+    case RGBDR_IMG_DEPTH_B_RG: f = ctx->d_depth_b; v.channels = 2; break;
+    case RGBDR_IMG_SILHOUETTE: f = ctx->d_sil; break;
+    case RGBDR_IMG_NORMAL: f = ctx->d_normal; v.channels = 3; break;
+    case RGBDR_IMG_QUALITY: f = ctx->d_quality; break;
+    case RGBDR_IMG_COLOR:
+      v.width = ctx->cfg.color_w;
+      v.height = ctx->cfg.color_h;
+      v.channels = 3;
+      v.element_bytes = 1;
+      v.ptr = ctx->d_color + (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3 * sensor;
+      break;
+    default: return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "unknown image id");
+  }
+  if (f) v.ptr = (void*)(f + px * v.channels * sensor);
+  v.stream = ctx->pstream();
+  *out = v;
+  return RGBDR_OK;
+}
+
 int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
@@ -1397,14 +1458,13 @@ int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z
   if (tiled) {
     if (z0 < g.slab_voxel_z0 || z1 > g.slab_voxel_z1 || z0 >= z1)
       return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "z rows outside this context's slab");
-    float4* tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&tmp, row * (size_t)(z1 - z0) * sizeof(float4)));
-    launch_untile_lut(ctx->d_lut_tiled, X, Y, g.tiles[0], g.tiles[1], g.slab_tile_z0, z0, z1, sensor, nsens(ctx), tmp,
-                      ctx->stream);
+    DevScratch tmp;
+    HIPCHK(hipMalloc(&tmp.p, row * (size_t)(z1 - z0) * sizeof(float4)));
+    launch_untile_lut(ctx->d_lut_tiled, X, Y, g.tiles[0], g.tiles[1], g.slab_tile_z0, z0, z1, sensor, nsens(ctx),
+                      tmp.as<float4>(), ctx->stream);
     LAUNCHCHK("untile_lut");
-    HIPCHK(hipMemcpyAsync(dst, tmp, row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dst, tmp.p, row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(tmp));
   } else {
     int lo, hi;
     const LutExtent ext = lut_extent(ctx);
@@ -1737,7 +1797,8 @@ int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const rgbdr_geometry& g = ctx->geo;
   const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
-  ++ctx->clear_epoch;  // the replay stores into the volume
+  { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the replay stores into the volume ...
+  ctx->integrated = false;  // ... whose contents are undefined until the next integrate
   // "steady" = the replay streams at the fastest level this hardware shows (>= 6.55 TB/s), or,
   // for an arena at one of the slower placements, the budget is used up.  (Agreement between
   // consecutive replays is not enough: a long wipe slows them all alike.)
@@ -1834,17 +1895,24 @@ int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint
   *count = 0;
   auto it = ctx->tm.find(name);
   if (it == ctx->tm.end()) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, std::string("no timer ") + name);
-  HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  // the intervals may have been recorded on either stream (pipelined mode: the pre_* timers
+  // and "bricks" live on the second one)
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   double total = 0.0;
-  for (auto& ev : it->second.pending) {
+  auto& pend = it->second.pending;
+  while (!pend.empty()) {
+    const auto ev = pend.back();
     float ms = 0.0f;
-    HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
-    total += (double)ms * 1.0e6;
-    ++*count;
+    // an interval whose end was never recorded (begin without end) is dropped, not reported
+    if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      total += (double)ms * 1.0e6;
+      ++*count;
+    } else {
+      (void)hipGetLastError();
+    }
     it->second.pool.push_back(ev);
+    pend.pop_back();
   }
-  it->second.pending.clear();
   *total_ns = (uint64_t)total;
   return RGBDR_OK;
 }
