@@ -312,6 +312,27 @@ int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device
  * The host alternates the two sets (rgbd-recon_amd/dist.py:HaloExchanger). */
 int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t* bytes);
 int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer);
+/* Raw copy of resident tile layers [first, first + count) of the slab allocation (layer 0 = the lower
+ * halo if any, rgbdr_tsdf_device_view.base) in the tile-linear device layout, layer_bytes each; drains
+ * every stream of the context first.  For hosts without HIP that inspect the halo layers. */
+int rgbdr_readback_tile_layers(rgbdr_ctx* ctx, int first, int count, float* dst);
+/* The one exchange of a Z-slab step over RCCL (the reference is single-GPU, its call order
+ * is source/kinect_client.cpp:572-602): grouped ncclSend / ncclRecv of the halo_tile_layers boundary
+ * layers to / from the Z neighbours.  nccl_comm is the host's ncclComm_t (RCCL is bound at run time from
+ * the copy loaded in the process: no link-time dependency); peer_lo / peer_hi are the communicator ranks
+ * of the slabs below / above (-1: none).
+ *   rgbdr_halo_exchange: one exchange on `hip_stream` (NULL: the context's stream), sending from
+ *     staging set `buffer` (0 / 1, filled by the last rgbdr_integrate after rgbdr_set_halo_staging) or,
+ *     with -1, straight from the owned boundary layers; receives into the halo layers of the volume.
+ *   rgbdr_halo_begin_step / _exchange_async / _wait: the same with the double-buffered staging, a side
+ *     stream and the events kept by the context, so that the transfer of step k overlaps step k+1:
+ *     begin_step() before rgbdr_integrate, exchange_async() after it, wait() before anything on the
+ *     context's stream samples across slab faces (rgbdr_raymarch_find / _shade).
+ * Timer "halo" (rgbdr_timer_ns / rgbdr_timer_stats) brackets the transfer on the stream it runs on. */
+int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi, int buffer, void* hip_stream);
+int rgbdr_halo_begin_step(rgbdr_ctx* ctx);
+int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi);
+int rgbdr_halo_wait(rgbdr_ctx* ctx);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);
@@ -404,8 +425,9 @@ int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* 
 
 /* ---- timers (TimerDatabase, framework/rendering/timer_database.cpp:26-49) -- */
 
-/* names: "morph","bilateral","boundary","normal","quality","1preprocess",
- * "2integrate","bricks".  Last completed interval, nanoseconds. */
+/* names: "morph","bilateral","boundary","normal","quality","1preprocess","2integrate","bricks",
+ * "draw","brickdraw","holefill" (timer_database.cpp:26-49, reconstruction.cpp:35-39,
+ * recon_integration.cpp:161-163,410-428) and "halo" (the slab exchange).  Last completed interval, ns. */
 int rgbdr_enable_timers(rgbdr_ctx* ctx, int on);
 int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns);
 /* Accumulating mode: every interval of a timed region keeps its own HIP event

@@ -192,6 +192,11 @@ SYMBOLS = {
     "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
     "rgbdr_halo_staging": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
     "rgbdr_set_halo_staging": (C.c_int, [_P, C.c_int]),
+    "rgbdr_readback_tile_layers": (C.c_int, [_P, C.c_int, C.c_int, _F]),
+    "rgbdr_halo_exchange": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "rgbdr_halo_begin_step": (C.c_int, [_P]),
+    "rgbdr_halo_exchange_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rgbdr_halo_wait": (C.c_int, [_P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),

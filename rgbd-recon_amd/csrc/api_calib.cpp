@@ -1,0 +1,470 @@
+// api_calib.cpp -- calibration volumes behind CalibVolumes (framework/calibration/CalibVolumes.cpp:22-159):
+// forward LUT upload, the grid-layout inverse-LUT arena, inverse-LUT generation on the device.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include "context.hpp"
+
+using namespace rgbdr;
+
+extern "C" {
+// ---------------------------------------------------------------------------
+int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, const rgbdr_lut* uv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!xyz || !uv || !xyz->data || !uv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null calibration volume");
+  for (int a = 0; a < 3; ++a)
+    if (xyz->res[a] < 1 || uv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty calibration volume");
+  if (!(xyz->depth_limits[1] > xyz->depth_limits[0]))
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz depth limits must satisfy max > min");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nx = (size_t)xyz->res[0] * xyz->res[1] * xyz->res[2];
+  const size_t nu = (size_t)uv->res[0] * uv->res[1] * uv->res[2];
+  (void)hipFree(ctx->d_cv_xyz[sensor]);
+  (void)hipFree(ctx->d_cv_uv[sensor]);
+  ctx->d_cv_xyz[sensor] = nullptr;
+  ctx->d_cv_uv[sensor] = nullptr;
+  ctx->have_calib[sensor] = false;
+  DevScratch tmp;
+  HIPCHK(hipMalloc(&tmp.p, nx * 12));
+  HIPCHK(hipMalloc((void**)&ctx->d_cv_xyz[sensor], nx * 16));
+  HIPCHK(hipMalloc((void**)&ctx->d_cv_uv[sensor], nu * 8));
+  HIPCHK(hipMemcpyAsync(tmp.p, xyz->data, nx * 12, hipMemcpyHostToDevice, ctx->stream));
+  launch_repack_xyz(tmp.as<float>(), ctx->d_cv_xyz[sensor], nx, ctx->stream);
+  LAUNCHCHK("repack_xyz");
+  HIPCHK(hipMemcpyAsync(ctx->d_cv_uv[sensor], uv->data, nu * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int a = 0; a < 3; ++a) {
+    ctx->xyz_res[sensor][a] = xyz->res[a];
+    ctx->uv_res[sensor][a] = uv->res[a];
+  }
+  ctx->min_ds[sensor] = xyz->depth_limits[0];
+  ctx->max_ds[sensor] = xyz->depth_limits[1];
+  camera_position((const float*)xyz->data, xyz->res, ctx->cam_pos[sensor]);
+  frustum_planes((const float*)xyz->data, xyz->res, ctx->planes[sensor]);
+  ctx->have_calib[sensor] = true;
+  return RGBDR_OK;
+}
+
+}  // extern "C"
+LutExtent rgbdr::lut_extent(const rgbdr_ctx* ctx)
+{
+  const rgbdr_geometry& g = ctx->geo;
+  LutExtent e;
+  e.t0 = g.slab_tile_z0 - ctx->halo < 0 ? 0 : g.slab_tile_z0 - ctx->halo;
+  e.t1 = g.slab_tile_z1 + ctx->halo > g.tiles[2] ? g.tiles[2] : g.slab_tile_z1 + ctx->halo;
+  e.vz0 = e.t0 * kTile;
+  e.vz1 = e.t1 * kTile > g.res_volume[2] ? g.res_volume[2] : e.t1 * kTile;
+  const ptrdiff_t layer = (ptrdiff_t)g.tiles[0] * g.tiles[1] * ctx->cfg.num_sensors * 3 * kTileVoxels;
+  e.dst = ctx->d_lut_tiled + (ptrdiff_t)(e.t0 - g.slab_tile_z0) * layer;
+  return e;
+}
+extern "C" {
+
+static int ensure_tiled_lut(rgbdr_ctx* ctx)
+{
+  if (ctx->d_lut_tiled) return RGBDR_OK;
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
+  const size_t layer = (size_t)g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
+  const size_t layers = (size_t)(g.slab_tile_z1 - g.slab_tile_z0) + 2 * (size_t)ctx->halo;
+  const size_t bytes = layer * layers * sizeof(float);
+  // Where the driver places this arena shifts the sweep time of integrate by a few per cent on some
+  // boxes (stable per allocation).  OPT-IN (RGBDR_ARENA_TRIALS=n, 2..16; default 1 = take
+  // the first allocation, no probing): time the kernel's memory streams on up to n candidate
+  // placements, keep the fastest.  Candidates are held while probing (otherwise the next hipMalloc
+  // returns the same place), so this transiently needs up to n x the arena; it stops at the first
+  // candidate at the fast level, when less than arena + 4 GiB is free, or after ~1 s.
+  int trials = 1;
+  if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
+  if (trials > 16) trials = 16;
+  if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain
+  float* cand[16] = {nullptr};
+  float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too: the volume is invalidated below
+  float best_ms = 0.0f;
+  int best = -1, got = 0;
+  bool probed = false;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int t = 0; t < trials; ++t) {
+    size_t free_b = 0, total_b = 0;
+    if (t > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)4 << 30))) break;
+    if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      cand[t] = nullptr;
+      if (t == 0) return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed: out of device memory");
+      break;
+    }
+    got = t + 1;
+    if (trials == 1) {
+      best = 0;
+      break;
+    }
+    const float ms = probe_arena_ms(cand[t] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+    probed = true;
+    ctx->arena_probe_ms[t] = ms;
+    if (ms > 0.0f && (best < 0 || ms < best_ms)) {
+      best = t;
+      best_ms = ms;
+    }
+    // stop at the first candidate that streams at the fastest level seen on this hardware
+    // (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s)
+    const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
+    if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) break;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > 1.0) break;
+  }
+  if (best < 0) best = 0;
+  ctx->arena_trials = got;
+  ctx->arena_chosen = best;
+  int freed = 0;
+  for (int t = 0; t < got; ++t)
+    if (t != best) {
+      (void)hipFree(cand[t]);
+      ++freed;
+    }
+  // Releasing that much memory slows the device down for a moment (the driver wipes released VRAM
+  // in the background): wait, at most 2 s, until the kept arena streams as it did when it was chosen.
+  if (freed > 0 && best_ms > 0.0f) {
+    for (int k = 0; k < 40; ++k) {
+      const float ms = probe_arena_ms(cand[best] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+      if (!(ms > best_ms * 1.01f)) break;
+      struct timespec ts = {0, 50000000};
+      nanosleep(&ts, nullptr);
+    }
+  }
+  ctx->d_lut_tiled_base = cand[best];
+  ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
+  if (probed) {  // the replay stored into the volume: clear it again, forget recorded clears, nothing is integrated
+    HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
+    { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }
+    ctx->integrated = false;
+  }
+  HIPCHK(hipMalloc((void**)&ctx->d_win, ntiles * nsens(ctx) * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_win, 0, ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* inv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!inv || !inv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null inverse calibration volume");
+  for (int a = 0; a < 3; ++a)
+    if (inv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty inverse calibration volume");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const int X = inv->res[0], Y = inv->res[1], Z = inv->res[2];
+  const float4* host = (const float4*)inv->data;
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  ctx->inv_set[sensor] = false;
+  ctx->inv_resampled[sensor] = false;
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = inv->res[a];
+  // Every sensor of a context is resident in the same layout, so LUTs of any mix of resolutions work
+  // together: the grid layout (a 1:1 LUT re-tiled, any other resolution resampled at the voxel centres
+  // once -- the lookup of tsdf_integration.vs:31 is static between frames) unless RGBDR_FLAG_NO_RESAMPLE
+  // asks for the file layout, or the arena did not fit when the first sensor was set.
+  bool others_tiled = false, others_file = false;
+  for (int i = 0; i < nsens(ctx); ++i) {
+    if (i == sensor || !ctx->inv_set[i]) continue;
+    others_tiled = others_tiled || ctx->inv_tiled[i];
+    others_file = others_file || !ctx->inv_tiled[i];
+  }
+  bool grid_layout = !(ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE) && !others_file;
+  if (grid_layout && ensure_tiled_lut(ctx) != RGBDR_OK) {
+    (void)hipGetLastError();
+    if (others_tiled) return RGBDR_ERR_HIP;  // message set by ensure_tiled_lut; cannot happen: the arena exists already
+    grid_layout = false;                     // the arena does not fit: keep the file's volume, sample per frame
+  }
+  const size_t row = (size_t)X * Y;
+  if (grid_layout && lut_is_one_to_one(inv->res, g.res_volume)) {
+    // stage whole tile layers through a bounded scratch buffer
+    const int chunk_layers = 8;
+    DevScratch tmp;
+    HIPCHK(hipMalloc(&tmp.p, row * kTile * chunk_layers * sizeof(float4)));
+    const LutExtent ext = lut_extent(ctx);
+    for (int tz = ext.t0; tz < ext.t1; tz += chunk_layers) {
+      const int tz_end = tz + chunk_layers < ext.t1 ? tz + chunk_layers : ext.t1;
+      const int vz0 = tz * kTile;
+      int vz1 = tz_end * kTile;
+      if (vz1 > Z) vz1 = Z;
+      HIPCHK(hipMemcpyAsync(tmp.p, host + row * vz0, row * (size_t)(vz1 - vz0) * sizeof(float4), hipMemcpyHostToDevice,
+                            ctx->stream));
+      float* dst = ext.dst + (size_t)(tz - ext.t0) * g.tiles[0] * g.tiles[1] * nsens(ctx) * 3 * kTileVoxels;
+      launch_tile_lut(tmp.as<float4>(), X, Y, Z, vz0, g.tiles[0], g.tiles[1], tz, tz_end - tz, sensor, nsens(ctx), dst,
+                      ctx->stream);
+      LAUNCHCHK("tile_lut");
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                        g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                        ctx->stream);
+    LAUNCHCHK("tile_windows");
+    ctx->inv_tiled[sensor] = true;
+  } else {
+    int lo, hi;
+    const LutExtent ext = lut_extent(ctx);
+    lut_z_range(Z, g.res_volume[2], ext.vz0, ext.vz1, &lo, &hi);
+    const size_t cnt = row * (size_t)(hi - lo + 1);
+    HIPCHK(hipMalloc((void**)&ctx->d_lut_generic[sensor], cnt * sizeof(float4)));
+    HIPCHK(hipMemcpyAsync(ctx->d_lut_generic[sensor], host + row * lo, cnt * sizeof(float4), hipMemcpyHostToDevice,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->zoff[sensor] = lo;
+    ctx->inv_tiled[sensor] = false;
+    if (grid_layout) {
+      launch_resample_lut(ctx->d_lut_generic[sensor], X, Y, Z, lo, g.res_volume[0], g.res_volume[1], g.res_volume[2],
+                          g.tiles[0], g.tiles[1], ext.t0, ext.t1 - ext.t0, sensor, nsens(ctx), ext.dst, ctx->stream);
+      LAUNCHCHK("resample_lut");
+      launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                          g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                          ctx->stream);
+      LAUNCHCHK("tile_windows");
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->d_lut_generic[sensor]);
+      ctx->d_lut_generic[sensor] = nullptr;
+      ctx->inv_tiled[sensor] = true;
+      ctx->inv_resampled[sensor] = true;
+    }
+  }
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+static int read_lut_file(rgbdr_ctx* ctx, const char* path, size_t rec_bytes, rgbdr_lut* lut, std::vector<char>* buf)
+{
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return ctx->fail(RGBDR_ERR_IO, std::string("cannot open ") + path);
+  bool ok = std::fread(lut->res, 4, 3, f) == 3 && std::fread(lut->depth_limits, 4, 2, f) == 2;
+  size_t n = 0;
+  if (ok) {
+    n = (size_t)lut->res[0] * lut->res[1] * lut->res[2] * rec_bytes;
+    buf->resize(n);
+    ok = std::fread(buf->data(), 1, n, f) == n;
+  }
+  std::fclose(f);
+  if (!ok) return ctx->fail(RGBDR_ERR_IO, std::string("short read from ") + path);
+  lut->data = buf->data();
+  return RGBDR_OK;
+}
+
+int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* pxyz, const char* puv, const char* pinv)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if ((pxyz == nullptr) != (puv == nullptr))
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz and cv_uv must be given together");
+  if (pxyz) {
+    rgbdr_lut a{}, b{};
+    std::vector<char> ba, bb;
+    int rc = read_lut_file(ctx, pxyz, 12, &a, &ba);
+    if (rc != RGBDR_OK) return rc;
+    rc = read_lut_file(ctx, puv, 8, &b, &bb);
+    if (rc != RGBDR_OK) return rc;
+    rc = rgbdr_set_calibration(ctx, sensor, &a, &b);
+    if (rc != RGBDR_OK) return rc;
+  }
+  if (pinv) {
+    rgbdr_lut c{};
+    std::vector<char> bc;
+    int rc = read_lut_file(ctx, pinv, 16, &c, &bc);
+    if (rc != RGBDR_OK) return rc;
+    rc = rgbdr_set_inverse_calibration(ctx, sensor, &c);
+    if (rc != RGBDR_OK) return rc;
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!cam) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null pinhole");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const uint32_t r[3] = {(uint32_t)g.res_volume[0], (uint32_t)g.res_volume[1], (uint32_t)g.res_volume[2]};
+  if (!lut_is_one_to_one(r, g.res_volume))
+    return ctx->fail(RGBDR_ERR_STATE, "synthetic inverse LUT needs a grid whose voxel centres hit texel centres exactly");
+  int rc = ensure_tiled_lut(ctx);
+  if (rc != RGBDR_OK) return rc;
+  const LutExtent ext = lut_extent(ctx);
+  launch_synth_inverse(*cam, ctx->cfg.depth_w, ctx->cfg.depth_h, ctx->cfg.bbox_min, ctx->cfg.bbox_max, g.res_volume[0],
+                       g.res_volume[1], g.res_volume[2], g.tiles[0], g.tiles[1], ext.t0, ext.t1 - ext.t0, sensor,
+                       nsens(ctx), ext.dst, ctx->stream);
+  LAUNCHCHK("synth_inverse");
+  launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                      g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                      ctx->stream);
+  LAUNCHCHK("tile_windows");
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = r[a];
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  ctx->inv_tiled[sensor] = true;
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+// CalibrationInverter::calculateInverseVolumes on the device (kernels_invert.hip)
+static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res[3], int window, InvertParams* p)
+{
+  *p = InvertParams{};
+  p->xyz = ctx->d_cv_xyz[sensor];
+  p->rx = (int)ctx->xyz_res[sensor][0];
+  p->ry = (int)ctx->xyz_res[sensor][1];
+  p->rz = (int)ctx->xyz_res[sensor][2];
+  std::memcpy(p->planes, ctx->planes[sensor], sizeof(p->planes));
+  for (int a = 0; a < 3; ++a) {
+    const float vstep = 1.0f / (float)vol_res[a];
+    p->step[a] = (ctx->cfg.bbox_max[a] - ctx->cfg.bbox_min[a]) * vstep;
+    p->start[a] = ctx->cfg.bbox_min[a] + p->step[a] * 0.5f;
+  }
+  p->X = vol_res[0];
+  p->Y = vol_res[1];
+  p->TX = (vol_res[0] + kTile - 1) / kTile;
+  p->TY = (vol_res[1] + kTile - 1) / kTile;
+  p->window = window < 1 ? 2 : window;
+  p->sensor = sensor;
+  p->N = ctx->cfg.num_sensors;
+}
+
+int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "compute_inverse_calibration before set_calibration");
+  if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int i = 0; i < nsens(ctx); ++i)
+    if (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i])
+      return ctx->fail(RGBDR_ERR_STATE, "other sensors hold file-layout inverse LUTs (RGBDR_FLAG_NO_RESAMPLE)");
+  int rc = ensure_tiled_lut(ctx);
+  if (rc != RGBDR_OK) return rc;
+  const rgbdr_geometry& g = ctx->geo;
+  InvertParams p;
+  fill_invert_params(ctx, sensor, g.res_volume, window, &p);
+  const LutExtent ext = lut_extent(ctx);
+  p.z0 = ext.vz0;
+  p.nz = ext.vz1 - ext.vz0;
+  p.out_tiled = ext.dst;
+  launch_invert_lut(p, ctx->stream);
+  LAUNCHCHK("invert_lut");
+  launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
+                      g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
+                      ctx->stream);
+  LAUNCHCHK("tile_windows");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->d_lut_generic[sensor]);
+  ctx->d_lut_generic[sensor] = nullptr;
+  for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = (uint32_t)g.res_volume[a];
+  ctx->inv_tiled[sensor] = true;
+  ctx->inv_resampled[sensor] = false;
+  ctx->inv_set[sensor] = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3], int window, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!res || !dst || res[0] < 1 || res[1] < 1 || res[2] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad resolution / destination");
+  if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "generate_inverse_lut before set_calibration");
+  if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int32_t vr[3] = {(int32_t)res[0], (int32_t)res[1], (int32_t)res[2]};
+  InvertParams p;
+  fill_invert_params(ctx, sensor, vr, window, &p);
+  const size_t row = (size_t)res[0] * res[1];
+  const int chunk = 64;
+  DevScratch tmp;
+  HIPCHK(hipMalloc(&tmp.p, row * chunk * sizeof(float4)));
+  for (int z = 0; z < (int)res[2]; z += chunk) {
+    p.z0 = z;
+    p.nz = z + chunk <= (int)res[2] ? chunk : (int)res[2] - z;
+    p.out_linear = tmp.as<float4>();
+    launch_invert_lut(p, ctx->stream);
+    LAUNCHCHK("invert_lut");
+    HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp.p, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!ctx->inv_set[sensor]) return ctx->fail(RGBDR_ERR_STATE, "inverse calibration of this sensor is not set");
+  HIPCHK(hipSetDevice(ctx->device));
+  const rgbdr_geometry& g = ctx->geo;
+  const bool tiled = ctx->inv_tiled[sensor];
+  const int X = tiled ? g.res_volume[0] : (int)ctx->inv_res[sensor][0];
+  const int Y = tiled ? g.res_volume[1] : (int)ctx->inv_res[sensor][1];
+  const size_t row = (size_t)X * Y;
+  if (tiled) {
+    if (z0 < g.slab_voxel_z0 || z1 > g.slab_voxel_z1 || z0 >= z1)
+      return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "z rows outside this context's slab");
+    DevScratch tmp;
+    HIPCHK(hipMalloc(&tmp.p, row * (size_t)(z1 - z0) * sizeof(float4)));
+    launch_untile_lut(ctx->d_lut_tiled, X, Y, g.tiles[0], g.tiles[1], g.slab_tile_z0, z0, z1, sensor, nsens(ctx),
+                      tmp.as<float4>(), ctx->stream);
+    LAUNCHCHK("untile_lut");
+    HIPCHK(hipMemcpyAsync(dst, tmp.p, row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    int lo, hi;
+    const LutExtent ext = lut_extent(ctx);
+    lut_z_range((int)ctx->inv_res[sensor][2], g.res_volume[2], ext.vz0, ext.vz1, &lo, &hi);
+    if (z0 < lo || z1 > hi + 1 || z0 >= z1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "texel rows not resident");
+    HIPCHK(hipMemcpyAsync(dst, ctx->d_lut_generic[sensor] + row * (size_t)(z0 - lo),
+                          row * (size_t)(z1 - z0) * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  return RGBDR_OK;
+}
+
+int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->d_lut_tiled) return ctx->fail(RGBDR_ERR_STATE, "settle before the inverse LUTs were set");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
+  { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the replay stores into the volume ...
+  ctx->integrated = false;  // ... whose contents are undefined until the next integrate
+  // "steady" = the replay streams at the fastest level this hardware shows (>= 6.55 TB/s), or,
+  // for an arena at one of the slower placements, the budget is used up.  (Agreement between
+  // consecutive replays is not enough: a long wipe slows them all alike.)
+  const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
+  float cur = -1.0f;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (;;) {
+    cur = probe_arena_ms(ctx->d_lut_tiled, ntiles, nsens(ctx), g.tiles[0], ctx->d_tsdf_owned, ctx->stream);
+    if (cur < 0.0f) return ctx->fail(RGBDR_ERR_HIP, "settle: the stream replay failed");
+    if (stream_bytes / (cur * 1e-3) >= 6.55e12) break;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > (double)max_seconds) break;
+    struct timespec ts = {0, 50000000};
+    nanosleep(&ts, nullptr);
+  }
+  if (stream_ms) *stream_ms = cur;
+  return RGBDR_OK;
+}
+
+int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ms) std::memcpy(ms, ctx->arena_probe_ms, sizeof(ctx->arena_probe_ms));
+  if (trials) *trials = ctx->arena_trials;
+  if (chosen) *chosen = ctx->arena_chosen;
+  return RGBDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+// api_halo.cpp -- Z-slab halo: staging sets and the RCCL neighbour exchange.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include <dlfcn.h>
+
+#include "context.hpp"
+
+using namespace rgbdr;
+
+namespace {
+// RCCL is bound at run time, from the copy that is already in the process (the host created the
+// communicator with it) or else the system's: the library has no link-time dependency on RCCL, so
+// single-GPU hosts need none.  Signatures: /opt/rocm/include/rccl/rccl.h (ncclFloat = 7).
+struct Rccl {
+  bool tried = false;
+  void* lib = nullptr;
+  int (*group_start)() = nullptr;
+  int (*group_end)() = nullptr;
+  int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*error_string)(int) = nullptr;
+  std::string why;
+};
+
+Rccl& rccl()
+{
+  static Rccl r;
+  if (r.tried) return r;
+  r.tried = true;
+  const char* env = std::getenv("RGBDR_RCCL_LIB");
+  const char* names[] = {env, "librccl.so.1", "librccl.so"};
+  for (int pass = 0; pass < 2 && !r.lib; ++pass)  // pass 0: only a copy that is loaded already
+    for (const char* n : names)
+      if (n && !r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+  if (!r.lib) {
+    r.why = "librccl.so.1 could not be loaded (set RGBDR_RCCL_LIB)";
+    return r;
+  }
+  r.group_start = (int (*)())dlsym(r.lib, "ncclGroupStart");
+  r.group_end = (int (*)())dlsym(r.lib, "ncclGroupEnd");
+  r.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclSend");
+  r.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclRecv");
+  r.error_string = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+  if (!r.group_start || !r.group_end || !r.send || !r.recv) {
+    r.why = "the RCCL library lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd";
+    r.lib = nullptr;
+  }
+  return r;
+}
+
+// One exchange on `st`: the h lowest owned tile layers (or staging buffer `lo`) go to peer_lo, the h
+// highest (or `hi`) to peer_hi; the neighbours' faces arrive in the halo layers below / above the owned
+// ones.  A tile layer range is contiguous in the tile-linear layout: one message per face, no packing.
+int exchange_on(rgbdr_ctx* ctx, void* comm, int peer_lo, int peer_hi, int buffer, hipStream_t st)
+{
+  Rccl& r = rccl();
+  if (!r.lib) return ctx->fail(RGBDR_ERR_STATE, r.why);
+  const size_t face = ctx->layer_floats * (size_t)ctx->halo;
+  const int owned = ctx->geo.slab_tile_z1 - ctx->geo.slab_tile_z0;
+  const float* send_lo = buffer >= 0 ? ctx->d_stage[buffer][0] : ctx->d_tsdf_owned;
+  const float* send_hi = buffer >= 0 ? ctx->d_stage[buffer][1] : ctx->d_tsdf_owned + ctx->layer_floats * (size_t)(owned - ctx->halo);
+  float* recv_lo = ctx->d_tsdf_base;
+  float* recv_hi = ctx->d_tsdf_owned + ctx->layer_floats * (size_t)owned;
+  auto chk = [&](int rc, const char* what) {
+    if (rc == 0) return 0;
+    return ctx->fail(RGBDR_ERR_HIP, std::string(what) + ": " + (r.error_string ? r.error_string(rc) : "RCCL error"));
+  };
+  tbegin(ctx, "halo", st);
+  int rc = chk(r.group_start(), "ncclGroupStart");
+  if (rc == 0 && peer_lo >= 0) {
+    rc = chk(r.send(send_lo, face, 7, peer_lo, comm, st), "ncclSend");
+    if (rc == 0) rc = chk(r.recv(recv_lo, face, 7, peer_lo, comm, st), "ncclRecv");
+  }
+  if (rc == 0 && peer_hi >= 0) {
+    rc = chk(r.send(send_hi, face, 7, peer_hi, comm, st), "ncclSend");
+    if (rc == 0) rc = chk(r.recv(recv_hi, face, 7, peer_hi, comm, st), "ncclRecv");
+  }
+  const int rc_end = chk(r.group_end(), "ncclGroupEnd");
+  tend(ctx, "halo", st);
+  return rc != 0 ? rc : rc_end;
+}
+
+int check_slab(rgbdr_ctx* ctx, int buffer)
+{
+  if (ctx->halo <= 0) return ctx->fail(RGBDR_ERR_STATE, "the halo exchange needs a Z-slab context (slab_count > 1)");
+  if (buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0, 1 or -1");
+  if (buffer >= 0 && (!ctx->d_stage[buffer][0] || !ctx->d_stage[buffer][1]))
+    return ctx->fail(RGBDR_ERR_STATE, "halo exchange from a staging set before rgbdr_halo_staging of that set");
+  return RGBDR_OK;
+}
+}  // namespace
+
+extern "C" {
+int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t* bytes)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (buffer < 0 || buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0 or 1");
+  if (ctx->halo <= 0) return ctx->fail(RGBDR_ERR_STATE, "halo staging needs a Z-slab context (slab_count > 1)");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t face = ctx->layer_floats * (size_t)ctx->halo * sizeof(float);
+  for (int f = 0; f < 2; ++f)
+    if (!ctx->d_stage[buffer][f]) {
+      HIPCHK(hipMalloc((void**)&ctx->d_stage[buffer][f], face));
+      HIPCHK(hipMemsetAsync(ctx->d_stage[buffer][f], 0, face, ctx->stream));
+    }
+  if (lo) *lo = ctx->d_stage[buffer][0];
+  if (hi) *hi = ctx->d_stage[buffer][1];
+  if (bytes) *bytes = face;
+  return RGBDR_OK;
+}
+
+int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0, 1 or -1");
+  if (buffer >= 0 && (!ctx->d_stage[buffer][0] || !ctx->d_stage[buffer][1]))
+    return ctx->fail(RGBDR_ERR_STATE, "set_halo_staging before rgbdr_halo_staging of that buffer");
+  ctx->stage_target = buffer < 0 ? -1 : buffer;
+  return RGBDR_OK;
+}
+
+int rgbdr_readback_tile_layers(rgbdr_ctx* ctx, int first, int count, float* dst)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
+  const int resident = ctx->geo.slab_tile_z1 - ctx->geo.slab_tile_z0 + 2 * ctx->halo;
+  if (first < 0 || count < 1 || first + count > resident) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "tile layers not resident");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  HIPCHK(hipMemcpy(dst, ctx->d_tsdf_base + ctx->layer_floats * (size_t)first, ctx->layer_floats * (size_t)count * sizeof(float),
+                   hipMemcpyDeviceToHost));
+  return RGBDR_OK;
+}
+
+int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi, int buffer, void* hip_stream)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
+  { int rc_ = check_slab(ctx, buffer); if (rc_ != RGBDR_OK) return rc_; }
+  HIPCHK(hipSetDevice(ctx->device));
+  return exchange_on(ctx, nccl_comm, peer_lo, peer_hi, buffer, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+// ---- the managed form: staging sets, side stream and events owned by the context ---------------------
+// Per step k (b = k mod 2), like rgbd-recon_amd/dist.py:HaloExchanger:
+//   begin_step      context stream: [wait: transfer k-2 done, it read set b]; the sweep will fill set b
+//   ... rgbdr_integrate ...
+//   exchange_async  context stream: record staged_k;  side stream: wait staged_k, send set b / receive
+//                   into the halo layers, record done_k
+//   wait            context stream waits for the newest done event (consumers that sample across faces)
+// The halo layers are only ever written by the side stream and only read after wait(), so a transfer
+// overlaps the whole next frame.
+int rgbdr_halo_begin_step(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  { int rc_ = check_slab(ctx, -1); if (rc_ != RGBDR_OK) return rc_; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->halo_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->halo_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_halo_done[b], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_halo_staged[b], hipEventDisableTiming));
+    }
+  }
+  const int b = ctx->halo_step & 1;
+  { int rc_ = rgbdr_halo_staging(ctx, b, nullptr, nullptr, nullptr); if (rc_ != RGBDR_OK) return rc_; }
+  if (ctx->halo_done_rec[b]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done[b], 0));
+  ctx->stage_target = b;
+  ctx->halo_begun = true;
+  return RGBDR_OK;
+}
+
+int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
+  if (!ctx->halo_begun) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_exchange_async before rgbdr_halo_begin_step + rgbdr_integrate");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int b = ctx->halo_step & 1;
+  ctx->halo_begun = false;
+  ++ctx->halo_step;
+  HIPCHK(hipEventRecord(ctx->ev_halo_staged[b], ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->halo_stream, ctx->ev_halo_staged[b], 0));
+  int rc = exchange_on(ctx, nccl_comm, peer_lo, peer_hi, b, ctx->halo_stream);
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->ev_halo_done[b], ctx->halo_stream));
+  ctx->halo_done_rec[b] = true;
+  ctx->halo_last = b;
+  return RGBDR_OK;
+}
+
+int rgbdr_halo_wait(rgbdr_ctx* ctx)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->halo_last < 0) return RGBDR_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done[ctx->halo_last], 0));
+  return RGBDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// api_view.cpp -- consumers of the volume: ReconIntegration::drawDepthLimits,
+// ::draw (ray-march, whole volume and Z slabs) and ::fillColors.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include "context.hpp"
+
+using namespace rgbdr;
+
+extern "C" {
+// d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4), first-hit index (1)
+static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
+{
+  if (ctx->view_pixels >= npix) return RGBDR_OK;
+  (void)hipFree(ctx->d_view);
+  ctx->d_view = nullptr;
+  ctx->view_pixels = 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 11 * sizeof(float)));
+  ctx->view_pixels = npix;
+  return RGBDR_OK;
+}
+
+static void mat4_product(const float* a, const float* b, float* o)  // glm association, column-major
+{
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) o[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3];
+}
+
+// ReconIntegration::drawDepthLimits into the peel image of the view buffers
+static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
+{
+  { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "depth limits before update_occupied_bricks");
+  PeelParams p{};
+  mat4_product(v->projection, v->modelview, p.pmv);
+  std::memcpy(p.modelview_inv, v->modelview_inv, 64);
+  std::memcpy(p.img_to_eye, v->img_to_eye, 64);
+  p.width = v->width;
+  p.height = v->height;
+  for (int a = 0; a < 3; ++a) {
+    p.bbox_min[a] = ctx->cfg.bbox_min[a];
+    p.res_bricks[a] = ctx->geo.res_bricks[a];
+  }
+  p.brick_size = ctx->geo.brick_size;
+  p.counters = ctx->d_counters;
+  p.mask = ctx->mask_buf(ctx->rbuf);
+  p.out = out;
+  tbegin(ctx, "brickdraw", ctx->stream);
+  launch_depth_peels(p, ctx->stream);
+  tend(ctx, "brickdraw", ctx->stream);
+  LAUNCHCHK("depth_peels");
+  return RGBDR_OK;
+}
+
+int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)v->width * v->height;
+  int rc = ensure_view_buffers(ctx, npix);
+  if (rc != RGBDR_OK) return rc;
+  float4* out = (float4*)(ctx->d_view + npix * 6);
+  rc = draw_depth_limits(ctx, v, out);
+  if (rc != RGBDR_OK) return rc;
+  if (peels) HIPCHK(hipMemcpyAsync(peels, out, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+// uniforms + resident data of the ray-marcher for `v`; runs the depth peels when asked
+static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
+{
+  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
+  if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
+  const int N = nsens(ctx);
+  bool tiled = true;
+  for (int i = 0; i < N; ++i) tiled = tiled && ctx->inv_tiled[i];
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)v->width * v->height;
+  {
+    int rc_ = ensure_view_buffers(ctx, npix);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
+  const rgbdr_geometry& g = ctx->geo;
+  if (ctx->cfg.slab_count > 1) {
+    const int rows = (int)std::ceil(ctx->cfg.tsdf_limit * (float)g.res_volume[2]) + 2;
+    if (rows > ctx->halo * kTile) return ctx->fail(RGBDR_ERR_STATE, "tsdf_limit grew beyond what the slab halo covers; recreate the context");
+  }
+  RaymarchParams& p = *pp;
+  p = RaymarchParams{};
+  p.skip_space = v->skip_space ? 1 : 0;
+  p.peels = (const float4*)(ctx->d_view + npix * 6);
+  if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
+    int rc_ = draw_depth_limits(ctx, v, (float4*)(ctx->d_view + npix * 6));
+    if (rc_ != RGBDR_OK) return rc_;
+  }
+  std::memcpy(p.projection, v->projection, 64);
+  std::memcpy(p.normal_matrix, v->normal_matrix, 64);
+  std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);
+  std::memcpy(p.vol_to_world_inv, v->vol_to_world_inv, 64);
+  std::memcpy(p.modelview_inv, v->modelview_inv, 64);
+  std::memcpy(p.img_to_eye, v->img_to_eye, 64);
+  // gl_ModelViewMatrix * vol_to_world, evaluated once (the shader forms it per fragment, :123)
+  mat4_product(v->modelview, v->vol_to_world, p.mv_vol_to_world);
+  std::memcpy(p.camera_pos, v->camera_pos, 12);
+  p.width = v->width;
+  p.height = v->height;
+  p.shade_mode = v->shade_mode;
+  p.limit = ctx->cfg.tsdf_limit;
+  p.N = N;
+  p.W = ctx->cfg.depth_w;
+  p.H = ctx->cfg.depth_h;
+  p.Wc = ctx->cfg.color_w;
+  p.Hc = ctx->cfg.color_h;
+  p.X = g.res_volume[0];
+  p.Y = g.res_volume[1];
+  p.Z = g.res_volume[2];
+  p.TX = g.tiles[0];
+  p.TY = g.tiles[1];
+  p.tz_alloc0 = g.slab_tile_z0 - ctx->halo;
+  p.own_z0 = g.slab_voxel_z0;
+  p.own_z1 = g.slab_voxel_z1;
+  p.res_z0 = (g.slab_tile_z0 - ctx->halo) * kTile < 0 ? 0 : (g.slab_tile_z0 - ctx->halo) * kTile;
+  p.res_z1 = (g.slab_tile_z1 + ctx->halo) * kTile > g.res_volume[2] ? g.res_volume[2] : (g.slab_tile_z1 + ctx->halo) * kTile;
+  p.tsdf = ctx->d_tsdf_base;
+  p.lut_tiled = tiled ? ctx->d_lut_tiled_base : nullptr;
+  const size_t img = (size_t)p.W * p.H;
+  for (int i = 0; i < N; ++i) {
+    p.lut[i] = ctx->d_lut_generic[i];
+    p.rx[i] = (int)ctx->inv_res[i][0];
+    p.ry[i] = (int)ctx->inv_res[i][1];
+    p.rz[i] = (int)ctx->inv_res[i][2];
+    p.zoff[i] = ctx->zoff[i];
+    p.cv_uv[i] = ctx->d_cv_uv[i];
+    for (int a = 0; a < 3; ++a) p.uv_res[i][a] = (int)ctx->uv_res[i][a];
+    p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
+  }
+  p.color = ctx->d_color;
+  p.out_color = (float4*)ctx->d_view;
+  p.out_depth = ctx->d_view + npix * 4;
+  p.out_samples = ctx->d_view + npix * 5;
+  p.khit = (int*)(ctx->d_view + npix * 10);
+  ctx->view_w = v->width;
+  ctx->view_h = v->height;
+  return RGBDR_OK;
+}
+
+static int download_view(rgbdr_ctx* ctx, const RaymarchParams& p, float* color, float* depth, float* num_samples)
+{
+  const size_t npix = (size_t)p.width * p.height;
+  if (color) HIPCHK(hipMemcpyAsync(color, p.out_color, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth) HIPCHK(hipMemcpyAsync(depth, p.out_depth, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (num_samples) HIPCHK(hipMemcpyAsync(num_samples, p.out_samples, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->cfg.slab_count > 1)
+    return ctx->fail(RGBDR_ERR_STATE, "a Z slab cannot ray-march alone: use rgbdr_raymarch_find / _shade across the slabs");
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, v, &p);
+  if (rc != RGBDR_OK) return rc;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, 0, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch");
+  return download_view(ctx, p, color, depth, num_samples);
+}
+
+int rgbdr_raymarch_find(rgbdr_ctx* ctx, const rgbdr_view* v, void** first_hit_device)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, v, &p);
+  if (rc != RGBDR_OK) return rc;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, 1, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch_find");
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (first_hit_device) *first_hit_device = p.khit;
+  return RGBDR_OK;
+}
+
+int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!v || ctx->view_w != v->width || ctx->view_h != v->height)
+    return ctx->fail(RGBDR_ERR_STATE, "raymarch_shade needs rgbdr_raymarch_find of the same view first");
+  const int skip = v->skip_space;
+  rgbdr_view v2 = *v;
+  v2.skip_space = 0;  // the peels of the find pass are still in the view buffers
+  RaymarchParams p;
+  int rc = prepare_raymarch(ctx, &v2, &p);
+  if (rc != RGBDR_OK) return rc;
+  p.skip_space = skip ? 1 : 0;
+  launch_raymarch(p, 2, ctx->stream);
+  LAUNCHCHK("raymarch_shade");
+  return download_view(ctx, p, color, depth, num_samples);
+}
+
+int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "fill_colors before raymarch");
+  HIPCHK(hipSetDevice(ctx->device));
+  FillLayout L;
+  make_fill_layout(ctx->view_w, ctx->view_h, &L);
+  const size_t na = (size_t)L.FW * L.H, npix = (size_t)L.W * L.H;
+  const size_t need = na * 10 + npix * 5;  // two atlases (rgba + depth) + the filled frame
+  if (ctx->fill_floats < need) {
+    (void)hipFree(ctx->d_fill);
+    ctx->d_fill = nullptr;
+    ctx->fill_floats = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_fill, need * sizeof(float)));
+    ctx->fill_floats = need;
+  }
+  float4* ncol = (float4*)ctx->d_fill;
+  float4* scol = (float4*)(ctx->d_fill + na * 4);
+  float4* ocol = (float4*)(ctx->d_fill + na * 8);
+  float* ndep = ctx->d_fill + na * 8 + npix * 4;
+  float* sdep = ndep + na;
+  float* odep = sdep + na;
+  tbegin(ctx, "holefill", ctx->stream);
+  launch_fill_colors(L, (const float4*)ctx->d_view, ctx->d_view + npix * 4, ncol, ndep, scol, sdep, ocol, odep,
+                     ctx->stream);
+  tend(ctx, "holefill", ctx->stream);
+  LAUNCHCHK("fill_colors");
+  if (color) HIPCHK(hipMemcpyAsync(color, ocol, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth) HIPCHK(hipMemcpyAsync(depth, odep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+
+int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* color, const float* depth)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (width < 1 || height < 1 || !color || !depth) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view frame");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const size_t npix = (size_t)width * height;
+  int rc = ensure_view_buffers(ctx, npix);
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipMemcpyAsync(ctx->d_view, color, npix * 16, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_view + npix * 4, depth, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->view_w = width;
+  ctx->view_h = height;
+  return RGBDR_OK;
+}
+
+}  // extern "C"

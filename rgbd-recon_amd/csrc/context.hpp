@@ -1,0 +1,176 @@
+// context.hpp -- private to the library: the context behind the opaque rgbdr_ctx of
+// include/rgbdr.h and the helpers the translation units of the C ABI share
+//   api.cpp         lifetime, frames, the per-frame calls, setters / getters, readbacks
+//   api_calib.cpp   calibration volumes: upload, grid-layout arena, inverse-LUT generation
+//   api_view.cpp    consumers of the volume: depth peels, ray-march, hole filling
+//   api_halo.cpp    Z-slab halo staging and the RCCL exchange
+//   api_timers.cpp  TimerDatabase
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rgbdr_internal.hpp"
+
+namespace rgbdr {
+extern thread_local std::string g_create_error;
+
+// One named interval.  In accumulate mode every begin/end takes a fresh event
+// pair so a whole timed region can be resolved afterwards without a host sync
+// inside it (bench.py reads the kernel's average launch duration that way).
+struct Timer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool recorded = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+};
+}  // namespace rgbdr
+
+struct rgbdr_ctx {
+  rgbdr_config cfg{};
+  rgbdr_geometry geo{};
+  int device = 0;
+  hipStream_t stream = nullptr;      // where work is enqueued
+  hipStream_t own_stream = nullptr;  // created with the context
+  // Pipelined mode (RGBDR_FLAG_PIPELINE): upload + pre_* chain + occupied update of
+  // frame k+1 run on pre_stream while integrate of frame k runs on `stream`.  The
+  // only state both touch -- packed frame, occupied mask, occupied count -- is
+  // double buffered; events order producer and consumer of each buffer.
+  hipStream_t pre_stream = nullptr;
+  int wbuf = 0, rbuf = 0;            // buffer the next process_textures writes / the latest one written
+  hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
+  bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
+  bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
+  hipStream_t pstream() const { return pipelined() ? pre_stream : stream; }
+  uint2* frame_buf(int b) const { return d_frame + (size_t)b * cfg.num_sensors * cfg.depth_w * cfg.depth_h; }
+  uint8_t* mask_buf(int b) const { return d_mask + (size_t)b * geo.num_bricks; }
+  uint32_t* count_buf(int b) const { return d_count + 4 * b; }
+  std::string err;
+
+  // images ([N][H][W][c])
+  float *d_depth_raw = nullptr, *d_depth_morph = nullptr, *d_depth_rg = nullptr, *d_lab = nullptr;
+  float *d_depth_b = nullptr, *d_sil = nullptr, *d_normal = nullptr, *d_quality = nullptr;
+  uint2* d_frame = nullptr;
+  uint8_t *d_color = nullptr, *d_depth_u8 = nullptr, *d_color_dxt = nullptr;
+  bool frame_uploaded = false, textures_processed = false;
+
+  // forward calibration
+  float4* d_cv_xyz[rgbdr::kMaxSensors] = {};
+  float2* d_cv_uv[rgbdr::kMaxSensors] = {};
+  uint32_t xyz_res[rgbdr::kMaxSensors][3] = {}, uv_res[rgbdr::kMaxSensors][3] = {};
+  float min_ds[rgbdr::kMaxSensors] = {}, max_ds[rgbdr::kMaxSensors] = {};
+  float cam_pos[rgbdr::kMaxSensors][3] = {};
+  float planes[rgbdr::kMaxSensors][6][4] = {};  // Frustum::getPlanes of cv_xyz
+  bool have_calib[rgbdr::kMaxSensors] = {};
+
+  // inverse calibration
+  bool inv_set[rgbdr::kMaxSensors] = {};
+  bool inv_tiled[rgbdr::kMaxSensors] = {};
+  bool inv_resampled[rgbdr::kMaxSensors] = {};  // tiled planes hold the LUT resampled at voxel centres
+  uint32_t inv_res[rgbdr::kMaxSensors][3] = {};
+  float* d_lut_tiled = nullptr;       // grid-layout LUT planes of the OWNED tile layers ...
+  float* d_lut_tiled_base = nullptr;  // ... inside an allocation with `halo` more layers on each side
+  // double_pbo of NetKinectArray (double_pixel_buffer.cpp:35-81): two page-locked host frame
+  // sets; the producer fills the back one, upload_mapped swaps and DMAs from the front one
+  void* h_depth[2] = {nullptr, nullptr};
+  void* h_color[2] = {nullptr, nullptr};
+  hipEvent_t ev_mapped[2] = {nullptr, nullptr};
+  bool ev_mapped_rec[2] = {false, false};
+  int mapped_back = 0;
+  int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
+  float arena_probe_ms[16] = {0};  // LUT-stream time of each candidate placement of the arena
+  int arena_trials = 0, arena_chosen = 0;
+  float4* d_lut_generic[rgbdr::kMaxSensors] = {};
+  int zoff[rgbdr::kMaxSensors] = {};
+
+  // volume
+  float *d_tsdf_base = nullptr, *d_tsdf_owned = nullptr;
+  size_t layer_floats = 0;
+  int halo = 0;
+  float* d_linear = nullptr;  // readback scratch
+  size_t linear_floats = 0;
+  float* d_view = nullptr;    // ray-march outputs: rgba, depth, samples
+  size_t view_pixels = 0;
+  int view_w = 0, view_h = 0; // size of the last ray-marched frame
+  float* d_fill = nullptr;    // hole-fill atlases (2 x colour + depth) and the filled frame
+  size_t fill_floats = 0;
+  bool integrated = false;
+
+  // bricks
+  uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
+  bool clear_pending = false;       // clearOccupiedBricks was called; the zeroing rides on the next k_morph
+  uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
+  uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
+  int tile_count_parity = 0;        // which of the two list counters the next brick sweep appends to
+  // halo staging for Z slabs: two sets of (lower face, upper face) buffers of `halo` tile layers
+  float* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int stage_target = -1;            // set the next integrate fills (-1: none)
+  // managed halo exchange (api_halo.cpp): side stream, per staging set "staged" / "transfer done" events
+  hipStream_t halo_stream = nullptr;
+  hipEvent_t ev_halo_staged[2] = {nullptr, nullptr}, ev_halo_done[2] = {nullptr, nullptr};
+  bool halo_done_rec[2] = {false, false};
+  bool halo_begun = false;
+  unsigned halo_step = 0;
+  int halo_last = -1;
+  uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
+  uint8_t* d_mask = nullptr;
+  bool mask_valid = false;
+  // brick -> voxel membership of divideBox / containedVoxels (geometry.cpp compute_brick_tables):
+  // device copy of vox[x] | vox[y] | vox[z] | tile[x] | tile[y] | tile[z]
+  rgbdr::BrickTables bt;
+  uint32_t* d_brick_tab = nullptr;
+
+  bool timers = false, accumulate = false;
+  int timer_detail = 2;  // 1: only "1preprocess" / "2integrate" / "bricks" ...; 2: also the five pre_* passes
+  std::map<std::string, rgbdr::Timer> tm;
+
+  int fail(int code, const std::string& m)
+  {
+    err = m;
+    return code;
+  }
+};
+
+#define HIPCHK(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess)                                                                                  \
+      return ctx->fail(RGBDR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+#define LAUNCHCHK(what)                                                                                    \
+  do {                                                                                                     \
+    hipError_t e_ = hipGetLastError();                                                                     \
+    if (e_ != hipSuccess) return ctx->fail(RGBDR_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+namespace rgbdr {
+// device scratch that is released on every return path (HIPCHK / LAUNCHCHK return early)
+struct DevScratch {
+  void* p = nullptr;
+  ~DevScratch() { (void)hipFree(p); }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+inline int nsens(const rgbdr_ctx* c) { return c->cfg.num_sensors; }
+inline size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->cfg.depth_w * c->cfg.depth_h; }
+
+// api.cpp
+int bump_clear_epoch(rgbdr_ctx* ctx);   // invalidates every recorded "this tile already holds -limit"
+int sync_all(rgbdr_ctx* ctx);           // drain both streams
+int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
+// api_timers.cpp
+void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);
+void tend(rgbdr_ctx* c, const char* name, hipStream_t st);
+void destroy_timers(rgbdr_ctx* c);
+// api_calib.cpp
+// Tile layers [t0, t1) of the grid-layout LUT that are resident: the owned layers plus
+// `halo` layers on each side where the volume has them; dst = where layer t0 lives.
+struct LutExtent {
+  int t0, t1, vz0, vz1;
+  float* dst;
+};
+LutExtent lut_extent(const rgbdr_ctx* ctx);
+}  // namespace rgbdr
+

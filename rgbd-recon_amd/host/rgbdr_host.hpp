@@ -219,13 +219,16 @@ class Backend {
     check(nullptr, rgbdr_create(&c, device, &raw));
     m_ctx.reset(raw, rgbdr_destroy);
     m_num = cf.num();
+    m_cfg = c;
   }
   rgbdr_ctx* ctx() const { return m_ctx.get(); }
   unsigned num() const { return m_num; }
+  rgbdr_config const& config() const { return m_cfg; }
 
  private:
   std::shared_ptr<rgbdr_ctx> m_ctx;
   unsigned m_num = 0;
+  rgbdr_config m_cfg{};
 };
 
 // kinect::CalibVolumes
@@ -284,6 +287,7 @@ class CalibVolumes {
       if (!ok) throw std::runtime_error("short write to " + out);
     }
   }
+  Backend& backend() const { return m_be; }
   std::vector<std::array<float, 3>> getCameraPositions() const
   {
     std::vector<std::array<float, 3>> out(m_cv_xyz_filenames.size());
@@ -316,6 +320,12 @@ inline void readStreamFrame(std::string const& path, size_t colorsize, size_t de
 class NetKinectArray {
  public:
   explicit NetKinectArray(Backend& be) : m_be(be) {}
+  // the reference's constructor arguments that concern the hot path (NetKinectArray.cpp:42: serverport and
+  // slaveport are transport and stay outside); both objects share the backend of `vols`
+  NetKinectArray(CalibrationFiles const* calibs, CalibVolumes const* vols) : m_be(vols->backend())
+  {
+    if (!calibs || calibs->num() != m_be.num()) throw std::invalid_argument("calibration files do not match the calibration volumes");
+  }
   // bool NetKinectArray::update(): upload the newest frame set
   bool update(const void* depth_all_sensors, const void* color_all_sensors)
   {
@@ -391,6 +401,21 @@ class NetKinectArray {
 class ReconIntegration {
  public:
   explicit ReconIntegration(Backend& be) : m_be(be) {}
+  // ReconIntegration(CalibrationFiles const&, CalibVolumes const*, gloost::BoundingBox const&, float limit,
+  // float size), recon_integration.cpp:30, as kinect_client.cpp:252 calls it.  The volume lives in the
+  // backend `cv` was built on, whose box must be `bbox`; limit and voxel size are applied like the
+  // constructor's setTsdfLimit / setVoxelSize (a changed voxel size reallocates the grid: load the
+  // inverse calibration volumes afterwards).
+  ReconIntegration(CalibrationFiles const& cfs, CalibVolumes const* cv, BoundingBox const& bbox, float limit, float size)
+      : m_be(cv->backend())
+  {
+    if (cfs.num() != m_be.num()) throw std::invalid_argument("calibration files do not match the calibration volumes");
+    for (int a = 0; a < 3; ++a)
+      if (bbox.getPMin()[a] != m_be.config().bbox_min[a] || bbox.getPMax()[a] != m_be.config().bbox_max[a])
+        throw std::invalid_argument("bounding box differs from the one the backend was created with");
+    setTsdfLimit(limit);
+    if (size != m_be.config().voxel_size) setVoxelSize(size);
+  }
   void integrate() { check(m_be.ctx(), rgbdr_integrate(m_be.ctx())); }
   void clearOccupiedBricks() const { check(m_be.ctx(), rgbdr_clear_occupied_bricks(m_be.ctx())); }
   void updateOccupiedBricks() { check(m_be.ctx(), rgbdr_update_occupied_bricks(m_be.ctx())); }
@@ -450,6 +475,39 @@ class ReconIntegration {
  private:
   Backend& m_be;
   bool m_fill_holes = true, m_skip_space = true;  // defaults of recon_integration.cpp:60-63
+};
+
+// The per-step halo exchange of a host that splits the volume into Z slabs, one context per GPU
+// (the reference is single-GPU and has no counterpart).  `nccl_comm` is the host's
+// ncclComm_t over the slab ranks (rank r owns slab r); the library binds RCCL at run time, so this
+// header needs neither HIP nor RCCL headers.  Per frame:
+//   halo.beginStep(); recon.integrate(); halo.exchangeAsync();      // transfer k overlaps frame k+1
+// and halo.wait() before anything samples across slab faces (drawing).  With `loopback` both
+// neighbours are `self_rank` (an inner slab exchanging with itself: tests on one GPU).
+class HaloExchanger {
+ public:
+  HaloExchanger(Backend& be, void* nccl_comm, int slab_rank, int slab_count, bool loopback = false, int self_rank = 0)
+      : m_be(be), m_comm(nccl_comm)
+  {
+    if (!nccl_comm) throw std::invalid_argument("null communicator");
+    m_lo = loopback ? self_rank : (slab_rank > 0 ? slab_rank - 1 : -1);
+    m_hi = loopback ? self_rank : (slab_rank < slab_count - 1 ? slab_rank + 1 : -1);
+  }
+  void beginStep() { check(m_be.ctx(), rgbdr_halo_begin_step(m_be.ctx())); }
+  void exchangeAsync() { check(m_be.ctx(), rgbdr_halo_exchange_async(m_be.ctx(), m_comm, m_lo, m_hi)); }
+  void wait() { check(m_be.ctx(), rgbdr_halo_wait(m_be.ctx())); }
+  // TimerDatabase::duration("halo") in ms: the last transfer (timers must be enabled)
+  double lastTransferMs() const
+  {
+    uint64_t ns = 0;
+    check(m_be.ctx(), rgbdr_timer_ns(m_be.ctx(), "halo", &ns));
+    return (double)ns * 1e-6;
+  }
+
+ private:
+  Backend& m_be;
+  void* m_comm;
+  int m_lo = -1, m_hi = -1;
 };
 
 // process_textures() of source/kinect_client.cpp:572-580

@@ -2,6 +2,7 @@
 NetKinectArray / ReconIntegration over the C ABI) driven by the example frame
 loop, fed with calibration volumes and a recorded .stream frame in the reference's
 on-disk formats."""
+import ctypes as C
 import os
 import subprocess
 
@@ -167,3 +168,72 @@ def test_calib_inverter_tool(pkg, orc, tmp_path):
         assert 0.02 < (got[..., 3] == 1.0).mean() < 0.98       # inside / outside the frustum
     ctx.close()
     assert subprocess.run([exe, os.path.join(d, "scene.txt")], capture_output=True).returncode == 1   # "No .ks file specified"
+
+
+SLAB_EXE = os.path.join(ROOT, "rgbd-recon_amd", "host", "slab_loop")
+
+
+def test_slab_loop_is_built_against_rccl_and_the_c_abi():
+    assert os.path.exists(SLAB_EXE), "run __graft_entry__.build()"
+    out = subprocess.run(["ldd", SLAB_EXE], capture_output=True, text=True).stdout
+    assert "librgbdr_hip.so" in out and "librccl" in out and "not found" not in out
+    assert subprocess.run([SLAB_EXE], capture_output=True).returncode == 2      # usage
+    # the library itself has no link-time dependency on RCCL (it is bound at run time)
+    lib = subprocess.run(["ldd", os.path.join(ROOT, "rgbd-recon_amd", "librgbdr_hip.so")], capture_output=True, text=True).stdout
+    assert "librccl" not in lib
+
+
+@pytest.mark.gpu
+def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path):
+    """The C++ host's multi-GPU frame loop (host/slab_loop.cpp: host::HaloExchanger over
+    rgbdr_halo_begin_step / _exchange_async / _wait, RCCL bound at run time by the library) as an
+    inner Z slab whose two neighbours are the process itself: four different frames with no host
+    synchronisation in between; afterwards the halo layers hold the boundary layers of the LAST frame."""
+    capi, synth = pkg.capi, pkg.synth
+    n, W, H, G, frames = 2, 128, 106, 96, 4
+    scenes = [synth.Scene(n, W, H, lut_res=(32, 27, 32), seed=1 + k, sphere_r=0.9 - 0.05 * k) for k in range(frames)]
+    first = scenes[0]
+    inv = first.inverse((G, G, G))
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "recordings"))
+    for i in range(n):
+        assert orc.lut_write(os.path.join(d, "s%d.cv_xyz" % i), first.xyz[i], 3) == 0
+        assert orc.lut_write(os.path.join(d, "s%d.cv_uv" % i), first.uv[i], 2) == 0
+        assert orc.lut_write(os.path.join(d, "s%d.cv_xyz_inv" % i), inv[i], 4) == 0
+        with open(os.path.join(d, "recordings", "s%d.stream" % i), "wb") as f:
+            for k in range(frames):
+                f.write(scenes[k].color[i].tobytes())
+                f.write(scenes[k].depth[i].tobytes())
+    out = os.path.join(d, "halo.bin")
+    r = subprocess.run([SLAB_EXE, d, str(n), str(W), str(H), str(G), str(frames), out, "--loopback"], capture_output=True,
+                       text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    raw = np.fromfile(out, dtype=np.uint8)
+    h, layer = np.frombuffer(raw[:8].tobytes(), dtype=np.int32)
+    body = np.frombuffer(raw[8:8 + 16 * h * layer].tobytes(), dtype=np.float32).reshape(4, h * layer)
+    ms = np.frombuffer(raw[8 + 16 * h * layer:].tobytes(), dtype=np.float64)[0]
+    halo_lo, face_lo, face_hi, halo_hi = body
+    # loopback: the lower face comes back through the "neighbour below" into the lower halo, the upper into the upper
+    assert same_bits(halo_lo, face_lo) and same_bits(halo_hi, face_hi)
+    assert ms > 0
+    # the faces are those of the LAST frame: slab 1 of 4 of a context fed the frames one by one
+    cfg = capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=1, slab_count=4)
+    ctx = capi.Context(cfg, 0)
+    assert ctx.geo.halo_tile_layers == h
+    for i in range(n):
+        ctx.set_calibration(i, first.xyz[i], first.lut_res, first.uv[i], first.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.set_use_bricks(False)
+    faces = []
+    for k in range(frames):
+        ctx.step(scenes[k].depth, scenes[k].color)
+        v = ctx.device_tsdf()
+        lo = np.empty(h * layer, np.float32)
+        hi = np.empty(h * layer, np.float32)
+        ctx._chk(capi.lib().rgbdr_readback_tile_layers(ctx._h, h, h, lo.ctypes.data_as(C.POINTER(C.c_float))))
+        ctx._chk(capi.lib().rgbdr_readback_tile_layers(ctx._h, v.owned_layers, h, hi.ctypes.data_as(C.POINTER(C.c_float))))
+        faces.append((lo, hi))
+    ctx.close()
+    assert same_bits(face_lo, faces[-1][0]) and same_bits(face_hi, faces[-1][1])
+    assert not same_bits(faces[-1][0], faces[-2][0])             # the frames differ at the faces
+    assert np.nanmax(np.abs(face_lo)) > 0
