@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librgbdr_oracle.so")
+# RGBDR_ORACLE_LIB: a differently built copy of the oracle (tests/mutation_check.py loads its mutants that way)
+LIB_PATH = os.environ.get("RGBDR_ORACLE_LIB") or os.path.join(HERE, "librgbdr_oracle.so")
 REF_PATH = os.path.join(HERE, "_ref", "libref_shim.so")
 _F = C.POINTER(C.c_float)
 

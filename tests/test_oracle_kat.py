@@ -73,6 +73,11 @@ def test_morph_keeps_valid_fills_holes(orc):
     e = np.zeros((5, 5), np.float32)
     assert np.array_equal(orc.morph(e, 0), e)          # nothing valid -> 0
     assert np.array_equal(orc.morph(d, 1), d)          # mode 1 = copy (pre_morph.fs:130-131)
+    # is_valid is 0.5 < d < 4.5, both strict (:36-39): exactly 0.5 m and 4.5 m are holes and get filled
+    for edge in (0.5, 4.5):
+        d = np.full((5, 5), 2.0, np.float32)
+        d[2, 2] = edge
+        assert orc.morph(d, 0)[2, 2] == 2.0
 
 
 def test_morph_second_mean_rejects_outliers(orc):
@@ -128,10 +133,24 @@ def test_boundary_classes(orc):
     lab2[4, 4] = (5.0, 0.0, 0.0)         # colour differs from the neighbourhood by > 0.5
     db3, _ = orc.boundary(rg, lab2, refine=True)
     assert tuple(db3[4, 4]) == (-1.0, np.float32(0.1))
+    # the confidence threshold is 0.65 (pre_boundary.fs:102): 0.66 is interior, 0.64 goes through the edge test
+    rg5 = rg.copy()
+    rg5[4, 4] = (0.4, 0.66)
+    rg5[6, 6] = (0.4, 0.64)
+    db5, sil5 = orc.boundary(rg5, lab, refine=True)
+    assert tuple(db5[4, 4]) == (np.float32(0.4), 0.0) and sil5[4, 4] == 1.0
+    assert tuple(db5[6, 6]) == (np.float32(0.4), 1.0) and sil5[6, 6] == 0.0
     rg4 = rg.copy()
     rg4[2:7, 2:7, 1] = 0.3               # fewer than 8 confident neighbours -> colour distance 1
     db4, _ = orc.boundary(rg4, lab, refine=True)
     assert tuple(db4[4, 4]) == (-1.0, np.float32(0.1))
+    # num_samples < total_samples * 0.5 = 8 (pre_boundary.fs:53): 7 confident neighbours of identical colour are not enough, 8 are
+    rg7 = rg4.copy()
+    rg7[2, 2:7, 1] = 0.9
+    rg7[3, 2:4, 1] = 0.9
+    assert tuple(orc.boundary(rg7, lab, refine=True)[0][4, 4]) == (-1.0, np.float32(0.1))
+    rg7[3, 4, 1] = 0.9
+    assert tuple(orc.boundary(rg7, lab, refine=True)[0][4, 4]) == (np.float32(0.4), 1.0)
 
 
 # ---- integration (SURVEY 8c i-iv) ------------------------------------------
@@ -181,6 +200,42 @@ def test_two_sensors_weighted_mean_and_order(orc):
     t2 = run([near_, far_])      # near in band, then far overwrites with -limit
     assert abs(t1[40, 0, 0] + 0.001) < 1e-6
     assert t2[40, 0, 0] == np.float32(-LIMIT)
+
+
+def test_silhouette_overwrites_only_an_untouched_voxel(orc):
+    # tsdf_integration.vs:33-38: `if (silhouette < 1.0) { if (weighted_tsd >= limit) { weighted_tsd = -limit; continue; } }`
+    # -- a sensor whose silhouette is 0 there clears the voxel only while no sensor has written it; once a value
+    # is in the band the same sensor is evaluated like any other (its depth and quality are still sampled)
+    G = 64
+    inv = identity_inverse(G)
+    zc = (31 + 0.5) / G
+    seen = plane_frame(4, 4, zc - 0.004, q=1.0)              # sdist +0.004, silhouette 1
+    sil0 = list(plane_frame(4, 4, zc - 0.008, q=1.0))        # sdist +0.008 but silhouette 0
+    sil0[0] = np.zeros((4, 4), np.float32)
+    run = lambda fr: orc.integrate([inv, inv], [f[0] for f in fr], [f[1] for f in fr], [f[2] for f in fr],
+                                   (G, G, G), LIMIT)
+    assert abs(run([seen, sil0])[31, 1, 1] - 0.006) < 1e-6   # already written: the mean of both
+    assert abs(run([sil0, seen])[31, 1, 1] - 0.004) < 1e-6   # untouched: cleared to -limit (weight 0), then `seen` alone
+    only = orc.integrate([inv], [sil0[0]], [sil0[1]], [sil0[2]], (G, G, G), LIMIT)
+    assert only[31, 1, 1] == np.float32(-LIMIT)
+
+
+def test_sdist_equal_to_the_limit_leaves_the_voxel_untouched(orc):
+    # :46-54: `sdist <= -limit` -> -limit, `sdist >= limit` -> nothing (neither value nor weight), else weighted mean.
+    # limit = 1/64 and a surface exactly 1/64 in front of / behind the voxel centre: every quantity is exact.
+    G, lim = 16, 1.0 / 64
+    inv = identity_inverse(G)
+    zc = (7 + 0.5) / G
+    at_plus, inband = plane_frame(4, 4, zc - lim, q=1.0), plane_frame(4, 4, zc - lim / 2, q=1.0)
+    run = lambda fr: orc.integrate([inv, inv], [f[0] for f in fr], [f[1] for f in fr], [f[2] for f in fr],
+                                   (G, G, G), lim)
+    # sdist == +limit contributes no weight: the in-band sensor's value stands alone, in either order
+    assert run([at_plus, inband])[7, 0, 0] == np.float32(lim / 2)
+    assert run([inband, at_plus])[7, 0, 0] == np.float32(lim / 2)
+    # sdist == -limit overwrites with -limit
+    at_minus = plane_frame(4, 4, zc + lim, q=1.0)
+    assert run([inband, at_minus])[7, 0, 0] == np.float32(-lim)
+    assert run([at_minus, inband])[7, 0, 0] == np.float32(lim / 2)       # (-limit * 0 + 1 * s) / 1
 
 
 def test_all_invalid_lut_gives_minus_limit(orc):

@@ -106,6 +106,15 @@ def test_bilateral_skips_taps_outside_the_calibrated_range(orc):
     rg = run_pre_depth(orc, d)
     gr = 1.0 - 0.02 / (0.35 * 0.6 / 4.5)
     assert abs(rg[6, 6, 1] - (165 + gr) / 169) < 2e-6
+    # a tap that ONLY the calibrated range excludes: centre 0.52 m (threshold 0.0404), taps at 0.49 m are 0.03 away
+    d = np.full((13, 13), 0.52, np.float32)
+    d[3, 2:6] = 0.49
+    rg = run_pre_depth(orc, d)
+    assert rg[6, 6, 1] == F(165.0) / F(169.0) and abs(rg[6, 6, 0] - 0.02 / 4.0) < 1e-6
+    # ... and likewise above cv_max_ds: centre 4.45 m (threshold 0.346), taps at 4.6 m
+    d = np.full((13, 13), 4.45, np.float32)
+    d[9, 2:7] = 4.6
+    assert run_pre_depth(orc, d)[6, 6, 1] == F(164.0) / F(169.0)
 
 
 def test_unfiltered_and_out_of_box_outputs(orc):
@@ -275,6 +284,12 @@ def test_quality_counts_invalid_and_distant_taps_as_border(orc):
     assert abs(quality_at(orc, db, (0, 0, -1), cam_in_front(d)) - want) < 2e-6
     db[2:15, 3, 0] = 1.0                                   # depth 1.0 is outside (d >= 1)
     assert abs(quality_at(orc, db, (0, 0, -1), cam_in_front(d)) - want) < 2e-6
+    # taps that ONLY is_outside excludes: centre 0.9 (threshold 0.315), a column at exactly 1.0 / at 1.05
+    for outside in (1.0, 1.05):
+        db = frame(0.9)
+        db[2:15, 3, 0] = outside
+        want9 = (156 / 169) ** 12 / (6.5 * 0.9)
+        assert abs(quality_at(orc, db, (0, 0, -1), cam_in_front(0.9)) - want9) < 2e-6
 
 
 def test_quality_range_weight_of_near_taps(orc):
