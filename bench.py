@@ -38,6 +38,29 @@ GRID_FOR_GPUS = {1: (512, 512, 512), 2: (512, 512, 1024), 4: (512, 1024, 1024), 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
 
+def choose_workload(world, loopback=False, weak=False, sensors=0, cubic_grid=0):
+    """Which BASELINE.json config a run with `world` GPUs is: (sensors, grid, config string, scaling)."""
+    if world == 1 or loopback or weak:
+        n = sensors or 4
+        grid = GRID_FOR_GPUS.get(world, (512, 512, 512))
+        cfg = "configs[2]: 4 sensors, 512^3 TSDF, full pre_* depth-filter chain on 1 MI355X" if world == 1 and not loopback \
+            else "weak-scaling grid (not a BASELINE config)"
+        scaling = "weak"
+    elif world == 8:
+        n = sensors or 8
+        grid = (1024, 1024, 1024)
+        cfg = "configs[4]: 8 sensors, 1024^3 TSDF across 8 MI355X + tsdf_colorfill/inpaint post-pass"
+        scaling = "weak"                 # 134 M voxels per GPU, like the 512^3 of one GPU
+    else:
+        n = sensors or 8
+        grid = (512, 512, 512)
+        cfg = "configs[3]: 8 sensors, 512^3 TSDF, Z-slab split across %d MI355X with RCCL brick-halo over xGMI" % world
+        scaling = "strong"
+    if cubic_grid:
+        grid = (cubic_grid,) * 3
+    return n, grid, cfg, scaling
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,25 +116,7 @@ def main():
     from rgbd_recon_amd import dist as rdist
 
     W, H = 512, 424
-    # which BASELINE.json config this run is
-    if world == 1 or loop or args.weak:
-        N = args.sensors or 4
-        grid = GRID_FOR_GPUS.get(world, (512, 512, 512))
-        baseline_config = "configs[2]: 4 sensors, 512^3 TSDF, full pre_* depth-filter chain on 1 MI355X" if world == 1 and not loop \
-            else "weak-scaling grid (not a BASELINE config)"
-        scaling = "weak"
-    elif world == 8:
-        N = args.sensors or 8
-        grid = (1024, 1024, 1024)
-        baseline_config = "configs[4]: 8 sensors, 1024^3 TSDF across 8 MI355X + tsdf_colorfill/inpaint post-pass"
-        scaling = "weak"                 # 134 M voxels per GPU, like the 512^3 of one GPU
-    else:
-        N = args.sensors or 8
-        grid = (512, 512, 512)
-        baseline_config = "configs[3]: 8 sensors, 512^3 TSDF, Z-slab split across %d MI355X with RCCL brick-halo over xGMI" % world
-        scaling = "strong"
-    if args.grid:
-        grid = (args.grid,) * 3
+    N, grid, baseline_config, scaling = choose_workload(world, loop, args.weak, args.sensors, args.grid)
     if loop:
         grid = (512, 512, 2048)          # four slabs of 512^3; this process is an inner one
     slab_rank, slab_count = (1, 4) if loop else (rank, world)

@@ -23,6 +23,10 @@ constexpr int BX = 16, BY = 16;   // pixel block
 constexpr int R13 = 6;            // 13x13 window radius
 constexpr int TW = BX + 2 * R13;  // 28
 constexpr int TH = BY + 2 * R13;
+// LDS row pitch of the 13x13 windows: a 32-lane ds_read_b32 group holds two 16-pixel rows of a wavefront;
+// 48 = 16 (mod 32) puts them on disjoint halves of the 32 banks (pitch 29 spent 49 % of the LDS cycles on
+// conflicts, profiles/r01_pmc_summary_v10.json)
+constexpr int TPITCH = 48;
 
 // 1 - length(vec2(x,y)) * (1/6) for x,y in [-6,6], filled by the host with the
 // same correctly-rounded sqrtf (pre_depth.fs:37-41,115)
@@ -224,7 +228,9 @@ __device__ __forceinline__ float3 rgb_to_lab(float3 rgb)
   return make_float3(fmaxf(0.0f, 116.0f * y - 16.0f), 500.0f * (x - y), 200.0f * (y - z));
 }
 
-__device__ __forceinline__ float3 color_bilinear(const uint8_t* __restrict__ img, int W, int H, float u, float v)
+// `unorm` = LDS table of i / 255.0f (twelve correctly rounded divisions per pixel otherwise)
+__device__ __forceinline__ float3 color_bilinear(const uint8_t* __restrict__ img, int W, int H, float u, float v,
+                                                 const float* unorm)
 {
   const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
   const uint8_t* p00 = img + ((size_t)Y.i0 * W + X.i0) * 3;
@@ -234,8 +240,8 @@ __device__ __forceinline__ float3 color_bilinear(const uint8_t* __restrict__ img
   float c[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float t00 = (float)p00[k] / 255.0f, t10 = (float)p10[k] / 255.0f;
-    const float t01 = (float)p01[k] / 255.0f, t11 = (float)p11[k] / 255.0f;
+    const float t00 = unorm[p00[k]], t10 = unorm[p10[k]];
+    const float t01 = unorm[p01[k]], t11 = unorm[p11[k]];
     c[k] = lerpf(lerpf(t00, t10, X.a), lerpf(t01, t11, X.a), Y.a);
   }
   return make_float3(c[0], c[1], c[2]);
@@ -251,7 +257,8 @@ __device__ __forceinline__ float pd_uncompress(float d, bool compress, float sca
 
 __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
 {
-  __shared__ float tile[TH][TW + 1];
+  __shared__ float tile[TH][TPITCH];
+  __shared__ float unorm[256];  // i / 255.0f: what the sampler returns for a u8 colour channel
   const int l = blockIdx.z;
   const int W = p.W, H = p.H;
   const float* depth = p.depth_in + (size_t)l * W * H;
@@ -264,6 +271,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   // the range test |ds - depth| > dist_range_max alone rejects them (NaN taps stay NaN, as they pass
   // all three tests in the shader).  A non-finite centre depth takes the three-test loop.
   const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
+  unorm[threadIdx.y * BX + threadIdx.x] = (float)(threadIdx.y * BX + threadIdx.x) / 255.0f;  // 256 threads, 256 entries
   for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
     const int ty = i / TW, tx = i - ty * TW;
     const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
                       pw.x <= p.bbox_max[0] && pw.y <= p.bbox_max[1] && pw.z <= p.bbox_max[2];
   const float dn_c = (depth_norm <= 0.0f || depth_norm >= 1.0f) ? 1.0f : depth_norm;
   const float2 cc = tex3d_uv(p.cv_uv[l], p.uv_res[l][0], p.uv_res[l][1], p.uv_res[l][2], u, v, dn_c);
-  const float3 rgb = color_bilinear(p.color + (size_t)l * p.Wc * p.Hc * 3, p.Wc, p.Hc, cc.x, cc.y);
+  const float3 rgb = color_bilinear(p.color + (size_t)l * p.Wc * p.Hc * 3, p.Wc, p.Hc, cc.x, cc.y, unorm);
   const float3 lab = rgb_to_lab(rgb);
   p.lab[o * 3 + 0] = lab.x;
   p.lab[o * 3 + 1] = lab.y;
@@ -508,7 +516,7 @@ void launch_normal(const PreParams& p, hipStream_t s)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
 {
-  __shared__ float tile[TH][TW + 1];
+  __shared__ float tile[TH][TPITCH];
   const int l = blockIdx.z;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;

@@ -37,6 +37,13 @@ def test_bench_line_contract():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mvoxels/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["parity_rows_bit_exact"] is True and c["parity_rows"] == 64
+    # box calibration: a replay of the kernel's memory streams on the same box, and the GPU state beside it
+    assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
+    assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
+    assert "4 sensors" in j["metric"] and "512^3" in j["metric"] and j["config"]["baseline_config"].startswith("configs[2]")
+    for extra in ("post_pass", "host_fed", "reference_defaults", "bricked", "other_schedule", "full_sweep_store_elision"):
+        assert extra in j and "error" not in j[extra], (extra, j[extra])
+    assert j["post_pass"]["raymarch_ms"] > 0 and j["post_pass"]["holefill_ms"] > 0 and j["post_pass"]["brickdraw_ms"] > 0
     assert j["bricked"]["ms_per_step"] < j["ms_per_step"]
     assert j["full_sweep_store_elision"]["ms_per_step"] < 1.02 * j["ms_per_step"]
 

@@ -522,6 +522,73 @@ def test_external_stream(pkg):
     ctx.close()
 
 
+def test_device_images_alias_what_readback_returns(pkg):
+    """rgbdr_device_image: zero-copy views for consumers that stay on the device (the textures the other
+    Reconstructions bind, recon_trigrid.cpp:30-33) -- every view is the memory rgbdr_readback_image copies from"""
+    import torch
+
+    from rgbd_recon_amd import dist as rdist
+
+    capi = pkg.capi
+    scene, ctx, inv = build(pkg)
+    ctx.step(scene.depth, scene.color)
+    ctx.sync()
+    dev = torch.device("cuda", 0)
+    for which in range(8):
+        for sensor in range(2):
+            v = ctx.device_image(which, sensor)
+            ch = capi.IMG_CHANNELS[which]
+            assert (v.width, v.height, v.channels, v.element_bytes) == (128, 106, ch, 4) and v.stream
+            t = rdist.wrap_device_floats(v.ptr, 128 * 106 * ch, dev).cpu().numpy().reshape(106, 128, ch)
+            want = ctx.readback_image(which, sensor).reshape(106, 128, ch)
+            assert same_bits(t, want), (which, sensor)
+    v = ctx.device_image(capi.IMG_COLOR, 1)
+    assert (v.width, v.height, v.channels, v.element_bytes) == (128, 106, 3, 1)
+    class U8:
+        __cuda_array_interface__ = {"shape": (128 * 106 * 3,), "typestr": "|u1", "data": (int(v.ptr), False), "version": 2}
+
+    raw = torch.as_tensor(U8(), device=dev)
+    assert np.array_equal(raw.cpu().numpy().reshape(106, 128, 3), ctx.readback_color(1))
+    # writing through the view is visible to the next consumer of the image (it IS the texture)
+    q = ctx.device_image(capi.IMG_QUALITY, 0)
+    rdist.wrap_device_floats(q.ptr, 128 * 106, dev).fill_(0.25)
+    torch.cuda.synchronize()
+    assert np.all(ctx.readback_image(capi.IMG_QUALITY, 0) == np.float32(0.25))
+    with pytest.raises(capi.RgbdrError):
+        ctx.device_image(9, 0)
+    with pytest.raises(capi.RgbdrError):
+        ctx.device_image(0, 2)
+    ctx.close()
+
+
+def test_inverse_luts_of_mixed_resolutions_in_one_context(pkg, orc):
+    """sensor 0 with a LUT 1:1 with the grid, sensor 1 with a coarser one (both end up in the grid layout);
+    and with RGBDR_FLAG_NO_RESAMPLE both stay in the file layout -- each against the oracle, which samples the
+    LUTs at their own resolutions"""
+    capi, synth = pkg.capi, pkg.synth
+    G = 64
+    for flags in (capi.FLAGS_DEFAULT, capi.FLAGS_DEFAULT | capi.FLAG_NO_RESAMPLE):
+        scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=1234)
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags), 0)
+        inv = [synth.inverse_lut(scene.sensors[0], (G, G, G)), synth.inverse_lut(scene.sensors[1], (45, 50, 41))]
+        for i in range(2):
+            ctx.set_calibration(i, scene.xyz[i], (32, 27, 32), scene.uv[i], (32, 27, 32), (0.5, 4.5))
+        ctx.set_inverse_calibration(0, inv[0], (G, G, G))
+        ctx.set_inverse_calibration(1, inv[1], (45, 50, 41))
+        for bricks in (True, False):
+            ctx.set_use_bricks(bricks)
+            ctx.step(scene.depth, scene.color)
+            ref = oracle_run(orc, scene, ctx, inv, use_bricks=bricks)
+            assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (flags, bricks, count_diff(ctx.readback_tsdf(), ref["tsdf"]))
+        # replacing one sensor's LUT by another resolution afterwards keeps working
+        inv[0] = synth.inverse_lut(scene.sensors[0], (50, 64, 37))
+        ctx.set_inverse_calibration(0, inv[0], (50, 64, 37))
+        ctx.step(scene.depth, scene.color)
+        ref = oracle_run(orc, scene, ctx, inv, use_bricks=False)
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+        ctx.close()
+
+
 def test_pipelined_mode_is_schedule_only(pkg):
     """RGBDR_FLAG_PIPELINE overlaps the pre_* chain of frame k+1 with integrate of
     frame k on two streams with double-buffered frames/masks; results per frame are
@@ -535,6 +602,8 @@ def test_pipelined_mode_is_schedule_only(pkg):
         ctx.step(f, scene.color)
         want.append(ctx.readback_tsdf())
         occ.append(ctx.get_occupied()[0])
+    want_quality = ctx.readback_image(7, 1)          # quality image of the last frame, sequential schedule
+    want_depth_b = ctx.readback_image(4, 0)
     ctx.set_pipelined(True)
     for rounds in range(2):
         for k, f in enumerate(frames):
@@ -544,7 +613,7 @@ def test_pipelined_mode_is_schedule_only(pkg):
                 assert np.array_equal(ctx.get_occupied()[0], occ[k])
         # second round: frames queued back to back, only the last one is inspected
     assert same_bits(ctx.readback_tsdf(), want[-1])
-    assert same_bits(ctx.readback_image(7, 1), ctx.readback_image(7, 1))
+    assert same_bits(ctx.readback_image(7, 1), want_quality) and same_bits(ctx.readback_image(4, 0), want_depth_b)
     # the brick-skipping sweep reads the right mask buffer
     ctx.set_pipelined(False)
     ctx.step(frames[2], scene.color)
@@ -581,28 +650,31 @@ def test_dxt_compressed_colour_frames(pkg, orc, mode):
 
 
 def test_lut_arena_placement_probe(pkg, monkeypatch):
-    """arenas of 256 MiB and more are placed by timing candidate allocations; the choice
-    never changes a result (same TSDF with the probe off)"""
-    import os
-
+    """placing the LUT arena by timing candidate allocations is opt-in (RGBDR_ARENA_TRIALS=n, arenas of 256 MiB
+    and more); by default the first allocation is taken and nothing is probed.  The choice never changes a
+    result, and a probe leaves the volume cleared and marked as not integrated."""
     out = []
-    for trials in ("1", None):
+    for trials in (None, "1", "4"):
         if trials:
             monkeypatch.setenv("RGBDR_ARENA_TRIALS", trials)
         else:
-            monkeypatch.delenv("RGBDR_ARENA_TRIALS")
+            monkeypatch.delenv("RGBDR_ARENA_TRIALS", raising=False)
         scene, ctx, _ = build(pkg, n=2, G=256, lut_res=(32, 27, 32))         # 2 x 256^3 x 12 B = 403 MB arena
         ms, kept = ctx.arena_probe()
-        if trials:
-            assert len(ms) == 1 and kept == 0
-        else:
-            assert 1 <= len(ms) <= 16 and 0 <= kept < len(ms) and all(m > 0 for m in ms)
+        if trials == "4":
+            assert 1 <= len(ms) <= 4 and 0 <= kept < len(ms) and all(m > 0 for m in ms)
             assert ms[kept] == min(ms)
+            view = pkg.capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 32, 24, BMIN, BMAX)
+            with pytest.raises(pkg.capi.RgbdrError):                          # the probe's replay wrote into the volume
+                ctx.raymarch(view)
+        else:
+            assert ms == [0.0] and kept == 0                                  # default and "1": no probing
         ctx.set_use_bricks(False)
         ctx.step(scene.depth, scene.color)
         out.append(ctx.readback_tsdf())
         ctx.close()
-    assert same_bits(out[0], out[1])
+    assert same_bits(out[0], out[1]) and same_bits(out[0], out[2])
+    monkeypatch.setenv("RGBDR_ARENA_TRIALS", "4")
     small = build(pkg)[1]                                                     # 64^3: below the threshold
     assert small.arena_probe() == ([0.0], 0)
     small.close()
