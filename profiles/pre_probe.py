@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""A/B of the pre_* chain on 1 / 2 / 4 concurrent sensor lanes (RGBDR_PRE_LANES) in ONE process, interleaved
-rounds: wall time of clear + process_textures + update_occupied per frame on the benchmark frame set, and a
-bit-for-bit comparison of every image / the brick counters between the lane counts.
+"""In-process timing of the pre_* chain (clear + process_textures + update_occupied per frame on the benchmark
+frame set) for contexts created under different environment knobs (round 2 used it for RGBDR_PRE_LANES = 1 / 2 / 4,
+a build that is not kept: profiles/r02_notes/pre_chain_experiments.md), interleaved rounds, with a bit-for-bit
+comparison of every image / the brick counters between the contexts.
 usage: python profiles/pre_probe.py [rounds]"""
 import json
 import os
