@@ -260,6 +260,15 @@ def main():
     occ = ctx.occupied_ratio()
     bint_ns, bint_n = stats_b["2integrate"]
 
+    # brick-skipping mode with the pre_* chain of frame k+1 overlapping the sweep of frame k (RGBDR_FLAG_PIPELINE):
+    # the sweep is short here, so the two streams overlap for most of it
+    bricked_pipelined = None
+    if world == 1 and not loop and not args.pipeline:
+        ctx.set_pipelined(True)
+        dtbp, _ = timed(True, bsteps, 2)
+        ctx.set_pipelined(False)
+        bricked_pipelined = round(dtbp / bsteps * 1e3, 4)
+
     # ---- the other schedule (extra keys): whichever of sequential / pipelined the headline did not use ----
     other = None
     if world == 1 and not loop:
@@ -317,7 +326,7 @@ def main():
         "bricked": {"ms_per_step": round(dtb / bsteps * 1e3, 4),
                     "value": round(V_total / (dtb / bsteps) / 1e6, 1),
                     "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
-                    "occupied_ratio": round(occ, 4)},
+                    "occupied_ratio": round(occ, 4), "ms_per_step_pipelined": bricked_pipelined},
         "other_schedule": other,
         "full_sweep_store_elision": elided,
     }
