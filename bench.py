@@ -79,6 +79,11 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="one GPU, real RCCL: run an inner Z slab (rank 1 of 4) whose two neighbours are this process "
                          "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
+    ap.add_argument("--arena-trials", type=int, default=6,
+                    help="RGBDR_ARENA_TRIALS for this run (the library's default is 1 = off): within one box the sweep "
+                         "time differs by up to 12 %% between processes with where hipMalloc placed the LUT arena; the "
+                         "library times up to this many candidate placements (about 5 ms each, at most 1 s) and keeps the "
+                         "fastest; the candidates' times are reported in roofline.arena_placement_probe_ms")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="bound the CPU baseline to this many z rows of the volume (0 = the whole volume, about 10 s)")
     args = ap.parse_args()
@@ -111,6 +116,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    os.environ.setdefault("RGBDR_ARENA_TRIALS", str(max(1, args.arena_trials)))
     load_package()
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
