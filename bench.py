@@ -464,7 +464,7 @@ def main():
                        "transfer_ms_rank0": exchanger.last_transfer_ms()}
     # ---- post-pass across the slabs (BASELINE configs[4]): slab ray-march (find, all-reduce MIN, shade,
     # composite) + tsdf_inpaint / tsdf_colorfill of the composited frame; outside `value` ----
-    if world > 1:
+    if multi:                             # --loopback runs it too (one slab's share of the frame): the same code path
         try:
             ctx.set_use_bricks(False)
             step(False)
@@ -489,8 +489,8 @@ def main():
                                 "holefill_ms": round(ctx.timer_ns("holefill") * 1e-6, 4),
                                 "surface_pixels": round(float((dep < 1).float().mean()), 4)}
             ctx.enable_timers(False)
-        except capi.RgbdrError as e:
-            out["post_pass"] = {"error": str(e)}
+        except Exception as e:  # noqa: BLE001 -- extra keys must never cost the headline line
+            out["post_pass"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

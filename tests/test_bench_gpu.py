@@ -53,3 +53,6 @@ def test_bench_loopback_runs_the_multi_gpu_path():
     assert j["config"]["halo_transport"] == "rccl" and "loopback" in j["config"]["parallelism"]
     assert j["halo"]["bytes_per_face"] > 0 and j["halo"]["transfer_ms_rank0"] > 0
     assert "cpu_baseline" not in j and j["other_schedule"] is None
+    # the slab post-pass of the multi-GPU runs (find, all-reduce MIN, shade, composite, hole filling)
+    assert "error" not in j["post_pass"], j["post_pass"]
+    assert j["post_pass"]["slab_raymarch_composited_ms"] > 0 and j["post_pass"]["holefill_ms"] > 0

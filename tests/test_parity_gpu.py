@@ -820,8 +820,9 @@ def run_random_sequence(pkg, orc, seed, slab):
     scenes = [scene, pkg.synth.Scene(2, 64, 53, lut_res=(16, 13, 16), seed=99, sphere_r=0.7)]
     state = dict(limit=np.float32(0.01), bricks=True, filt=True, proc=True, refine=True, min_voxels=10)
     cur = 0
+    G = 48 if slab else 32
     for step_no in range(28):
-        op = rng.integers(0, 12)
+        op = rng.integers(0, 13)
         if op == 0:
             state["bricks"] = not state["bricks"]
             ctx.set_use_bricks(state["bricks"])
@@ -848,6 +849,10 @@ def run_random_sequence(pkg, orc, seed, slab):
             ctx.settle(0.05)
         elif op == 9 and slab:
             ctx.set_halo_staging(int(rng.integers(-1, 2)))
+        elif op == 10:
+            # setBrickSize: bricks of 5 / 6 / 8 / 10 voxels (not tile multiples; at G = 48 the reference's brick ->
+            # voxel lists share rows between neighbouring bricks for 5 and 8); the volume and the LUTs stay
+            ctx.set_brick_size(float(rng.choice([5, 6, 8, 10])) * 2.0 / G)
         else:
             cur = int(rng.integers(0, 2))
         sc = scenes[cur]
