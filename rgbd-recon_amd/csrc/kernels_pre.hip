@@ -7,8 +7,8 @@
 //   k_normal     glsl/pre_normal.fs + inc_bricks.glsl mark_brick           (:382-397)
 //   k_quality    glsl/pre_quality.fs     (:400-414)
 // The launch geometry replaces ScreenQuad (one fragment per depth texel,
-// framework/rendering/screen_quad.cpp:7-35): blockIdx.z is the sensor layer,
-// 16x16 pixel blocks (4 wavefronts).  The two 13x13 passes stage their depth
+// framework/rendering/screen_quad.cpp:7-35): 16x16 pixel blocks (4 wavefronts), the sensor layers interleaved
+// along grid.x (block_pos).  The two 13x13 passes stage their depth
 // window (16+12)^2 in LDS once per block instead of 169 texture fetches per pixel.
 // These passes move ~56 B/pixel of compulsory traffic and are ALU/latency bound;
 // they are reported as time, not as a roofline fraction.
@@ -27,6 +27,23 @@ constexpr int TH = BY + 2 * R13;
 // 48 = 16 (mod 32) puts them on disjoint halves of the 32 banks (pitch 29 spent 49 % of the LDS cycles on
 // conflicts, profiles/r01_pmc_summary_v10.json)
 constexpr int TPITCH = 48;
+
+// Block -> (sensor layer, block column).  The sensors are interleaved along x (grid.x = N * columns) instead of
+// being stacked in grid.z: the blocks that carry a surface -- and run the 169-tap loops, 29 of k_pre_depth's 53 us
+// -- cluster in the same image region of every sensor, and with one sensor after the other they reached the
+// machine in N bursts of about one heavy wavefront per SIMD, which then issues at a single wavefront's rate
+// (dependencies and LDS waits exposed).  Interleaved, the heavy wavefronts of all sensors are resident together.
+struct BlockPos {
+  int l, bx;
+};
+__device__ __forceinline__ BlockPos block_pos(int N)
+{
+  BlockPos b;
+  b.bx = (int)blockIdx.x / N;
+  b.l = (int)blockIdx.x - b.bx * N;
+  return b;
+}
+static dim3 pass_grid(const PreParams& p) { return dim3((unsigned)(((p.W + BX - 1) / BX) * p.N), (unsigned)((p.H + BY - 1) / BY), 1); }
 
 // 1 - length(vec2(x,y)) * (1/6) for x,y in [-6,6], filled by the host with the
 // same correctly-rounded sqrtf (pre_depth.fs:37-41,115)
@@ -148,7 +165,7 @@ void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, siz
 __device__ __forceinline__ bool morph_valid(float d) { return d > 0.5f && d < 4.5f; }
 
 __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_all, float* __restrict__ out_all, int W,
-                                                  int H, uint32_t* __restrict__ zero, unsigned nzero)
+                                                  int H, int N, uint32_t* __restrict__ zero, unsigned nzero)
 {
   // clearOccupiedBricks rides along (a separate fill launch costs more stream time than
   // zeroing the 1 MiB): the counters are next touched by k_normal, three launches later
@@ -157,10 +174,11 @@ __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_a
     const unsigned tid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
     for (unsigned i = tid; i < nzero; i += nthreads) zero[i] = 0u;
   }
-  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const BlockPos bp = block_pos(N);
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
-  const float* in = in_all + (size_t)blockIdx.z * W * H;
-  float* out = out_all + (size_t)blockIdx.z * W * H;
+  const float* in = in_all + (size_t)bp.l * W * H;
+  float* out = out_all + (size_t)bp.l * W * H;
   const float depth = in[(size_t)py * W + px];
   float res;
   if (morph_valid(depth)) {
@@ -203,8 +221,7 @@ __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_a
 
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s)
 {
-  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_morph, grid, dim3(BX, BY), 0, s, in, out, p.W, p.H, zero, nzero);
+  hipLaunchKernelGGL(k_morph, pass_grid(p), dim3(BX, BY), 0, s, in, out, p.W, p.H, p.N, zero, nzero);
 }
 
 // ---------------------------------------------------------------------------
@@ -259,13 +276,14 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
 {
   __shared__ float tile[TH][TPITCH];
   __shared__ float unorm[256];  // i / 255.0f: what the sampler returns for a u8 colour channel
-  const int l = blockIdx.z;
+  const BlockPos bp = block_pos(p.N);
+  const int l = bp.l;
   const int W = p.W, H = p.H;
   const float* depth = p.depth_in + (size_t)l * W * H;
   const bool compress = p.compress != 0;
   const float scale = p.far_[l] - p.near_[l];
   const float scaled_near = scale / 255.0f;
-  const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
+  const int bx0 = bp.bx * BX - R13, by0 = blockIdx.y * BY - R13;
   // stage the (clamped) depth window once per block.  Taps outside [min_ds, max_ds] are skipped by
   // the filter (pre_depth.fs:100-103); they are staged as +inf so that, for a finite centre depth,
   // the range test |ds - depth| > dist_range_max alone rejects them (NaN taps stay NaN, as they pass
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
     tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? __builtin_inff() : ds;
   }
   __syncthreads();
-  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t o = (size_t)l * W * H + (size_t)py * W + px;
   const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
@@ -345,8 +363,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
 
 void launch_pre_depth(const PreParams& p, hipStream_t s)
 {
-  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_pre_depth, grid, dim3(BX, BY), 0, s, p);
+  hipLaunchKernelGGL(k_pre_depth, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
@@ -364,9 +381,10 @@ __global__ __launch_bounds__(BX* BY) void k_boundary(PreParams p)
   constexpr int T = BX + 4;
   __shared__ float2 t_rg[T][T + 1];
   __shared__ float t_lab[T][T + 1][3];
-  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const BlockPos bp = block_pos(p.N);
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   const int W = p.W, H = p.H;
-  const size_t lo = (size_t)blockIdx.z * W * H;
+  const size_t lo = (size_t)bp.l * W * H;
   const float* drg = p.depth_rg + lo * 2;
   const float* lab = p.lab + lo * 3;
   const bool inside = px < W && py < H;
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(BX* BY) void k_boundary(PreParams p)
   const bool edge = inside && !(dx <= 0.0f) && !(dy > 0.65f);  // exactly the pixels that take the 5x5 branch below (NaN included)
   const bool any = __syncthreads_or(edge) != 0;
   if (any) {
-    const int bx0 = blockIdx.x * BX - 2, by0 = blockIdx.y * BY - 2;
+    const int bx0 = bp.bx * BX - 2, by0 = blockIdx.y * BY - 2;
     for (int i = threadIdx.y * BX + threadIdx.x; i < T * T; i += BX * BY) {
       const int ty = i / T, tx = i - ty * T;
       const size_t os = (size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1);
@@ -421,8 +439,7 @@ __global__ __launch_bounds__(BX* BY) void k_boundary(PreParams p)
 
 void launch_boundary(const PreParams& p, hipStream_t s)
 {
-  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_boundary, grid, dim3(BX, BY), 0, s, p);
+  hipLaunchKernelGGL(k_boundary, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
@@ -483,8 +500,9 @@ __device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos, int& 
 
 __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
 {
-  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
-  const int W = p.W, H = p.H, l = blockIdx.z;
+  const BlockPos bp = block_pos(p.N);
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int W = p.W, H = p.H, l = bp.l;
   if (px >= W || py >= H) return;
   const size_t lo = (size_t)l * W * H;
   const float* db = p.depth_b_rg + lo * 2;
@@ -531,19 +549,19 @@ __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
 
 void launch_normal(const PreParams& p, hipStream_t s)
 {
-  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_normal, grid, dim3(BX, BY), 0, s, p);
+  hipLaunchKernelGGL(k_normal, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
 {
   __shared__ float tile[TH][TPITCH];
-  const int l = blockIdx.z;
+  const BlockPos bp = block_pos(p.N);
+  const int l = bp.l;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
   const float* db = p.depth_b_rg + lo * 2;
-  const int bx0 = blockIdx.x * BX - R13, by0 = blockIdx.y * BY - R13;
+  const int bx0 = bp.bx * BX - R13, by0 = blockIdx.y * BY - R13;
   for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
     const int ty = i / TW, tx = i - ty * TW;
     // taps outside (0,1) count as border (pre_quality.fs:62-66).  They are staged as +inf: for a
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
     tile[ty][tx] = unit_outside(d) ? __builtin_inff() : d;  // NaN stays NaN (it is not "outside" in the shader either)
   }
   __syncthreads();
-  const int px = blockIdx.x * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t o = (size_t)py * W + px;
   const float depth = db[o * 2];
@@ -599,8 +617,7 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
 
 void launch_quality(const PreParams& p, hipStream_t s)
 {
-  dim3 grid((p.W + BX - 1) / BX, (p.H + BY - 1) / BY, p.N);
-  hipLaunchKernelGGL(k_quality, grid, dim3(BX, BY), 0, s, p);
+  hipLaunchKernelGGL(k_quality, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------
