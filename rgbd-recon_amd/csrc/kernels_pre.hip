@@ -285,16 +285,17 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   const float scaled_near = scale / 255.0f;
   const int bx0 = bp.bx * BX - R13, by0 = blockIdx.y * BY - R13;
   // stage the (clamped) depth window once per block.  Taps outside [min_ds, max_ds] are skipped by
-  // the filter (pre_depth.fs:100-103); they are staged as +inf so that, for a finite centre depth,
-  // the range test |ds - depth| > dist_range_max alone rejects them (NaN taps stay NaN, as they pass
-  // all three tests in the shader).  A non-finite centre depth takes the three-test loop.
+  // the filter (pre_depth.fs:100-103); they are staged as the finite sentinel 3e38 so that, for a centre
+  // depth of ordinary magnitude, the range test |ds - depth| > dist_range_max alone rejects them (NaN taps
+  // stay NaN, as they pass all three tests in the shader).  A non-finite or huge centre depth takes the
+  // three-test loop.
   const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
   unorm[threadIdx.y * BX + threadIdx.x] = (float)(threadIdx.y * BX + threadIdx.x) / 255.0f;  // 256 threads, 256 entries
   for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
     const int ty = i / TW, tx = i - ty * TW;
     const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
     const float ds = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
-    tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? __builtin_inff() : ds;
+    tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? 3.0e38f : ds;
   }
   __syncthreads();
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
@@ -324,22 +325,25 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
     const float dist_range_max = 0.35f * (depth0 / 4.5f);
     const float dist_range_max_inv = 1.0f / dist_range_max;
     float depth_bf = 0.0f, w = 0.0f, w_range = 0.0f;
-    if (fabsf(depth0) <= 3.0e38f) {
+    if (fabsf(depth0) <= 1.0e20f) {
+      // Branch-free form of the shader's `continue`: a rejected tap contributes gr = +0, i.e. w_range += 0,
+      // w += gs * 0 (= +-0) and depth_bf += (+-0) * ds.  That leaves the three sums unchanged bit for bit: they
+      // start at +0 and a float sum only becomes -0 from -0 + -0, and ds is finite for every rejected tap (the
+      // sentinel, or a value inside the calibrated range) so (+-0) * ds is a zero.  No exec-mask juggling per tap.
       for (int y = 0; y < 13; ++y) {
 #pragma unroll
         for (int x = 0; x < 13; ++x) {
           const float ds = tile[threadIdx.y + y][threadIdx.x + x];
           const float dr = fabsf(ds - depth0);
-          if (dr > dist_range_max) continue;  // also the staged +inf of out-of-range taps
-          const float gs = c_gauss_space[y * 13 + x];
-          const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
-          const float ws = gs * gr;
+          float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+          gr = (dr > dist_range_max) ? 0.0f : gr;  // also the staged sentinel of out-of-range taps
+          const float ws = c_gauss_space[y * 13 + x] * gr;
           depth_bf += ws * ds;
           w += ws;
           w_range += gr;
         }
       }
-    } else {  // inf / NaN centre: the shader's three tests, on the window re-read from memory
+    } else {  // inf / NaN / huge centre: the shader's three tests, on the window re-read from memory
       for (int y = 0; y < 13; ++y)
         for (int x = 0; x < 13; ++x) {
           const float d = depth[(size_t)clampi(py + y - R13, 0, H - 1) * W + clampi(px + x - R13, 0, W - 1)];
@@ -579,19 +583,22 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
   if (!unit_outside(depth)) {
     const float dist_range_max = 0.35f * (depth / 1.0f);
     const float dist_range_max_inv = 1.0f / dist_range_max;
-    float w_range = 0.0f, border = 0.0f;
+    // branch-free: a border tap (outside (0,1): staged +inf, or beyond the range threshold) adds 1 to an integer
+    // count (exact up to 169) and +0 to w_range, which never changes a float sum that started at +0
+    float w_range = 0.0f;
+    int nborder = 0;
     for (int y = 0; y < 13; ++y) {
 #pragma unroll
       for (int x = 0; x < 13; ++x) {
         const float ds = tile[threadIdx.y + y][threadIdx.x + x];
         const float dr = fabsf(ds - depth);
-        if (dr > dist_range_max) {
-          border += 1.0f;
-          continue;
-        }
-        w_range += 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+        const bool is_border = dr > dist_range_max;
+        const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+        nborder += is_border ? 1 : 0;
+        w_range += is_border ? 0.0f : gr;
       }
     }
+    const float border = (float)nborder;
     const float lateral = 1.0f - border / 169.0f;
     const float l2 = lateral * lateral, l4 = l2 * l2;
     q = l4 * l2;
