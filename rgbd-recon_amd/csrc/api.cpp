@@ -285,7 +285,8 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
                 {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol},
                 {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 32},
-                {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors}};
+                {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors},
+                {(void**)&ctx->d_cc_far, n * 8},         {(void**)&ctx->d_box_flags, n}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
       ctx->err = "hipMalloc of image buffers failed";
@@ -343,7 +344,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   }
   void* ptrs[] = {ctx->d_depth_raw, ctx->d_depth_morph, ctx->d_depth_rg, ctx->d_lab,   ctx->d_depth_b, ctx->d_sil,
                   ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count,
-                  ctx->d_color_dxt};
+                  ctx->d_color_dxt, ctx->d_cc_far,    ctx->d_box_flags};
   for (void* p : ptrs) (void)hipFree(p);
   for (int i = 0; i < kMaxSensors; ++i) {
     (void)hipFree(ctx->d_cv_xyz[i]);
@@ -497,6 +498,8 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   p.silhouette = ctx->d_sil;
   p.normal = ctx->d_normal;
   p.quality = ctx->d_quality;
+  p.cc_far = ctx->d_cc_far;
+  p.box_flags = ctx->d_box_flags;
   // m_use_processed_depth: the filter pass reads the morph output instead of the
   // raw depth (NetKinectArray.cpp:287-289)
   p.depth_in = (ctx->cfg.flags & RGBDR_FLAG_PROCESSED) ? ctx->d_depth_morph : ctx->d_depth_raw;

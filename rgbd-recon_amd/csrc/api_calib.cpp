@@ -46,6 +46,24 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, cons
   ctx->max_ds[sensor] = xyz->depth_limits[1];
   camera_position((const float*)xyz->data, xyz->res, ctx->cam_pos[sensor]);
   frustum_planes((const float*)xyz->data, xyz->res, ctx->planes[sensor]);
+  {  // the lookups of pre_depth.fs that depend on the pixel only (kernels_pre.hip k_pre_cache)
+    PreParams p{};
+    p.W = ctx->cfg.depth_w;
+    p.H = ctx->cfg.depth_h;
+    for (int a = 0; a < 3; ++a) {
+      p.bbox_min[a] = ctx->cfg.bbox_min[a];
+      p.bbox_max[a] = ctx->cfg.bbox_max[a];
+      p.xyz_res[sensor][a] = (int)xyz->res[a];
+      p.uv_res[sensor][a] = (int)uv->res[a];
+    }
+    p.cv_xyz[sensor] = ctx->d_cv_xyz[sensor];
+    p.cv_uv[sensor] = ctx->d_cv_uv[sensor];
+    p.cc_far = ctx->d_cc_far;
+    p.box_flags = ctx->d_box_flags;
+    launch_pre_cache(p, sensor, ctx->stream);
+    LAUNCHCHK("pre_cache");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
   ctx->have_calib[sensor] = true;
   return RGBDR_OK;
 }

@@ -52,6 +52,8 @@ struct rgbdr_ctx {
   float *d_depth_raw = nullptr, *d_depth_morph = nullptr, *d_depth_rg = nullptr, *d_lab = nullptr;
   float *d_depth_b = nullptr, *d_sil = nullptr, *d_normal = nullptr, *d_quality = nullptr;
   uint2* d_frame = nullptr;
+  float2* d_cc_far = nullptr;            // per pixel: frame-independent lookups of pre_depth.fs (k_pre_cache, set_calibration)
+  unsigned char* d_box_flags = nullptr;
   uint8_t *d_color = nullptr, *d_depth_u8 = nullptr, *d_color_dxt = nullptr;
   bool frame_uploaded = false, textures_processed = false;
 

@@ -66,6 +66,9 @@ struct PreParams {
   float* normal;
   float* quality;
   uint2* frame;            // packed texel for integration: {depth_b.r, quality with !silhouette in the sign bit}
+  // frame-independent lookups of pre_depth.fs per pixel, filled at set_calibration (k_pre_cache)
+  float2* cc_far;          // texture(cv_uv, (u, v, 1.0))
+  unsigned char* box_flags;  // bit 0 / 1: texture(cv_xyz, (u, v, first / last z plane)) lies inside the box
 };
 
 struct IntegrateParams {
@@ -187,6 +190,7 @@ void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, siz
                        hipStream_t s);
 void launch_repack_xyz(const float* src_xyz3, float4* dst, size_t n, hipStream_t s);
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s);
+void launch_pre_cache(const PreParams& p, int sensor, hipStream_t s);
 void launch_pre_depth(const PreParams& p, hipStream_t s);
 void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
