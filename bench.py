@@ -499,14 +499,42 @@ def main():
 
 
 def gpu_state():
-    """power / clocks of device 0 as rocm-smi reports them right after the timed steps (a box that shows
-    hundreds of watts with this process idle is shared); {} when rocm-smi is unavailable"""
+    """power / clocks of the first GPU right after the timed steps (a box that shows hundreds of watts with
+    this process idle is shared).  Read from sysfs: no child process, because under
+    `rocprofv3 --pmc` every child inherits the profiler's preloaded library and a script child (rocm-smi is
+    one) re-executes itself after that library has initialised the GPU.  rocm-smi is the fallback only when
+    sysfs has nothing and no profiler is preloaded."""
+    import glob
+    keep = {}
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        if not os.path.exists(dev + "/pp_dpm_mclk"):
+            continue
+        for name in ("sclk", "mclk", "fclk"):
+            try:
+                cur = [ln for ln in open(f"{dev}/pp_dpm_{name}").read().splitlines() if ln.rstrip().endswith("*")]
+                if cur:
+                    keep[name] = cur[0].split(":", 1)[1].strip(" *")
+            except OSError:
+                pass
+        try:
+            keep["perf_level"] = open(dev + "/power_dpm_force_performance_level").read().strip()
+        except OSError:
+            pass
+        for pw in glob.glob(dev + "/hwmon/hwmon*/power1_average") + glob.glob(dev + "/hwmon/hwmon*/power1_input"):
+            try:
+                keep["power_W"] = round(int(open(pw).read()) / 1e6, 1)
+                break
+            except (OSError, ValueError):
+                pass
+        if keep:
+            return keep
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or os.environ.get("LD_PRELOAD"):
+        return {"unavailable": "profiler preloaded"}
     import subprocess
     try:
         r = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks", "--showperflevel", "--json"],
                            capture_output=True, text=True, timeout=30)
         card = next(iter(json.loads(r.stdout).values()))
-        keep = {}
         for k, v in card.items():
             kl = k.lower()
             if "power" in kl or kl.startswith("sclk") or kl.startswith("mclk") or kl.startswith("fclk") or "performance" in kl:

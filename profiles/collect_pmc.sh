@@ -6,7 +6,7 @@
 # WRITE_SIZE 2, SQ has 8).
 TAG=${1:-r01}
 OUT=$PWD/gpurun_out/pmc_$TAG
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT   # a tag is one run: never mix counter files of two runs
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
