@@ -5,7 +5,7 @@ OUT=$PWD/gpurun_out/pmc_pre_${TAG}_v$V
 mkdir -p $OUT
 ROOT=$PWD
 cd /tmp && export TMPDIR=/tmp
-export RGBDR_PRE_VARIANT=$V
+# ($V only tags the output directory; set library knobs such as RGBDR_SEPARATE_PASSES in the environment)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/profiles/pre_only.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq1 -- python3 $ROOT/profiles/pre_only.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/sq2 -- python3 $ROOT/profiles/pre_only.py > /dev/null 2>&1

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """In-process timing of the pre_* chain (clear + process_textures + update_occupied per frame on the benchmark
-frame set) for contexts created under different environment knobs (round 2 used it for RGBDR_PRE_LANES = 1 / 2 / 4,
-a build that is not kept: profiles/r02_notes/pre_chain_experiments.md), interleaved rounds, with a bit-for-bit
+frame set) for contexts created under different values of one environment knob the library reads at context
+creation (RGBDR_SEPARATE_PASSES, RGBDR_NQ_WAVES ...; "-" = unset), interleaved rounds, with a bit-for-bit
 comparison of every image / the brick counters between the contexts.
-usage: python profiles/pre_probe.py [rounds]"""
+usage: python profiles/pre_probe.py [rounds] [KNOB value value ...]"""
 import json
 import os
 import sys
@@ -22,10 +22,13 @@ from rgbd_recon_amd import capi, synth  # noqa: E402
 N, W, H, G = 4, 512, 424, 64
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
-LANES = (1, 2, 4)
+KNOB = sys.argv[2] if len(sys.argv) > 2 else "RGBDR_SEPARATE_PASSES"
+LANES = tuple(sys.argv[3:]) if len(sys.argv) > 3 else ("-", "1")
 ctxs = {}
 for k in LANES:
-    os.environ["RGBDR_PRE_LANES"] = str(k)
+    os.environ.pop(KNOB, None)
+    if k != "-":
+        os.environ[KNOB] = k
     c = capi.Context(capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
     for i in range(N):
         c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
@@ -51,8 +54,8 @@ for k in LANES:
     chain(ctxs[k], 3)          # several frames: the counters must be cleared and rebuilt identically each time
     imgs[k] = images(ctxs[k])
 same = all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for k in LANES[1:] for w in range(1, 8)
-           for a, b in zip(imgs[1][w], imgs[k][w]))
-same = same and all(np.array_equal(imgs[1]["counters"], imgs[k]["counters"]) for k in LANES[1:])
+           for a, b in zip(imgs[LANES[0]][w], imgs[k][w]))
+same = same and all(np.array_equal(imgs[LANES[0]]["counters"], imgs[k]["counters"]) for k in LANES[1:])
 wall = {k: [] for k in LANES}
 for r in range(rounds):
     for k in LANES:
@@ -62,6 +65,6 @@ for r in range(rounds):
         chain(ctxs[k], 200)
         ctxs[k].sync()
         wall[k].append((time.perf_counter() - t0) / 200 * 1e3)
-print(json.dumps({"images_and_counters_bit_identical": bool(same), "counters_sum": int(imgs[1]["counters"].sum()),
-                  "chain_ms_per_frame_by_lanes": {k: {"median": round(float(np.median(w)), 4), "min": round(min(w), 4)}
+print(json.dumps({"images_and_counters_bit_identical": bool(same), "counters_sum": int(imgs[LANES[0]]["counters"].sum()),
+                  "knob": KNOB, "chain_ms_per_frame": {k: {"median": round(float(np.median(w)), 4), "min": round(min(w), 4)}
                                                   for k, w in wall.items()}}))

@@ -93,6 +93,7 @@ static int alloc_brick_table(rgbdr_ctx* ctx, const rgbdr_config& cfg, const rgbd
   std::vector<uint32_t> host;
   for (int a = 0; a < 3; ++a) host.insert(host.end(), bt.vox[a].begin(), bt.vox[a].end());
   for (int a = 0; a < 3; ++a) host.insert(host.end(), bt.tile[a].begin(), bt.tile[a].end());
+  for (int a = 0; a < 3; ++a) host.insert(host.end(), bt.whole[a].begin(), bt.whole[a].end());
   uint32_t *counters = nullptr, *ids = nullptr, *tab = nullptr;
   uint8_t* mask = nullptr;
   const size_t nb = (size_t)g.num_bricks;
@@ -520,12 +521,18 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   tbegin(ctx, "boundary", ps);
   launch_boundary(p, ps);
   tend(ctx, "boundary", ps);
-  tbegin(ctx, "normal", ps);
-  launch_normal(p, ps);
-  tend(ctx, "normal", ps);
-  tbegin(ctx, "quality", ps);
-  launch_quality(p, ps);
-  tend(ctx, "quality", ps);
+  // the normal and quality passes run as one launch unless the host asked for the per-pass timers
+  // ("normal" / "quality" of NetKinectArray.cpp:381-414), which need the two separate ones
+  if ((ctx->timers && ctx->timer_detail >= 2) || ctx->separate_passes) {
+    tbegin(ctx, "normal", ps);
+    launch_normal(p, ps);
+    tend(ctx, "normal", ps);
+    tbegin(ctx, "quality", ps);
+    launch_quality(p, ps);
+    tend(ctx, "quality", ps);
+  } else {
+    launch_normal_quality(p, ps, ctx->nq_waves);
+  }
   tend(ctx, "1preprocess", ps);
   LAUNCHCHK("process_textures");
   ctx->rbuf = w;
@@ -626,6 +633,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.tbx = p.vbz + g.res_volume[2];
   p.tby = p.tbx + g.tiles[0];
   p.tbz = p.tby + g.tiles[1];
+  p.twx = p.tbz + g.tiles[2];
+  p.twy = p.twx + g.tiles[0];
+  p.twz = p.twy + g.tiles[1];
   p.ovx = ctx->bt.overflow[0];
   p.ovy = ctx->bt.overflow[1];
   p.bx = g.res_bricks[0];

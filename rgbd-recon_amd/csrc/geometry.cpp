@@ -175,6 +175,14 @@ int compute_brick_tables(const rgbdr_config& cfg, const rgbdr_geometry& g, Brick
       }
       d = l | (h << 16);
     }
+    // a tile is "whole" along this axis when its 8 coordinates all lie inside the volume and all belong to
+    // at least one brick: then "every brick the tile touches is occupied" implies "every voxel is"
+    t->whole[a].assign((size_t)ntile, 0u);
+    for (int tt = 0; tt < ntile; ++tt) {
+      bool w = (tt + 1) * kTile <= res;
+      for (int v = tt * kTile; w && v < (tt + 1) * kTile; ++v) w = (t->vox[a][v] & 0xffffu) <= (t->vox[a][v] >> 16);
+      t->whole[a][tt] = w ? 1u : 0u;
+    }
   }
   return RGBDR_OK;
 }

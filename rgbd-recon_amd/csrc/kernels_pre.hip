@@ -549,6 +549,56 @@ __device__ __forceinline__ void mark_brick(const PreParams& p, float3 pos, int& 
   home_id = (idx[2] * ry + idx[1]) * rx + idx[0];
 }
 
+// pre_normal.fs:26-56 for one pixel with a depth inside (0,1): `dt/dbm/dl/dr` are the depth_b values of the four
+// neighbours (clamped at the image edge).  Returns the unit normal.
+__device__ __forceinline__ float3 world_at(const PreParams& p, int l, int px, int py, float depth)
+{
+  const float u = ((float)px + 0.5f) / (float)p.W, v = ((float)py + 0.5f) / (float)p.H;
+  return tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], p.xyz_res[l][2], 0, u, v, depth);
+}
+template <bool PAIRS>
+__device__ __forceinline__ float3 normal_at(const PreParams& p, int l, int px, int py, float depth, float dt, float dbm,
+                                            float dl, float dr)
+{
+  const int W = p.W, H = p.H;
+  const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
+  const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
+  const float4* lut = p.cv_xyz[l];
+  const int rx = p.xyz_res[l][0], ry = p.xyz_res[l][1], rz = p.xyz_res[l][2];
+  dt = unit_outside(dt) ? depth : dt;
+  dbm = unit_outside(dbm) ? depth : dbm;
+  dl = unit_outside(dl) ? depth : dl;
+  dr = unit_outside(dr) ? depth : dr;
+  // PAIRS: two rounds of two lookups, deliberately not unrolled, for the kernel that also runs the quality pass
+  // (all five lookups in flight at once are 40 gathers = 108 VGPRs here and 178 there: two wavefronts per SIMD).
+  // (Keeping the centre's eight LUT corners in registers for the neighbours, which mostly fall into the same
+  // cell, measured slower: the repeated gathers hit L1 and the compare costs more.)
+  float ax = 0.0f, ay = 0.0f, az = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+  if (PAIRS) {
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j) {
+      const float3 w0 = tex3d_xyz(lut, rx, ry, rz, 0, j ? u + tsx : u, j ? v : v + tsy, j ? dr : dt);   // wt | wr
+      const float3 w1 = tex3d_xyz(lut, rx, ry, rz, 0, j ? u - tsx : u, j ? v : v - tsy, j ? dl : dbm);  // wb | wl
+      const float ex = w1.x - w0.x, ey = w1.y - w0.y, ez = w1.z - w0.z;
+      if (j == 0) {
+        ax = ex, ay = ey, az = ez;  // wb - wt
+      } else {
+        bx = ex, by = ey, bz = ez;  // wl - wr
+      }
+    }
+  } else {
+    const float3 wt = tex3d_xyz(lut, rx, ry, rz, 0, u, v + tsy, dt);
+    const float3 wb = tex3d_xyz(lut, rx, ry, rz, 0, u, v - tsy, dbm);
+    const float3 wl = tex3d_xyz(lut, rx, ry, rz, 0, u - tsx, v, dl);
+    const float3 wr = tex3d_xyz(lut, rx, ry, rz, 0, u + tsx, v, dr);
+    ax = wb.x - wt.x, ay = wb.y - wt.y, az = wb.z - wt.z;
+    bx = wl.x - wr.x, by = wl.y - wr.y, bz = wl.z - wr.z;
+  }
+  const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
+  const float len = sqrtf(cx * cx + cy * cy + cz * cz);
+  return make_float3(cx / len, cy / len, cz / len);
+}
+
 __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
 {
   const BlockPos bp = block_pos(p.N);
@@ -563,31 +613,12 @@ __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
   int home_id = -1, nb_id = -1;
   unsigned nb_inc = 0u;
   if (!unit_outside(depth)) {
-    const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
-    const float tsx = 1.0f / (float)W, tsy = 1.0f / (float)H;
-    const float4* lut = p.cv_xyz[l];
-    const int rx = p.xyz_res[l][0], ry = p.xyz_res[l][1], rz = p.xyz_res[l][2];
-    const float3 world = tex3d_xyz(lut, rx, ry, rz, 0, u, v, depth);
-    if (p.brick_counters) mark_brick(p, world, home_id, nb_id, nb_inc);
-    float dt = db[((size_t)clampi(py + 1, 0, H - 1) * W + px) * 2];
-    float dbm = db[((size_t)clampi(py - 1, 0, H - 1) * W + px) * 2];
-    float dl = db[((size_t)py * W + clampi(px - 1, 0, W - 1)) * 2];
-    float dr = db[((size_t)py * W + clampi(px + 1, 0, W - 1)) * 2];
-    dt = unit_outside(dt) ? depth : dt;
-    dbm = unit_outside(dbm) ? depth : dbm;
-    dl = unit_outside(dl) ? depth : dl;
-    dr = unit_outside(dr) ? depth : dr;
-    // (keeping the centre's eight LUT corners in registers for the neighbours, which mostly fall
-    // into the same cell, measured slower: the repeated gathers hit L1 and the compare costs more)
-    const float3 wt = tex3d_xyz(lut, rx, ry, rz, 0, u, v + tsy, dt);
-    const float3 wb = tex3d_xyz(lut, rx, ry, rz, 0, u, v - tsy, dbm);
-    const float3 wl = tex3d_xyz(lut, rx, ry, rz, 0, u - tsx, v, dl);
-    const float3 wr = tex3d_xyz(lut, rx, ry, rz, 0, u + tsx, v, dr);
-    const float ax = wb.x - wt.x, ay = wb.y - wt.y, az = wb.z - wt.z;
-    const float bx = wl.x - wr.x, by = wl.y - wr.y, bz = wl.z - wr.z;
-    const float cx = ay * bz - by * az, cy = az * bx - bz * ax, cz = ax * by - bx * ay;
-    const float len = sqrtf(cx * cx + cy * cy + cz * cz);
-    n = make_float3(cx / len, cy / len, cz / len);
+    const float dt = db[((size_t)clampi(py + 1, 0, H - 1) * W + px) * 2];
+    const float dbm = db[((size_t)clampi(py - 1, 0, H - 1) * W + px) * 2];
+    const float dl = db[((size_t)py * W + clampi(px - 1, 0, W - 1)) * 2];
+    const float dr = db[((size_t)py * W + clampi(px + 1, 0, W - 1)) * 2];
+    if (p.brick_counters) mark_brick(p, world_at(p, l, px, py, depth), home_id, nb_id, nb_inc);
+    n = normal_at<false>(p, l, px, py, depth, dt, dbm, dl, dr);
   }
   p.normal[(lo + o) * 3 + 0] = n.x;
   p.normal[(lo + o) * 3 + 1] = n.y;
@@ -604,6 +635,70 @@ void launch_normal(const PreParams& p, hipStream_t s)
 }
 
 // ---------------------------------------------------------------------------
+// pre_quality.fs.  The 28x28 depth_b window of a block in LDS: taps outside (0,1) count as border
+// (pre_quality.fs:62-66) and are staged as +inf: for a centre depth inside (0,1) -- the only pixels that run the
+// loop -- |inf - depth| = inf exceeds the range limit, so the one range test classifies them without the two
+// bound tests.  NaN stays NaN (it is not "outside" in the shader either).
+__device__ __forceinline__ void stage_depth_b(float (*tile)[TPITCH], const float* __restrict__ db, int bx0, int by0, int W,
+                                              int H)
+{
+  for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
+    const int ty = i / TW, tx = i - ty * TW;
+    const float d = db[((size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)) * 2];
+    tile[ty][tx] = unit_outside(d) ? __builtin_inff() : d;
+  }
+}
+
+// lateral^6 * range^6 / (6.5 depth) of pre_quality.fs:64-112 for a centre depth inside (0,1).
+// Branch-free: a border tap (outside (0,1): staged +inf, or beyond the range threshold) adds 1 to an integer count
+// (exact up to 169) and +0 to w_range, which never changes a float sum that started at +0.
+__device__ __forceinline__ float quality_taps(const float (*tile)[TPITCH], float depth)
+{
+  const float dist_range_max = 0.35f * (depth / 1.0f);
+  const float dist_range_max_inv = 1.0f / dist_range_max;
+  float w_range = 0.0f;
+  int nborder = 0;
+  for (int y = 0; y < 13; ++y) {
+#pragma unroll
+    for (int x = 0; x < 13; ++x) {
+      const float ds = tile[threadIdx.y + y][threadIdx.x + x];
+      const float dr = fabsf(ds - depth);
+      const bool is_border = dr > dist_range_max;
+      const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
+      nborder += is_border ? 1 : 0;
+      w_range += is_border ? 0.0f : gr;
+    }
+  }
+  const float border = (float)nborder;
+  const float lateral = 1.0f - border / 169.0f;
+  const float l2 = lateral * lateral, l4 = l2 * l2;
+  float q = l4 * l2;
+  const float wr = w_range / 169.0f;
+  const float w2 = wr * wr, w4 = w2 * w2;
+  q *= w4 * w2;
+  q /= depth * 6.5f;
+  return q;
+}
+
+// pre_quality.fs:114-118: squared cosine between the view ray of the pixel's position and its normal
+__device__ __forceinline__ float quality_angle(const PreParams& p, int l, float3 wp, float3 nrm)
+{
+  const float dx = p.cam_pos[l][0] - wp.x, dy = p.cam_pos[l][1] - wp.y, dz = p.cam_pos[l][2] - wp.z;
+  const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float angle = (dx / len) * nrm.x + (dy / len) * nrm.y + (dz / len) * nrm.z;
+  return angle * angle;
+}
+
+// quality image + the packed 8-B texel the integration kernel samples: depth_b.r and the quality
+// with "silhouette == 0" folded into its sign bit.  quality is a product of
+// non-negative factors (or NaN), so the sign bit is free; |NaN| stays NaN.
+__device__ __forceinline__ void store_quality(const PreParams& p, size_t i, float depth, float q)
+{
+  p.quality[i] = q;
+  const unsigned qbits = (__float_as_uint(q) & 0x7fffffffu) | (p.silhouette[i] < 1.0f ? 0x80000000u : 0u);
+  p.frame[i] = make_uint2(__float_as_uint(depth), qbits);
+}
+
 __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
 {
   __shared__ float tile[TH][TPITCH];
@@ -612,15 +707,7 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
   const float* db = p.depth_b_rg + lo * 2;
-  const int bx0 = bp.bx * BX - R13, by0 = blockIdx.y * BY - R13;
-  for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
-    const int ty = i / TW, tx = i - ty * TW;
-    // taps outside (0,1) count as border (pre_quality.fs:62-66).  They are staged as +inf: for a
-    // centre depth inside (0,1) -- the only pixels that run the loop -- |inf - depth| = inf exceeds
-    // the range limit, so the one range test below classifies them without the two bound tests.
-    const float d = db[((size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)) * 2];
-    tile[ty][tx] = unit_outside(d) ? __builtin_inff() : d;  // NaN stays NaN (it is not "outside" in the shader either)
-  }
+  stage_depth_b(tile, db, bp.bx * BX - R13, blockIdx.y * BY - R13, W, H);
   __syncthreads();
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
@@ -628,50 +715,72 @@ __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
   const float depth = db[o * 2];
   float q = 0.0f;
   if (!unit_outside(depth)) {
-    const float dist_range_max = 0.35f * (depth / 1.0f);
-    const float dist_range_max_inv = 1.0f / dist_range_max;
-    // branch-free: a border tap (outside (0,1): staged +inf, or beyond the range threshold) adds 1 to an integer
-    // count (exact up to 169) and +0 to w_range, which never changes a float sum that started at +0
-    float w_range = 0.0f;
-    int nborder = 0;
-    for (int y = 0; y < 13; ++y) {
-#pragma unroll
-      for (int x = 0; x < 13; ++x) {
-        const float ds = tile[threadIdx.y + y][threadIdx.x + x];
-        const float dr = fabsf(ds - depth);
-        const bool is_border = dr > dist_range_max;
-        const float gr = 1.0f - fminf(dr, dist_range_max) * dist_range_max_inv;
-        nborder += is_border ? 1 : 0;
-        w_range += is_border ? 0.0f : gr;
-      }
-    }
-    const float border = (float)nborder;
-    const float lateral = 1.0f - border / 169.0f;
-    const float l2 = lateral * lateral, l4 = l2 * l2;
-    q = l4 * l2;
-    const float wr = w_range / 169.0f;
-    const float w2 = wr * wr, w4 = w2 * w2;
-    q *= w4 * w2;
-    q /= depth * 6.5f;
-    const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
-    const float3 wp = tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], p.xyz_res[l][2], 0, u, v, depth);
-    const float dx = p.cam_pos[l][0] - wp.x, dy = p.cam_pos[l][1] - wp.y, dz = p.cam_pos[l][2] - wp.z;
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    q = quality_taps(tile, depth);
+    const float3 wp = world_at(p, l, px, py, depth);
     const float* nrm = p.normal + (lo + o) * 3;
-    const float angle = (dx / len) * nrm[0] + (dy / len) * nrm[1] + (dz / len) * nrm[2];
-    q *= angle * angle;
+    q *= quality_angle(p, l, wp, make_float3(nrm[0], nrm[1], nrm[2]));
   }
-  p.quality[lo + o] = q;
-  // packed 8-B texel the integration kernel samples: depth_b.r and the quality
-  // with "silhouette == 0" folded into its sign bit.  quality is a product of
-  // non-negative factors (or NaN), so the sign bit is free; |NaN| stays NaN.
-  const unsigned qbits = (__float_as_uint(q) & 0x7fffffffu) | (p.silhouette[lo + o] < 1.0f ? 0x80000000u : 0u);
-  p.frame[lo + o] = make_uint2(__float_as_uint(depth), qbits);
+  store_quality(p, lo + o, depth, q);
 }
 
 void launch_quality(const PreParams& p, hipStream_t s)
 {
   hipLaunchKernelGGL(k_quality, pass_grid(p), dim3(BX, BY), 0, s, p);
+}
+
+// ---------------------------------------------------------------------------
+// pre_normal.fs + pre_quality.fs in one launch (the default; the two kernels above run when a host asks for the
+// per-pass timers).  quality needs the normal of its own pixel only, and both need the pixel's position at its
+// depth_b: one launch, one cv_xyz lookup and no normal re-read less, and the wavefronts waiting on the five
+// lookups of the normal share their SIMD with wavefronts in the 169-tap loop.  Same expressions, same images.
+template <int WAVES>
+__global__ __launch_bounds__(BX* BY, WAVES) void k_normal_quality(PreParams p)
+{
+  __shared__ float tile[TH][TPITCH];
+  const BlockPos bp = block_pos(p.N);
+  const int l = bp.l;
+  const int W = p.W, H = p.H;
+  const size_t lo = (size_t)l * W * H;
+  const float* db = p.depth_b_rg + lo * 2;
+  stage_depth_b(tile, db, bp.bx * BX - R13, blockIdx.y * BY - R13, W, H);
+  __syncthreads();
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  if (px >= W || py >= H) return;
+  const size_t o = (size_t)py * W + px;
+  const float depth = db[o * 2];
+  float3 n = make_float3(0.0f, 0.0f, 0.0f);
+  float q = 0.0f;
+  int home_id = -1, nb_id = -1;
+  unsigned nb_inc = 0u;
+  if (!unit_outside(depth)) {
+    // the staged window holds the (edge-clamped) neighbours; +inf there means "outside (0,1)", which is
+    // what normal_at tests for
+    const int cy = threadIdx.y + R13, cx = threadIdx.x + R13;
+    const float3 world = world_at(p, l, px, py, depth);
+    if (p.brick_counters) mark_brick(p, world, home_id, nb_id, nb_inc);
+    n = normal_at<true>(p, l, px, py, depth, tile[cy + 1][cx], tile[cy - 1][cx], tile[cy][cx - 1], tile[cy][cx + 1]);
+    q = quality_taps(tile, depth);
+    q *= quality_angle(p, l, world, n);
+  }
+  p.normal[(lo + o) * 3 + 0] = n.x;
+  p.normal[(lo + o) * 3 + 1] = n.y;
+  p.normal[(lo + o) * 3 + 2] = n.z;
+  store_quality(p, lo + o, depth, q);
+  if (p.brick_counters) {  // reconverged: every live lane of the wavefront takes part
+    wave_add(p.brick_counters, nb_id, nb_inc);
+    wave_add(p.brick_counters, home_id, 1u);
+  }
+}
+
+void launch_normal_quality(const PreParams& p, hipStream_t s, int waves)
+{
+  switch (waves) {  // experiment: wavefronts per SIMD the register allocation aims at
+    case 2: hipLaunchKernelGGL(k_normal_quality<2>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(k_normal_quality<3>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
+    case 5: hipLaunchKernelGGL(k_normal_quality<5>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
+    case 6: hipLaunchKernelGGL(k_normal_quality<6>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
+    default: hipLaunchKernelGGL(k_normal_quality<4>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -25,6 +25,7 @@ struct BrickTables {
   std::vector<int32_t> first[3], last[3];
   std::vector<uint32_t> vox[3];
   std::vector<uint32_t> tile[3];  // the union of vox[a] over the 8 coordinates of a storage tile, same packing
+  std::vector<uint32_t> whole[3]; // 1: the tile's 8 coordinates are inside the volume and each lies in some brick
   int overflow[3] = {0, 0, 0};
 };
 int compute_brick_tables(const rgbdr_config& cfg, const rgbdr_geometry& g, BrickTables* t, std::string* err);
@@ -97,6 +98,9 @@ struct IntegrateParams {
   const uint32_t* tbx;     // the same per storage tile (BrickTables::tile)
   const uint32_t* tby;
   const uint32_t* tbz;
+  const uint32_t* twx;     // BrickTables::whole per storage tile
+  const uint32_t* twy;
+  const uint32_t* twz;
   int ovx, ovy;            // BrickTables::overflow of x and y (indices past the z end leave the VBO: dropped)
   float* tsdf;             // first owned tile layer
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
@@ -195,6 +199,7 @@ void launch_pre_depth(const PreParams& p, hipStream_t s);
 void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
 void launch_quality(const PreParams& p, hipStream_t s);
+void launch_normal_quality(const PreParams& p, hipStream_t s, int waves);  // both passes in one launch
 void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask,
                             uint32_t* count, hipStream_t s);
 void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);

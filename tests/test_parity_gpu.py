@@ -280,6 +280,33 @@ def test_edge_cases(pkg, orc):
     ctx.close()
 
 
+def test_normal_and_quality_in_one_launch_or_two(pkg, orc):
+    """process_textures runs pre_normal + pre_quality as one kernel; a host that asks for the per-pass timers
+    ("normal" / "quality", NetKinectArray.cpp:381-414) gets the two separate ones.  Same images, same brick
+    counters, bit for bit, also with non-finite depth_b values reaching both passes."""
+    scene, ctx, inv = build(pkg, n=3, wh=(200, 150), G=64, lut_res=(32, 27, 32))
+    d = scene.depth.copy()
+    rng = np.random.default_rng(11)
+    for val in (np.nan, np.inf, -np.inf, -3.0, 1e30, 0.0):
+        for _ in range(20):
+            d[rng.integers(0, 3), rng.integers(0, 150), rng.integers(0, 200)] = val
+    d[1, 60:64, 90:95] = np.nan
+    for processed in (True, False):
+        ctx.use_processed_depths(processed)
+        ref = oracle_run(orc, scene, ctx, inv, depth_override=d, processed=processed)
+        got = {}
+        for timers in (False, True):
+            ctx.enable_timers(timers)
+            ctx.set_timer_detail(2)
+            ctx.step(d, scene.color)
+            check_images(ctx, ref, 3)
+            assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+            assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+            got[timers] = [ctx.readback_image(w, i) for w in (6, 7) for i in range(3)]
+        assert all(same_bits(a, b) for a, b in zip(got[False], got[True]))
+    ctx.close()
+
+
 def test_bricked_equals_full_sweep_on_occupied_bricks(pkg):
     scene, ctx, inv = build(pkg)
     ctx.step(scene.depth, scene.color)
