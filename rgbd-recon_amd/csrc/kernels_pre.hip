@@ -225,23 +225,37 @@ void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zer
 }
 
 // ---------------------------------------------------------------------------
+// x / C for a compile-time constant C as q = x * R, q + fma(-q, C, x) * R with R = RN(1 / C): three instructions
+// instead of the ~12 of a correctly rounded division.  tests/const_division_check.c compares it with x / C for
+// every binary32 x: for the constants used below the two differ only for |x| < 1e-30 (results near the
+// denormal range), +-inf and -0.  Lab conversion never sees such an x: its input is a bilinear blend of u8
+// colours / 255 with weights that are 0 or >= 2^-25 (the fraction of a coordinate near a texel centre is a
+// multiple of half an ulp of 0.5), so every dividend below is +0, NaN or between 1e-22 and 1e3.
+__device__ __forceinline__ float divc(float x, float C, float R)
+{
+  const float q = x * R;
+  return __builtin_fmaf(__builtin_fmaf(-q, C, x), R, q);
+}
+#define RGBDR_DIVC(x, C) divc((x), (C), 1.0f / (C))
+
 // inc_color.glsl.  With the reference's extra /255 (:14-16) a [0,1] colour never
 // reaches either pow() branch; they are kept for inputs outside that range.
 __device__ __forceinline__ float pivot_rgb(float n)
 {
-  return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : n / 12.92f) * 100.0f;
+  return (n > 0.04045f ? powf((n + 0.055f) / 1.055f, 2.4f) : RGBDR_DIVC(n, 12.92f)) * 100.0f;
 }
 __device__ __forceinline__ float pivot_xyz(float n)
 {
-  return n > 0.008856f ? powf(n, 1.0f / 3.0f) : (903.3f * n + 16.0f) / 116.0f;
+  return n > 0.008856f ? powf(n, 1.0f / 3.0f) : RGBDR_DIVC(903.3f * n + 16.0f, 116.0f);
 }
 __device__ __forceinline__ float3 rgb_to_lab(float3 rgb)
 {
-  const float r = pivot_rgb(rgb.x / 255.0f), g = pivot_rgb(rgb.y / 255.0f), b = pivot_rgb(rgb.z / 255.0f);
+  const float r = pivot_rgb(RGBDR_DIVC(rgb.x, 255.0f)), g = pivot_rgb(RGBDR_DIVC(rgb.y, 255.0f)),
+              b = pivot_rgb(RGBDR_DIVC(rgb.z, 255.0f));
   const float X = r * 0.4124f + g * 0.3576f + b * 0.1805f;
   const float Y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
   const float Z = r * 0.0193f + g * 0.1192f + b * 0.9505f;
-  const float x = pivot_xyz(X / 95.047f), y = pivot_xyz(Y / 100.000f), z = pivot_xyz(Z / 108.883f);
+  const float x = pivot_xyz(RGBDR_DIVC(X, 95.047f)), y = pivot_xyz(RGBDR_DIVC(Y, 100.000f)), z = pivot_xyz(RGBDR_DIVC(Z, 108.883f));
   return make_float3(fmaxf(0.0f, 116.0f * y - 16.0f), 500.0f * (x - y), 200.0f * (y - z));
 }
 
