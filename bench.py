@@ -296,6 +296,29 @@ def main():
         elided = {"ms_per_step": round(dte / args.steps * 1e3, 4), "value": round(V_total / (dte / args.steps) / 1e6, 1),
                   "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4)}
 
+    # ---- RGBDR_FLAG_SKIP_BACKGROUND (extra keys): LUT planes of (tile, sensor) pairs that can only carve stay unread ----
+    skipbg = None
+    if world == 1 and not loop:
+        ctx.set_skip_background(True)
+        dts, stats_s = timed(False, args.steps, args.warmup)
+        skipped, total = ctx.skipped_pairs()
+        ctx.set_elide_stores(True)
+        dtse, stats_se = timed(False, args.steps, args.warmup)
+        ctx.set_elide_stores(False)
+        ctx.set_skip_background(False)
+        si_ns, si_n = stats_s["2integrate"]
+        sei_ns, sei_n = stats_se["2integrate"]
+        lut_bytes = (total - skipped) * 3 * 512 * 4
+        skipbg = {"ms_per_step": round(dts / args.steps * 1e3, 4), "value": round(V_total / (dts / args.steps) / 1e6, 1),
+                  "integrate_ms": round(si_ns / max(si_n, 1) * 1e-6, 4),
+                  "pairs_skipped": int(skipped), "pairs": int(total), "frac_skipped": round(skipped / max(total, 1), 4),
+                  # bytes this sweep asks for: TSDF stores + LUT planes of the pairs it reads + per pair the origin,
+                  # depth bound and window bound words + the frame texels
+                  "bytes_per_launch": int(V_local * 4 + lut_bytes + total * 12 + N * W * H * 8),
+                  "with_store_elision": {"ms_per_step": round(dtse / args.steps * 1e3, 4),
+                                         "integrate_ms": round(sei_ns / max(sei_n, 1) * 1e-6, 4)}}
+        skipbg["GBps"] = round(skipbg["bytes_per_launch"] / (si_ns / max(si_n, 1)), 1)
+
     out = {
         "metric": "Mvoxels/s TSDF integration (%d sensors, %s grid) + frames/s" % (
             N, "%d^3" % grid[0] if grid[0] == grid[1] == grid[2] else "%dx%dx%d" % grid),
@@ -335,6 +358,7 @@ def main():
                     "occupied_ratio": round(occ, 4), "ms_per_step_pipelined": bricked_pipelined},
         "other_schedule": other,
         "full_sweep_store_elision": elided,
+        "full_sweep_background_skip": skipbg,
     }
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):

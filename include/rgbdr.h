@@ -64,7 +64,15 @@ enum {
    * (every voxel is still evaluated; only the store of identical bytes is left out -- 97 % of
    * the tiles of a typical scene).  Off by default so that the benchmark's full sweep performs
    * every store of the reference's clear + draw. */
-  RGBDR_FLAG_ELIDE_STORES = 64u
+  RGBDR_FLAG_ELIDE_STORES = 64u,
+  /* Full sweep with a 1:1 / resampled inverse LUT only: a sensor whose frame shows nothing but background
+   * (silhouette 0) in the 16x16-pixel window a tile projects into, and from which every voxel of the tile
+   * lies at least the truncation limit behind the largest depth in that window, can only carve
+   * (tsdf_integration.vs:34-37: tsd = -limit where tsd >= limit).  With the flag the sweep applies exactly
+   * that without reading the sensor's three LUT planes of the tile (6 KiB) -- same volume bit for bit; how
+   * much is skipped depends on the frame (rgbdr_skipped_pairs).  Off by default so that the benchmark's
+   * full sweep streams every LUT entry, like the reference's draw call samples every vertex. */
+  RGBDR_FLAG_SKIP_BACKGROUND = 128u
 };
 
 /* Replaces the constructor arguments of NetKinectArray (NetKinectArray.cpp:42),
@@ -241,6 +249,10 @@ int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size);
 int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int active);
 int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on);           /* RGBDR_FLAG_PIPELINE at run time; drains both streams */
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on);        /* RGBDR_FLAG_ELIDE_STORES at run time */
+int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on);     /* RGBDR_FLAG_SKIP_BACKGROUND at run time */
+/* (tile, sensor) pairs of the owned slab whose LUT planes a RGBDR_FLAG_SKIP_BACKGROUND sweep of the frame
+ * processed last leaves unread, and the number of pairs (diagnostic: the byte accounting of such a sweep). */
+int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total);
 int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n);
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on);         /* unlike the reference these three do not re-run */
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on);    /* processTextures() themselves (SURVEY.md A.5:   */

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Full sweep with RGBDR_FLAG_SKIP_BACKGROUND at the benchmark configuration (for kernel traces / timing)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+load_package()
+import torch  # noqa: E402,F401
+from rgbd_recon_amd import capi, synth  # noqa: E402
+
+N, W, H = 4, 512, 424
+scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
+c = capi.Context(capi.make_config(N, (W, H), voxel_size=2.0 / 512, brick_size=8 * 2.0 / 512), 0)
+for i in range(N):
+    c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+    c.synth_inverse_calibration(i, scene.pinhole(i))
+c.set_use_bricks(False)
+c.update(scene.depth, scene.color)
+for skip in (False, True):
+    c.set_skip_background(skip)
+    for _ in range(5):
+        c.clear_occupied_bricks(); c.process_textures(); c.update_occupied_bricks(); c.integrate()
+    c.sync()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        c.clear_occupied_bricks(); c.process_textures(); c.update_occupied_bricks(); c.integrate()
+    c.sync()
+    print("skip", skip, "ms per frame %.4f" % ((time.perf_counter() - t0) / 40 * 1e3), c.skipped_pairs() if skip else "")
+c.close()

@@ -21,6 +21,7 @@ FLAGS_DEFAULT = 15
 FLAG_PIPELINE = 16
 FLAG_NO_RESAMPLE = 32
 FLAG_ELIDE_STORES = 64
+FLAG_SKIP_BACKGROUND = 128
 
 IMG_DEPTH_RAW, IMG_DEPTH_MORPH, IMG_DEPTH_RG, IMG_LAB, IMG_DEPTH_B_RG, IMG_SILHOUETTE, IMG_NORMAL, IMG_QUALITY = range(8)
 IMG_COLOR = 8
@@ -168,6 +169,8 @@ SYMBOLS = {
     "rgbdr_set_use_bricks": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_pipelined": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_elide_stores": (C.c_int, [_P, C.c_int]),
+    "rgbdr_set_skip_background": (C.c_int, [_P, C.c_int]),
+    "rgbdr_skipped_pairs": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
     "rgbdr_filter_textures": (C.c_int, [_P, C.c_int]),
     "rgbdr_use_processed_depths": (C.c_int, [_P, C.c_int]),
@@ -437,6 +440,16 @@ class Context:
     def set_elide_stores(self, on):
         self._chk(lib().rgbdr_set_elide_stores(self._h, int(on)))
         self._flag(FLAG_ELIDE_STORES, on)
+
+    def set_skip_background(self, on):
+        self._chk(lib().rgbdr_set_skip_background(self._h, int(on)))
+        self._flag(FLAG_SKIP_BACKGROUND, on)
+
+    def skipped_pairs(self):
+        """(skipped, total) (tile, sensor) pairs of a RGBDR_FLAG_SKIP_BACKGROUND sweep of the current frame"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(lib().rgbdr_skipped_pairs(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_min_voxels_per_brick(self, n):
         self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))

@@ -69,6 +69,11 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_lut_tiled_base);
   c->d_lut_tiled_base = nullptr;
   (void)hipFree(c->d_win);
+  (void)hipFree(c->d_bgmax);
+  (void)hipFree(c->d_skip_mask);
+  c->d_bgmax = nullptr;
+  c->d_skip_mask = nullptr;
+  c->skip_mask_tiles = 0;
   c->d_win = nullptr;
   c->d_tsdf_base = c->d_tsdf_owned = c->d_linear = nullptr;
   c->d_counters = c->d_ids = nullptr;
@@ -541,6 +546,7 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
     ctx->ev_pre_rec[w] = true;
   }
   ctx->textures_processed = true;
+  ctx->bgmax_for = -1;
   return RGBDR_OK;
 }
 
@@ -579,6 +585,41 @@ int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count)
   ctx->mask_valid = true;
   return RGBDR_OK;
 }
+
+}  // extern "C"
+// RGBDR_FLAG_SKIP_BACKGROUND: the per-window bounds of the frame process_textures wrote last (once per frame)
+int rgbdr::ensure_window_background(rgbdr_ctx* ctx)
+{
+  const int N = nsens(ctx);
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t n = (size_t)N * (ctx->cfg.depth_w + 1) * (ctx->cfg.depth_h + 1);
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
+  const size_t mask_bytes = (ntiles * N + 3) & ~(size_t)3;
+  if (!ctx->d_bgmax) HIPCHK(hipMalloc((void**)&ctx->d_bgmax, n * sizeof(float)));
+  if (ctx->skip_mask_tiles != ntiles) {
+    (void)hipFree(ctx->d_skip_mask);
+    ctx->d_skip_mask = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_skip_mask, mask_bytes + sizeof(unsigned)));
+    ctx->skip_mask_tiles = ntiles;
+    ctx->bgmax_for = -1;
+  }
+  if (ctx->bgmax_for == ctx->rbuf && ctx->skip_limit == ctx->cfg.tsdf_limit) return RGBDR_OK;
+  launch_window_background(ctx->frame_buf(ctx->rbuf), ctx->cfg.depth_w, ctx->cfg.depth_h, N, ctx->d_bgmax, ctx->stream);
+  IntegrateParams p{};
+  p.N = N;
+  p.W = ctx->cfg.depth_w;
+  p.H = ctx->cfg.depth_h;
+  p.limit = ctx->cfg.tsdf_limit;
+  p.win = ctx->d_win;
+  p.win_dmin = reinterpret_cast<const float*>(ctx->d_win + ntiles * N);
+  p.bgmax = ctx->d_bgmax;
+  launch_skip_mask(p, (unsigned)(ntiles * N), ctx->d_skip_mask, ctx->stream);
+  LAUNCHCHK("window_background");
+  ctx->bgmax_for = ctx->rbuf;
+  ctx->skip_limit = ctx->cfg.tsdf_limit;
+  return RGBDR_OK;
+}
+extern "C" {
 
 int rgbdr_integrate(rgbdr_ctx* ctx)
 {
@@ -649,6 +690,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.tile_state = ctx->d_tile_state;
   const bool elide = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_ELIDE_STORES) != 0;
   p.elide_stores = elide ? 1 : 0;
+  const bool skip_bg = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_SKIP_BACKGROUND) != 0 && p.limit > 0.0f;
+  p.skip_background = skip_bg ? 1 : 0;
+  p.win_dmin = reinterpret_cast<const float*>(ctx->d_win + (size_t)p.TX * p.TY * p.ntz * N);
   if ((!bricks && !elide) || !all_tiled) {  // sweeps that overwrite tiles without keeping tile_state
     int rc_ = bump_clear_epoch(ctx);
     if (rc_ != RGBDR_OK) return rc_;
@@ -669,6 +713,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
     }
   }
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+  if (skip_bg) { int rc_ = ensure_window_background(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  p.bgmax = ctx->d_bgmax;
+  p.skip_mask = ctx->d_skip_mask;
   tbegin(ctx, "2integrate", ctx->stream);
   launch_integrate(p, all_tiled, ctx->stream);
   tend(ctx, "2integrate", ctx->stream);
@@ -773,6 +820,34 @@ int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
   return set_flag(ctx, RGBDR_FLAG_PIPELINE, on);
 }
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_ELIDE_STORES, on); }
+int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_SKIP_BACKGROUND, on); }
+
+int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total)
+{
+  if (!ctx || !skipped || !total) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "skipped_pairs before process_textures");
+  const int N = nsens(ctx);
+  for (int i = 0; i < N; ++i)
+    if (!ctx->inv_set[i] || !ctx->inv_tiled[i])
+      return ctx->fail(RGBDR_ERR_STATE, "skipped_pairs needs a 1:1 or resampled inverse LUT of every sensor");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  { int rc_ = ensure_window_background(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  const rgbdr_geometry& g = ctx->geo;
+  const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), npairs = ntiles * N;
+  unsigned h = 0;
+  if (ctx->cfg.tsdf_limit > 0.0f) {
+    unsigned* count = reinterpret_cast<unsigned*>(ctx->d_skip_mask + ((npairs + 3) & ~(size_t)3));
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(unsigned), ctx->stream));
+    launch_count_bytes(ctx->d_skip_mask, (unsigned)npairs, count, ctx->stream);
+    LAUNCHCHK("count_bytes");
+    HIPCHK(hipMemcpyAsync(&h, count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  *skipped = h;
+  *total = npairs;
+  return RGBDR_OK;
+}
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_PROCESSED, on); }
 int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }

@@ -81,7 +81,12 @@ struct rgbdr_ctx {
   hipEvent_t ev_mapped[2] = {nullptr, nullptr};
   bool ev_mapped_rec[2] = {false, false};
   int mapped_back = 0;
-  int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin
+  int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin; second plane: smallest projected depth
+  uint8_t* d_skip_mask = nullptr;  // ... and per (tile, sensor) pair 1 = skipped; [ntiles * N] bytes + a 4-B counter behind them
+  float* d_bgmax = nullptr;  // RGBDR_FLAG_SKIP_BACKGROUND: [N][(H+1)][(W+1)] window bounds of the current frame
+  size_t skip_mask_tiles = 0;
+  float skip_limit = 0.0f;   // truncation limit the mask was built for
+  int bgmax_for = -1;        // frame buffer d_bgmax was computed from since the last process_textures (-1: stale)
   float arena_probe_ms[16] = {0};  // LUT-stream time of each candidate placement of the arena
   int arena_trials = 0, arena_chosen = 0;
   float4* d_lut_generic[rgbdr::kMaxSensors] = {};
@@ -165,6 +170,7 @@ inline size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->c
 // api.cpp
 int bump_clear_epoch(rgbdr_ctx* ctx);   // invalidates every recorded "this tile already holds -limit"
 int sync_all(rgbdr_ctx* ctx);           // drain both streams
+int ensure_window_background(rgbdr_ctx* c);
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);

@@ -31,6 +31,15 @@
 
 namespace rgbdr {
 
+// Block-uniform words that no kernel writes while the sweep runs (tables, window origins, the list) are read
+// through the constant address space: scalar loads.  As plain global loads they become vector loads that are
+// waited for with vmcnt(0), which would drain the prefetched stage every time.
+template <class T>
+__device__ __forceinline__ __attribute__((address_space(4))) const T* ro(const T* p)
+{
+  return (__attribute__((address_space(4))) const T*)p;
+}
+
 constexpr int kWin = 16;      // frame window edge staged in LDS per (tile, sensor)
 // LDS row pitch of a window in texels.  16 texels would be 128 B = all 32 banks, so
 // footprints in the same column of different rows would collide (measured: 79 % of
@@ -157,15 +166,35 @@ __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx,
 // ---------------------------------------------------------------------------
 // Sensors [S0, S0+CNT) of one tile: issue every global load (CNT*3 LUT planes, CNT
 // frame windows), one barrier, then fold the 4 voxels of this thread.
-template <int CNT, bool NT>
+// SKIP (RGBDR_FLAG_SKIP_BACKGROUND): a sensor whose 16x16 frame window holds nothing but background texels
+// (silhouette 0, depth <= some bound), seen from a tile whose 512 footprints all lie inside that window and whose
+// projected depths all exceed the bound by the truncation limit, does to every voxel of the tile what
+// tsdf_integration.vs:34-37 does for a silhouette miss -- tsd = -limit where tsd >= limit -- and nothing else:
+// the interpolated silhouette is 0 + a * (0 - 0) = 0 < 1 for the finite weights of finite coordinates, and where
+// tsd < limit the shader goes on to sdist = pc.z - depth >= limit (rounding is monotonic: fl(pc.z - depth) >=
+// fl(dmin - bound)), which changes nothing.  So its three LUT planes and its window need not be read.  `dmin`
+// (per tile and sensor; -inf when a footprint leaves the window or an entry is not finite) comes from
+// k_tile_windows at LUT upload, the bound per window origin from k_window_background and the decision per pair
+// from k_skip_mask, once per frame.
+template <int CNT, bool NT, bool SKIP>
 __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsigned tile, int q, int s0, int ntot,
                                                 uint2 (*win)[kWin * kWinPitch], bool windows_in_use, float limit,
-                                                float* tsd, float* wsum)
+                                                float* tsd, float* wsum, unsigned skipbits = 0u)
 {
+  int wx0[CNT], wy0[CNT];
+  bool skip[CNT];
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int d = p.win[(size_t)tile * ntot + s0 + i];
+    wx0[i] = (int)(short)(d & 0xffff);
+    wy0[i] = (int)(short)(d >> 16);
+    skip[i] = SKIP && ((skipbits >> (s0 + i)) & 1u) != 0;
+  }
   const float4* lut = reinterpret_cast<const float4*>(p.lut_tiled + ((size_t)tile * ntot + s0) * (3 * kTileVoxels)) + q;
   float4 U[CNT], V[CNT], D[CNT];
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
+    if (SKIP && skip[i]) continue;
     if (NT) {  // read-once stream: non-temporal, measured 7-8 % faster than default-policy loads
       typedef float v4f __attribute__((ext_vector_type(4)));
       const v4f* l = reinterpret_cast<const v4f*>(lut);
@@ -181,14 +210,11 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
       D[i] = lut[(i * 3 + 2) * (kTileVoxels / 4)];
     }
   }
-  int wx0[CNT], wy0[CNT];
   uint2 ta[CNT], tb[CNT];
   const int wr = q >> 3, wc = (q & 7) * 2;
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    const int d = p.win[(size_t)tile * ntot + s0 + i];
-    wx0[i] = (int)(short)(d & 0xffff);
-    wy0[i] = (int)(short)(d >> 16);
+    if (SKIP && skip[i]) continue;
     const int row = clampi(wy0[i] + wr, 0, p.H - 1) * p.W;
     ta[i] = p.frame[s0 + i][row + clampi(wx0[i] + wc, 0, p.W - 1)];
     tb[i] = p.frame[s0 + i][row + clampi(wx0[i] + wc + 1, 0, p.W - 1)];
@@ -196,12 +222,18 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
   if (windows_in_use) __syncthreads();  // the previous group's footprints are all read
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
+    if (SKIP && skip[i]) continue;
     win[i][wr * kWinPitch + wc] = ta[i];
     win[i][wr * kWinPitch + wc + 1] = tb[i];
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
+    if (SKIP && skip[i]) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tsd[j] = (tsd[j] >= limit) ? -limit : tsd[j];
+      continue;
+    }
     const uint2* frame = p.frame[s0 + i];
     fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].x, V[i].x, D[i].x, limit, tsd[0], wsum[0]);
     fold_voxel_window(win[i], wx0[i], wy0[i], frame, p.W, p.H, U[i].y, V[i].y, D[i].y, limit, tsd[1], wsum[1]);
@@ -219,7 +251,7 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
 // folded in two groups (the running tsd / weight stay in registers), which keeps
 // the kernel at <= ~100 VGPRs for every N.
 // One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
-template <int N, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false>
+template <int N, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false, bool SKIP = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
@@ -229,8 +261,14 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
   const float limit = p.limit;
   float tsd[4] = {limit, limit, limit, limit};
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  integrate_group<G1, NT>(p, tile, q, 0, N, win, false, limit, tsd, wsum);
-  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT>(p, tile, q, G1, N, win, true, limit, tsd, wsum);
+  // sensors (bit s) whose LUT planes this tile leaves unread for the current frame (k_skip_mask: a byte per pair)
+  unsigned skipbits = 0u;
+  if (SKIP) {
+#pragma unroll
+    for (int s = 0; s < N; ++s) skipbits |= (unsigned)ro(p.skip_mask)[(size_t)tile * N + s] << s;
+  }
+  integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, skipbits);
+  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, skipbits);
   if (ELIDE) {
     // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
     // of this epoch (tile_state, see k_brick_clear) need not be written again
@@ -258,7 +296,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
 }
 
 // Full sweep: one block per tile.
-template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false>
+template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false, bool SKIP = false>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
@@ -274,7 +312,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
     tile = (chunk * 8u + xcd) * p.order_chunk + within;
   }
-  integrate_tile<N, MAXG, NT, ELIDE, STAGE>(p, tile, win);
+  integrate_tile<N, MAXG, NT, ELIDE, STAGE, SKIP>(p, tile, win);
 }
 
 // ---------------------------------------------------------------------------
@@ -310,15 +348,6 @@ struct TileWords {   // block-uniform words of one list entry
   int org[N];        // window origins (int16 x | int16 y << 16) per sensor
   uint32_t rx, ry, rz;  // BrickTables::tile ranges (partial tiles)
 };
-
-// Block-uniform words that no kernel writes while the sweep runs (tables, window origins, the list) are read
-// through the constant address space: scalar loads.  As plain global loads they become vector loads that are
-// waited for with vmcnt(0), which would drain the prefetched stage every time.
-template <class T>
-__device__ __forceinline__ __attribute__((address_space(4))) const T* ro(const T* p)
-{
-  return (__attribute__((address_space(4))) const T*)p;
-}
 
 // `entry` was fetched an iteration earlier (0xffffffff: past the end of the list), so nothing here waits on a load
 template <int N>
@@ -566,9 +595,11 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
 // tile's voxels whose footprint lies inside the image (others -- invalid -1
 // entries, far-off projections -- take the global path in the kernel).
 __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ lut_tiled, int W, int H, int sensor,
-                                                      int N, int32_t* __restrict__ win)
+                                                      int N, int32_t* __restrict__ win, float* __restrict__ win_dmin)
 {
   __shared__ int smin[2][2];
+  __shared__ int org[2];
+  __shared__ float sdmin[2];
   const unsigned tile = blockIdx.x;
   const int q = threadIdx.x;
   const float4* lut = reinterpret_cast<const float4*>(lut_tiled + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
@@ -611,12 +642,115 @@ __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ 
     my = min(smin[0][1], smin[1][1]);
     if (mx == 0x7fffffff) mx = my = 0;
     win[(size_t)tile * N + sensor] = (int32_t)(((uint32_t)(my & 0xffff) << 16) | (uint32_t)(mx & 0xffff));
+    org[0] = (int)(short)(mx & 0xffff);  // as the sweep decodes it
+    org[1] = (int)(short)(my & 0xffff);
+  }
+  __syncthreads();
+  // RGBDR_FLAG_SKIP_BACKGROUND: the smallest projected depth of the tile, provided every entry is finite and every
+  // 2x2 footprint lies inside the window (then the sweep touches no texel outside it); -inf otherwise
+  const float4 D = lut[2 * (kTileVoxels / 4)];
+  const float ds[4] = {D.x, D.y, D.z, D.w};
+  bool ok = true;
+  float dm = __builtin_inff();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a;
+    const int rx = footprint(us[j], W, a) - org[0], ry = footprint(vs[j], H, a) - org[1];
+    ok = ok && (unsigned)rx < (unsigned)(kWin - 1) && (unsigned)ry < (unsigned)(kWin - 1) &&
+         fabsf(us[j]) < __builtin_inff() && fabsf(vs[j]) < __builtin_inff() && fabsf(ds[j]) < __builtin_inff();
+    dm = fminf(dm, ds[j]);
+  }
+  const bool all_ok = __syncthreads_and(ok) != 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dm = fminf(dm, __shfl_xor(dm, o));
+  if ((q & 63) == 0) sdmin[q >> 6] = dm;
+  __syncthreads();
+  if (q == 0) win_dmin[(size_t)tile * N + sensor] = all_ok ? fminf(sdmin[0], sdmin[1]) : -__builtin_inff();
+}
+
+// RGBDR_FLAG_SKIP_BACKGROUND, once per frame: for every window origin (ox, oy) in [-1, W-1] x [-1, H-1] the largest
+// depth_b among the 16x16 (edge-clamped) texels the sweep would stage from there, provided all of them are
+// background (silhouette 0, depth not NaN); +inf otherwise.  bgmax[sensor][(oy + 1) * (W + 1) + (ox + 1)].
+__global__ __launch_bounds__(256) void k_window_background(const uint2* __restrict__ frames, int W, int H,
+                                                           float* __restrict__ bgmax)
+{
+  constexpr int T = 16 + kWin - 1;  // 31 texels per axis feed 16 origins
+  __shared__ float tex[T][T + 1];
+  __shared__ float hmax[T][16 + 1];
+  const int l = blockIdx.z;
+  const uint2* frame = frames + (size_t)l * W * H;
+  const int ox0 = (int)blockIdx.x * 16 - 1, oy0 = (int)blockIdx.y * 16 - 1;
+  const int t = threadIdx.y * 16 + threadIdx.x;
+  for (int i = t; i < T * T; i += 256) {
+    const int ty = i / T, tx = i - ty * T;
+    const uint2 v = frame[(size_t)clampi(oy0 + ty, 0, H - 1) * W + clampi(ox0 + tx, 0, W - 1)];
+    const float d = texel_depth(v);
+    tex[ty][tx] = ((v.y >> 31) && d == d) ? d : __builtin_inff();
+  }
+  __syncthreads();
+  for (int i = t; i < T * 16; i += 256) {
+    const int ty = i / 16, ox = i - ty * 16;
+    float m = tex[ty][ox];
+#pragma unroll
+    for (int k = 1; k < kWin; ++k) m = fmaxf(m, tex[ty][ox + k]);
+    hmax[ty][ox] = m;
+  }
+  __syncthreads();
+  const int ox = ox0 + (int)threadIdx.x, oy = oy0 + (int)threadIdx.y;
+  if (ox > W - 1 || oy > H - 1) return;
+  float m = hmax[threadIdx.y][threadIdx.x];
+#pragma unroll
+  for (int k = 1; k < kWin; ++k) m = fmaxf(m, hmax[threadIdx.y + k][threadIdx.x]);
+  bgmax[(size_t)l * (W + 1) * (H + 1) + (size_t)(oy + 1) * (W + 1) + (ox + 1)] = m;
+}
+void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_window_background, dim3((unsigned)((W + 1 + 15) / 16), (unsigned)((H + 1 + 15) / 16), (unsigned)N),
+                     dim3(16, 16), 0, s, frames, W, H, bgmax);
+}
+
+// The decision per (tile, sensor) pair, once per frame: one byte each.
+__global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restrict__ mask)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npairs) return;
+  const int s = (int)(i % (unsigned)p.N);
+  const int d = p.win[i];
+  const int wx0 = (int)(short)(d & 0xffff), wy0 = (int)(short)(d >> 16);
+  const float bound = p.bgmax[(size_t)s * (p.W + 1) * (p.H + 1) + (size_t)(wy0 + 1) * (p.W + 1) + (wx0 + 1)];
+  mask[i] = (p.win_dmin[i] - bound) >= p.limit ? 1 : 0;  // false for dmin = -inf and for bound = +inf (not background)
+}
+void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_skip_mask, dim3((npairs + 255) / 256), dim3(256), 0, s, p, npairs, mask);
+}
+// sum of the mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
+__global__ __launch_bounds__(1024) void k_count_bytes(const uint8_t* __restrict__ mask, unsigned n, unsigned* __restrict__ count)
+{
+  __shared__ unsigned part[16];
+  unsigned c = 0;
+  for (unsigned i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) c += mask[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    atomicAdd(count, t);
   }
 }
+void launch_count_bytes(const uint8_t* mask, unsigned n, unsigned* count, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_count_bytes, dim3(64), dim3(1024), 0, s, mask, n, count);
+}
+
+// `win` holds two planes of ntiles * N words: the window origins, then the tiles' smallest projected depths
 void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
                          hipStream_t s)
 {
-  hipLaunchKernelGGL(k_tile_windows, dim3((unsigned)ntiles), dim3(128), 0, s, lut_tiled, W, H, sensor, N, win);
+  hipLaunchKernelGGL(k_tile_windows, dim3((unsigned)ntiles), dim3(128), 0, s, lut_tiled, W, H, sensor, N, win,
+                     reinterpret_cast<float*>(win + (size_t)ntiles * N));
 }
 
 // ---------------------------------------------------------------------------
@@ -683,7 +817,11 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
-  if (p.elide_stores)
+  if (p.skip_background && p.elide_stores)
+    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);
+  else if (p.skip_background)
+    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, false, true>), dim3(ntiles), dim3(128), 0, s, p);
+  else if (p.elide_stores)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
   else if (p.stage_lo || p.stage_hi)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);
@@ -695,7 +833,7 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
 // 1:1 / resampled LUT); for every other sweep the caller copies the layers afterwards
 bool integrate_stages_halo(const IntegrateParams& p, bool one_to_one)
 {
-  if (!one_to_one || p.use_bricks || p.elide_stores) return false;
+  if (!one_to_one || p.use_bricks || p.elide_stores || p.skip_background) return false;
   static const bool knobs = getenv("RGBDR_INTEGRATE_GROUP") || getenv("RGBDR_NT");
   return !knobs;
 }

@@ -84,6 +84,12 @@ struct IntegrateParams {
   // origin of the 16x16 frame window that tile projects into (int16 x | int16 y << 16)
   const float* lut_tiled;
   const int32_t* win;
+  // RGBDR_FLAG_SKIP_BACKGROUND: per (tile, sensor) the smallest projected depth (k_tile_windows), per sensor and
+  // window origin the largest depth of an all-background window (k_window_background); see integrate_group
+  const float* win_dmin;
+  const float* bgmax;
+  const uint8_t* skip_mask;  // per (tile, sensor): 1 = skipped for the current frame (k_skip_mask)
+  int skip_background;
   // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
   const float4* lut[kMaxSensors];
   int rx[kMaxSensors], ry[kMaxSensors], rz[kMaxSensors], zoff[kMaxSensors];
@@ -215,6 +221,9 @@ void launch_resample_lut(const float4* src_rgba, int rx, int ry, int rz, int zof
                          int tz0, int ntz, int sensor, int N, float* dst_tiled, hipStream_t s);
 // average time (ms) of one replay of the integrate kernel's LUT stream over `arena`; < 0 on error
 float probe_arena_ms(const float* arena, size_t ntiles, int N, int TX, float* sink, hipStream_t s);
+void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s);
+void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s);
+void launch_count_bytes(const uint8_t* mask, unsigned n, unsigned* count, hipStream_t s);
 void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
                          hipStream_t s);
 void launch_synth_inverse(const rgbdr_pinhole& cam, int W, int H, const float bbox_min[3], const float bbox_max[3],

@@ -788,6 +788,54 @@ def test_settle_leaves_a_usable_context(pkg, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("n,G,wh", [(2, 64, (128, 106)), (5, 64, (128, 106)), (3, 96, (200, 150)), (1, 32, (64, 53))])
+def test_full_sweep_background_skip(pkg, orc, n, G, wh):
+    """RGBDR_FLAG_SKIP_BACKGROUND leaves the LUT planes of (tile, sensor) pairs unread whose window shows only
+    background; the volume is the oracle's bit for bit, with and without the flag, also next to store elision,
+    for frames with holes / non-finite depths, an empty frame and a frame that is all surface."""
+    scene, ctx, inv = build(pkg, n=n, wh=wh, G=G)
+    ctx.set_use_bricks(False)
+    rng = np.random.default_rng(5)
+    frames = [scene.depth.copy()]
+    d = scene.depth.copy()
+    for val in (np.nan, np.inf, -np.inf, -3.0, 1e30, 0.0):
+        for _ in range(16):
+            d[rng.integers(0, n), rng.integers(0, wh[1]), rng.integers(0, wh[0])] = val
+    frames.append(d)
+    frames.append(np.zeros_like(scene.depth))                      # nothing but background
+    frames.append(np.full_like(scene.depth, 2.0))                  # a wall through the box
+    fracs = []
+    for k, dep in enumerate(frames):
+        ref = oracle_run(orc, scene, ctx, inv, depth_override=dep, use_bricks=False)
+        for skip, elide in ((False, False), (True, False), (True, True), (False, False)):
+            ctx.set_skip_background(skip)
+            ctx.set_elide_stores(elide)
+            for _ in range(2):   # twice: the second sweep of an elided pair runs against recorded tile states
+                ctx.step(dep, scene.color)
+            got = ctx.readback_tsdf()
+            assert same_bits(got, ref["tsdf"]), "frame %d skip %d elide %d: %d voxels differ" % (
+                k, skip, elide, count_diff(got, ref["tsdf"]))
+        skipped, total = ctx.skipped_pairs()
+        assert total == np.prod(ctx.geo.tiles) * n
+        fracs.append(skipped / total)
+    assert fracs[2] >= fracs[0] > 0.05 and fracs[2] > 0.5, fracs   # mostly background / nothing but background
+    ctx.close()
+
+
+def test_background_skip_on_slabs_and_resampled_luts(pkg, orc):
+    scene, ctx, inv = build(pkg, n=3, wh=(128, 106), G=64, inv_res=(40, 44, 48), slab_rank=1, slab_count=3)
+    ctx.set_use_bricks(False)
+    g = ctx.geo
+    ref = oracle_run(orc, scene, ctx, inv, use_bricks=False)
+    for skip in (False, True):
+        ctx.set_skip_background(skip)
+        ctx.step(scene.depth, scene.color)
+        got = ctx.readback_tsdf()
+        assert same_bits(got, ref["tsdf"][g.slab_voxel_z0:g.slab_voxel_z1])
+    assert ctx.skipped_pairs()[0] > 0
+    ctx.close()
+
+
 def test_full_sweep_store_elision(pkg, orc):
     """RGBDR_FLAG_ELIDE_STORES: identical volumes, through every event that changes which
     tiles hold -limit (another frame, the brick sweep in between, another limit, settle)"""
