@@ -253,6 +253,15 @@ int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on);     /* RGBDR_FLAG_SKIP_BA
 /* (tile, sensor) pairs of the owned slab whose LUT planes a RGBDR_FLAG_SKIP_BACKGROUND sweep of the frame
  * processed last leaves unread, and the number of pairs (diagnostic: the byte accounting of such a sweep). */
 int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total);
+/* Diagnostic copies of what RGBDR_FLAG_SKIP_BACKGROUND decides from (host buffers sized by the caller):
+ *   which = 0: the verdict byte per (tile, sensor) of the frame processed last (0 read the LUT, 1 carve,
+ *              2 in front of everything the window shows, 3 hidden), [owned tiles][N] bytes
+ *   which = 1: per (tile, sensor) the window origin (int16 x | int16 y << 16), the smallest and the largest
+ *              projected depth (-inf / +inf: a footprint leaves the window) and the size class of the square
+ *              that holds the footprints (0 / 1 / 2: 4 / 8 / 16 texels), 4 planes of [owned tiles][N] words
+ *   which = 2: per sensor, size class and origin the three bounds of what the square's texels have in common
+ *              (largest depth if all background; smallest, largest depth if all surface), [N][3][3][H + 1][W + 1] floats */
+int rgbdr_readback_skip_tables(rgbdr_ctx* ctx, int which, void* dst, size_t bytes);
 int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n);
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on);         /* unlike the reference these three do not re-run */
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on);    /* processTextures() themselves (SURVEY.md A.5:   */

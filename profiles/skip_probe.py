@@ -30,4 +30,26 @@ for skip in (False, True):
         c.clear_occupied_bricks(); c.process_textures(); c.update_occupied_bricks(); c.integrate()
     c.sync()
     print("skip", skip, "ms per frame %.4f" % ((time.perf_counter() - t0) / 40 * 1e3), c.skipped_pairs() if skip else "")
+import numpy as np  # noqa: E402
+v = c.readback_skip_tables(0)
+org, dmin, dmax, ext = c.readback_skip_tables(1)
+bounds = c.readback_skip_tables(2)
+print("verdicts", {k: int((v == k).sum()) for k in range(4)}, "tiles with every sensor decided", int((v != 0).all(axis=1).sum()), "of", v.shape[0])
+und = v == 0
+notcont = und & ~np.isfinite(dmin)
+ox = (org & 0xffff).astype(np.int16).astype(int) + 1
+oy = (org >> 16).astype(np.int16).astype(int) + 1
+s_idx = np.broadcast_to(np.arange(N), v.shape)
+bg = bounds[s_idx, ext, 0, oy, ox]
+lo = bounds[s_idx, ext, 1, oy, ox]
+hi = bounds[s_idx, ext, 2, oy, ox]
+print('size classes', {k: int((ext == k).sum()) for k in range(3)})
+mixed = und & np.isfinite(dmin) & ~np.isfinite(bg) & ~np.isfinite(hi)
+surf = und & np.isfinite(dmin) & np.isfinite(hi)
+bgw = und & np.isfinite(dmin) & np.isfinite(bg)
+print("undecided: footprints leave window %d, mixed window %d, surface window (near the surface) %d, background window %d"
+      % (notcont.sum(), mixed.sum(), surf.sum(), bgw.sum()))
+if surf.any():
+    print("surface windows: depth spread hi-lo median %.4f p90 %.4f (limit %.4f)" % (
+        np.median((hi - lo)[surf]), np.percentile((hi - lo)[surf], 90), c.cfg.tsdf_limit))
 c.close()

@@ -171,6 +171,7 @@ SYMBOLS = {
     "rgbdr_set_elide_stores": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_skip_background": (C.c_int, [_P, C.c_int]),
     "rgbdr_skipped_pairs": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rgbdr_readback_skip_tables": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
     "rgbdr_filter_textures": (C.c_int, [_P, C.c_int]),
     "rgbdr_use_processed_depths": (C.c_int, [_P, C.c_int]),
@@ -450,6 +451,22 @@ class Context:
         a, b = C.c_uint64(), C.c_uint64()
         self._chk(lib().rgbdr_skipped_pairs(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def readback_skip_tables(self, which):
+        """diagnostic tables of RGBDR_FLAG_SKIP_BACKGROUND: 0 verdict bytes [tiles][N]; 1 (origins int32, dmin f32,
+        dmax f32, size class int32) each [tiles][N]; 2 bounds f32 [N][size class][3][H+1][W+1]"""
+        n = self.cfg.num_sensors
+        pairs = self.skipped_pairs()[1]
+        if which == 0:
+            out = np.empty((pairs // n, n), dtype=np.uint8)
+        elif which == 1:
+            out = np.empty((4, pairs // n, n), dtype=np.int32)
+        else:
+            out = np.empty((n, 3, 3, self.cfg.depth_h + 1, self.cfg.depth_w + 1), dtype=np.float32)
+        self._chk(lib().rgbdr_readback_skip_tables(self._h, which, out.ctypes.data, out.nbytes))
+        if which == 1:
+            return out[0], out[1].view(np.float32), out[2].view(np.float32), out[3]
+        return out
 
     def set_min_voxels_per_brick(self, n):
         self._chk(lib().rgbdr_set_min_voxels_per_brick(self._h, n))

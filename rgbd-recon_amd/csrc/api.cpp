@@ -592,7 +592,7 @@ int rgbdr::ensure_window_background(rgbdr_ctx* ctx)
 {
   const int N = nsens(ctx);
   const rgbdr_geometry& g = ctx->geo;
-  const size_t n = (size_t)N * (ctx->cfg.depth_w + 1) * (ctx->cfg.depth_h + 1);
+  const size_t n = (size_t)N * 9 * (ctx->cfg.depth_w + 1) * (ctx->cfg.depth_h + 1);
   const size_t ntiles = (size_t)g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0);
   const size_t mask_bytes = (ntiles * N + 3) & ~(size_t)3;
   if (!ctx->d_bgmax) HIPCHK(hipMalloc((void**)&ctx->d_bgmax, n * sizeof(float)));
@@ -612,6 +612,8 @@ int rgbdr::ensure_window_background(rgbdr_ctx* ctx)
   p.limit = ctx->cfg.tsdf_limit;
   p.win = ctx->d_win;
   p.win_dmin = reinterpret_cast<const float*>(ctx->d_win + ntiles * N);
+  p.win_dmax = reinterpret_cast<const float*>(ctx->d_win + 2 * ntiles * N);
+  p.win_ext = ctx->d_win + 3 * ntiles * N;
   p.bgmax = ctx->d_bgmax;
   launch_skip_mask(p, (unsigned)(ntiles * N), ctx->d_skip_mask, ctx->stream);
   LAUNCHCHK("window_background");
@@ -686,13 +688,14 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.tile_list = ctx->d_tile_list;
   p.tile_count = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz + ctx->tile_count_parity;
   p.tile_count_next = ctx->d_tile_list + (size_t)p.TX * p.TY * p.ntz + (1 - ctx->tile_count_parity);
-  if (bricks && all_tiled) ctx->tile_count_parity ^= 1;
   p.tile_state = ctx->d_tile_state;
   const bool elide = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_ELIDE_STORES) != 0;
   p.elide_stores = elide ? 1 : 0;
   const bool skip_bg = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_SKIP_BACKGROUND) != 0 && p.limit > 0.0f;
+  if (bricks && all_tiled) ctx->tile_count_parity ^= 1;
   p.skip_background = skip_bg ? 1 : 0;
   p.win_dmin = reinterpret_cast<const float*>(ctx->d_win + (size_t)p.TX * p.TY * p.ntz * N);
+  p.win_dmax = reinterpret_cast<const float*>(ctx->d_win + 2 * (size_t)p.TX * p.TY * p.ntz * N);
   if ((!bricks && !elide) || !all_tiled) {  // sweeps that overwrite tiles without keeping tile_state
     int rc_ = bump_clear_epoch(ctx);
     if (rc_ != RGBDR_OK) return rc_;
@@ -821,6 +824,32 @@ int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
 }
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_ELIDE_STORES, on); }
 int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_SKIP_BACKGROUND, on); }
+
+int rgbdr_readback_skip_tables(rgbdr_ctx* ctx, int which, void* dst, size_t bytes)
+{
+  if (!ctx || !dst) return RGBDR_ERR_INVALID_ARGUMENT;
+  uint64_t a = 0, b = 0;
+  int rc = rgbdr_skipped_pairs(ctx, &a, &b);  // state checks + tables of the current frame
+  if (rc != RGBDR_OK) return rc;
+  const size_t npairs = (size_t)b;
+  const void* src = nullptr;
+  size_t n = 0;
+  if (which == 0) {
+    src = ctx->d_skip_mask;
+    n = npairs;
+  } else if (which == 1) {
+    src = ctx->d_win;
+    n = 4 * npairs * sizeof(int32_t);
+  } else if (which == 2) {
+    src = ctx->d_bgmax;
+    n = (size_t)nsens(ctx) * 9 * (ctx->cfg.depth_w + 1) * (ctx->cfg.depth_h + 1) * sizeof(float);
+  } else {
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "which must be 0, 1 or 2");
+  }
+  if (bytes != n) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "destination size does not match the table");
+  HIPCHK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+  return RGBDR_OK;
+}
 
 int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total)
 {

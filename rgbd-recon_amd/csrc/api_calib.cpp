@@ -162,9 +162,9 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }
     ctx->integrated = false;
   }
-  // two planes: window origins, then the tiles' smallest projected depths (launch_tile_windows)
-  HIPCHK(hipMalloc((void**)&ctx->d_win, 2 * ntiles * nsens(ctx) * sizeof(int32_t)));
-  HIPCHK(hipMemsetAsync(ctx->d_win, 0, 2 * ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
+  // four planes: window origins, the tiles' smallest and largest projected depths, footprint size class (launch_tile_windows)
+  HIPCHK(hipMalloc((void**)&ctx->d_win, 4 * ntiles * nsens(ctx) * sizeof(int32_t)));
+  HIPCHK(hipMemsetAsync(ctx->d_win, 0, 4 * ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
   return RGBDR_OK;
 }
 

@@ -166,35 +166,40 @@ __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx,
 // ---------------------------------------------------------------------------
 // Sensors [S0, S0+CNT) of one tile: issue every global load (CNT*3 LUT planes, CNT
 // frame windows), one barrier, then fold the 4 voxels of this thread.
-// SKIP (RGBDR_FLAG_SKIP_BACKGROUND): a sensor whose 16x16 frame window holds nothing but background texels
-// (silhouette 0, depth <= some bound), seen from a tile whose 512 footprints all lie inside that window and whose
-// projected depths all exceed the bound by the truncation limit, does to every voxel of the tile what
-// tsdf_integration.vs:34-37 does for a silhouette miss -- tsd = -limit where tsd >= limit -- and nothing else:
-// the interpolated silhouette is 0 + a * (0 - 0) = 0 < 1 for the finite weights of finite coordinates, and where
-// tsd < limit the shader goes on to sdist = pc.z - depth >= limit (rounding is monotonic: fl(pc.z - depth) >=
-// fl(dmin - bound)), which changes nothing.  So its three LUT planes and its window need not be read.  `dmin`
-// (per tile and sensor; -inf when a footprint leaves the window or an entry is not finite) comes from
-// k_tile_windows at LUT upload, the bound per window origin from k_window_background and the decision per pair
-// from k_skip_mask, once per frame.
+// SKIP (RGBDR_FLAG_SKIP_BACKGROUND): what one sensor does to a tile is often known without its LUT planes.  Take a
+// tile whose 512 footprints all lie inside the sensor's 16x16 frame window and whose entries are finite, with
+// projected depths in [dmin, dmax] (k_tile_windows, at LUT upload), and look at the window's texels
+// (k_window_background, once per frame):
+//   * all background (silhouette 0), depths <= hi, and fl(dmin - hi) >= limit: the interpolated silhouette is
+//     0 + a * (0 - 0) = 0 < 1, so tsdf_integration.vs:34-37 carves -- tsd = -limit where tsd >= limit -- and where it
+//     does not, sdist = pc.z - depth >= limit (rounding is monotonic: fl(pc.z - depth) >= fl(dmin - hi)) changes
+//     nothing                                                                                   -> kSkipCarve
+//   * all surface (silhouette 1: the interpolation gives 1 + a * (1 - 1) = 1, no carve), depths in [lo, hi]:
+//       fl(dmax - lo) <= -limit: every voxel lies in front of everything the window shows, sdist <= -limit,
+//       tsd = -limit (tsdf_integration.vs:44-45)                                                 -> kSkipFront
+//       fl(dmin - hi) >= limit: every voxel is hidden, sdist >= limit, nothing happens           -> kSkipBehind
+// k_skip_mask stores the verdict per (tile, sensor) and frame; the sweep then applies it to its four voxels in
+// the sensor's turn and leaves the three LUT planes (6 KiB) and the window of that pair unread.
+enum : unsigned { kSkipNone = 0u, kSkipCarve = 1u, kSkipFront = 2u, kSkipBehind = 3u };
 template <int CNT, bool NT, bool SKIP>
 __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsigned tile, int q, int s0, int ntot,
                                                 uint2 (*win)[kWin * kWinPitch], bool windows_in_use, float limit,
-                                                float* tsd, float* wsum, unsigned skipbits = 0u)
+                                                float* tsd, float* wsum, unsigned actions = 0u)
 {
   int wx0[CNT], wy0[CNT];
-  bool skip[CNT];
+  unsigned act[CNT];
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
     const int d = p.win[(size_t)tile * ntot + s0 + i];
     wx0[i] = (int)(short)(d & 0xffff);
     wy0[i] = (int)(short)(d >> 16);
-    skip[i] = SKIP && ((skipbits >> (s0 + i)) & 1u) != 0;
+    act[i] = SKIP ? (actions >> (2 * (s0 + i))) & 3u : kSkipNone;
   }
   const float4* lut = reinterpret_cast<const float4*>(p.lut_tiled + ((size_t)tile * ntot + s0) * (3 * kTileVoxels)) + q;
   float4 U[CNT], V[CNT], D[CNT];
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    if (SKIP && skip[i]) continue;
+    if (SKIP && act[i] != kSkipNone) continue;
     if (NT) {  // read-once stream: non-temporal, measured 7-8 % faster than default-policy loads
       typedef float v4f __attribute__((ext_vector_type(4)));
       const v4f* l = reinterpret_cast<const v4f*>(lut);
@@ -214,7 +219,7 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
   const int wr = q >> 3, wc = (q & 7) * 2;
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    if (SKIP && skip[i]) continue;
+    if (SKIP && act[i] != kSkipNone) continue;
     const int row = clampi(wy0[i] + wr, 0, p.H - 1) * p.W;
     ta[i] = p.frame[s0 + i][row + clampi(wx0[i] + wc, 0, p.W - 1)];
     tb[i] = p.frame[s0 + i][row + clampi(wx0[i] + wc + 1, 0, p.W - 1)];
@@ -222,16 +227,19 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
   if (windows_in_use) __syncthreads();  // the previous group's footprints are all read
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    if (SKIP && skip[i]) continue;
+    if (SKIP && act[i] != kSkipNone) continue;
     win[i][wr * kWinPitch + wc] = ta[i];
     win[i][wr * kWinPitch + wc + 1] = tb[i];
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    if (SKIP && skip[i]) {
+    if (SKIP && act[i] != kSkipNone) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tsd[j] = (tsd[j] >= limit) ? -limit : tsd[j];
+      for (int j = 0; j < 4; ++j) {
+        if (act[i] == kSkipCarve) tsd[j] = (tsd[j] >= limit) ? -limit : tsd[j];
+        if (act[i] == kSkipFront) tsd[j] = -limit;
+      }
       continue;
     }
     const uint2* frame = p.frame[s0 + i];
@@ -261,14 +269,14 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
   const float limit = p.limit;
   float tsd[4] = {limit, limit, limit, limit};
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  // sensors (bit s) whose LUT planes this tile leaves unread for the current frame (k_skip_mask: a byte per pair)
-  unsigned skipbits = 0u;
+  // what each sensor does to this tile without its LUT planes, two bits per sensor (k_skip_mask: a byte per pair)
+  unsigned actions = 0u;
   if (SKIP) {
 #pragma unroll
-    for (int s = 0; s < N; ++s) skipbits |= (unsigned)ro(p.skip_mask)[(size_t)tile * N + s] << s;
+    for (int s = 0; s < N; ++s) actions |= (unsigned)ro(p.skip_mask)[(size_t)tile * N + s] << (2 * s);
   }
-  integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, skipbits);
-  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, skipbits);
+  integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, actions);
+  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
   if (ELIDE) {
     // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
     // of this epoch (tile_state, see k_brick_clear) need not be written again
@@ -327,6 +335,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 //   * a tile whose bricks are all occupied (bit 31 of the list entry, k_brick_clear) skips the occupancy test;
 //   * for the others the range words are loaded with the LUT planes and the mask bytes of the few bricks the
 //     tile touches go to LDS with the frame windows, so occupancy adds no load latency of its own.
+// Five wavefronts per SIMD (96 VGPRs), 10 blocks per CU.
 // Tried and dropped (profiles/r02_notes): issuing the next tile's loads before folding the current one (two
 // wavefronts per SIMD instead of four: 0.082 vs 0.072 ms), folding two or four voxels of a lane together for
 // instruction-level parallelism (spills at four wavefronts per SIMD: 0.081 / 0.146 ms), 3 / 5 / 6 wavefronts
@@ -459,7 +468,7 @@ __device__ __forceinline__ void fold_stage(const IntegrateParams& p, const TileW
 }
 
 template <int N>
-__global__ __launch_bounds__(128, 4) void k_integrate_tiled_list(IntegrateParams p)
+__global__ __launch_bounds__(128, 5) void k_integrate_tiled_list(IntegrateParams p)
 {
   constexpr int GS = N <= 4 ? N : (N + 1) / 2;  // sensors per stage
   constexpr int NG = (N + GS - 1) / GS;         // stages per tile (1 or 2)
@@ -524,6 +533,7 @@ __global__ __launch_bounds__(128, 4) void k_integrate_tiled_list(IntegrateParams
   }
 }
 
+constexpr int kClearTiles = 256;
 // Brick-skipping sweep, first half (the clear of recon_integration.cpp:246-249 for everything
 // integrate will not touch).  One lane per tile: does the tile overlap an occupied brick?
 // Then it goes on the work list of k_integrate_tiled_list.  Otherwise it must hold -limit --
@@ -531,7 +541,6 @@ __global__ __launch_bounds__(128, 4) void k_integrate_tiled_list(IntegrateParams
 // epoch whenever anything else may have written the volume or the limit changed), so a
 // steady stream only rewrites the tiles the surface has just left.  Tiles that do need the
 // clear are collected per block and streamed out by all 256 lanes (2 KiB each, non-temporal).
-constexpr int kClearTiles = 256;
 __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned ntiles)
 {
   __shared__ unsigned todo[kClearTiles];
@@ -595,11 +604,13 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
 // tile's voxels whose footprint lies inside the image (others -- invalid -1
 // entries, far-off projections -- take the global path in the kernel).
 __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ lut_tiled, int W, int H, int sensor,
-                                                      int N, int32_t* __restrict__ win, float* __restrict__ win_dmin)
+                                                      int N, int32_t* __restrict__ win, float* __restrict__ win_dmin,
+                                                      float* __restrict__ win_dmax, int32_t* __restrict__ win_ext)
 {
   __shared__ int smin[2][2];
   __shared__ int org[2];
-  __shared__ float sdmin[2];
+  __shared__ float sdmin[2], sdmax[2];
+  __shared__ int sext[2];
   const unsigned tile = blockIdx.x;
   const int q = threadIdx.x;
   const float4* lut = reinterpret_cast<const float4*>(lut_tiled + ((size_t)tile * N + sensor) * 3 * kTileVoxels) + q;
@@ -646,12 +657,13 @@ __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ 
     org[1] = (int)(short)(my & 0xffff);
   }
   __syncthreads();
-  // RGBDR_FLAG_SKIP_BACKGROUND: the smallest projected depth of the tile, provided every entry is finite and every
-  // 2x2 footprint lies inside the window (then the sweep touches no texel outside it); -inf otherwise
+  // RGBDR_FLAG_SKIP_BACKGROUND: the smallest and largest projected depth of the tile, provided every entry is finite
+  // and every 2x2 footprint lies inside the window (then the sweep touches no texel outside it); -inf / +inf otherwise
   const float4 D = lut[2 * (kTileVoxels / 4)];
   const float ds[4] = {D.x, D.y, D.z, D.w};
   bool ok = true;
-  float dm = __builtin_inff();
+  float dm = __builtin_inff(), dx = -__builtin_inff();
+  int ext = 0;  // texels per axis the footprints span from the window origin
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float a;
@@ -659,49 +671,105 @@ __global__ __launch_bounds__(128) void k_tile_windows(const float* __restrict__ 
     ok = ok && (unsigned)rx < (unsigned)(kWin - 1) && (unsigned)ry < (unsigned)(kWin - 1) &&
          fabsf(us[j]) < __builtin_inff() && fabsf(vs[j]) < __builtin_inff() && fabsf(ds[j]) < __builtin_inff();
     dm = fminf(dm, ds[j]);
+    dx = fmaxf(dx, ds[j]);
+    ext = max(ext, max(rx, ry) + 2);
   }
   const bool all_ok = __syncthreads_and(ok) != 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dm = fminf(dm, __shfl_xor(dm, o));
-  if ((q & 63) == 0) sdmin[q >> 6] = dm;
+  for (int o = 32; o > 0; o >>= 1) {
+    dm = fminf(dm, __shfl_xor(dm, o));
+    dx = fmaxf(dx, __shfl_xor(dx, o));
+    ext = max(ext, __shfl_xor(ext, o));
+  }
+  if ((q & 63) == 0) {
+    sdmin[q >> 6] = dm;
+    sdmax[q >> 6] = dx;
+    sext[q >> 6] = ext;
+  }
   __syncthreads();
-  if (q == 0) win_dmin[(size_t)tile * N + sensor] = all_ok ? fminf(sdmin[0], sdmin[1]) : -__builtin_inff();
+  if (q == 0) {
+    win_dmin[(size_t)tile * N + sensor] = all_ok ? fminf(sdmin[0], sdmin[1]) : -__builtin_inff();
+    win_dmax[(size_t)tile * N + sensor] = all_ok ? fmaxf(sdmax[0], sdmax[1]) : __builtin_inff();
+    // the square of 4, 8 or 16 texels at the window origin that holds every footprint (k_window_background has
+    // bounds for each size: the smaller the square, the more often it is all background or all surface)
+    const int e = max(sext[0], sext[1]);
+    win_ext[(size_t)tile * N + sensor] = e <= 4 ? 0 : (e <= 8 ? 1 : 2);
+  }
 }
 
-// RGBDR_FLAG_SKIP_BACKGROUND, once per frame: for every window origin (ox, oy) in [-1, W-1] x [-1, H-1] the largest
-// depth_b among the 16x16 (edge-clamped) texels the sweep would stage from there, provided all of them are
-// background (silhouette 0, depth not NaN); +inf otherwise.  bgmax[sensor][(oy + 1) * (W + 1) + (ox + 1)].
+// RGBDR_FLAG_SKIP_BACKGROUND, once per frame: for every origin (ox, oy) in [-1, W-1] x [-1, H-1] and the squares of
+// 4, 8 and 16 (edge-clamped) texels from there, what the texels have in common, as three bounds
+// ([sensor][size class][3][(H+1)][(W+1)], index (oy + 1) * (W + 1) + (ox + 1)):
+//   bound 0: all background (silhouette 0, depth not NaN) -> their largest depth, else +inf
+//   bound 1, 2: all surface (silhouette 1, depth not NaN) -> their smallest / largest depth, else -inf / +inf
+// Squares of 8 and 16 are folded from two of the next smaller size, along x and then along y.
 __global__ __launch_bounds__(256) void k_window_background(const uint2* __restrict__ frames, int W, int H,
                                                            float* __restrict__ bgmax)
 {
   constexpr int T = 16 + kWin - 1;  // 31 texels per axis feed 16 origins
-  __shared__ float tex[T][T + 1];
-  __shared__ float hmax[T][16 + 1];
+  __shared__ float tex[3][T][T + 1];  // rows, then reduced along x in place
   const int l = blockIdx.z;
   const uint2* frame = frames + (size_t)l * W * H;
   const int ox0 = (int)blockIdx.x * 16 - 1, oy0 = (int)blockIdx.y * 16 - 1;
   const int t = threadIdx.y * 16 + threadIdx.x;
+  const float inf = __builtin_inff();
   for (int i = t; i < T * T; i += 256) {
     const int ty = i / T, tx = i - ty * T;
     const uint2 v = frame[(size_t)clampi(oy0 + ty, 0, H - 1) * W + clampi(ox0 + tx, 0, W - 1)];
     const float d = texel_depth(v);
-    tex[ty][tx] = ((v.y >> 31) && d == d) ? d : __builtin_inff();
-  }
-  __syncthreads();
-  for (int i = t; i < T * 16; i += 256) {
-    const int ty = i / 16, ox = i - ty * 16;
-    float m = tex[ty][ox];
-#pragma unroll
-    for (int k = 1; k < kWin; ++k) m = fmaxf(m, tex[ty][ox + k]);
-    hmax[ty][ox] = m;
+    const bool num = d == d, bg = (v.y >> 31) != 0;
+    tex[0][ty][tx] = (bg && num) ? d : inf;    // max-reduced
+    tex[1][ty][tx] = (!bg && num) ? d : -inf;  // min-reduced
+    tex[2][ty][tx] = (!bg && num) ? d : inf;   // max-reduced
   }
   __syncthreads();
   const int ox = ox0 + (int)threadIdx.x, oy = oy0 + (int)threadIdx.y;
-  if (ox > W - 1 || oy > H - 1) return;
-  float m = hmax[threadIdx.y][threadIdx.x];
+  const bool live = ox <= W - 1 && oy <= H - 1;
+  const size_t plane = (size_t)(W + 1) * (H + 1), o = (size_t)(oy + 1) * (W + 1) + (ox + 1);
+  // per thread: the square of 4 at (threadIdx.x, threadIdx.y) and its neighbours at +4, +8, +12 -- each output
+  // needs 16 squares of 4; computed on the fly from LDS rows reduced over 4 along x
+  __shared__ float r4[3][T][T + 1];  // max / min / max over x .. x+3
+  for (int i = t; i < T * (T - 3); i += 256) {
+    const int ty = i / (T - 3), tx = i - ty * (T - 3);
 #pragma unroll
-  for (int k = 1; k < kWin; ++k) m = fmaxf(m, hmax[threadIdx.y + k][threadIdx.x]);
-  bgmax[(size_t)l * (W + 1) * (H + 1) + (size_t)(oy + 1) * (W + 1) + (ox + 1)] = m;
+    for (int b = 0; b < 3; ++b) {
+      float m = tex[b][ty][tx];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) m = (b == 1) ? fminf(m, tex[b][ty][tx + k]) : fmaxf(m, tex[b][ty][tx + k]);
+      r4[b][ty][tx] = m;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    // s4[j][i]: square of 4 at (x + 4 i, y + 4 j)
+    float s4[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float m = r4[b][threadIdx.y + 4 * j][threadIdx.x + 4 * i];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          const float v = r4[b][threadIdx.y + 4 * j + k][threadIdx.x + 4 * i];
+          m = (b == 1) ? fminf(m, v) : fmaxf(m, v);
+        }
+        s4[j][i] = m;
+      }
+    auto red = [&](float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
+    const float q4 = s4[0][0];
+    const float q8 = red(red(s4[0][0], s4[0][1]), red(s4[1][0], s4[1][1]));
+    float q16 = q8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q16 = red(q16, s4[j][i]);
+    if (live) {
+      bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = q4;
+      bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = q8;
+      bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
+    }
+  }
 }
 void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s)
 {
@@ -709,7 +777,7 @@ void launch_window_background(const uint2* frames, int W, int H, int N, float* b
                      dim3(16, 16), 0, s, frames, W, H, bgmax);
 }
 
-// The decision per (tile, sensor) pair, once per frame: one byte each.
+// The verdict per (tile, sensor) pair, once per frame: one byte each (kSkip*).
 __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restrict__ mask)
 {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,19 +785,26 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
   const int s = (int)(i % (unsigned)p.N);
   const int d = p.win[i];
   const int wx0 = (int)(short)(d & 0xffff), wy0 = (int)(short)(d >> 16);
-  const float bound = p.bgmax[(size_t)s * (p.W + 1) * (p.H + 1) + (size_t)(wy0 + 1) * (p.W + 1) + (wx0 + 1)];
-  mask[i] = (p.win_dmin[i] - bound) >= p.limit ? 1 : 0;  // false for dmin = -inf and for bound = +inf (not background)
+  const size_t plane = (size_t)(p.W + 1) * (p.H + 1), o = (size_t)(wy0 + 1) * (p.W + 1) + (wx0 + 1);
+  const float* b = p.bgmax + ((size_t)s * 3 + (size_t)p.win_ext[i]) * 3 * plane + o;
+  const float dmin = p.win_dmin[i], dmax = p.win_dmax[i];
+  // every comparison is false for the "does not apply" values (dmin = -inf, dmax = +inf, bounds of a mixed window)
+  unsigned a = kSkipNone;
+  if ((dmin - b[0]) >= p.limit) a = kSkipCarve;
+  else if ((dmax - b[plane]) <= -p.limit) a = kSkipFront;
+  else if ((dmin - b[2 * plane]) >= p.limit) a = kSkipBehind;
+  mask[i] = (uint8_t)a;
 }
 void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s)
 {
   hipLaunchKernelGGL(k_skip_mask, dim3((npairs + 255) / 256), dim3(256), 0, s, p, npairs, mask);
 }
-// sum of the mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
+// number of non-zero mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
 __global__ __launch_bounds__(1024) void k_count_bytes(const uint8_t* __restrict__ mask, unsigned n, unsigned* __restrict__ count)
 {
   __shared__ unsigned part[16];
   unsigned c = 0;
-  for (unsigned i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) c += mask[i];
+  for (unsigned i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) c += mask[i] != 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
@@ -745,12 +820,14 @@ void launch_count_bytes(const uint8_t* mask, unsigned n, unsigned* count, hipStr
   hipLaunchKernelGGL(k_count_bytes, dim3(64), dim3(1024), 0, s, mask, n, count);
 }
 
-// `win` holds two planes of ntiles * N words: the window origins, then the tiles' smallest projected depths
+// `win` holds four planes of ntiles * N words: the window origins, the tiles' smallest and largest projected depths,
+// the size class of the footprints' square
 void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
                          hipStream_t s)
 {
   hipLaunchKernelGGL(k_tile_windows, dim3((unsigned)ntiles), dim3(128), 0, s, lut_tiled, W, H, sensor, N, win,
-                     reinterpret_cast<float*>(win + (size_t)ntiles * N));
+                     reinterpret_cast<float*>(win + (size_t)ntiles * N), reinterpret_cast<float*>(win + 2 * (size_t)ntiles * N),
+                     win + 3 * (size_t)ntiles * N);
 }
 
 // ---------------------------------------------------------------------------
@@ -802,7 +879,7 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
 {
   if (p.use_bricks) {
     hipLaunchKernelGGL(k_brick_clear, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
-    const unsigned blocks = ntiles < 2048u ? ntiles : 2048u;  // 8 resident blocks (4 wavefronts per SIMD) on each of the 256 CUs
+    const unsigned blocks = ntiles < 2560u ? ntiles : 2560u;  // 10 resident blocks (5 wavefronts per SIMD) on each of the 256 CUs
     hipLaunchKernelGGL((k_integrate_tiled_list<N>), dim3(blocks), dim3(128), 0, s, p);
     return;
   }

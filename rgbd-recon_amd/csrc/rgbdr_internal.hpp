@@ -87,8 +87,10 @@ struct IntegrateParams {
   // RGBDR_FLAG_SKIP_BACKGROUND: per (tile, sensor) the smallest projected depth (k_tile_windows), per sensor and
   // window origin the largest depth of an all-background window (k_window_background); see integrate_group
   const float* win_dmin;
+  const float* win_dmax;
+  const int32_t* win_ext;   // 0 / 1 / 2: the footprints fit the square of 4 / 8 / 16 texels at the window origin
   const float* bgmax;
-  const uint8_t* skip_mask;  // per (tile, sensor): 1 = skipped for the current frame (k_skip_mask)
+  const uint8_t* skip_mask;  // per (tile, sensor): what the sensor does to the tile without its LUT (kSkip*, k_skip_mask)
   int skip_background;
   // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
   const float4* lut[kMaxSensors];
