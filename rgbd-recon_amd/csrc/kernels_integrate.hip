@@ -271,12 +271,25 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   // what each sensor does to this tile without its LUT planes, two bits per sensor (k_skip_mask: a byte per pair)
   unsigned actions = 0u;
+  bool decided = SKIP;  // every sensor has a verdict: no loads, no window exchange
   if (SKIP) {
 #pragma unroll
-    for (int s = 0; s < N; ++s) actions |= (unsigned)ro(p.skip_mask)[(size_t)tile * N + s] << (2 * s);
+    for (int s = 0; s < N; ++s) {
+      const unsigned a = (unsigned)ro(p.skip_mask)[(size_t)tile * N + s];
+      actions |= a << (2 * s);
+      decided = decided && a != kSkipNone;
+    }
   }
-  integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, actions);
-  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
+  if (SKIP && decided) {
+    // over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that;
+    // hidden from every sensor: stays +limit
+    const bool negative = ((actions & 0x5555u) ^ ((actions >> 1) & 0x5555u)) != 0u;  // some pair of bits is 01 or 10
+    const float v = negative ? -limit : limit;
+    tsd[0] = tsd[1] = tsd[2] = tsd[3] = v;
+  } else {
+    integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, actions);
+    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
+  }
   if (ELIDE) {
     // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
     // of this epoch (tile_state, see k_brick_clear) need not be written again
@@ -726,49 +739,39 @@ __global__ __launch_bounds__(256) void k_window_background(const uint2* __restri
   const int ox = ox0 + (int)threadIdx.x, oy = oy0 + (int)threadIdx.y;
   const bool live = ox <= W - 1 && oy <= H - 1;
   const size_t plane = (size_t)(W + 1) * (H + 1), o = (size_t)(oy + 1) * (W + 1) + (ox + 1);
-  // per thread: the square of 4 at (threadIdx.x, threadIdx.y) and its neighbours at +4, +8, +12 -- each output
-  // needs 16 squares of 4; computed on the fly from LDS rows reduced over 4 along x
-  __shared__ float r4[3][T][T + 1];  // max / min / max over x .. x+3
+  // squares by doubling, each level staged in LDS: rows of 4 -> squares of 4 (c4, in place of tex) -> squares of 8
+  // (c8, in place of r4) -> squares of 16 from four c8
+  __shared__ float r4[3][T][T + 1];
+  auto red = [](int b, float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
   for (int i = t; i < T * (T - 3); i += 256) {
     const int ty = i / (T - 3), tx = i - ty * (T - 3);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      float m = tex[b][ty][tx];
-#pragma unroll
-      for (int k = 1; k < 4; ++k) m = (b == 1) ? fminf(m, tex[b][ty][tx + k]) : fmaxf(m, tex[b][ty][tx + k]);
-      r4[b][ty][tx] = m;
-    }
+    for (int b = 0; b < 3; ++b)
+      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 1]), red(b, tex[b][ty][tx + 2], tex[b][ty][tx + 3]));
   }
   __syncthreads();
+  for (int i = t; i < (T - 3) * (T - 3); i += 256) {  // c4[y][x], x, y in [0, 27]
+    const int ty = i / (T - 3), tx = i - ty * (T - 3);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      tex[b][ty][tx] = red(b, red(b, r4[b][ty][tx], r4[b][ty + 1][tx]), red(b, r4[b][ty + 2][tx], r4[b][ty + 3][tx]));
+  }
+  __syncthreads();
+  for (int i = t; i < (T - 7) * (T - 7); i += 256) {  // c8[y][x], x, y in [0, 23]
+    const int ty = i / (T - 7), tx = i - ty * (T - 7);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 4]), red(b, tex[b][ty + 4][tx], tex[b][ty + 4][tx + 4]));
+  }
+  __syncthreads();
+  if (!live) return;
+  const int x = threadIdx.x, y = threadIdx.y;
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    // s4[j][i]: square of 4 at (x + 4 i, y + 4 j)
-    float s4[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float m = r4[b][threadIdx.y + 4 * j][threadIdx.x + 4 * i];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-          const float v = r4[b][threadIdx.y + 4 * j + k][threadIdx.x + 4 * i];
-          m = (b == 1) ? fminf(m, v) : fmaxf(m, v);
-        }
-        s4[j][i] = m;
-      }
-    auto red = [&](float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
-    const float q4 = s4[0][0];
-    const float q8 = red(red(s4[0][0], s4[0][1]), red(s4[1][0], s4[1][1]));
-    float q16 = q8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) q16 = red(q16, s4[j][i]);
-    if (live) {
-      bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = q4;
-      bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = q8;
-      bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
-    }
+    const float q16 = red(b, red(b, r4[b][y][x], r4[b][y][x + 8]), red(b, r4[b][y + 8][x], r4[b][y + 8][x + 8]));
+    bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = tex[b][y][x];
+    bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = r4[b][y][x];
+    bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
   }
 }
 void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s)

@@ -423,6 +423,9 @@ class ReconIntegration {
   void setTsdfLimit(float limit) { check(m_be.ctx(), rgbdr_set_tsdf_limit(m_be.ctx(), limit)); }
   void setBrickSize(float size) { check(m_be.ctx(), rgbdr_set_brick_size(m_be.ctx(), size)); }
   void setUseBricks(bool active) { check(m_be.ctx(), rgbdr_set_use_bricks(m_be.ctx(), active)); }
+  // full sweeps only, same volume bit for bit (not in the reference: see RGBDR_FLAG_ELIDE_STORES / _SKIP_BACKGROUND)
+  void setElideStores(bool active) { check(m_be.ctx(), rgbdr_set_elide_stores(m_be.ctx(), active)); }
+  void setSkipBackground(bool active) { check(m_be.ctx(), rgbdr_set_skip_background(m_be.ctx(), active)); }
   void setMinVoxelsPerBrick(unsigned i) { check(m_be.ctx(), rgbdr_set_min_voxels_per_brick(m_be.ctx(), i)); }
   unsigned numBricks() const { return rgbdr_num_bricks(m_be.ctx()); }
   float occupiedRatio() const { return rgbdr_occupied_ratio(m_be.ctx()); }
