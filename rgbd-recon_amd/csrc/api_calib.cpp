@@ -224,6 +224,7 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
                         g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                         ctx->stream);
     LAUNCHCHK("tile_windows");
+    ctx->bgmax_for = -1;  // the skip verdicts of the current frame were taken from the old planes
     ctx->inv_tiled[sensor] = true;
   } else {
     int lo, hi;
@@ -244,6 +245,7 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
                           g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                           ctx->stream);
       LAUNCHCHK("tile_windows");
+      ctx->bgmax_for = -1;  // the skip verdicts of the current frame were taken from the old planes
       HIPCHK(hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->d_lut_generic[sensor]);
       ctx->d_lut_generic[sensor] = nullptr;
@@ -319,6 +321,7 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
                       g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                       ctx->stream);
   LAUNCHCHK("tile_windows");
+  ctx->bgmax_for = -1;  // the skip verdicts of the current frame were taken from the old planes
   for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = r[a];
   (void)hipFree(ctx->d_lut_generic[sensor]);
   ctx->d_lut_generic[sensor] = nullptr;
@@ -375,6 +378,7 @@ int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
                       g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                       ctx->stream);
   LAUNCHCHK("tile_windows");
+  ctx->bgmax_for = -1;  // the skip verdicts of the current frame were taken from the old planes
   HIPCHK(hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->d_lut_generic[sensor]);
   ctx->d_lut_generic[sensor] = nullptr;

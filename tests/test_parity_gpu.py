@@ -822,6 +822,30 @@ def test_full_sweep_background_skip(pkg, orc, n, G, wh):
     ctx.close()
 
 
+def test_background_skip_verdicts_follow_lut_and_limit_changes(pkg, orc):
+    """the verdicts are per frame AND per LUT / truncation limit: integrate again after either changed, without
+    a new process_textures in between"""
+    scene, ctx, inv = build(pkg, n=2, wh=(128, 106), G=64)
+    ctx.set_use_bricks(False)
+    ctx.set_skip_background(True)
+    ctx.step(scene.depth, scene.color)
+    first = ctx.skipped_pairs()[0]
+    swapped = [inv[1], inv[0]]
+    for i in range(2):
+        ctx.set_inverse_calibration(i, swapped[i], tuple(ctx.geo.res_volume))
+    ctx.integrate()
+    ref = oracle_run(orc, scene, ctx, swapped, use_bricks=False)
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    ctx.set_tsdf_limit(0.04)
+    ctx.integrate()
+    ref = oracle_run(orc, scene, ctx, swapped, use_bricks=False, limit=np.float32(0.04))
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    assert ctx.skipped_pairs()[0] != first
+    v = ctx.readback_skip_tables(0)
+    assert v.shape == (int(np.prod(ctx.geo.tiles)), 2) and set(np.unique(v)) <= {0, 1, 2, 3}
+    ctx.close()
+
+
 def test_background_skip_on_slabs_and_resampled_luts(pkg, orc):
     scene, ctx, inv = build(pkg, n=3, wh=(128, 106), G=64, inv_res=(40, 44, 48), slab_rank=1, slab_count=3)
     ctx.set_use_bricks(False)
@@ -883,7 +907,7 @@ def test_random_call_sequences_on_a_slab(pkg, orc, seed, slab):
 
 def run_random_sequence(pkg, orc, seed, slab):
     """state machine check: random interleavings of the setters, both sweeps, both schedules,
-    store elision, settle and two different frames -- after every frame the volume, the images
+    store elision, background skip, inverse-LUT re-uploads, settle and two different frames -- after every frame the volume, the images
     and the brick table equal the oracle run with the settings in force"""
     rng = np.random.default_rng(seed)
     kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
@@ -896,8 +920,9 @@ def run_random_sequence(pkg, orc, seed, slab):
     state = dict(limit=np.float32(0.01), bricks=True, filt=True, proc=True, refine=True, min_voxels=10)
     cur = 0
     G = 48 if slab else 32
+    inv = list(inv)
     for step_no in range(28):
-        op = rng.integers(0, 13)
+        op = rng.integers(0, 16)
         if op == 0:
             state["bricks"] = not state["bricks"]
             ctx.set_use_bricks(state["bricks"])
@@ -928,6 +953,13 @@ def run_random_sequence(pkg, orc, seed, slab):
             # setBrickSize: bricks of 5 / 6 / 8 / 10 voxels (not tile multiples; at G = 48 the reference's brick ->
             # voxel lists share rows between neighbouring bricks for 5 and 8); the volume and the LUTs stay
             ctx.set_brick_size(float(rng.choice([5, 6, 8, 10])) * 2.0 / G)
+        elif op == 11:
+            ctx.set_skip_background(bool(rng.integers(0, 2)))
+        elif op == 12:
+            # the two sensors trade inverse LUTs (each voxel is then projected into the other sensor's frame)
+            inv[0], inv[1] = inv[1], inv[0]
+            for i in range(2):
+                ctx.set_inverse_calibration(i, inv[i], tuple(ctx.geo.res_volume))
         else:
             cur = int(rng.integers(0, 2))
         sc = scenes[cur]
