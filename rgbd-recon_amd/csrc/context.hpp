@@ -5,6 +5,7 @@
 //   api_view.cpp    consumers of the volume: depth peels, ray-march, hole filling
 //   api_halo.cpp    Z-slab halo staging and the RCCL exchange
 //   api_timers.cpp  TimerDatabase
+//   api_skip.cpp    RGBDR_FLAG_SKIP_BACKGROUND tables
 #pragma once
 #include <hip/hip_runtime.h>
 
