@@ -296,28 +296,26 @@ def main():
         elided = {"ms_per_step": round(dte / args.steps * 1e3, 4), "value": round(V_total / (dte / args.steps) / 1e6, 1),
                   "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4)}
 
-    # ---- RGBDR_FLAG_SKIP_BACKGROUND (extra keys): LUT planes of (tile, sensor) pairs that can only carve stay unread ----
+    # ---- RGBDR_FLAG_SKIP_BACKGROUND (extra keys): LUT planes of (tile, sensor) pairs whose frame window decides the
+    # outcome stay unread, tiles that are constants are not rewritten while they hold their constant ----
     skipbg = None
     if world == 1 and not loop:
         ctx.set_skip_background(True)
         dts, stats_s = timed(False, args.steps, args.warmup)
         skipped, total = ctx.skipped_pairs()
-        ctx.set_elide_stores(True)
-        dtse, stats_se = timed(False, args.steps, args.warmup)
-        ctx.set_elide_stores(False)
+        verdicts = ctx.readback_skip_tables(0)
         ctx.set_skip_background(False)
         si_ns, si_n = stats_s["2integrate"]
-        sei_ns, sei_n = stats_se["2integrate"]
-        lut_bytes = (total - skipped) * 3 * 512 * 4
+        listed = int((verdicts == 0).any(axis=1).sum())
+        # bytes a steady-state sweep asks for: per pair the four words the classifier reads; per listed tile its
+        # list entry, its TSDF store and the LUT planes of its undecided sensors; the frame texels (windows) once
+        nbytes = int(total * 16 + listed * (8 + 2048) + (total - skipped) * 3 * 512 * 4 + N * W * H * 8)
         skipbg = {"ms_per_step": round(dts / args.steps * 1e3, 4), "value": round(V_total / (dts / args.steps) / 1e6, 1),
                   "integrate_ms": round(si_ns / max(si_n, 1) * 1e-6, 4),
-                  "pairs_skipped": int(skipped), "pairs": int(total), "frac_skipped": round(skipped / max(total, 1), 4),
-                  # bytes this sweep asks for: TSDF stores + LUT planes of the pairs it reads + per pair the origin,
-                  # depth bound and window bound words + the frame texels
-                  "bytes_per_launch": int(V_local * 4 + lut_bytes + total * 12 + N * W * H * 8),
-                  "with_store_elision": {"ms_per_step": round(dtse / args.steps * 1e3, 4),
-                                         "integrate_ms": round(sei_ns / max(sei_n, 1) * 1e-6, 4)}}
-        skipbg["GBps"] = round(skipbg["bytes_per_launch"] / (si_ns / max(si_n, 1)), 1)
+                  "pairs_decided": int(skipped), "pairs": int(total), "frac_decided": round(skipped / max(total, 1), 4),
+                  "verdicts": {k: int((verdicts == i).sum()) for i, k in enumerate(("none", "carve", "in_front", "hidden"))},
+                  "tiles_listed": listed, "tiles": int(verdicts.shape[0]),
+                  "bytes_per_launch": nbytes, "GBps": round(nbytes / (si_ns / max(si_n, 1)), 1)}
 
     out = {
         "metric": "Mvoxels/s TSDF integration (%d sensors, %s grid) + frames/s" % (

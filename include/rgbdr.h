@@ -69,8 +69,10 @@ enum {
    * (silhouette 0) in the 16x16-pixel window a tile projects into, and from which every voxel of the tile
    * lies at least the truncation limit behind the largest depth in that window, can only carve
    * (tsdf_integration.vs:34-37: tsd = -limit where tsd >= limit).  With the flag the sweep applies exactly
-   * that without reading the sensor's three LUT planes of the tile (6 KiB) -- same volume bit for bit; how
-   * much is skipped depends on the frame (rgbdr_skipped_pairs).  Off by default so that the benchmark's
+   * that without reading the sensor's three LUT planes of the tile (6 KiB); likewise for windows that show
+   * nothing but surface in front of / behind which the whole tile lies; a tile all of whose sensors are decided
+   * is a constant and is not rewritten while it holds it -- same volume bit for bit; how much is decided
+   * depends on the frame (rgbdr_skipped_pairs).  Off by default so that the benchmark's
    * full sweep streams every LUT entry, like the reference's draw call samples every vertex. */
   RGBDR_FLAG_SKIP_BACKGROUND = 128u
 };

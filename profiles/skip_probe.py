@@ -22,6 +22,7 @@ c.set_use_bricks(False)
 c.update(scene.depth, scene.color)
 for skip in (False, True):
     c.set_skip_background(skip)
+    c.set_elide_stores(os.environ.get('SKIP_PROBE_ELIDE') == '1')
     for _ in range(5):
         c.clear_occupied_bricks(); c.process_textures(); c.update_occupied_bricks(); c.integrate()
     c.sync()

@@ -71,6 +71,8 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_bgmax);
   (void)hipFree(c->d_skip_mask);
+  (void)hipFree(c->d_skip_list);
+  c->d_skip_list = nullptr;
   c->d_bgmax = nullptr;
   c->d_skip_mask = nullptr;
   c->skip_mask_tiles = 0;
@@ -325,6 +327,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     for (int b = 0; b < 2; ++b) {
       if (ctx->h_depth[b]) (void)hipHostFree(ctx->h_depth[b]);
       if (ctx->h_color[b]) (void)hipHostFree(ctx->h_color[b]);
+      if (b == 0 && ctx->h_skip_count) (void)hipHostFree(ctx->h_skip_count);
       if (ctx->ev_mapped[b]) (void)hipEventDestroy(ctx->ev_mapped[b]);
       ctx->h_depth[b] = ctx->h_color[b] = nullptr;
       ctx->ev_mapped[b] = nullptr;
@@ -659,7 +662,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.skip_background = skip_bg ? 1 : 0;
   p.win_dmin = reinterpret_cast<const float*>(ctx->d_win + (size_t)p.TX * p.TY * p.ntz * N);
   p.win_dmax = reinterpret_cast<const float*>(ctx->d_win + 2 * (size_t)p.TX * p.TY * p.ntz * N);
-  if ((!bricks && !elide) || !all_tiled) {  // sweeps that overwrite tiles without keeping tile_state
+  if ((!bricks && !elide && !skip_bg) || !all_tiled) {  // sweeps that overwrite tiles without keeping tile_state
     int rc_ = bump_clear_epoch(ctx);
     if (rc_ != RGBDR_OK) return rc_;
   }
@@ -679,11 +682,13 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
     }
   }
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
-  if (skip_bg) { int rc_ = ensure_window_background(ctx); if (rc_ != RGBDR_OK) return rc_; }
-  p.bgmax = ctx->d_bgmax;
-  p.skip_mask = ctx->d_skip_mask;
   tbegin(ctx, "2integrate", ctx->stream);
-  launch_integrate(p, all_tiled, ctx->stream);
+  if (skip_bg) {
+    int rc_ = skip_sweep(ctx, p);
+    if (rc_ != RGBDR_OK) return rc_;
+  } else {
+    launch_integrate(p, all_tiled, ctx->stream);
+  }
   tend(ctx, "2integrate", ctx->stream);
   LAUNCHCHK("integrate");
   if (copy_faces) {  // sweeps that do not stage by themselves: copy the boundary layers after them

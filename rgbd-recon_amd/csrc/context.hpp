@@ -85,6 +85,10 @@ struct rgbdr_ctx {
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin; second plane: smallest projected depth
   uint8_t* d_skip_mask = nullptr;  // ... and per (tile, sensor) pair 1 = skipped; [ntiles * N] bytes + a 4-B counter behind them
   float* d_bgmax = nullptr;  // RGBDR_FLAG_SKIP_BACKGROUND: [N][(H+1)][(W+1)] window bounds of the current frame
+  unsigned long long* d_skip_list = nullptr;     // {tile, verdicts} of the tiles the sweep still has to work on + two counters
+  unsigned* h_skip_count = nullptr; // page-locked: list length of the previous sweep
+  int skip_parity = 0;
+  bool skip_mask_valid = false;     // d_skip_mask holds the verdict bytes of the current frame
   size_t skip_mask_tiles = 0;
   float skip_limit = 0.0f;   // truncation limit the mask was built for
   int bgmax_for = -1;        // frame buffer d_bgmax was computed from since the last process_textures (-1: stale)
@@ -172,6 +176,7 @@ inline size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->c
 int bump_clear_epoch(rgbdr_ctx* ctx);   // invalidates every recorded "this tile already holds -limit"
 int sync_all(rgbdr_ctx* ctx);           // drain both streams
 int ensure_window_background(rgbdr_ctx* c);
+int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);

@@ -178,8 +178,9 @@ __device__ __forceinline__ bool voxel_occupied(const IntegrateParams& p, int vx,
 //       fl(dmax - lo) <= -limit: every voxel lies in front of everything the window shows, sdist <= -limit,
 //       tsd = -limit (tsdf_integration.vs:44-45)                                                 -> kSkipFront
 //       fl(dmin - hi) >= limit: every voxel is hidden, sdist >= limit, nothing happens           -> kSkipBehind
-// k_skip_mask stores the verdict per (tile, sensor) and frame; the sweep then applies it to its four voxels in
-// the sensor's turn and leaves the three LUT planes (6 KiB) and the window of that pair unread.
+// k_skip_classify takes the verdicts per tile and frame; a tile with an undecided sensor goes to
+// k_integrate_tiled_listed, which applies the verdicts of the others to its four voxels in the sensors' turns and
+// leaves their LUT planes (6 KiB per pair) and windows unread.
 enum : unsigned { kSkipNone = 0u, kSkipCarve = 1u, kSkipFront = 2u, kSkipBehind = 3u };
 template <int CNT, bool NT, bool SKIP>
 __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsigned tile, int q, int s0, int ntot,
@@ -259,7 +260,7 @@ __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsign
 // folded in two groups (the running tsd / weight stay in registers), which keeps
 // the kernel at <= ~100 VGPRs for every N.
 // One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
-template <int N, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false, bool SKIP = false>
+template <int N, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
@@ -269,27 +270,8 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
   const float limit = p.limit;
   float tsd[4] = {limit, limit, limit, limit};
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  // what each sensor does to this tile without its LUT planes, two bits per sensor (k_skip_mask: a byte per pair)
-  unsigned actions = 0u;
-  bool decided = SKIP;  // every sensor has a verdict: no loads, no window exchange
-  if (SKIP) {
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-      const unsigned a = (unsigned)ro(p.skip_mask)[(size_t)tile * N + s];
-      actions |= a << (2 * s);
-      decided = decided && a != kSkipNone;
-    }
-  }
-  if (SKIP && decided) {
-    // over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that;
-    // hidden from every sensor: stays +limit
-    const bool negative = ((actions & 0x5555u) ^ ((actions >> 1) & 0x5555u)) != 0u;  // some pair of bits is 01 or 10
-    const float v = negative ? -limit : limit;
-    tsd[0] = tsd[1] = tsd[2] = tsd[3] = v;
-  } else {
-    integrate_group<G1, NT, SKIP>(p, tile, q, 0, N, win, false, limit, tsd, wsum, actions);
-    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, SKIP>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
-  }
+  integrate_group<G1, NT, false>(p, tile, q, 0, N, win, false, limit, tsd, wsum);
+  if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, false>(p, tile, q, G1, N, win, true, limit, tsd, wsum);
   if (ELIDE) {
     // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
     // of this epoch (tile_state, see k_brick_clear) need not be written again
@@ -317,7 +299,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
 }
 
 // Full sweep: one block per tile.
-template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false, bool SKIP = false>
+template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
   constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
@@ -333,7 +315,7 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
     const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
     tile = (chunk * 8u + xcd) * p.order_chunk + within;
   }
-  integrate_tile<N, MAXG, NT, ELIDE, STAGE, SKIP>(p, tile, win);
+  integrate_tile<N, MAXG, NT, ELIDE, STAGE>(p, tile, win);
 }
 
 // ---------------------------------------------------------------------------
@@ -780,27 +762,135 @@ void launch_window_background(const uint2* frames, int W, int H, int N, float* b
                      dim3(16, 16), 0, s, frames, W, H, bgmax);
 }
 
-// The verdict per (tile, sensor) pair, once per frame: one byte each (kSkip*).
-__global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restrict__ mask)
+// The verdict of one (tile, sensor) pair for the current frame (kSkip*)
+__device__ __forceinline__ unsigned skip_verdict(const IntegrateParams& p, size_t i, int s)
 {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npairs) return;
-  const int s = (int)(i % (unsigned)p.N);
   const int d = p.win[i];
   const int wx0 = (int)(short)(d & 0xffff), wy0 = (int)(short)(d >> 16);
   const size_t plane = (size_t)(p.W + 1) * (p.H + 1), o = (size_t)(wy0 + 1) * (p.W + 1) + (wx0 + 1);
   const float* b = p.bgmax + ((size_t)s * 3 + (size_t)p.win_ext[i]) * 3 * plane + o;
   const float dmin = p.win_dmin[i], dmax = p.win_dmax[i];
   // every comparison is false for the "does not apply" values (dmin = -inf, dmax = +inf, bounds of a mixed window)
-  unsigned a = kSkipNone;
-  if ((dmin - b[0]) >= p.limit) a = kSkipCarve;
-  else if ((dmax - b[plane]) <= -p.limit) a = kSkipFront;
-  else if ((dmin - b[2 * plane]) >= p.limit) a = kSkipBehind;
-  mask[i] = (uint8_t)a;
+  if ((dmin - b[0]) >= p.limit) return kSkipCarve;
+  if ((dmax - b[plane]) <= -p.limit) return kSkipFront;
+  if ((dmin - b[2 * plane]) >= p.limit) return kSkipBehind;
+  return kSkipNone;
 }
+
+// one byte per pair (the diagnostics of rgbdr_skipped_pairs / rgbdr_readback_skip_tables)
+__global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restrict__ mask)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npairs) mask[i] = (uint8_t)skip_verdict(p, i, (int)(i % (unsigned)p.N));
+}
+
+// First half of the RGBDR_FLAG_SKIP_BACKGROUND sweep (the role k_brick_clear has for bricks): one lane per tile
+// takes the verdicts of its N sensors.  If every sensor has one, the tile's 512 voxels all end as the same value --
+// over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that; hidden from
+// every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
+// this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
+// Otherwise tile | verdicts << 32 goes on the list of k_integrate_tiled_listed.
+constexpr int kClassifyTiles = 256;
+__global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsigned ntiles)
+{
+  __shared__ unsigned todo[kClassifyTiles];  // tile | (value is +limit) << 31
+  __shared__ unsigned ntodo;
+  if (threadIdx.x == 0) ntodo = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.skip_count_next = 0u;  // the counter the next sweep appends to
+  __syncthreads();
+  const unsigned tile = blockIdx.x * kClassifyTiles + threadIdx.x;
+  bool listed = false, fill = false, positive = false;
+  unsigned actions = 0u;
+  if (tile < ntiles) {
+    bool all = true, negative = false;
+    for (int s = 0; s < p.N; ++s) {
+      const unsigned a = skip_verdict(p, (size_t)tile * p.N + s, s);
+      actions |= a << (2 * s);
+      all = all && a != kSkipNone;
+      negative = negative || a == kSkipCarve || a == kSkipFront;
+    }
+    listed = !all;
+    if (all) {
+      positive = !negative;
+      fill = !(negative && p.tile_state[tile] == p.epoch);
+      p.tile_state[tile] = negative ? p.epoch : 0u;
+    } else {
+      p.tile_state[tile] = 0u;  // about to hold integrated values
+    }
+  }
+  {
+    const unsigned long long m = __ballot(listed);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (m) {
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.skip_count, (unsigned)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1);
+      if (listed) p.skip_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned long long)tile | ((unsigned long long)actions << 32);
+    }
+  }
+  if (fill) todo[atomicAdd(&ntodo, 1u)] = tile | (positive ? 0x80000000u : 0u);
+  __syncthreads();
+  const unsigned n = ntodo;
+  if (n == 0) return;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f* out = reinterpret_cast<v4f*>(p.tsdf);
+  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += 256) {
+    const unsigned e = todo[i / (kTileVoxels / 4)];
+    const float l = (e >> 31) ? p.limit : -p.limit;
+    const v4f fillv = {l, l, l, l};
+    __builtin_nontemporal_store(fillv, out + (size_t)(e & 0x7fffffffu) * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
+  }
+}
+
+// Second half: one block per listed tile (the host sizes the grid from the previous frame's list length; blocks
+// stride over the list, so any grid is correct).  Verdicts come with the list entry: no load in front of the
+// LUT loads but the entry itself.
+template <int N>
+__global__ __launch_bounds__(128, N <= 7 ? 5 : 4) void k_integrate_tiled_listed(IntegrateParams p)
+{
+  constexpr int G1 = N <= 4 ? N : (N + 1) / 2;
+  constexpr int G2 = N - G1;
+  __shared__ uint2 win[G1][kWin * kWinPitch];
+  const unsigned n = *ro(p.skip_count);
+  const int q = threadIdx.x;
+  const float limit = p.limit;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    const unsigned long long e = ro(p.skip_list)[i];
+    const unsigned tile = (unsigned)e, actions = (unsigned)(e >> 32);
+    float tsd[4] = {limit, limit, limit, limit};
+    float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    integrate_group<G1, true, true>(p, tile, q, 0, N, win, i != blockIdx.x, limit, tsd, wsum, actions);
+    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), true, true>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f r = {tsd[0], tsd[1], tsd[2], tsd[3]};
+    __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(p.tsdf + (size_t)tile * kTileVoxels) + q);
+  }
+}
+
 void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s)
 {
   hipLaunchKernelGGL(k_skip_mask, dim3((npairs + 255) / 256), dim3(256), 0, s, p, npairs, mask);
+}
+template <int N>
+static void launch_listed_n(const IntegrateParams& p, unsigned blocks, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_integrate_tiled_listed<N>), dim3(blocks), dim3(128), 0, s, p);
+}
+// the background-skip sweep: classifier + one block per listed tile (`blocks`: the host's estimate of the list length)
+void launch_skip_sweep(const IntegrateParams& p, unsigned blocks, hipStream_t s)
+{
+  const unsigned ntiles = (unsigned)p.TX * p.TY * p.ntz;
+  hipLaunchKernelGGL(k_skip_classify, dim3((ntiles + kClassifyTiles - 1) / kClassifyTiles), dim3(256), 0, s, p, ntiles);
+  switch (p.N) {
+    case 1: launch_listed_n<1>(p, blocks, s); break;
+    case 2: launch_listed_n<2>(p, blocks, s); break;
+    case 3: launch_listed_n<3>(p, blocks, s); break;
+    case 4: launch_listed_n<4>(p, blocks, s); break;
+    case 5: launch_listed_n<5>(p, blocks, s); break;
+    case 6: launch_listed_n<6>(p, blocks, s); break;
+    case 7: launch_listed_n<7>(p, blocks, s); break;
+    default: launch_listed_n<8>(p, blocks, s); break;
+  }
 }
 // number of non-zero mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
 __global__ __launch_bounds__(1024) void k_count_bytes(const uint8_t* __restrict__ mask, unsigned n, unsigned* __restrict__ count)
@@ -897,11 +987,7 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
-  if (p.skip_background && p.elide_stores)
-    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);
-  else if (p.skip_background)
-    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, false, true>), dim3(ntiles), dim3(128), 0, s, p);
-  else if (p.elide_stores)
+  if (p.elide_stores)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
   else if (p.stage_lo || p.stage_hi)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);

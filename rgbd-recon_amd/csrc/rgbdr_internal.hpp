@@ -90,7 +90,9 @@ struct IntegrateParams {
   const float* win_dmax;
   const int32_t* win_ext;   // 0 / 1 / 2: the footprints fit the square of 4 / 8 / 16 texels at the window origin
   const float* bgmax;
-  const uint8_t* skip_mask;  // per (tile, sensor): what the sensor does to the tile without its LUT (kSkip*, k_skip_mask)
+  unsigned long long* skip_list;  // tile | verdicts (2 bits per sensor) << 32 of the tiles with an undecided sensor (k_skip_classify)
+  unsigned* skip_count;      // its length (double-buffered like tile_count)
+  unsigned* skip_count_next;
   int skip_background;
   // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
   const float4* lut[kMaxSensors];
@@ -225,6 +227,7 @@ void launch_resample_lut(const float4* src_rgba, int rx, int ry, int rz, int zof
 float probe_arena_ms(const float* arena, size_t ntiles, int N, int TX, float* sink, hipStream_t s);
 void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s);
 void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s);
+void launch_skip_sweep(const IntegrateParams& p, unsigned blocks, hipStream_t s);
 void launch_count_bytes(const uint8_t* mask, unsigned n, unsigned* count, hipStream_t s);
 void launch_tile_windows(const float* lut_tiled, int W, int H, int ntiles, int sensor, int N, int32_t* win,
                          hipStream_t s);

@@ -41,11 +41,16 @@ def test_bench_line_contract():
     assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
     assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
     assert "4 sensors" in j["metric"] and "512^3" in j["metric"] and j["config"]["baseline_config"].startswith("configs[2]")
-    for extra in ("post_pass", "host_fed", "reference_defaults", "bricked", "other_schedule", "full_sweep_store_elision"):
+    for extra in ("post_pass", "host_fed", "reference_defaults", "bricked", "other_schedule", "full_sweep_store_elision",
+                  "full_sweep_background_skip"):
         assert extra in j and "error" not in j[extra], (extra, j[extra])
     assert j["post_pass"]["raymarch_ms"] > 0 and j["post_pass"]["holefill_ms"] > 0 and j["post_pass"]["brickdraw_ms"] > 0
     assert j["bricked"]["ms_per_step"] < j["ms_per_step"]
     assert j["full_sweep_store_elision"]["ms_per_step"] < 1.02 * j["ms_per_step"]
+    sk = j["full_sweep_background_skip"]
+    assert sk["ms_per_step"] < 0.8 * j["ms_per_step"] and 0.3 < sk["frac_decided"] <= 1.0
+    assert sum(sk["verdicts"].values()) == sk["pairs"] and sk["verdicts"]["none"] == sk["pairs"] - sk["pairs_decided"]
+    assert sk["GBps"] < 8000.0   # the bytes it asks for over its time: never above the HBM peak
 
 
 def test_bench_loopback_runs_the_multi_gpu_path():
