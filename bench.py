@@ -340,7 +340,7 @@ def main():
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": ("zslab%d" % world if world > 1 else "single") + (" (loopback: an inner slab of 4)" if loop else ""),
                    "halo_transport": transport["kind"] if multi else None},
-        "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, %s, false>" % (N, "true" if multi else "false"),
+        "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, %s>" % (N, "true" if multi else "false"),
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                      "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
