@@ -126,6 +126,7 @@ static int alloc_brick_table(rgbdr_ctx* ctx, const rgbdr_config& cfg, const rgbd
   ctx->d_brick_tab = tab;
   ctx->bt = std::move(bt);
   ctx->mask_valid = false;
+  ctx->occ_lazy = false;
   return RGBDR_OK;
 }
 
@@ -453,9 +454,22 @@ int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
 
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
+// the filter of a lazy rgbdr_update_occupied_bricks, for consumers other than the brick sweep and before
+// anything changes the counters it was asked for
+int rgbdr::materialise_mask(rgbdr_ctx* ctx)
+{
+  if (!ctx->occ_lazy) return RGBDR_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->occ_lazy_min, ctx->mask_buf(ctx->rbuf),
+                         ctx->count_buf(ctx->rbuf), ctx->pstream());
+  LAUNCHCHK("update_occupied");
+  ctx->occ_lazy = false;
+  return RGBDR_OK;
+}
 int rgbdr::flush_clear(rgbdr_ctx* ctx)
 {
   if (!ctx->clear_pending) return RGBDR_OK;
+  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->pstream()));
   ctx->clear_pending = false;
@@ -513,6 +527,7 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   // raw depth (NetKinectArray.cpp:287-289)
   p.depth_in = (ctx->cfg.flags & RGBDR_FLAG_PROCESSED) ? ctx->d_depth_morph : ctx->d_depth_raw;
 
+  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the counters are about to change
   hipStream_t ps = ctx->pstream();
   const int w = ctx->wbuf;
   p.frame = ctx->frame_buf(w);
@@ -561,8 +576,16 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
   hipStream_t ps = ctx->pstream();
   const int w = ctx->rbuf;  // belongs to the frame process_textures just wrote
   tbegin(ctx, "bricks", ps);
-  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick,
-                         ctx->mask_buf(w), ctx->count_buf(w), ps);
+  if (!ctx->pipelined()) {
+    // one stream: nothing can touch the counters before the next call of this library does, so the filter is left
+    // to the first consumer -- the brick sweep folds it into its first kernel
+    ctx->occ_lazy = true;
+    ctx->occ_lazy_min = ctx->cfg.min_voxels_per_brick;
+  } else {
+    ctx->occ_lazy = false;
+    launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick,
+                           ctx->mask_buf(w), ctx->count_buf(w), ps);
+  }
   tend(ctx, "bricks", ps);
   LAUNCHCHK("update_occupied");
   if (ctx->pipelined()) {
@@ -585,6 +608,7 @@ int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count)
   }
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipMemcpy(ctx->mask_buf(ctx->rbuf), mask.data(), nb, hipMemcpyHostToDevice));
+  ctx->occ_lazy = false;  // the host's list replaces whatever the counters would have given
   ctx->mask_valid = true;
   return RGBDR_OK;
 }
@@ -636,6 +660,19 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.win = ctx->d_win;
   p.use_bricks = bricks ? 1 : 0;
   p.brick_mask = ctx->mask_buf(ctx->rbuf);
+  p.brick_counters = nullptr;
+  if (bricks && ctx->occ_lazy) {
+    if (all_tiled) {  // k_brick_clear<true> filters on the way
+      p.brick_counters = ctx->d_counters;
+      p.min_voxels = ctx->occ_lazy_min;
+      p.brick_mask_out = ctx->mask_buf(ctx->rbuf);
+      p.num_bricks = g.num_bricks;
+      ctx->occ_lazy = false;
+    } else {
+      int rc_ = materialise_mask(ctx);
+      if (rc_ != RGBDR_OK) return rc_;
+    }
+  }
   p.vbx = ctx->d_brick_tab;
   p.vby = p.vbx + g.res_volume[0];
   p.vbz = p.vby + g.res_volume[1];
@@ -784,7 +821,8 @@ int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FL
 int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  int rc = sync_all(ctx);
+  int rc = materialise_mask(ctx);  // (the lazy filter is a single-stream shortcut)
+  if (rc == RGBDR_OK) rc = sync_all(ctx);
   if (rc != RGBDR_OK) return rc;
   ctx->wbuf = ctx->rbuf;  // keep reading what was written last
   ctx->ev_pre_rec[0] = ctx->ev_pre_rec[1] = ctx->ev_int_rec[0] = ctx->ev_int_rec[1] = false;
@@ -945,6 +983,7 @@ int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* c
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null count");
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "get_occupied before update_occupied_bricks");
+  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   launch_compact_occupied(ctx->mask_buf(ctx->rbuf), (uint32_t)ctx->geo.num_bricks, ctx->d_ids,

@@ -34,6 +34,7 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
 {
   { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "depth limits before update_occupied_bricks");
+  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }
   PeelParams p{};
   mat4_product(v->projection, v->modelview, p.pmv);
   std::memcpy(p.modelview_inv, v->modelview_inv, 64);

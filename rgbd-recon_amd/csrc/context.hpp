@@ -129,6 +129,10 @@ struct rgbdr_ctx {
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool mask_valid = false;
+  // rgbdr_update_occupied_bricks only noted the threshold: mask_buf(rbuf) is to be rebuilt from the counters by
+  // whoever needs it first -- the brick sweep's first kernel does it on the way (materialise_mask otherwise)
+  bool occ_lazy = false;
+  uint32_t occ_lazy_min = 0;
   // brick -> voxel membership of divideBox / containedVoxels (geometry.cpp compute_brick_tables):
   // device copy of vox[x] | vox[y] | vox[z] | tile[x] | tile[y] | tile[z]
   rgbdr::BrickTables bt;
@@ -178,6 +182,7 @@ int sync_all(rgbdr_ctx* ctx);           // drain both streams
 int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
+int materialise_mask(rgbdr_ctx* ctx);   // perform a pending (lazy) updateOccupiedBricks filter
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);
 void tend(rgbdr_ctx* c, const char* name, hipStream_t st);

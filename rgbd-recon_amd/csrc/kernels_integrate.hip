@@ -536,6 +536,10 @@ constexpr int kClearTiles = 256;
 // epoch whenever anything else may have written the volume or the limit changed), so a
 // steady stream only rewrites the tiles the surface has just left.  Tiles that do need the
 // clear are collected per block and streamed out by all 256 lanes (2 KiB each, non-temporal).
+// LAZY: updateOccupiedBricks' filter rides along (rgbdr_update_occupied_bricks only noted the threshold): the
+// decisions below read the counters themselves, and every lane also writes mask bytes for the sweep that follows
+// and for later consumers -- one launch less per frame.
+template <bool LAZY>
 __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned ntiles)
 {
   __shared__ unsigned todo[kClearTiles];
@@ -544,6 +548,10 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_next = 0u;  // the counter the next sweep appends to
   __syncthreads();
   const unsigned tile = blockIdx.x * kClearTiles + threadIdx.x;
+  if (LAZY) {
+    for (unsigned b = tile; b < (unsigned)p.num_bricks; b += gridDim.x * kClearTiles)
+      p.brick_mask_out[b] = p.brick_counters[b] >= p.min_voxels ? 1 : 0;
+  }
   bool any = false, whole = false, clear = false;
   if (tile < ntiles) {
     const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, tz = p.tz0 + tile / (p.TX * p.TY);
@@ -557,7 +565,8 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
     for (uint32_t bz = lo[2]; bz <= hi[2]; ++bz)
       for (uint32_t by = lo[1]; by <= hi[1]; ++by)
         for (uint32_t bx = lo[0]; bx <= hi[0]; ++bx) {
-          const bool o = p.brick_mask[((size_t)bz * p.by + by) * p.bx + bx] != 0;
+          const size_t id = ((size_t)bz * p.by + by) * p.bx + bx;
+          const bool o = LAZY ? p.brick_counters[id] >= p.min_voxels : p.brick_mask[id] != 0;
           any |= o;
           all &= o;
         }
@@ -971,7 +980,10 @@ template <int N>
 static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
 {
   if (p.use_bricks) {
-    hipLaunchKernelGGL(k_brick_clear, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
+    if (p.brick_counters)
+      hipLaunchKernelGGL(k_brick_clear<true>, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
+    else
+      hipLaunchKernelGGL(k_brick_clear<false>, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
     const unsigned blocks = ntiles < 2560u ? ntiles : 2560u;  // 10 resident blocks (5 wavefronts per SIMD) on each of the 256 CUs
     hipLaunchKernelGGL((k_integrate_tiled_list<N>), dim3(blocks), dim3(128), 0, s, p);
     return;

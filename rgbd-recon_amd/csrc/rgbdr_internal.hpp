@@ -100,6 +100,11 @@ struct IntegrateParams {
   // bricks
   int use_bricks;
   const uint8_t* brick_mask;
+  // lazy occupied filter (k_brick_clear<true>): counters + threshold in, mask bytes out; null: the mask is current
+  const uint32_t* brick_counters;
+  uint32_t min_voxels;
+  uint8_t* brick_mask_out;
+  int num_bricks;
   int bx, by, bz;          // m_res_bricks
   // per voxel coordinate the range of bricks holding it (BrickTables::vox), on the device
   const uint32_t* vbx;

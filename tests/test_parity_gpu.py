@@ -1019,6 +1019,39 @@ def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
     ctx.close()
 
 
+def test_occupied_filter_is_a_snapshot_whoever_evaluates_it(pkg, orc):
+    """rgbdr_update_occupied_bricks may leave the filter to its first consumer (the brick sweep folds it into its
+    first kernel): the result is that of the moment of the call -- later changes of the threshold or of the
+    counters do not leak into it -- whichever consumer comes first, and in both schedules"""
+    scene, ctx, inv = build(pkg)
+    ctx.step(scene.depth, scene.color)
+    ref = oracle_run(orc, scene, ctx, inv)
+    want = ref["occupied"]
+    for pipelined in (False, True):
+        ctx.set_pipelined(pipelined)
+        for first in ("integrate", "get_occupied", "process_textures", "clear", "min_voxels", "switch"):
+            ctx.set_min_voxels_per_brick(10)
+            ctx.clear_occupied_bricks()
+            ctx.process_textures()
+            ctx.update_occupied_bricks()
+            if first == "min_voxels":
+                ctx.set_min_voxels_per_brick(100000)     # after the update: must not matter
+            elif first == "process_textures":
+                ctx.process_textures()                   # counters double, the filter result stays
+            elif first == "clear":
+                ctx.clear_occupied_bricks()
+                ctx.readback_brick_counters()            # flushes the clear
+            elif first == "switch":
+                ctx.set_pipelined(not pipelined)
+                ctx.set_pipelined(pipelined)
+            if first != "get_occupied":
+                ctx.integrate()
+                assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (pipelined, first)
+            ids, _ = ctx.get_occupied()
+            assert np.array_equal(ids, want), (pipelined, first)
+    ctx.close()
+
+
 def test_deferred_counter_clear(pkg):
     """clearOccupiedBricks is performed by the next process_textures -- or by whoever reads the
     counters first"""
