@@ -104,10 +104,10 @@ static int alloc_brick_table(rgbdr_ctx* ctx, const rgbdr_config& cfg, const rgbd
   uint32_t *counters = nullptr, *ids = nullptr, *tab = nullptr;
   uint8_t* mask = nullptr;
   const size_t nb = (size_t)g.num_bricks;
-  if (hipMalloc((void**)&counters, nb * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&ids, nb * sizeof(uint32_t)) != hipSuccess ||
+  if (hipMalloc((void**)&counters, 2 * nb * sizeof(uint32_t)) != hipSuccess || hipMalloc((void**)&ids, nb * sizeof(uint32_t)) != hipSuccess ||
       hipMalloc((void**)&mask, nb * 2) != hipSuccess || hipMalloc((void**)&tab, host.size() * sizeof(uint32_t)) != hipSuccess ||
       hipMemcpy(tab, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemsetAsync(counters, 0, nb * sizeof(uint32_t), ctx->stream) != hipSuccess ||
+      hipMemsetAsync(counters, 0, 2 * nb * sizeof(uint32_t), ctx->stream) != hipSuccess ||
       hipMemsetAsync(mask, 0, nb * 2, ctx->stream) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipFree(counters);
@@ -121,6 +121,7 @@ static int alloc_brick_table(rgbdr_ctx* ctx, const rgbdr_config& cfg, const rgbd
   (void)hipFree(ctx->d_mask);
   (void)hipFree(ctx->d_brick_tab);
   ctx->d_counters = counters;
+  ctx->cbuf = 0;
   ctx->d_ids = ids;
   ctx->d_mask = mask;
   ctx->d_brick_tab = tab;
@@ -448,7 +449,17 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  ctx->clear_pending = true;  // performed by the first kernel of process_textures, or by whoever reads the counters first
+  if (!ctx->clear_pending) {
+    // the counting moves to the other buffer (zeroed by the first kernel of process_textures, or by whoever reads
+    // the counters first): a filter still pending on the one just left is not disturbed; one pending on the buffer
+    // coming back into use (two clears without an update in between) has to be evaluated now
+    if (ctx->occ_lazy && ctx->occ_lazy_cbuf == (ctx->cbuf ^ 1)) {
+      int rc_ = materialise_mask(ctx);
+      if (rc_ != RGBDR_OK) return rc_;
+    }
+    ctx->cbuf ^= 1;
+  }
+  ctx->clear_pending = true;
   return RGBDR_OK;
 }
 
@@ -460,7 +471,8 @@ int rgbdr::materialise_mask(rgbdr_ctx* ctx)
 {
   if (!ctx->occ_lazy) return RGBDR_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->occ_lazy_min, ctx->mask_buf(ctx->rbuf),
+  launch_update_occupied(ctx->d_counters + (size_t)ctx->occ_lazy_cbuf * ctx->geo.num_bricks, (uint32_t)ctx->geo.num_bricks,
+                         ctx->occ_lazy_min, ctx->mask_buf(ctx->rbuf),
                          ctx->count_buf(ctx->rbuf), ctx->pstream());
   LAUNCHCHK("update_occupied");
   ctx->occ_lazy = false;
@@ -469,9 +481,9 @@ int rgbdr::materialise_mask(rgbdr_ctx* ctx)
 int rgbdr::flush_clear(rgbdr_ctx* ctx)
 {
   if (!ctx->clear_pending) return RGBDR_OK;
-  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  if (ctx->occ_lazy && ctx->occ_lazy_cbuf == ctx->cbuf) { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemsetAsync(ctx->d_counters, 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->pstream()));
+  HIPCHK(hipMemsetAsync(ctx->counters_cur(), 0, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), ctx->pstream()));
   ctx->clear_pending = false;
   return RGBDR_OK;
 }
@@ -512,7 +524,7 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
     p.far_[i] = ctx->cfg.far_[i];
   }
   p.brick_size = ctx->geo.brick_size;
-  p.brick_counters = ctx->d_counters;
+  p.brick_counters = ctx->counters_cur();
   p.color = ctx->d_color;
   p.depth_morph = ctx->d_depth_morph;
   p.depth_rg = ctx->d_depth_rg;
@@ -527,14 +539,17 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   // raw depth (NetKinectArray.cpp:287-289)
   p.depth_in = (ctx->cfg.flags & RGBDR_FLAG_PROCESSED) ? ctx->d_depth_morph : ctx->d_depth_raw;
 
-  { int rc_ = materialise_mask(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the counters are about to change
+  if (ctx->occ_lazy && ctx->occ_lazy_cbuf == ctx->cbuf) {  // the counters a pending filter reads are about to change
+    int rc_ = materialise_mask(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   hipStream_t ps = ctx->pstream();
   const int w = ctx->wbuf;
   p.frame = ctx->frame_buf(w);
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
   tbegin(ctx, "1preprocess", ps);
   tbegin(ctx, "morph", ps);
-  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->clear_pending ? ctx->d_counters : nullptr,
+  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->clear_pending ? ctx->counters_cur() : nullptr,
                (unsigned)ctx->geo.num_bricks, ps);
   ctx->clear_pending = false;
   tend(ctx, "morph", ps);
@@ -579,11 +594,12 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
   if (!ctx->pipelined()) {
     // one stream: nothing can touch the counters before the next call of this library does, so the filter is left
     // to the first consumer -- the brick sweep folds it into its first kernel
-    ctx->occ_lazy = true;
+    ctx->occ_lazy = true;  // (replaces a filter still pending from the frame before: nobody asked for it)
     ctx->occ_lazy_min = ctx->cfg.min_voxels_per_brick;
+    ctx->occ_lazy_cbuf = ctx->cbuf;
   } else {
     ctx->occ_lazy = false;
-    launch_update_occupied(ctx->d_counters, (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick,
+    launch_update_occupied(ctx->counters_cur(), (uint32_t)ctx->geo.num_bricks, ctx->cfg.min_voxels_per_brick,
                            ctx->mask_buf(w), ctx->count_buf(w), ps);
   }
   tend(ctx, "bricks", ps);
@@ -663,7 +679,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   p.brick_counters = nullptr;
   if (bricks && ctx->occ_lazy) {
     if (all_tiled) {  // k_brick_clear<true> filters on the way
-      p.brick_counters = ctx->d_counters;
+      p.brick_counters = ctx->d_counters + (size_t)ctx->occ_lazy_cbuf * g.num_bricks;  // the buffer the update saw
       p.min_voxels = ctx->occ_lazy_min;
       p.brick_mask_out = ctx->mask_buf(ctx->rbuf);
       p.num_bricks = g.num_bricks;
@@ -973,7 +989,7 @@ int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(dst, ctx->d_counters, (size_t)ctx->geo.num_bricks * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst, ctx->counters_cur(), (size_t)ctx->geo.num_bricks * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }

@@ -46,7 +46,7 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
     p.res_bricks[a] = ctx->geo.res_bricks[a];
   }
   p.brick_size = ctx->geo.brick_size;
-  p.counters = ctx->d_counters;
+  p.counters = ctx->counters_cur();
   p.mask = ctx->mask_buf(ctx->rbuf);
   p.out = out;
   tbegin(ctx, "brickdraw", ctx->stream);

@@ -111,7 +111,11 @@ struct rgbdr_ctx {
   bool integrated = false;
 
   // bricks
+  // brick counters: two buffers, switched by clearOccupiedBricks, so that a lazy occupied filter (occ_lazy) of the
+  // frame before survives the next frame's clear and counting and is simply dropped when the next update replaces it
   uint32_t *d_counters = nullptr, *d_ids = nullptr, *d_count = nullptr;
+  int cbuf = 0;
+  uint32_t* counters_cur() const { return d_counters + (size_t)cbuf * geo.num_bricks; }
   bool clear_pending = false;       // clearOccupiedBricks was called; the zeroing rides on the next k_morph
   uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
   uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
@@ -133,6 +137,7 @@ struct rgbdr_ctx {
   // whoever needs it first -- the brick sweep's first kernel does it on the way (materialise_mask otherwise)
   bool occ_lazy = false;
   uint32_t occ_lazy_min = 0;
+  int occ_lazy_cbuf = 0;            // the counter buffer the pending filter reads
   // brick -> voxel membership of divideBox / containedVoxels (geometry.cpp compute_brick_tables):
   // device copy of vox[x] | vox[y] | vox[z] | tile[x] | tile[y] | tile[z]
   rgbdr::BrickTables bt;

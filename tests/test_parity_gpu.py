@@ -1049,6 +1049,19 @@ def test_occupied_filter_is_a_snapshot_whoever_evaluates_it(pkg, orc):
                 assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (pipelined, first)
             ids, _ = ctx.get_occupied()
             assert np.array_equal(ids, want), (pipelined, first)
+        # two more frames counted (the counters alternate between two buffers) without an update: the filter result
+        # is still the one of the last update
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        empty = np.zeros_like(scene.depth)
+        for _ in range(2):
+            ctx.clear_occupied_bricks()
+            ctx.update(empty, scene.color)
+            ctx.process_textures()
+        assert ctx.readback_brick_counters().sum() == 0
+        assert np.array_equal(ctx.get_occupied()[0], want), pipelined
+        ctx.update(scene.depth, scene.color)
     ctx.close()
 
 
