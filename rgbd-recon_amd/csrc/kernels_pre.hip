@@ -333,19 +333,12 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   // three-test loop.
   const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
   unorm[threadIdx.y * BX + threadIdx.x] = (float)(threadIdx.y * BX + threadIdx.x) / 255.0f;  // 256 threads, 256 entries
-  for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
-    const int ty = i / TW, tx = i - ty * TW;
-    const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
-    const float ds = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
-    tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? 3.0e38f : ds;
-  }
-  __syncthreads();
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
-  if (px >= W || py >= H) return;
-  const size_t o = (size_t)l * W * H + (size_t)py * W + px;
+  const bool inside = px < W && py < H;
+  const size_t o = (size_t)l * W * H + (inside ? (size_t)py * W + px : 0);
   const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
   const float range = max_ds - min_ds;
-  const float depth0 = pd_uncompress(depth[(size_t)py * W + px], compress, scale, scaled_near, p.near_[l]);
+  const float depth0 = pd_uncompress(inside ? depth[(size_t)py * W + px] : 0.0f, compress, scale, scaled_near, p.near_[l]);
   const float depth_norm = (depth0 - min_ds) / range;
   // A pixel without a measurement (depth 0, or anything nearer than the first / beyond the last z texel of
   // cv_xyz) looks cv_xyz up in its clamped first / last z plane, and every depth_norm outside (0,1) looks cv_uv
@@ -354,11 +347,25 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   // take this path and skip both trilinear lookups (240 of the ~540 VALU instructions of this prologue).
   const int rz = p.xyz_res[l][2];
   const float tz = depth_norm * (float)rz - 0.5f;  // axis_linear's t on the z axis
-  const unsigned char cached = p.box_flags[o];
+  const unsigned char cached = inside ? p.box_flags[o] : 0;
+  const bool first_plane = tz < 0.0f && tz > -3.0e38f, last_plane = tz >= (float)(rz - 1) && tz < 3.0e38f;
+  // Only a pixel inside the box runs the filter, and for a pixel of the first / last plane that is known already:
+  // a block without a candidate (two thirds of the blocks) does not stage the 28 x 28 window at all.
+  const bool candidate = inside && p.filter && (first_plane ? (cached & 1u) != 0 : (last_plane ? (cached & 2u) != 0 : true));
+  if (__syncthreads_or(candidate)) {
+    for (int i = threadIdx.y * BX + threadIdx.x; i < TW * TH; i += BX * BY) {
+      const int ty = i / TW, tx = i - ty * TW;
+      const float d = depth[(size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1)];
+      const float ds = pd_uncompress(d, compress, scale, scaled_near, p.near_[l]);
+      tile[ty][tx] = ((ds < min_ds) || (ds > max_ds)) ? 3.0e38f : ds;
+    }
+    __syncthreads();
+  }
+  if (!inside) return;
   bool in_box;
-  if (tz < 0.0f && tz > -3.0e38f) {
+  if (first_plane) {
     in_box = (cached & 1u) != 0;   // both z texels clamp to plane 0: lerp(c, c, a) = c for the finite a of a finite tz
-  } else if (tz >= (float)(rz - 1) && tz < 3.0e38f) {
+  } else if (last_plane) {
     in_box = (cached & 2u) != 0;   // ... to plane rz - 1
   } else {
     const float3 pw = tex3d_xyz(p.cv_xyz[l], p.xyz_res[l][0], p.xyz_res[l][1], rz, 0, u, v, depth_norm);
@@ -756,12 +763,23 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_normal_quality(PreParams p)
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
   const float* db = p.depth_b_rg + lo * 2;
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const bool inside = px < W && py < H;
+  const size_t o = inside ? (size_t)py * W + px : 0;
+  const float depth = inside ? db[o * 2] : 0.0f;
+  // two thirds of the blocks hold no pixel with a depth in (0,1) -- nothing to compute, nothing to stage: they
+  // write their zeros and leave (the window is 784 texels for 256 pixels)
+  if (!__syncthreads_or(inside && !unit_outside(depth))) {
+    if (!inside) return;
+    p.normal[(lo + o) * 3 + 0] = 0.0f;
+    p.normal[(lo + o) * 3 + 1] = 0.0f;
+    p.normal[(lo + o) * 3 + 2] = 0.0f;
+    store_quality(p, lo + o, depth, 0.0f);
+    return;
+  }
   stage_depth_b(tile, db, bp.bx * BX - R13, blockIdx.y * BY - R13, W, H);
   __syncthreads();
-  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
-  if (px >= W || py >= H) return;
-  const size_t o = (size_t)py * W + px;
-  const float depth = db[o * 2];
+  if (!inside) return;
   float3 n = make_float3(0.0f, 0.0f, 0.0f);
   float q = 0.0f;
   int home_id = -1, nb_id = -1;
