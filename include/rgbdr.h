@@ -231,7 +231,9 @@ int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth_dev, const void*
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx);
 /* NetKinectArray::processTextures (NetKinectArray.cpp:311-428) */
 int rgbdr_process_textures(rgbdr_ctx* ctx);
-/* ReconIntegration::updateOccupiedBricks (recon_integration.cpp:431-446), device side, no readback */
+/* ReconIntegration::updateOccupiedBricks (recon_integration.cpp:431-446), device side, no readback.  The set of
+ * occupied bricks is that of the moment of the call (counters and threshold as they are now); the library may
+ * evaluate the filter later, together with its first consumer. */
 int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx);
 /* Replaces m_bricks_occupied (recon_integration.cpp:434-441) with the caller's own list of brick ids
  * (divideBox order, x fastest) -- for a host that filters the counters itself, as the reference does on
