@@ -41,12 +41,14 @@ __global__ void k_fc_init(FillLayout L, const float4* __restrict__ frame_col, co
   dep[(size_t)y * L.FW + x] = d;
 }
 
-// framebuffer_transfer.fs into the LOD-0 viewport of a freshly cleared atlas
+// framebuffer_transfer.fs into the LOD-0 viewport of a freshly cleared atlas; texels [x0, x1) x [y0, ...) only
+// (the reference redraws the whole atlas after every LOD; only the texels whose source lies in the LOD just
+// inpainted can change, launch_fill_colors)
 __global__ void k_fc_transfer(FillLayout L, const float4* __restrict__ scol, const float* __restrict__ sdep,
-                              float4* __restrict__ dcol, float* __restrict__ ddep)
+                              float4* __restrict__ dcol, float* __restrict__ ddep, int x0, int x1, int y0)
 {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= L.FW) return;
+  const int x = x0 + (int)(blockIdx.x * blockDim.x + threadIdx.x), y = y0 + (int)blockIdx.y;
+  if (x >= x1) return;
   float4 c = make_float4(0.0f, 1.0f, 0.0f, 0.0f);
   float d = 1.0f;
   if (x < L.W) {
@@ -188,11 +190,22 @@ void launch_fill_colors(const FillLayout& L, const float4* frame_col, const floa
 {
   const dim3 full((L.FW + 127) / 128, L.H), blk(128);
   hipLaunchKernelGGL(k_fc_init, full, blk, 0, s, L, frame_col, frame_dep, ncol, ndep);
-  hipLaunchKernelGGL(k_fc_transfer, full, blk, 0, s, L, ncol, ndep, scol, sdep);
+  hipLaunchKernelGGL(k_fc_transfer, full, blk, 0, s, L, ncol, ndep, scol, sdep, 0, L.FW, 0);
   for (int i = 1; i < L.num_lods; ++i) {
     const dim3 g((L.res[i][0] + 127) / 128, L.res[i][1]);
     hipLaunchKernelGGL(k_fc_inpaint, g, blk, 0, s, L, i - 1, scol, sdep, ncol, ndep);
-    hipLaunchKernelGGL(k_fc_transfer, full, blk, 0, s, L, ncol, ndep, scol, sdep);
+    // the squeezed copy again, where it can have changed: texel (x, y) of it reads the native atlas at
+    // ((int)((x + 0.5) / W * FW), y), i.e. about 1.5 x -- the texels whose source lies in LOD i (+- 2 texels for
+    // the rounding; recomputing a texel whose source did not change writes the same value)
+    const int sx0 = L.off[i][0], sx1 = L.off[i][0] + L.res[i][0];
+    int x0 = (int)((double)sx0 * L.W / L.FW) - 2, x1 = (int)((double)sx1 * L.W / L.FW) + 3;
+    int y0 = L.off[i][1] - 1, y1 = L.off[i][1] + L.res[i][1] + 1;
+    x0 = x0 < 0 ? 0 : x0;
+    x1 = x1 > L.W ? L.W : x1;
+    y0 = y0 < 0 ? 0 : y0;
+    y1 = y1 > L.H ? L.H : y1;
+    if (x1 > x0 && y1 > y0)
+      hipLaunchKernelGGL(k_fc_transfer, dim3((x1 - x0 + 127) / 128, y1 - y0), blk, 0, s, L, ncol, ndep, scol, sdep, x0, x1, y0);
   }
   hipLaunchKernelGGL(k_fc_colorfill, dim3((L.W + 127) / 128, L.H), blk, 0, s, L, ncol, ndep, out_col, out_dep);
 }
