@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """In-process timing of the pre_* chain (clear + process_textures + update_occupied per frame on the benchmark
 frame set) for contexts created under different values of one environment knob the library reads at context
-creation (RGBDR_SEPARATE_PASSES, RGBDR_NQ_WAVES ...; "-" = unset), interleaved rounds, with a bit-for-bit
+creation (RGBDR_SEPARATE_PASSES ...; "-" = unset), interleaved rounds, with a bit-for-bit
 comparison of every image / the brick counters between the contexts.
 usage: python profiles/pre_probe.py [rounds] [KNOB value value ...]"""
 import json

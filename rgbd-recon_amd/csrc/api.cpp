@@ -569,7 +569,7 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
     launch_quality(p, ps);
     tend(ctx, "quality", ps);
   } else {
-    launch_normal_quality(p, ps, ctx->nq_waves);
+    launch_normal_quality(p, ps);
   }
   tend(ctx, "1preprocess", ps);
   LAUNCHCHK("process_textures");

@@ -144,9 +144,8 @@ struct rgbdr_ctx {
   uint32_t* d_brick_tab = nullptr;
 
   bool timers = false, accumulate = false;
-  // developer A/B knobs, read when the context is created
+  // developer A/B knob, read when the context is created
   bool separate_passes = getenv("RGBDR_SEPARATE_PASSES") != nullptr;
-  int nq_waves = getenv("RGBDR_NQ_WAVES") ? atoi(getenv("RGBDR_NQ_WAVES")) : 4;
   int timer_detail = 2;  // 1: only "1preprocess" / "2integrate" / "bricks" ...; 2: also the five pre_* passes
   std::map<std::string, rgbdr::Timer> tm;
 

@@ -804,15 +804,10 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_normal_quality(PreParams p)
   }
 }
 
-void launch_normal_quality(const PreParams& p, hipStream_t s, int waves)
+void launch_normal_quality(const PreParams& p, hipStream_t s)
 {
-  switch (waves) {  // experiment: wavefronts per SIMD the register allocation aims at
-    case 2: hipLaunchKernelGGL(k_normal_quality<2>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
-    case 3: hipLaunchKernelGGL(k_normal_quality<3>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
-    case 5: hipLaunchKernelGGL(k_normal_quality<5>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
-    case 6: hipLaunchKernelGGL(k_normal_quality<6>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
-    default: hipLaunchKernelGGL(k_normal_quality<4>, pass_grid(p), dim3(BX, BY), 0, s, p); break;
-  }
+  // four wavefronts per SIMD (114 VGPRs); three and five measured the same, two and six slower
+  hipLaunchKernelGGL(k_normal_quality<4>, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 // ---------------------------------------------------------------------------

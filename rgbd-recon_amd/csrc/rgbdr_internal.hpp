@@ -214,7 +214,7 @@ void launch_pre_depth(const PreParams& p, hipStream_t s);
 void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
 void launch_quality(const PreParams& p, hipStream_t s);
-void launch_normal_quality(const PreParams& p, hipStream_t s, int waves);  // both passes in one launch
+void launch_normal_quality(const PreParams& p, hipStream_t s);  // both passes in one launch
 void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask,
                             uint32_t* count, hipStream_t s);
 void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);
