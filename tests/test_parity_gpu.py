@@ -970,6 +970,8 @@ def run_random_sequence(pkg, orc, seed, slab):
         if step_no % 7 == 0:
             check_images(ctx, ref, 2)
             assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        if step_no % 3 == 0:   # (the occupied filter may have been left to this call: it must be the frame's)
+            assert np.array_equal(ctx.get_occupied()[0], ref["occupied"]), (seed, step_no, int(op), state)
     ctx.close()
 
 
