@@ -138,11 +138,29 @@ __global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int 
     }
   }
   const int x0 = (b % bw) * 4, y0 = (b / bw) * 4;
+  // a block row is 12 bytes: three aligned words when the image rows are (W * 3 a multiple of 4; x0 * 3 is a
+  // multiple of 12) and the block lies inside the image -- 12 word stores per block instead of 48 byte stores
+  const bool words = ((W * 3) & 3) == 0 && x0 + 4 <= W && (((size_t)rgb) & 3) == 0;
   for (int py = 0; py < 4; ++py) {
     const int bits = src[4 + py];
+    const int sy = y0 + py;
+    if (sy >= H) continue;
+    if (words) {
+      uint32_t px[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = (bits >> (2 * k)) & 3;
+        px[k] = (uint32_t)codes[idx][0] | ((uint32_t)codes[idx][1] << 8) | ((uint32_t)codes[idx][2] << 16);
+      }
+      uint32_t* o = reinterpret_cast<uint32_t*>(rgb + ((size_t)sy * W + x0) * 3);
+      o[0] = px[0] | (px[1] << 24);
+      o[1] = (px[1] >> 8) | (px[2] << 16);
+      o[2] = (px[2] >> 16) | (px[3] << 8);
+      continue;
+    }
     for (int px = 0; px < 4; ++px) {
-      const int sx = x0 + px, sy = y0 + py;
-      if (sx >= W || sy >= H) continue;
+      const int sx = x0 + px;
+      if (sx >= W) continue;
       const int idx = (bits >> (2 * px)) & 3;
       uint8_t* o = rgb + ((size_t)sy * W + sx) * 3;
       o[0] = (uint8_t)codes[idx][0];
