@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <ctime>
@@ -381,22 +382,27 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
     ctx->frame_uploaded = true;
     return RGBDR_OK;
   }
+  // Compressed colour stays in its DXT blocks: pre_depth decodes the four taps of its bilinear lookup itself, and the
+  // whole frame is only decoded when a consumer of the RGB8 image asks (ensure_color_decoded).  Frames that are
+  // already on the device: depth (or u8 depth) and the colour blocks / RGB8 frame move in one launch where the
+  // pointers allow it.
+  const bool dev = kind == hipMemcpyDeviceToDevice;
+  const size_t layer = color_frame_bytes(ctx->cfg);
+  const void* csrc = color;
+  void* cdst = ctx->cfg.compress_rgb ? (void*)ctx->d_color_dxt : (void*)ctx->d_color;
+  const size_t cbytes = ctx->cfg.compress_rgb ? layer * nsens(ctx) : ncol;
+  bool color_done = false;
   if (ctx->cfg.compress_depth) {
-    HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
-    launch_u8_to_unit(ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
+    if (!dev) HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
+    launch_u8_to_unit(dev ? (const uint8_t*)depth : ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
     LAUNCHCHK("u8_to_unit");
+  } else if (dev && launch_copy_frames(depth, ctx->d_depth_raw, n * 4, csrc, cdst, cbytes, ps)) {
+    color_done = true;
   } else {
     HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ps));
   }
-  if (ctx->cfg.compress_rgb) {
-    const size_t layer = color_frame_bytes(ctx->cfg);
-    HIPCHK(hipMemcpyAsync(ctx->d_color_dxt, color, layer * nsens(ctx), kind, ps));
-    launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx), layer,
-                      ctx->d_color, ps);
-    LAUNCHCHK("decode_dxt");
-  } else {
-    HIPCHK(hipMemcpyAsync(ctx->d_color, color, ncol, kind, ps));
-  }
+  if (!color_done) HIPCHK(hipMemcpyAsync(cdst, csrc, cbytes, kind, ps));
+  ctx->color_decoded = !ctx->cfg.compress_rgb;
   ctx->frame_uploaded = true;
   return RGBDR_OK;
 }
@@ -465,6 +471,18 @@ int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
 
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
+// the RGB8 colour frame for consumers other than pre_depth (which reads DXT blocks directly)
+int rgbdr::ensure_color_decoded(rgbdr_ctx* ctx)
+{
+  if (ctx->color_decoded) return RGBDR_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
+                    color_frame_bytes(ctx->cfg), ctx->d_color, ctx->pstream());
+  LAUNCHCHK("decode_dxt");
+  if (ctx->pipelined()) HIPCHK(hipStreamSynchronize(ctx->pstream()));  // consumers may sit on the other stream
+  ctx->color_decoded = true;
+  return RGBDR_OK;
+}
 // the filter of a lazy rgbdr_update_occupied_bricks, for consumers other than the brick sweep and before
 // anything changes the counters it was asked for
 int rgbdr::materialise_mask(rgbdr_ctx* ctx)
@@ -526,6 +544,9 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   p.brick_size = ctx->geo.brick_size;
   p.brick_counters = ctx->counters_cur();
   p.color = ctx->d_color;
+  p.color_dxt = ctx->color_decoded ? nullptr : ctx->d_color_dxt;
+  p.color_layer_bytes = color_frame_bytes(ctx->cfg);
+  p.color_mode = ctx->cfg.compress_rgb;
   p.depth_morph = ctx->d_depth_morph;
   p.depth_rg = ctx->d_depth_rg;
   p.lab = ctx->d_lab;
@@ -956,6 +977,7 @@ int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device
     case RGBDR_IMG_NORMAL: f = ctx->d_normal; v.channels = 3; break;
     case RGBDR_IMG_QUALITY: f = ctx->d_quality; break;
     case RGBDR_IMG_COLOR:
+      { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }
       v.width = ctx->cfg.color_w;
       v.height = ctx->cfg.color_h;
       v.channels = 3;
@@ -975,6 +997,7 @@ int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst)
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t img = (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3;
   HIPCHK(hipMemcpyAsync(dst, ctx->d_color + img * sensor, img, hipMemcpyDeviceToHost, ctx->stream));

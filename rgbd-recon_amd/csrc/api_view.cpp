@@ -141,6 +141,7 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
     for (int a = 0; a < 3; ++a) p.uv_res[i][a] = (int)ctx->uv_res[i][a];
     p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
   }
+  { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the shader samples the RGB8 frames
   p.color = ctx->d_color;
   p.out_color = (float4*)ctx->d_view;
   p.out_depth = ctx->d_view + npix * 4;

@@ -132,6 +132,7 @@ struct rgbdr_ctx {
   int halo_last = -1;
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
+  bool color_decoded = true;        // d_color holds the uploaded frame (false: only d_color_dxt does)
   bool mask_valid = false;
   // rgbdr_update_occupied_bricks only noted the threshold: mask_buf(rbuf) is to be rebuilt from the counters by
   // whoever needs it first -- the brick sweep's first kernel does it on the way (materialise_mask otherwise)
@@ -186,7 +187,8 @@ int sync_all(rgbdr_ctx* ctx);           // drain both streams
 int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
-int materialise_mask(rgbdr_ctx* ctx);   // perform a pending (lazy) updateOccupiedBricks filter
+int materialise_mask(rgbdr_ctx* ctx);
+int ensure_color_decoded(rgbdr_ctx* ctx);  // RGB8 frame of a DXT upload, decoded on demand   // perform a pending (lazy) updateOccupiedBricks filter
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);
 void tend(rgbdr_ctx* c, const char* name, hipStream_t st);

@@ -114,15 +114,9 @@ __device__ __forceinline__ void unpack565(const uint8_t* p, int* c)
   c[2] = ((b << 3) | (b >> 2)) & 0xff;
 }
 
-__global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int H, int mode, size_t layer_bytes,
-                             uint8_t* __restrict__ rgb_all)
+// the four colours of a block (squish::DecompressColour, external/squish/colourblock.cpp:140-214)
+__device__ __forceinline__ void dxt_palette(const uint8_t* src, int mode, int codes[4][3])
 {
-  const int bw = (W + 3) / 4, bh = (H + 3) / 4;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bw * bh) return;
-  const uint8_t* src = blocks_all + (size_t)blockIdx.y * layer_bytes + (size_t)b * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8);
-  uint8_t* rgb = rgb_all + (size_t)blockIdx.y * W * H * 3;
-  int codes[4][3];
   unpack565(src, codes[0]);
   unpack565(src + 2, codes[1]);
   const int a = (int)src[0] | ((int)src[1] << 8), bb = (int)src[2] | ((int)src[3] << 8);
@@ -137,6 +131,31 @@ __global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int 
       codes[3][i] = (c + 2 * d) / 3;
     }
   }
+}
+
+// one texel of a DXT1 / DXT5 layer: what k_decode_dxt stores at (x, y)
+__device__ __forceinline__ void dxt_texel(const uint8_t* __restrict__ layer, int W, int mode, int x, int y, int* rgb)
+{
+  const int bw = (W + 3) / 4;
+  const uint8_t* src = layer + (size_t)((y >> 2) * bw + (x >> 2)) * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8);
+  int codes[4][3];
+  dxt_palette(src, mode, codes);
+  const int idx = (src[4 + (y & 3)] >> (2 * (x & 3))) & 3;
+  rgb[0] = codes[idx][0];
+  rgb[1] = codes[idx][1];
+  rgb[2] = codes[idx][2];
+}
+
+__global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int H, int mode, size_t layer_bytes,
+                             uint8_t* __restrict__ rgb_all)
+{
+  const int bw = (W + 3) / 4, bh = (H + 3) / 4;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bw * bh) return;
+  const uint8_t* src = blocks_all + (size_t)blockIdx.y * layer_bytes + (size_t)b * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8);
+  uint8_t* rgb = rgb_all + (size_t)blockIdx.y * W * H * 3;
+  int codes[4][3];
+  dxt_palette(src, mode, codes);
   const int x0 = (b % bw) * 4, y0 = (b / bw) * 4;
   // a block row is 12 bytes: three aligned words when the image rows are (W * 3 a multiple of 4; x0 * 3 is a
   // multiple of 12) and the block lies inside the image -- 12 word stores per block instead of 48 byte stores
@@ -296,6 +315,28 @@ __device__ __forceinline__ float3 color_bilinear(const uint8_t* __restrict__ img
   return make_float3(c[0], c[1], c[2]);
 }
 
+// the same lookup with the colour frame still in its DXT blocks: the four texels are decoded on the spot (what
+// k_decode_dxt would have stored), so the 15 us decode launch and 16 MB of RGB8 per frame are only spent when a
+// consumer asks for the decoded frame
+__device__ __forceinline__ float3 color_bilinear_dxt(const uint8_t* __restrict__ layer, int W, int H, int mode, float u,
+                                                     float v, const float* unorm)
+{
+  const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
+  int p00[3], p10[3], p01[3], p11[3];
+  dxt_texel(layer, W, mode, X.i0, Y.i0, p00);
+  dxt_texel(layer, W, mode, X.i1, Y.i0, p10);
+  dxt_texel(layer, W, mode, X.i0, Y.i1, p01);
+  dxt_texel(layer, W, mode, X.i1, Y.i1, p11);
+  float c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t00 = unorm[p00[k]], t10 = unorm[p10[k]];
+    const float t01 = unorm[p01[k]], t11 = unorm[p11[k]];
+    c[k] = lerpf(lerpf(t00, t10, X.a), lerpf(t01, t11, X.a), Y.a);
+  }
+  return make_float3(c[0], c[1], c[2]);
+}
+
 // pre_depth.fs:51-72 sample(): optional u8 un-compress
 __device__ __forceinline__ float pd_uncompress(float d, bool compress, float scale, float scaled_near, float near_)
 {
@@ -396,7 +437,8 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   } else {
     cc = tex3d_uv(p.cv_uv[l], p.uv_res[l][0], p.uv_res[l][1], p.uv_res[l][2], u, v, depth_norm);
   }
-  const float3 rgb = color_bilinear(p.color + (size_t)l * p.Wc * p.Hc * 3, p.Wc, p.Hc, cc.x, cc.y, unorm);
+  const float3 rgb = p.color_dxt ? color_bilinear_dxt(p.color_dxt + (size_t)l * p.color_layer_bytes, p.Wc, p.Hc, p.color_mode, cc.x, cc.y, unorm)
+                                 : color_bilinear(p.color + (size_t)l * p.Wc * p.Hc * 3, p.Wc, p.Hc, cc.x, cc.y, unorm);
   const float3 lab = rgb_to_lab(rgb);
   p.lab[o * 3 + 0] = lab.x;
   p.lab[o * 3 + 1] = lab.y;

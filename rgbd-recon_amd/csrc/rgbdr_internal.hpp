@@ -59,6 +59,10 @@ struct PreParams {
   // images, all [N][H][W][channels]
   const float* depth_in;   // what the "raw_depth" unit holds for the filter pass
   const uint8_t* color;    // [N][Hc][Wc][3]
+  // the same frame still in DXT1 / DXT5 blocks (null: `color` is current): pre_depth decodes its four taps itself
+  const uint8_t* color_dxt;
+  size_t color_layer_bytes;
+  int color_mode;
   float* depth_morph;
   float* depth_rg;
   float* lab;
