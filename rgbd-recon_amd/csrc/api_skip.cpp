@@ -1,5 +1,5 @@
 // api_skip.cpp -- RGBDR_FLAG_SKIP_BACKGROUND: the per-frame tables behind the verdicts of the full sweep
-// (kernels_integrate.hip: integrate_group, k_window_background, k_skip_mask) and their diagnostics.
+// (kernels_skip.hip, integrate_fold.cuh: integrate_group) and their diagnostics.
 #include <cstring>
 
 #include "context.hpp"

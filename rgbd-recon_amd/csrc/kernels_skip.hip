@@ -1,0 +1,232 @@
+// kernels_skip.hip -- RGBDR_FLAG_SKIP_BACKGROUND: the full sweep with verdicts instead of LUT planes (integrate_fold.cuh:
+// integrate_group<..., SKIP>).  Per frame: k_window_background (what the squares of 4 / 8 / 16 texels at
+// every window origin have in common), k_skip_classify (verdicts per tile; constant tiles filled, the others listed),
+// k_integrate_tiled_listed (one block per listed tile); k_skip_mask / k_count_bytes are the diagnostics.
+#include <hip/hip_runtime.h>
+
+#include "integrate_fold.cuh"
+
+namespace rgbdr {
+
+// RGBDR_FLAG_SKIP_BACKGROUND, once per frame: for every origin (ox, oy) in [-1, W-1] x [-1, H-1] and the squares of
+// 4, 8 and 16 (edge-clamped) texels from there, what the texels have in common, as three bounds
+// ([sensor][size class][3][(H+1)][(W+1)], index (oy + 1) * (W + 1) + (ox + 1)):
+//   bound 0: all background (silhouette 0, depth not NaN) -> their largest depth, else +inf
+//   bound 1, 2: all surface (silhouette 1, depth not NaN) -> their smallest / largest depth, else -inf / +inf
+// Squares of 8 and 16 are folded from two of the next smaller size, along x and then along y.
+__global__ __launch_bounds__(256) void k_window_background(const uint2* __restrict__ frames, int W, int H,
+                                                           float* __restrict__ bgmax)
+{
+  constexpr int T = 16 + kWin - 1;  // 31 texels per axis feed 16 origins
+  __shared__ float tex[3][T][T + 1];  // rows, then reduced along x in place
+  const int l = blockIdx.z;
+  const uint2* frame = frames + (size_t)l * W * H;
+  const int ox0 = (int)blockIdx.x * 16 - 1, oy0 = (int)blockIdx.y * 16 - 1;
+  const int t = threadIdx.y * 16 + threadIdx.x;
+  const float inf = __builtin_inff();
+  for (int i = t; i < T * T; i += 256) {
+    const int ty = i / T, tx = i - ty * T;
+    const uint2 v = frame[(size_t)clampi(oy0 + ty, 0, H - 1) * W + clampi(ox0 + tx, 0, W - 1)];
+    const float d = texel_depth(v);
+    const bool num = d == d, bg = (v.y >> 31) != 0;
+    tex[0][ty][tx] = (bg && num) ? d : inf;    // max-reduced
+    tex[1][ty][tx] = (!bg && num) ? d : -inf;  // min-reduced
+    tex[2][ty][tx] = (!bg && num) ? d : inf;   // max-reduced
+  }
+  __syncthreads();
+  const int ox = ox0 + (int)threadIdx.x, oy = oy0 + (int)threadIdx.y;
+  const bool live = ox <= W - 1 && oy <= H - 1;
+  const size_t plane = (size_t)(W + 1) * (H + 1), o = (size_t)(oy + 1) * (W + 1) + (ox + 1);
+  // squares by doubling, each level staged in LDS: rows of 4 -> squares of 4 (c4, in place of tex) -> squares of 8
+  // (c8, in place of r4) -> squares of 16 from four c8
+  __shared__ float r4[3][T][T + 1];
+  auto red = [](int b, float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
+  for (int i = t; i < T * (T - 3); i += 256) {
+    const int ty = i / (T - 3), tx = i - ty * (T - 3);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 1]), red(b, tex[b][ty][tx + 2], tex[b][ty][tx + 3]));
+  }
+  __syncthreads();
+  for (int i = t; i < (T - 3) * (T - 3); i += 256) {  // c4[y][x], x, y in [0, 27]
+    const int ty = i / (T - 3), tx = i - ty * (T - 3);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      tex[b][ty][tx] = red(b, red(b, r4[b][ty][tx], r4[b][ty + 1][tx]), red(b, r4[b][ty + 2][tx], r4[b][ty + 3][tx]));
+  }
+  __syncthreads();
+  for (int i = t; i < (T - 7) * (T - 7); i += 256) {  // c8[y][x], x, y in [0, 23]
+    const int ty = i / (T - 7), tx = i - ty * (T - 7);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 4]), red(b, tex[b][ty + 4][tx], tex[b][ty + 4][tx + 4]));
+  }
+  __syncthreads();
+  if (!live) return;
+  const int x = threadIdx.x, y = threadIdx.y;
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const float q16 = red(b, red(b, r4[b][y][x], r4[b][y][x + 8]), red(b, r4[b][y + 8][x], r4[b][y + 8][x + 8]));
+    bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = tex[b][y][x];
+    bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = r4[b][y][x];
+    bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
+  }
+}
+void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_window_background, dim3((unsigned)((W + 1 + 15) / 16), (unsigned)((H + 1 + 15) / 16), (unsigned)N),
+                     dim3(16, 16), 0, s, frames, W, H, bgmax);
+}
+
+// The verdict of one (tile, sensor) pair for the current frame (kSkip*)
+__device__ __forceinline__ unsigned skip_verdict(const IntegrateParams& p, size_t i, int s)
+{
+  const int d = p.win[i];
+  const int wx0 = (int)(short)(d & 0xffff), wy0 = (int)(short)(d >> 16);
+  const size_t plane = (size_t)(p.W + 1) * (p.H + 1), o = (size_t)(wy0 + 1) * (p.W + 1) + (wx0 + 1);
+  const float* b = p.bgmax + ((size_t)s * 3 + (size_t)p.win_ext[i]) * 3 * plane + o;
+  const float dmin = p.win_dmin[i], dmax = p.win_dmax[i];
+  // every comparison is false for the "does not apply" values (dmin = -inf, dmax = +inf, bounds of a mixed window)
+  if ((dmin - b[0]) >= p.limit) return kSkipCarve;
+  if ((dmax - b[plane]) <= -p.limit) return kSkipFront;
+  if ((dmin - b[2 * plane]) >= p.limit) return kSkipBehind;
+  return kSkipNone;
+}
+
+// one byte per pair (the diagnostics of rgbdr_skipped_pairs / rgbdr_readback_skip_tables)
+__global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restrict__ mask)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < npairs) mask[i] = (uint8_t)skip_verdict(p, i, (int)(i % (unsigned)p.N));
+}
+
+// First half of the RGBDR_FLAG_SKIP_BACKGROUND sweep (the role k_brick_clear has for bricks): one lane per tile
+// takes the verdicts of its N sensors.  If every sensor has one, the tile's 512 voxels all end as the same value --
+// over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that; hidden from
+// every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
+// this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
+// Otherwise tile | verdicts << 32 goes on the list of k_integrate_tiled_listed.
+constexpr int kClassifyTiles = 256;
+__global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsigned ntiles)
+{
+  __shared__ unsigned todo[kClassifyTiles];  // tile | (value is +limit) << 31
+  __shared__ unsigned ntodo;
+  if (threadIdx.x == 0) ntodo = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.skip_count_next = 0u;  // the counter the next sweep appends to
+  __syncthreads();
+  const unsigned tile = blockIdx.x * kClassifyTiles + threadIdx.x;
+  bool listed = false, fill = false, positive = false;
+  unsigned actions = 0u;
+  if (tile < ntiles) {
+    bool all = true, negative = false;
+    for (int s = 0; s < p.N; ++s) {
+      const unsigned a = skip_verdict(p, (size_t)tile * p.N + s, s);
+      actions |= a << (2 * s);
+      all = all && a != kSkipNone;
+      negative = negative || a == kSkipCarve || a == kSkipFront;
+    }
+    listed = !all;
+    if (all) {
+      positive = !negative;
+      fill = !(negative && p.tile_state[tile] == p.epoch);
+      p.tile_state[tile] = negative ? p.epoch : 0u;
+    } else {
+      p.tile_state[tile] = 0u;  // about to hold integrated values
+    }
+  }
+  {
+    const unsigned long long m = __ballot(listed);
+    const int lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (m) {
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.skip_count, (unsigned)__popcll(m));
+      base = __shfl(base, __ffsll((long long)m) - 1);
+      if (listed) p.skip_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned long long)tile | ((unsigned long long)actions << 32);
+    }
+  }
+  if (fill) todo[atomicAdd(&ntodo, 1u)] = tile | (positive ? 0x80000000u : 0u);
+  __syncthreads();
+  const unsigned n = ntodo;
+  if (n == 0) return;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f* out = reinterpret_cast<v4f*>(p.tsdf);
+  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += 256) {
+    const unsigned e = todo[i / (kTileVoxels / 4)];
+    const float l = (e >> 31) ? p.limit : -p.limit;
+    const v4f fillv = {l, l, l, l};
+    __builtin_nontemporal_store(fillv, out + (size_t)(e & 0x7fffffffu) * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
+  }
+}
+
+// Second half: one block per listed tile (the host sizes the grid from the previous frame's list length; blocks
+// stride over the list, so any grid is correct).  Verdicts come with the list entry: no load in front of the
+// LUT loads but the entry itself.
+template <int N>
+__global__ __launch_bounds__(128, N <= 7 ? 5 : 4) void k_integrate_tiled_listed(IntegrateParams p)
+{
+  constexpr int G1 = N <= 4 ? N : (N + 1) / 2;
+  constexpr int G2 = N - G1;
+  __shared__ uint2 win[G1][kWin * kWinPitch];
+  const unsigned n = *ro(p.skip_count);
+  const int q = threadIdx.x;
+  const float limit = p.limit;
+  for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+    const unsigned long long e = ro(p.skip_list)[i];
+    const unsigned tile = (unsigned)e, actions = (unsigned)(e >> 32);
+    float tsd[4] = {limit, limit, limit, limit};
+    float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    integrate_group<G1, true, true>(p, tile, q, 0, N, win, i != blockIdx.x, limit, tsd, wsum, actions);
+    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), true, true>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f r = {tsd[0], tsd[1], tsd[2], tsd[3]};
+    __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(p.tsdf + (size_t)tile * kTileVoxels) + q);
+  }
+}
+
+void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_skip_mask, dim3((npairs + 255) / 256), dim3(256), 0, s, p, npairs, mask);
+}
+template <int N>
+static void launch_listed_n(const IntegrateParams& p, unsigned blocks, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_integrate_tiled_listed<N>), dim3(blocks), dim3(128), 0, s, p);
+}
+// the background-skip sweep: classifier + one block per listed tile (`blocks`: the host's estimate of the list length)
+void launch_skip_sweep(const IntegrateParams& p, unsigned blocks, hipStream_t s)
+{
+  const unsigned ntiles = (unsigned)p.TX * p.TY * p.ntz;
+  hipLaunchKernelGGL(k_skip_classify, dim3((ntiles + kClassifyTiles - 1) / kClassifyTiles), dim3(256), 0, s, p, ntiles);
+  switch (p.N) {
+    case 1: launch_listed_n<1>(p, blocks, s); break;
+    case 2: launch_listed_n<2>(p, blocks, s); break;
+    case 3: launch_listed_n<3>(p, blocks, s); break;
+    case 4: launch_listed_n<4>(p, blocks, s); break;
+    case 5: launch_listed_n<5>(p, blocks, s); break;
+    case 6: launch_listed_n<6>(p, blocks, s); break;
+    case 7: launch_listed_n<7>(p, blocks, s); break;
+    default: launch_listed_n<8>(p, blocks, s); break;
+  }
+}
+// number of non-zero mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
+__global__ __launch_bounds__(1024) void k_count_bytes(const uint8_t* __restrict__ mask, unsigned n, unsigned* __restrict__ count)
+{
+  __shared__ unsigned part[16];
+  unsigned c = 0;
+  for (unsigned i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) c += mask[i] != 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += part[w];
+    atomicAdd(count, t);
+  }
+}
+void launch_count_bytes(const uint8_t* mask, unsigned n, unsigned* count, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_count_bytes, dim3(64), dim3(1024), 0, s, mask, n, count);
+}
+
+}  // namespace rgbdr

@@ -203,7 +203,7 @@ void make_fill_layout(int W, int H, FillLayout* L);  // geometry.cpp
 void launch_fill_colors(const FillLayout& L, const float4* frame_col, const float* frame_dep, float4* ncol, float* ndep,
                         float4* scol, float* sdep, float4* out_col, float* out_dep, hipStream_t s);
 
-// ---- launchers (kernels_pre.hip / kernels_integrate.hip) ----------------------
+// ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 bool launch_copy_frames(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
@@ -223,6 +223,7 @@ void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_v
                             uint32_t* count, hipStream_t s);
 void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);
 void launch_integrate(const IntegrateParams& p, bool one_to_one, hipStream_t s);
+void launch_brick_sweep(const IntegrateParams& p, unsigned ntiles, hipStream_t s);  // kernels_bricks.hip
 bool integrate_stages_halo(const IntegrateParams& p, bool one_to_one);
 void launch_detile(const float* tiled, float* linear, int X, int Y, int TX, int TY, int tz0, int vz0, int vz1,
                    hipStream_t s);
