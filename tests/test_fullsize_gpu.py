@@ -84,6 +84,16 @@ def test_four_sensors_single_gpu(pkg, orc, G):
         r = check_rows(orc, ctx, full[z0:z0 + 8], z0, 8)
         touched += int((np.abs(r) < np.float32(0.01)).sum())
     assert touched > 1000                                      # the bands cut through the surface
+    # the same full sweep with verdicts instead of LUT planes / without re-storing constant tiles: the whole volume again
+    for skip, elide in ((True, False), (False, True), (True, True)):
+        ctx.set_skip_background(skip)
+        ctx.set_elide_stores(elide)
+        for _ in range(2):
+            ctx.integrate()
+        got = ctx.readback_tsdf()
+        assert same_bits(got, full), "skip %d elide %d: %d voxels differ" % (skip, elide, count_diff(got, full))
+    decided, pairs = ctx.skipped_pairs()
+    assert pairs == (G // 8) ** 3 * 4 and decided > pairs // 2
     ctx.close()
     # Z slabs of the same grid concatenate to the whole volume
     parts = []
