@@ -43,8 +43,8 @@ int rgbdr::ensure_window_background(rgbdr_ctx* ctx)
     ctx->d_skip_mask = nullptr;
     ctx->d_skip_list = nullptr;
     HIPCHK(hipMalloc((void**)&ctx->d_skip_mask, mask_bytes + sizeof(unsigned)));
-    HIPCHK(hipMalloc((void**)&ctx->d_skip_list, (ntiles + 1) * sizeof(unsigned long long)));  // last entry: the two counters
-    HIPCHK(hipMemsetAsync(ctx->d_skip_list + ntiles, 0, sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMalloc((void**)&ctx->d_skip_list, (ntiles * (2 + N) + 2) * sizeof(unsigned)));  // behind the list: its two counters
+    HIPCHK(hipMemsetAsync(ctx->d_skip_list + ntiles * (2 + N), 0, 2 * sizeof(unsigned), ctx->stream));
     ctx->skip_parity = 0;
     ctx->skip_mask_tiles = ntiles;
     ctx->bgmax_for = -1;
@@ -78,7 +78,7 @@ int rgbdr::skip_sweep(rgbdr_ctx* ctx, IntegrateParams& p)
   { int rc_ = ensure_window_background(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t ntiles = ctx->skip_mask_tiles;
   skip_params(ctx, p);
-  unsigned* counts = reinterpret_cast<unsigned*>(ctx->d_skip_list + ntiles);
+  unsigned* counts = ctx->d_skip_list + ntiles * (2 + (size_t)nsens(ctx));
   p.skip_list = ctx->d_skip_list;
   p.skip_count = counts + ctx->skip_parity;
   p.skip_count_next = counts + (1 - ctx->skip_parity);

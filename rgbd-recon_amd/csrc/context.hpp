@@ -85,7 +85,7 @@ struct rgbdr_ctx {
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin; second plane: smallest projected depth
   uint8_t* d_skip_mask = nullptr;  // ... and per (tile, sensor) pair 1 = skipped; [ntiles * N] bytes + a 4-B counter behind them
   float* d_bgmax = nullptr;  // RGBDR_FLAG_SKIP_BACKGROUND: [N][(H+1)][(W+1)] window bounds of the current frame
-  unsigned long long* d_skip_list = nullptr;     // {tile, verdicts} of the tiles the sweep still has to work on + two counters
+  unsigned* d_skip_list = nullptr;  // {tile, verdicts, origins} of the tiles the sweep still has to work on + two counters
   unsigned* h_skip_count = nullptr; // page-locked: list length of the previous sweep
   int skip_parity = 0;
   bool skip_mask_valid = false;     // d_skip_mask holds the verdict bytes of the current frame

@@ -164,13 +164,14 @@ enum : unsigned { kSkipNone = 0u, kSkipCarve = 1u, kSkipFront = 2u, kSkipBehind 
 template <int CNT, bool NT, bool SKIP>
 __device__ __forceinline__ void integrate_group(const IntegrateParams& p, unsigned tile, int q, int s0, int ntot,
                                                 uint2 (*win)[kWin * kWinPitch], bool windows_in_use, float limit,
-                                                float* tsd, float* wsum, unsigned actions = 0u)
+                                                float* tsd, float* wsum, unsigned actions = 0u,
+                                                const int* origins = nullptr)
 {
   int wx0[CNT], wy0[CNT];
   unsigned act[CNT];
 #pragma unroll
   for (int i = 0; i < CNT; ++i) {
-    const int d = p.win[(size_t)tile * ntot + s0 + i];
+    const int d = origins ? origins[s0 + i] : p.win[(size_t)tile * ntot + s0 + i];  // (the listed sweep brings them along)
     wx0[i] = (int)(short)(d & 0xffff);
     wy0[i] = (int)(short)(d >> 16);
     act[i] = SKIP ? (actions >> (2 * (s0 + i))) & 3u : kSkipNone;

@@ -105,7 +105,7 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
 // over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that; hidden from
 // every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
 // this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
-// Otherwise tile | verdicts << 32 goes on the list of k_integrate_tiled_listed.
+// Otherwise {tile, verdicts, window origins} goes on the list of k_integrate_tiled_listed.
 constexpr int kClassifyTiles = 256;
 __global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsigned ntiles)
 {
@@ -141,7 +141,12 @@ __global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsign
     if (m) {
       if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.skip_count, (unsigned)__popcll(m));
       base = __shfl(base, __ffsll((long long)m) - 1);
-      if (listed) p.skip_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned long long)tile | ((unsigned long long)actions << 32);
+      if (listed) {  // entry: tile, verdicts, the N window origins (so that the sweep's window loads wait for one load, not two)
+        unsigned* e = p.skip_list + (size_t)(base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + p.N);
+        e[0] = tile;
+        e[1] = actions;
+        for (int s = 0; s < p.N; ++s) e[2 + s] = (unsigned)p.win[(size_t)tile * p.N + s];
+      }
     }
   }
   if (fill) todo[atomicAdd(&ntodo, 1u)] = tile | (positive ? 0x80000000u : 0u);
@@ -171,12 +176,15 @@ __global__ __launch_bounds__(128, N <= 7 ? 5 : 4) void k_integrate_tiled_listed(
   const int q = threadIdx.x;
   const float limit = p.limit;
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
-    const unsigned long long e = ro(p.skip_list)[i];
-    const unsigned tile = (unsigned)e, actions = (unsigned)(e >> 32);
+    const auto e = ro(p.skip_list) + (size_t)i * (2 + N);
+    const unsigned tile = e[0], actions = e[1];
+    int origins[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) origins[s] = (int)e[2 + s];
     float tsd[4] = {limit, limit, limit, limit};
     float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    integrate_group<G1, true, true>(p, tile, q, 0, N, win, i != blockIdx.x, limit, tsd, wsum, actions);
-    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), true, true>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions);
+    integrate_group<G1, true, true>(p, tile, q, 0, N, win, i != blockIdx.x, limit, tsd, wsum, actions, origins);
+    if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), true, true>(p, tile, q, G1, N, win, true, limit, tsd, wsum, actions, origins);
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f r = {tsd[0], tsd[1], tsd[2], tsd[3]};
     __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(p.tsdf + (size_t)tile * kTileVoxels) + q);

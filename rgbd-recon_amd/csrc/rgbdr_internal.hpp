@@ -94,7 +94,7 @@ struct IntegrateParams {
   const float* win_dmax;
   const int32_t* win_ext;   // 0 / 1 / 2: the footprints fit the square of 4 / 8 / 16 texels at the window origin
   const float* bgmax;
-  unsigned long long* skip_list;  // tile | verdicts (2 bits per sensor) << 32 of the tiles with an undecided sensor (k_skip_classify)
+  unsigned* skip_list;       // per tile with an undecided sensor: tile, verdicts (2 bits per sensor), N window origins (k_skip_classify)
   unsigned* skip_count;      // its length (double-buffered like tile_count)
   unsigned* skip_count_next;
   int skip_background;
