@@ -34,7 +34,8 @@ int rgbdr::ensure_window_background(rgbdr_ctx* ctx)
   const size_t mask_bytes = (ntiles * N + 3) & ~(size_t)3;
   if (!ctx->d_bgmax) HIPCHK(hipMalloc((void**)&ctx->d_bgmax, n * sizeof(float)));
   if (!ctx->h_skip_count) {
-    HIPCHK(hipHostMalloc((void**)&ctx->h_skip_count, sizeof(unsigned), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_skip_count, sizeof(unsigned), hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void**)&ctx->d_skip_count_host, ctx->h_skip_count, 0));
     *ctx->h_skip_count = 0xffffffffu;  // no estimate yet
   }
   if (ctx->skip_mask_tiles != ntiles) {
@@ -83,7 +84,7 @@ int rgbdr::skip_sweep(rgbdr_ctx* ctx, IntegrateParams& p)
   p.skip_count = counts + ctx->skip_parity;
   p.skip_count_next = counts + (1 - ctx->skip_parity);
   ctx->skip_parity ^= 1;
-  // grid: the list length of the previous sweep (copied to page-locked memory after it; whatever it holds right
+  // grid: the list length of the previous sweep (written to page-locked memory by that sweep; whatever it holds right
   // now is an estimate -- the blocks stride over the list) plus a margin, at least a machine-full of blocks
   const unsigned est = *(volatile unsigned*)ctx->h_skip_count;
   unsigned blocks = (unsigned)ntiles;
@@ -92,9 +93,9 @@ int rgbdr::skip_sweep(rgbdr_ctx* ctx, IntegrateParams& p)
     blocks = (unsigned)(want < 2560 ? 2560 : want);
     if (blocks > ntiles) blocks = (unsigned)ntiles;
   }
+  p.skip_count_host = ctx->d_skip_count_host;  // written by the sweep itself: no copy on the stream
   launch_skip_sweep(p, blocks, ctx->stream);
   LAUNCHCHK("skip_sweep");
-  HIPCHK(hipMemcpyAsync(ctx->h_skip_count, p.skip_count, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   return RGBDR_OK;
 }
 

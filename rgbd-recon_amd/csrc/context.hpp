@@ -86,7 +86,8 @@ struct rgbdr_ctx {
   uint8_t* d_skip_mask = nullptr;  // ... and per (tile, sensor) pair 1 = skipped; [ntiles * N] bytes + a 4-B counter behind them
   float* d_bgmax = nullptr;  // RGBDR_FLAG_SKIP_BACKGROUND: [N][(H+1)][(W+1)] window bounds of the current frame
   unsigned* d_skip_list = nullptr;  // {tile, verdicts, origins} of the tiles the sweep still has to work on + two counters
-  unsigned* h_skip_count = nullptr; // page-locked: list length of the previous sweep
+  unsigned* h_skip_count = nullptr; // page-locked, mapped: list length of the previous sweep
+  unsigned* d_skip_count_host = nullptr;  // its device address
   int skip_parity = 0;
   bool skip_mask_valid = false;     // d_skip_mask holds the verdict bytes of the current frame
   size_t skip_mask_tiles = 0;

@@ -175,6 +175,10 @@ __global__ __launch_bounds__(128, N <= 7 ? 5 : 4) void k_integrate_tiled_listed(
   const unsigned n = *ro(p.skip_count);
   const int q = threadIdx.x;
   const float limit = p.limit;
+  if (blockIdx.x == 0 && q == 0 && p.skip_count_host) {  // the host sizes the next sweep's grid from this (page-locked word)
+    *p.skip_count_host = n;
+    __threadfence_system();
+  }
   for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
     const auto e = ro(p.skip_list) + (size_t)i * (2 + N);
     const unsigned tile = e[0], actions = e[1];

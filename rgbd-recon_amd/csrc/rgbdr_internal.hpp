@@ -97,6 +97,7 @@ struct IntegrateParams {
   unsigned* skip_list;       // per tile with an undecided sensor: tile, verdicts (2 bits per sensor), N window origins (k_skip_classify)
   unsigned* skip_count;      // its length (double-buffered like tile_count)
   unsigned* skip_count_next;
+  volatile unsigned* skip_count_host;  // device address of a page-locked word: the list length, for the host's next grid size
   int skip_background;
   // generic mode: linear RGBA volumes, z range [zoff, zoff+nz) resident
   const float4* lut[kMaxSensors];
