@@ -673,6 +673,18 @@ def test_dxt_compressed_colour_frames(pkg, orc, mode):
     ref = oracle_run(orc, s2, ctx, inv)
     check_images(ctx, ref, 2)
     assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    # the pre_* chain read the colour above from the RGB8 frame (readback_color had it decoded); a fresh upload is
+    # read straight from its DXT blocks, and a consumer of the RGB8 image gets it decoded then
+    ctx.step(scene.depth, blocks)
+    check_images(ctx, ref, 2)
+    assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    view = ctx.device_image(8, 1)
+    assert view.width == W and view.height == H and view.channels == 3
+    assert np.array_equal(ctx.readback_color(1), decoded[1])
+    ctx.process_textures()
+    ctx.clear_occupied_bricks()
+    ctx.step(scene.depth, blocks)
+    check_images(ctx, ref, 2)
     ctx.close()
 
 
