@@ -376,9 +376,13 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
+  ctx->morph_current = false;
   if (kind == hipMemcpyDeviceToDevice && !ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
-      launch_copy_frames(depth, ctx->d_depth_raw, n * 4, color, ctx->d_color, ncol, ps)) {
-    LAUNCHCHK("copy_frames");
+      launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw, ctx->d_depth_morph, color,
+                          ctx->d_color, ncol, ps)) {
+    LAUNCHCHK("upload_morph");
+    ctx->morph_current = true;
+    ctx->color_decoded = true;
     ctx->frame_uploaded = true;
     return RGBDR_OK;
   }
@@ -396,8 +400,10 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
     if (!dev) HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
     launch_u8_to_unit(dev ? (const uint8_t*)depth : ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
     LAUNCHCHK("u8_to_unit");
-  } else if (dev && launch_copy_frames(depth, ctx->d_depth_raw, n * 4, csrc, cdst, cbytes, ps)) {
+  } else if (dev && launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw,
+                                        ctx->d_depth_morph, csrc, cdst, cbytes, ps)) {
     color_done = true;
+    ctx->morph_current = true;
   } else {
     HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ps));
   }
@@ -569,13 +575,18 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   p.frame = ctx->frame_buf(w);
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
   tbegin(ctx, "1preprocess", ps);
+  // whichever kernel comes first performs a pending clearOccupiedBricks; the morph image of a frame that was
+  // uploaded from device memory was written with the upload
+  uint32_t* zero = ctx->clear_pending ? ctx->counters_cur() : nullptr;
   tbegin(ctx, "morph", ps);
-  launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, ctx->clear_pending ? ctx->counters_cur() : nullptr,
-               (unsigned)ctx->geo.num_bricks, ps);
-  ctx->clear_pending = false;
+  if (!ctx->morph_current) {
+    launch_morph(p, ctx->d_depth_raw, ctx->d_depth_morph, zero, (unsigned)ctx->geo.num_bricks, ps);
+    zero = nullptr;
+  }
   tend(ctx, "morph", ps);
   tbegin(ctx, "bilateral", ps);
-  launch_pre_depth(p, ps);
+  launch_pre_depth(p, zero, (unsigned)ctx->geo.num_bricks, ps);
+  ctx->clear_pending = false;
   tend(ctx, "bilateral", ps);
   tbegin(ctx, "boundary", ps);
   launch_boundary(p, ps);

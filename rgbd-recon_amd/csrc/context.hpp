@@ -133,6 +133,7 @@ struct rgbdr_ctx {
   int halo_last = -1;
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
+  bool morph_current = false;       // d_depth_morph was written with the upload (k_upload_morph): the chain skips k_morph
   bool color_decoded = true;        // d_color holds the uploaded frame (false: only d_color_dxt does)
   bool mask_valid = false;
   // rgbdr_update_occupied_bricks only noted the threshold: mask_buf(rbuf) is to be rebuilt from the counters by

@@ -62,33 +62,6 @@ void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s)
   hipLaunchKernelGGL(k_u8_to_unit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
 }
 
-// NetKinectArray::update for frames already on the device: the depth and the colour set in one
-// launch (two blit launches cost ~10 us of stream time, more than moving the 6 MB)
-__global__ __launch_bounds__(256) void k_copy_frames(const uint4* __restrict__ a_src, uint4* __restrict__ a_dst, size_t a_n16,
-                                                     const uint4* __restrict__ b_src, uint4* __restrict__ b_dst, size_t b_n16,
-                                                     const uint8_t* a_tail_src, uint8_t* a_tail_dst, int a_tail,
-                                                     const uint8_t* b_tail_src, uint8_t* b_tail_dst, int b_tail)
-{
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < a_n16) a_dst[i] = a_src[i];
-  else if (i < a_n16 + b_n16) b_dst[i - a_n16] = b_src[i - a_n16];
-  if (i < (size_t)a_tail) a_tail_dst[i] = a_tail_src[i];
-  if (i < (size_t)b_tail) b_tail_dst[i] = b_tail_src[i];
-}
-bool launch_copy_frames(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
-                        hipStream_t s)
-{
-  // 16-byte vectors need aligned pointers; otherwise the caller falls back to two memcpys
-  if ((((uintptr_t)a_src | (uintptr_t)a_dst | (uintptr_t)b_src | (uintptr_t)b_dst) & 15u) != 0) return false;
-  const size_t a16 = a_bytes / 16, b16 = b_bytes / 16;
-  const size_t n = a16 + b16 > 16 ? a16 + b16 : 16;
-  hipLaunchKernelGGL(k_copy_frames, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint4*)a_src, (uint4*)a_dst, a16,
-                     (const uint4*)b_src, (uint4*)b_dst, b16, (const uint8_t*)a_src + a16 * 16, (uint8_t*)a_dst + a16 * 16,
-                     (int)(a_bytes - a16 * 16), (const uint8_t*)b_src + b16 * 16, (uint8_t*)b_dst + b16 * 16,
-                     (int)(b_bytes - b16 * 16));
-  return true;
-}
-
 __global__ void k_repack_xyz(const float* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,64 +174,98 @@ void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, siz
 // m_textures_depth2.front holds after processDepth().
 __device__ __forceinline__ bool morph_valid(float d) { return d > 0.5f && d < 4.5f; }
 
+// pre_morph.fs mode 0 for one pixel of one layer
+__device__ __forceinline__ float morph_pixel(const float* __restrict__ in, int W, int H, int px, int py)
+{
+  const float depth = in[(size_t)py * W + px];
+  if (morph_valid(depth)) return depth;
+  float nb[9];
+#pragma unroll
+  for (int y = -1; y < 2; ++y)
+#pragma unroll
+    for (int x = -1; x < 2; ++x)
+      nb[(y + 1) * 3 + (x + 1)] = in[(size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)];
+  float average = 0.0f, num = 0.0f;
+  bool valid = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    if (morph_valid(nb[k])) {
+      valid = true;
+      average += nb[k];
+      num += 1.0f;
+    }
+  if (!valid) return 0.0f;
+  average /= num;
+  float nd = 0.0f;
+  num = 0.0f;
+  valid = false;
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+    if (morph_valid(nb[k]) && fabsf(average - nb[k]) < 0.2f) {
+      valid = true;
+      nd += nb[k];
+      num += 1.0f;
+    }
+  return valid ? nd / num : 0.0f;
+}
+
+// clearOccupiedBricks rides along in the first kernel of the chain (a separate fill launch costs more stream
+// time than zeroing the 1 MiB): the counters are next touched by k_normal, launches later
+__device__ __forceinline__ void zero_words(uint32_t* __restrict__ zero, unsigned nzero)
+{
+  if (!zero) return;
+  const unsigned nthreads = gridDim.x * gridDim.y * gridDim.z * (BX * BY);
+  const unsigned tid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
+  for (unsigned i = tid; i < nzero; i += nthreads) zero[i] = 0u;
+}
+
 __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_all, float* __restrict__ out_all, int W,
                                                   int H, int N, uint32_t* __restrict__ zero, unsigned nzero)
 {
-  // clearOccupiedBricks rides along (a separate fill launch costs more stream time than
-  // zeroing the 1 MiB): the counters are next touched by k_normal, three launches later
-  if (zero) {
-    const unsigned nthreads = gridDim.x * gridDim.y * gridDim.z * (BX * BY);
-    const unsigned tid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
-    for (unsigned i = tid; i < nzero; i += nthreads) zero[i] = 0u;
-  }
+  zero_words(zero, nzero);
   const BlockPos bp = block_pos(N);
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
-  const float* in = in_all + (size_t)bp.l * W * H;
-  float* out = out_all + (size_t)bp.l * W * H;
-  const float depth = in[(size_t)py * W + px];
-  float res;
-  if (morph_valid(depth)) {
-    res = depth;
-  } else {
-    float nb[9];
-#pragma unroll
-    for (int y = -1; y < 2; ++y)
-#pragma unroll
-      for (int x = -1; x < 2; ++x)
-        nb[(y + 1) * 3 + (x + 1)] = in[(size_t)clampi(py + y, 0, H - 1) * W + clampi(px + x, 0, W - 1)];
-    float average = 0.0f, num = 0.0f;
-    bool valid = false;
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-      if (morph_valid(nb[k])) {
-        valid = true;
-        average += nb[k];
-        num += 1.0f;
-      }
-    if (!valid) {
-      res = 0.0f;
-    } else {
-      average /= num;
-      float nd = 0.0f;
-      num = 0.0f;
-      valid = false;
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (morph_valid(nb[k]) && fabsf(average - nb[k]) < 0.2f) {
-          valid = true;
-          nd += nb[k];
-          num += 1.0f;
-        }
-      res = valid ? nd / num : 0.0f;
-    }
-  }
-  out[(size_t)py * W + px] = res;
+  const size_t lo = (size_t)bp.l * W * H;
+  out_all[lo + (size_t)py * W + px] = morph_pixel(in_all + lo, W, H, px, py);
+}
+
+// A frame that is already on the device: the copy into the context's buffers and the morph pass in one launch (the
+// 3x3 neighbourhood is read from the caller's buffer); `b_*`: the colour frame / DXT blocks, copied by the same lanes.
+__global__ __launch_bounds__(BX* BY) void k_upload_morph(const float* __restrict__ src, float* __restrict__ raw,
+                                                         float* __restrict__ morph, int W, int H, int N,
+                                                         const uint4* __restrict__ b_src, uint4* __restrict__ b_dst, size_t b_n16,
+                                                         const uint8_t* b_tail_src, uint8_t* b_tail_dst, int b_tail)
+{
+  const size_t nthreads = (size_t)gridDim.x * gridDim.y * (BX * BY);
+  const size_t tid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
+  for (size_t i = tid; i < b_n16; i += nthreads) b_dst[i] = b_src[i];
+  if (tid < (size_t)b_tail) b_tail_dst[tid] = b_tail_src[tid];
+  const BlockPos bp = block_pos(N);
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  if (px >= W || py >= H) return;
+  const size_t lo = (size_t)bp.l * W * H, o = lo + (size_t)py * W + px;
+  raw[o] = src[o];
+  morph[o] = morph_pixel(src + lo, W, H, px, py);
 }
 
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s)
 {
   hipLaunchKernelGGL(k_morph, pass_grid(p), dim3(BX, BY), 0, s, in, out, p.W, p.H, p.N, zero, nzero);
+}
+bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
+                         size_t b_bytes, hipStream_t s)
+{
+  if ((((uintptr_t)depth_src & 3u) | (((uintptr_t)b_src | (uintptr_t)b_dst) & 15u)) != 0) return false;
+  PreParams p{};
+  p.W = W;
+  p.H = H;
+  p.N = N;
+  const size_t b16 = b_bytes / 16;
+  hipLaunchKernelGGL(k_upload_morph, pass_grid(p), dim3(BX, BY), 0, s, (const float*)depth_src, raw, morph, W, H, N,
+                     (const uint4*)b_src, (uint4*)b_dst, b16, (const uint8_t*)b_src + b16 * 16, (uint8_t*)b_dst + b16 * 16,
+                     (int)(b_bytes - b16 * 16));
+  return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -373,8 +380,9 @@ void launch_pre_cache(const PreParams& p, int sensor, hipStream_t s)
   hipLaunchKernelGGL(k_pre_cache, grid, dim3(BX, BY), 0, s, p, sensor);
 }
 
-__global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
+__global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p, uint32_t* __restrict__ zero, unsigned nzero)
 {
+  zero_words(zero, nzero);  // (when the morph pass did not run in this chain: it was done with the upload)
   __shared__ float tile[TH][TPITCH];
   __shared__ float unorm[256];  // i / 255.0f: what the sampler returns for a u8 colour channel
   const BlockPos bp = block_pos(p.N);
@@ -493,9 +501,9 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p)
   p.depth_rg[o * 2 + 1] = out.y;
 }
 
-void launch_pre_depth(const PreParams& p, hipStream_t s)
+void launch_pre_depth(const PreParams& p, uint32_t* zero, unsigned nzero, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pre_depth, pass_grid(p), dim3(BX, BY), 0, s, p);
+  hipLaunchKernelGGL(k_pre_depth, pass_grid(p), dim3(BX, BY), 0, s, p, zero, nzero);
 }
 
 // ---------------------------------------------------------------------------

@@ -207,15 +207,15 @@ void launch_fill_colors(const FillLayout& L, const float4* frame_col, const floa
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
-bool launch_copy_frames(const void* a_src, void* a_dst, size_t a_bytes, const void* b_src, void* b_dst, size_t b_bytes,
-                        hipStream_t s);
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
 void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, size_t layer_bytes, uint8_t* rgb,
                        hipStream_t s);
 void launch_repack_xyz(const float* src_xyz3, float4* dst, size_t n, hipStream_t s);
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s);
 void launch_pre_cache(const PreParams& p, int sensor, hipStream_t s);
-void launch_pre_depth(const PreParams& p, hipStream_t s);
+void launch_pre_depth(const PreParams& p, uint32_t* zero, unsigned nzero, hipStream_t s);
+bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
+                         size_t b_bytes, hipStream_t s);
 void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
 void launch_quality(const PreParams& p, hipStream_t s);
