@@ -86,48 +86,147 @@ def main():
                          "fastest; the candidates' times are reported in roofline.arena_placement_probe_ms")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="bound the CPU baseline to this many z rows of the volume (0 = the whole volume, about 10 s)")
+    ap.add_argument("--slab", default="",
+                    help="r/k: one GPU, real RCCL: run Z slab r of k of BASELINE configs[3] (k = 2, 4: 8 sensors, 512^3) or "
+                         "configs[4] (k = 8: 8 sensors, 1024^3) exactly as rank r of a --gpus k run would -- the sweep that "
+                         "stages its boundary layers, the exchange on the side stream with this process as its own "
+                         "neighbour(s); value is this slab's share")
+    ap.add_argument("--slab-sweep", type=int, default=0,
+                    help="k: --slab r/k for every r in one process, one JSON line with a row per rank (projection of the "
+                         "multi-GPU balance from single-GPU runs; DESIGN.md section 6)")
+    ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N > 1 self-launch: seconds before the ranks are stopped")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` without a launcher around it (how the driver starts it): this process becomes
+    # the parent of N ranks.  It must not touch the GPU (nor import torch) before or after that.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout=args.launch_timeout))
+    if args.slab_sweep:
+        sys.exit(slab_sweep(args))
+    run_rank(args)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, timeout=3600.0, child_cmd=None, poll_s=0.2):
+    """Parent of a `--gpus n` run that was started as a plain process: one child per rank with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment (what torch.distributed.run would set; the
+    reference's frame loop is one process too, source/kinect_client.cpp:1013-1014).  The parent never touches
+    the GPU, so starting children is not an exec from a GPU process.  Rank 0 inherits stdout and prints the
+    one JSON line; the other ranks' stdout goes to stderr.  Returns 0 when every rank did; otherwise the
+    first failing rank's code after stopping the rest (by their own PIDs), 124 after `timeout`."""
+    import subprocess
+    cmd = list(child_cmd) if child_cmd else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n)})
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + timeout
+    rc = 0
+    live = set(range(n))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write("[bench launcher] rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                break
+        if live and rc == 0:
+            if time.monotonic() > deadline:
+                rc = 124
+                sys.stderr.write("[bench launcher] %d rank(s) still running after %.0f s; stopping them\n" % (len(live), timeout))
+                break
+            time.sleep(poll_s)
+    if rc != 0:
+        for r in live:
+            procs[r].terminate()
+        t_kill = time.monotonic() + 10.0
+        for r in live:
+            try:
+                procs[r].wait(max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return rc
+
+
+def parse_slab(text):
+    """'r/k' -> (r, k)"""
+    try:
+        r, k = (int(t) for t in text.split("/"))
+    except ValueError:
+        raise SystemExit("--slab takes r/k, e.g. 1/4")
+    if k not in (2, 4, 8) or not 0 <= r < k:
+        raise SystemExit("--slab r/k: k is 2 or 4 (configs[3]) or 8 (configs[4]), 0 <= r < k")
+    return r, k
+
+
+def run_rank(args, slab=None, quiet=False, shared=None):
+    """One rank of the benchmark: the whole single-GPU run, rank `RANK` of a --gpus N run, or (slab = (r, k))
+    slab r of k on this GPU with itself as its neighbours.  Returns the JSON object (printed by rank 0 unless quiet)."""
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                             % (args.gpus, args.gpus))
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if slab is None and args.slab:
+        slab = parse_slab(args.slab)
+    if slab is None and args.loopback:
+        slab = (1, 4)                    # --loopback: an inner slab of configs[3]
+    if slab is not None and world != 1:
+        raise SystemExit("--slab / --loopback run on one GPU (they stand in for a --gpus k run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    loop = bool(args.loopback) and world == 1
+    loop = slab is not None              # one GPU stands in for rank r of k: it is its own neighbour(s)
     multi = world > 1 or loop
+    shared = shared if shared is not None else {}
     if loop:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-    if multi:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if multi and not shared.get("pg"):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        shared["pg"] = True
 
-    os.environ.setdefault("RGBDR_ARENA_TRIALS", str(max(1, args.arena_trials)))
+    # several ranks on one GPU (--backend gloo, debugging): no placement shopping, it would hold world x 10 arenas
+    trials = 1 if (args.backend == "gloo" and world > 1) else max(1, args.arena_trials)
+    os.environ["RGBDR_ARENA_TRIALS"] = os.environ.get("RGBDR_ARENA_TRIALS_FORCE", str(trials))
     load_package()
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
 
     W, H = 512, 424
-    N, grid, baseline_config, scaling = choose_workload(world, loop, args.weak, args.sensors, args.grid)
-    if loop:
-        grid = (512, 512, 2048)          # four slabs of 512^3; this process is an inner one
-    slab_rank, slab_count = (1, 4) if loop else (rank, world)
+    slab_rank, slab_count = slab if loop else (rank, world)
+    N, grid, baseline_config, scaling = choose_workload(slab_count, False, args.weak, args.sensors, args.grid)
     G = grid[0]
-    scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
+    if shared.get("scene_n") != N:
+        shared["scene"], shared["scene_n"] = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234), N
+        shared["d_depth"] = torch.from_numpy(shared["scene"].depth).to(dev)
+        shared["d_color"] = torch.from_numpy(shared["scene"].color).to(dev)
+    scene, d_depth, d_color = shared["scene"], shared["d_depth"], shared["d_color"]
     flags = capi.FLAGS_DEFAULT | (capi.FLAG_PIPELINE if args.pipeline else 0)
     cfg = capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags,
                            res_override=grid, slab_rank=slab_rank, slab_count=slab_count)
@@ -136,8 +235,6 @@ def main():
     for i in range(N):
         ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
         ctx.synth_inverse_calibration(i, scene.pinhole(i))
-    d_depth = torch.from_numpy(scene.depth).to(dev)
-    d_color = torch.from_numpy(scene.color).to(dev)
     torch.cuda.synchronize()
 
     halo, transport = None, None
@@ -150,23 +247,23 @@ def main():
         torch.cuda.set_stream(main)
         ctx.set_stream(main.cuda_stream)
         # Probe the device transport once before anything is timed.  If RCCL point-to-point
-        # on these buffers fails on this node, say so in the JSON line and carry the halos
-        # over a gloo group through the host instead of losing the whole scaling run.
+        # on these buffers fails on this node, say so in the JSON line and stop: a run whose halos
+        # go through host memory would measure PCIe, not xGMI.
         transport = {"kind": "rccl" if args.backend == "nccl" else args.backend + " (host-staged)", "group": None}
         if args.backend == "nccl":
-            fallback = dist.new_group(backend="gloo")
+            if "fallback" not in shared:
+                shared["fallback"] = dist.new_group(backend="gloo")
             ok, why = 1, ""
             try:
                 ctx.sync()
-                rdist.exchange_halo(*halo, rank=rank, world=world, loopback=loop)
+                rdist.exchange_halo(*halo, rank=slab_rank, world=slab_count, loopback=loop)
                 torch.cuda.synchronize()
             except Exception as e:  # noqa: BLE001 -- reported, not swallowed
                 ok, why = 0, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200])
             flag = torch.tensor([ok], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=fallback)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=shared["fallback"])
             if int(flag[0]) == 0:
-                # a run whose halos go through host memory would measure PCIe, not xGMI: never time it
-                # (--backend gloo asks for that path explicitly, for debugging several ranks on one GPU)
+                # (--backend gloo asks for the host-staged path explicitly, for debugging several ranks on one GPU)
                 sys.stderr.write("[bench rank %d] RCCL point-to-point failed (%s); refusing to time a host-staged "
                                  "fallback\n" % (rank, why or "on another rank"))
                 if rank == 0:
@@ -196,7 +293,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(bricks, steps, warmup, detail=0):
+    def timed(bricks, steps, warmup, detail=0, sample_box=None):
         ctx.set_use_bricks(bricks)
         for _ in range(warmup):
             step(bricks)
@@ -209,6 +306,8 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step(bricks)
+        if sample_box is not None:       # the queue still holds most of the steps: clocks / power under load
+            sample_box.update(gpu_state())
         barrier()
         dt = time.perf_counter() - t0
         names = ("2integrate",) + (("1preprocess", "bricks") if detail > 0 else ()) + \
@@ -217,8 +316,9 @@ def main():
         ctx.enable_timer_accumulation(False)
         ctx.enable_timers(False)
         ctx.set_timer_detail(2)          # the library's default again (detail 0 mutes every timer but "2integrate")
+        timed.local_dt = dt
         if multi:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, stats
@@ -232,7 +332,8 @@ def main():
         dist.barrier()
 
     # ---- headline: full sweep ------------------------------------------------
-    dt, stats = timed(False, args.steps, args.warmup)
+    box = {}
+    dt, stats = timed(False, args.steps, args.warmup, sample_box=box)
     V_local = g.res_volume[0] * g.res_volume[1] * (g.slab_voxel_z1 - g.slab_voxel_z0)
     V_total = g.res_volume[0] * g.res_volume[1] * g.res_volume[2] if not loop else V_local   # loopback: this slab only
     ms_per_step = dt / args.steps * 1e3
@@ -251,18 +352,48 @@ def main():
     # box moves, whatever its level.
     replay_ms = ctx.settle(0.0)
     box_stream = V_local * (4 + 12 * N) / (replay_ms * 1e-3) if replay_ms > 0 else 0.0
-    box = gpu_state()
+    local_ms_per_step = timed.local_dt / args.steps * 1e3
+    halo_ms = exchanger.last_transfer_ms() if multi else None
+    plain_ms = None
+    if loop:
+        # what the staging costs the sweep: the same slab without a staging set (plain kernel, no exchange)
+        halo_keep, halo = halo, None
+        ctx.set_halo_staging(-1)
+        dt_plain, stats_plain = timed(False, args.steps, args.warmup)
+        halo = halo_keep
+        plain_ms = (stats_plain["2integrate"][0] / max(stats_plain["2integrate"][1], 1) * 1e-6, dt_plain / args.steps * 1e3)
+    # every rank's numbers on rank 0: the N > 1 line carries per-rank arrays and prices the SLOWEST rank's kernel
+    # (rank 0 is an edge slab with one neighbour and one staged face; inner slabs stage two)
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([int_s * 1e3, -1.0 if halo_ms is None else halo_ms, local_ms_per_step, float(bytes_launch),
+                             replay_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        rows = [r.cpu().tolist() for r in rows]
+        slowest = max(range(world), key=lambda r: rows[r][0])
+        per_rank = {"integrate_ms": [round(r[0], 4) for r in rows],
+                    "halo_ms": [None if r[1] < 0 else round(r[1], 4) for r in rows],
+                    "ms_per_step": [round(r[2], 4) for r in rows],
+                    "roofline_frac": [round(r[3] / (r[0] * 1e-3) / HBM_PEAK, 4) if r[0] > 0 else None for r in rows],
+                    "box_stream_replay_ms": [round(r[4], 4) for r in rows],
+                    "slowest_rank": slowest}
+        int_s, bytes_launch, replay_ms = rows[slowest][0] * 1e-3, int(rows[slowest][3]), rows[slowest][4]
+        achieved = bytes_launch / int_s if int_s > 0 else 0.0
+        box_stream = (bytes_launch - N * W * H * 8) / (replay_ms * 1e-3) if replay_ms > 0 else 0.0
 
     # breakdown, not part of the headline timing: the totals from a run with the three total timers,
     # the five passes from a run with every timer (their event records inflate the totals)
-    _, tot_stats = timed(False, 5, 1, detail=1)
-    _, pass_stats = timed(False, 5, 1, detail=2)
-    stats.update({k: v for k, v in tot_stats.items() if k not in stats})
-    stats.update({k: v for k, v in pass_stats.items() if k not in stats})
+    lean = bool(shared.get("lean"))      # --slab-sweep: only the headline of every slab
+    if not lean:
+        _, tot_stats = timed(False, 5, 1, detail=1)
+        _, pass_stats = timed(False, 5, 1, detail=2)
+        stats.update({k: v for k, v in tot_stats.items() if k not in stats})
+        stats.update({k: v for k, v in pass_stats.items() if k not in stats})
 
     # ---- brick-skipping mode (reference default) -------------------------------
-    dtb, stats_b = timed(True, max(args.steps // 2, 1), 2)
     bsteps = max(args.steps // 2, 1)
+    dtb, stats_b = timed(True, bsteps, 2) if not lean else (0.0, {"2integrate": (0, 0)})
     occ = ctx.occupied_ratio()
     bint_ns, bint_n = stats_b["2integrate"]
 
@@ -328,7 +459,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4),
         "frames_per_s": round(args.steps / dt, 2),
         "higher_is_better": True,
-        "scaling": scaling,
+        "scaling": scaling if world > 1 else None,      # one GPU: nothing scales
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -338,33 +469,59 @@ def main():
                    "baseline_config": baseline_config,
                    "grid": list(g.res_volume), "sensors": N, "tsdf_limit": 0.01,
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
-                   "parallelism": ("zslab%d" % world if world > 1 else "single") + (" (loopback: an inner slab of 4)" if loop else ""),
+                   "parallelism": ("zslab%d" % world if world > 1 else "single") + (
+                       " (loopback: slab %d of %d on one GPU, its own neighbour over RCCL)" % (slab_rank, slab_count) if loop else ""),
                    "halo_transport": transport["kind"] if multi else None},
         "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, %s>" % (N, "true" if multi else "false"),
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK, 4), "traffic": None, "traffic_source": None,
                      "bytes_per_launch": bytes_launch, "avg_launch_ms": round(int_s * 1e3, 4),
-                     "launches_timed": int_n,
+                     "launches_timed": int_n, "rank": per_rank["slowest_rank"] if per_rank else (slab_rank if loop else 0),
                      "box_stream_GBps": round(box_stream / 1e9, 1), "box_stream_replay_ms": round(replay_ms, 4),
                      "frac_of_box_stream": round(achieved / box_stream, 4) if box_stream > 0 else None,
                      "box": box,
                      "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1]},
         "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
-        "bricked": {"ms_per_step": round(dtb / bsteps * 1e3, 4),
-                    "value": round(V_total / (dtb / bsteps) / 1e6, 1),
-                    "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
-                    "occupied_ratio": round(occ, 4), "ms_per_step_pipelined": bricked_pipelined},
+        "bricked": None if lean else {"ms_per_step": round(dtb / bsteps * 1e3, 4),
+                                      "value": round(V_total / (dtb / bsteps) / 1e6, 1),
+                                      "integrate_ms": round(bint_ns / max(bint_n, 1) * 1e-6, 4),
+                                      "occupied_ratio": round(occ, 4), "ms_per_step_pipelined": bricked_pipelined},
         "other_schedule": other,
         "full_sweep_store_elision": elided,
         "full_sweep_background_skip": skipbg,
     }
+    # What a default library user gets (RGBDR_ARENA_TRIALS unset = 1: the first hipMalloc result, no probing): the
+    # stream replay of candidate 0, priced like the kernel (which runs at frac_of_box_stream of its replay).
+    probe_ms, kept = ctx.arena_probe()
+    if len(probe_ms) > 1 and probe_ms[0] > 0 and probe_ms[kept] > 0 and world == 1:
+        first_ms = int_s * 1e3 * probe_ms[0] / probe_ms[kept]
+        out["roofline"]["avg_launch_ms_first_placement"] = round(first_ms, 4)
+        out["roofline"]["frac_first_placement"] = round(bytes_launch / (first_ms * 1e-3) / HBM_PEAK, 4)
+        out["roofline"]["placement_note"] = ("bench.py opts into RGBDR_ARENA_TRIALS=%d (library default 1 = off): `frac` is on "
+                                             "the fastest of the probed placements of the LUT arena, frac_first_placement scales "
+                                             "the measured launch time by replay(candidate 0) / replay(kept)" % len(probe_ms))
+    elif world == 1:
+        out["roofline"]["frac_first_placement"] = out["roofline"]["frac"]       # a single placement was looked at
+        out["roofline"]["avg_launch_ms_first_placement"] = out["roofline"]["avg_launch_ms"]
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    if loop:
+        out["slab"] = {"rank": slab_rank, "of": slab_count, "owned_z_rows": int(g.slab_voxel_z1 - g.slab_voxel_z0),
+                       "faces_staged": int(slab_rank > 0) + int(slab_rank < slab_count - 1),
+                       "integrate_ms": round(int_s * 1e3, 4), "integrate_ms_without_staging": round(plain_ms[0], 4),
+                       "staging_overhead_ms": round(int_s * 1e3 - plain_ms[0], 4),
+                       "ms_per_step": round(ms_per_step, 4), "ms_per_step_without_halo": round(plain_ms[1], 4),
+                       "roofline_frac": round(achieved / HBM_PEAK, 4), "halo_ms_to_self": halo_ms}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
             t = json.load(open(traffic_file))
             key = "%dx%d" % (N, G)
-            if key in t and world == 1 and tuple(g.res_volume) == (G, G, G):
+            if key in t and world == 1 and not loop and tuple(g.res_volume) == (G, G, G):
+                # NOT measured in this run: the PMC passes of profiles/collect_pmc.sh on the same kernel and workload
                 out["roofline"]["traffic"] = t[key]["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of %s, not this run)" % t[key].get(
+                    "source", "profiles/collect_pmc.sh")
         except Exception:
             pass
 
@@ -483,10 +640,11 @@ def main():
     if multi:
         torch.cuda.synchronize()
         out["halo"] = {"layers_per_face": int(g.halo_tile_layers), "bytes_per_face": int(halo[0].numel() * 4),
-                       "transfer_ms_rank0": exchanger.last_transfer_ms()}
+                       "transfer_ms_rank0": exchanger.last_transfer_ms(),
+                       "transfer_ms_max": max([h for h in per_rank["halo_ms"] if h is not None], default=None) if per_rank else halo_ms}
     # ---- post-pass across the slabs (BASELINE configs[4]): slab ray-march (find, all-reduce MIN, shade,
     # composite) + tsdf_inpaint / tsdf_colorfill of the composited frame; outside `value` ----
-    if multi:                             # --loopback runs it too (one slab's share of the frame): the same code path
+    if multi and not lean:                # --loopback / --slab run it too (one slab's share of the frame): the same code path
         try:
             ctx.set_use_bricks(False)
             step(False)
@@ -513,11 +671,49 @@ def main():
             ctx.enable_timers(False)
         except Exception as e:  # noqa: BLE001 -- extra keys must never cost the headline line
             out["post_pass"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if rank == 0:
+    if rank == 0 and not quiet:
         print(json.dumps(out))
     ctx.close()
     if multi:
-        dist.destroy_process_group()
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+        if not shared.get("keep_pg"):
+            dist.destroy_process_group()
+            shared["pg"] = False
+    return out
+
+
+def slab_sweep(args):
+    """--slab-sweep k: every slab r of k of BASELINE configs[3] (k = 2, 4) / configs[4] (k = 8) on this one GPU, one
+    after the other in this process, each exactly as rank r of a --gpus k run executes it (sweep with staging,
+    exchange over RCCL to itself on the side stream).  One JSON line: a row per rank, the spread, and the frame rate
+    a k-GPU run would show if nothing but the slowest rank's step bounded it.  A projection from single-GPU runs,
+    not a scaling measurement."""
+    k = args.slab_sweep
+    parse_slab("0/%d" % k)
+    shared = {"lean": True, "keep_pg": True}
+    rows, line = [], None
+    for r in range(k):
+        line = run_rank(args, slab=(r, k), quiet=True, shared=shared)
+        row = dict(line["slab"])
+        row["arena_placement_probe_ms"] = line["roofline"]["arena_placement_probe_ms"]
+        row["frac_of_box_stream"] = line["roofline"]["frac_of_box_stream"]
+        rows.append(row)
+        sys.stderr.write("[slab %d/%d] %s\n" % (r, k, json.dumps(row)))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+    steps = [r["ms_per_step"] for r in rows]
+    ints = [r["integrate_ms"] for r in rows]
+    grid = line["config"]["grid"]
+    V = grid[0] * grid[1] * grid[2]
+    out = {"metric": line["metric"], "unit": "Mvoxels/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "projection": "single-GPU per-rank runs of %s -- no scaling curve was measured" % line["config"]["baseline_config"],
+           "ranks": rows,
+           "integrate_ms_max": max(ints), "integrate_ms_min": min(ints), "integrate_spread": round(max(ints) / min(ints), 4),
+           "ms_per_step_max": max(steps), "ms_per_step_min": min(steps),
+           "projected_value_if_bound_by_slowest_rank": round(V / (max(steps) * 1e-3) / 1e6, 1),
+           "config": line["config"], "dtype": "f32", "data": "synthetic"}
+    print(json.dumps(out))
+    return 0
 
 
 def gpu_state():

@@ -49,8 +49,13 @@ def exchange_halo(send_lo, send_hi, recv_lo, recv_hi, rank=None, world=None, gro
     through the same send/recv pairs."""
     if loopback:
         me = dist.get_rank(group)
-        ops = [dist.P2POp(dist.isend, send_lo, me, group), dist.P2POp(dist.irecv, recv_hi, me, group),
-               dist.P2POp(dist.isend, send_hi, me, group), dist.P2POp(dist.irecv, recv_lo, me, group)]
+        if rank is not None and world is not None and rank == 0:            # stands in for the lowest slab: one face
+            ops = [dist.P2POp(dist.isend, send_hi, me, group), dist.P2POp(dist.irecv, recv_hi, me, group)]
+        elif rank is not None and world is not None and rank == world - 1:  # ... the highest slab
+            ops = [dist.P2POp(dist.isend, send_lo, me, group), dist.P2POp(dist.irecv, recv_lo, me, group)]
+        else:
+            ops = [dist.P2POp(dist.isend, send_lo, me, group), dist.P2POp(dist.irecv, recv_hi, me, group),
+                   dist.P2POp(dist.isend, send_hi, me, group), dist.P2POp(dist.irecv, recv_lo, me, group)]
         for r in dist.batch_isend_irecv(ops):
             r.wait()
         return

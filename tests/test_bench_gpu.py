@@ -22,10 +22,10 @@ def run_bench(*args):
 def test_bench_line_contract():
     j = run_bench("--steps", "6", "--warmup", "2", "--cpu-rows", "64")
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
-                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str)):
+                     ("ms_per_step", float), ("higher_is_better", bool), ("dtype", str), ("data", str)):
         assert isinstance(j[key], typ), key
     assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2 and j["higher_is_better"] is True
-    assert j["vs_baseline"] is None and j["scaling"] == "weak" and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert j["vs_baseline"] is None and j["scaling"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
     assert j["unit"] == "Mvoxels/s" and "workload" in j["config"] and "model" not in j["config"]
     assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
     r = j["roofline"]
@@ -40,6 +40,9 @@ def test_bench_line_contract():
     # box calibration: a replay of the kernel's memory streams on the same box, and the GPU state beside it
     assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
     assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
+    # the placement probe is bench.py's opt-in: the line also carries what the first placement (library default) gives
+    assert 0.5 < r["frac_first_placement"] <= r["frac"] * 1.02 and r["avg_launch_ms_first_placement"] > 0
+    assert r["traffic"] is None or "not this run" in r["traffic_source"]
     assert "4 sensors" in j["metric"] and "512^3" in j["metric"] and j["config"]["baseline_config"].startswith("configs[2]")
     for extra in ("post_pass", "host_fed", "reference_defaults", "bricked", "other_schedule", "full_sweep_store_elision",
                   "full_sweep_background_skip"):
@@ -61,3 +64,32 @@ def test_bench_loopback_runs_the_multi_gpu_path():
     # the slab post-pass of the multi-GPU runs (find, all-reduce MIN, shade, composite, hole filling)
     assert "error" not in j["post_pass"], j["post_pass"]
     assert j["post_pass"]["slab_raymarch_composited_ms"] > 0 and j["post_pass"]["holefill_ms"] > 0
+
+
+def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
+    """`python3 bench.py --gpus 2` exactly as the driver starts it (no torch.distributed.run around it); gloo because
+    the box has one GPU: both ranks share it and the halos travel through the host"""
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1")
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
+    assert j["config"]["baseline_config"].startswith("configs[3]") and "8 sensors" in j["metric"]
+    pr = j["per_rank"]
+    for key in ("integrate_ms", "halo_ms", "ms_per_step", "roofline_frac"):
+        assert len(pr[key]) == 2 and all(v is not None and v > 0 for v in pr[key]), (key, pr[key])
+    slow = pr["slowest_rank"]
+    assert pr["integrate_ms"][slow] == max(pr["integrate_ms"])
+    r = j["roofline"]
+    assert r["rank"] == slow and abs(r["avg_launch_ms"] - pr["integrate_ms"][slow]) < 1e-3
+    assert r["bytes_per_launch"] == 512 * 512 * 256 * (4 + 12 * 8) + 8 * 512 * 424 * 8
+    assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
+    assert j["ms_per_step"] >= max(pr["ms_per_step"]) * 0.999
+    assert "host-staged" in j["config"]["halo_transport"] and j["halo"]["transfer_ms_max"] > 0
+
+
+def test_one_slab_of_config_3_as_its_rank_would_run_it():
+    j = run_bench("--slab", "0/4", "--steps", "6", "--warmup", "2")
+    s = j["slab"]
+    assert (s["rank"], s["of"], s["owned_z_rows"], s["faces_staged"]) == (0, 4, 128, 1)
+    assert s["integrate_ms"] > 0 and s["integrate_ms_without_staging"] > 0 and 0.4 < s["roofline_frac"] < 1.0
+    assert j["config"]["baseline_config"].startswith("configs[3]") and j["config"]["sensors"] == 8
+    assert j["roofline"]["bytes_per_launch"] == 512 * 512 * 128 * (4 + 12 * 8) + 8 * 512 * 424 * 8
+    assert "true>" in j["roofline"]["kernel"] and j["config"]["halo_transport"] == "rccl"
