@@ -101,9 +101,23 @@ def main():
     # the parent of N ranks.  It must not touch the GPU (nor import torch) before or after that.
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout=args.launch_timeout))
+    # stdout carries the one JSON line and nothing else: RCCL's version banner, gloo's connection notes and any
+    # other chatter of the libraries below go to stderr
+    global EMIT
+    sys.stdout.flush()
+    EMIT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.slab_sweep:
         sys.exit(slab_sweep(args))
     run_rank(args)
+
+
+EMIT = sys.stdout
+
+
+def emit(obj):
+    EMIT.write(json.dumps(obj) + "\n")
+    EMIT.flush()
 
 
 def free_port():
@@ -267,8 +281,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                 sys.stderr.write("[bench rank %d] RCCL point-to-point failed (%s); refusing to time a host-staged "
                                  "fallback\n" % (rank, why or "on another rank"))
                 if rank == 0:
-                    print(json.dumps({"error": "RCCL point-to-point halo exchange failed: %s" % (why or "on another rank"),
-                                      "n_gpus": world}))
+                    emit({"error": "RCCL point-to-point halo exchange failed: %s" % (why or "on another rank"), "n_gpus": world})
                 ctx.close()
                 dist.destroy_process_group()
                 sys.exit(3)
@@ -497,9 +510,10 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         first_ms = int_s * 1e3 * probe_ms[0] / probe_ms[kept]
         out["roofline"]["avg_launch_ms_first_placement"] = round(first_ms, 4)
         out["roofline"]["frac_first_placement"] = round(bytes_launch / (first_ms * 1e-3) / HBM_PEAK, 4)
-        out["roofline"]["placement_note"] = ("bench.py opts into RGBDR_ARENA_TRIALS=%d (library default 1 = off): `frac` is on "
-                                             "the fastest of the probed placements of the LUT arena, frac_first_placement scales "
-                                             "the measured launch time by replay(candidate 0) / replay(kept)" % len(probe_ms))
+        out["roofline"]["placement_note"] = ("bench.py opts into RGBDR_ARENA_TRIALS=%d (library default 1 = off; %d placements were "
+                                             "probed): `frac` is on the fastest of the probed placements of the LUT arena, "
+                                             "frac_first_placement scales the measured launch time by replay(candidate 0) / "
+                                             "replay(kept)" % (trials, len(probe_ms)))
     elif world == 1:
         out["roofline"]["frac_first_placement"] = out["roofline"]["frac"]       # a single placement was looked at
         out["roofline"]["avg_launch_ms_first_placement"] = out["roofline"]["avg_launch_ms"]
@@ -672,7 +686,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         except Exception as e:  # noqa: BLE001 -- extra keys must never cost the headline line
             out["post_pass"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0 and not quiet:
-        print(json.dumps(out))
+        emit(out)
     ctx.close()
     if multi:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
@@ -712,7 +726,7 @@ def slab_sweep(args):
            "ms_per_step_max": max(steps), "ms_per_step_min": min(steps),
            "projected_value_if_bound_by_slowest_rank": round(V / (max(steps) * 1e-3) / 1e6, 1),
            "config": line["config"], "dtype": "f32", "data": "synthetic"}
-    print(json.dumps(out))
+    emit(out)
     return 0
 
 

@@ -22,7 +22,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "oracle", "rgbdr_oracle.c")
-KATS = ["tests/test_oracle_kat.py", "tests/test_oracle_kat_passes.py", "tests/test_bricks_cpu.py"]
+KATS = ["tests/test_oracle_kat.py", "tests/test_oracle_kat_passes.py", "tests/test_bricks_cpu.py", "tests/test_oracle_kat_view.py"]
 
 # (name, text in oracle/rgbdr_oracle.c -- must occur exactly once --, replacement)
 MUTANTS = [
@@ -95,6 +95,46 @@ MUTANTS = [
     ("bricks: float upper bound of containedVoxels (orc_brick_voxel_mask)",
      "for (unsigned x = (unsigned)(pos[0] / stepv[0]); (float)x < (pos[0] + bs[0]) / stepv[0]; ++x)\n              for (unsigned z = (unsigned)(pos[2] / stepv[2]); (float)z < (pos[2] + bs[2]) / stepv[2]; ++z) {\n                const size_t id",
      "for (unsigned x = (unsigned)(pos[0] / stepv[0]); x < (unsigned)((pos[0] + bs[0]) / stepv[0]); ++x)\n              for (unsigned z = (unsigned)(pos[2] / stepv[2]); (float)z < (pos[2] + bs[2]) / stepv[2]; ++z) {\n                const size_t id"),
+    # tsdf_raymarch.fs (f-2)
+    ("raymarch: step is limit / 2", "const float limit = p->limit, sd = limit * 0.5f;", "const float limit = p->limit, sd = limit * 0.25f;"),
+    ("raymarch: secant prev / (density - prev)", "const float f = prev / (density - prev);", "const float f = prev / (density + prev);"),
+    ("raymarch: refinement starts one step back", "for (int a = 0; a < 3; ++a) sp[a] = (sp[a] - step[a]) - step[a] * f;",
+     "for (int a = 0; a < 3; ++a) sp[a] = sp[a] - step[a] * f;"),
+    ("raymarch: density > 0 is inside, 0 is not", "if (density > 0.0f) {", "if (density >= 0.0f) {"),
+    ("raymarch: the first sample is assumed outside (-limit)", "      float prev = -limit;\n      unsigned num = 0;", "      float prev = 0.0f;\n      unsigned num = 0;"),
+    ("raymarch: camera inside the cube starts at the camera", "t_near = t_near < 0.0f ? 0.0f : t_near;", "t_near = t_near;"),
+    ("raymarch: gradient points to smaller density", "d[a] = tsdf_sample(tsdf, res, pp) - tsdf_sample(tsdf, res, pm);",
+     "d[a] = tsdf_sample(tsdf, res, pm) - tsdf_sample(tsdf, res, pp);"),
+    ("raymarch: sample count image scale 0.0027", "out_samples[o] = (float)num * 0.0027f;", "out_samples[o] = (float)num * 0.0028f;"),
+    ("raymarch: blend weight quality / (dist + 0.01)", "        tw += q / (dist + 0.01f);", "        tw += q / (dist + 0.1f);"),
+    ("raymarch: quality only within limit of the surface", "if (dist < limit) tex2d_linear(quality[i], 1, 1, p->W, p->H, pcal[0], pcal[1], &q);",
+     "if (dist < 3.0f * limit) tex2d_linear(quality[i], 1, 1, p->W, p->H, pcal[0], pcal[1], &q);"),
+    ("raymarch: fallback blend weighs by 1 / distance", "          tc2[k] += col[k] / dist;", "          tc2[k] += col[k];"),
+    ("raymarch: fallback blend has alpha -1", "          diff[3] = -1.0f;", "          diff[3] = 1.0f;"),
+    ("raymarch: camera mode is white without weights", "rgba[k] = (cwt <= 0.0f) ? 1.0f : cw[k] / cwt;", "rgba[k] = (cwt <= 0.0f) ? 0.0f : cw[k] / cwt;"),
+    ("raymarch: gl_FragDepth divides by -z", "/ -vp[2] * 0.5f + 0.5f;", "/ vp[2] * 0.5f + 0.5f;"),
+    ("raymarch: fragments at the far plane fail the depth test", "if (!(dclamped < 1.0f)) continue;", "if (0) continue;"),
+    ("raymarch: phong specular exponent 20", "sl = r16 * r4;", "sl = r16;"),
+    ("raymarch: phong ambient 0.2", "rgba[k] = (ld[k] * 0.2f) * 0.5f", "rgba[k] = (ld[k] * 0.3f) * 0.5f"),
+    # getStartPos (f-4)
+    ("start pos: sample budget is distance / step", "fmaxs = ceilf(distance3(pf, pb) / sd);", "fmaxs = ceilf(distance3(pf, pb) / limit);"),
+    ("start pos: a culled front face starts at the near plane", "dr = (dr >= dbk) ? 0.0f : dr; /* gl_DepthRange.near */", "dr = (dr > dbk) ? 0.0f : dr;"),
+    ("start pos: the back face depth is -g", "k == 0 ? dr : -dg, 1.0f};", "k == 0 ? dr : dg, 1.0f};"),
+    ("start pos: no face at all means no samples", "        if (dr >= 1.0f) {\n          pb[0] = pf[0];", "        if (0) {\n          pb[0] = pf[0];"),
+    # bricks.{gs,fs}
+    ("peels: neighbour culls a face when its counter > 10", "]] > 10u;", "]] >= 10u;"),
+    ("peels: blue keeps the nearest BACK face only", "            r = fminf(r, z);\n            gneg = fminf(gneg, -z);\n          }\n          if (prev_list",
+     "            r = fminf(r, z);\n            gneg = fminf(gneg, -z);\n            b = fminf(b, z);\n          }\n          if (prev_list"),
+    ("peels: green is MIN of -z (the farthest face)", "            gneg = fminf(gneg, -z);\n            b = fminf(b, z);\n          }\n        }\n      }\n    }\n    first = 0;",
+     "            gneg = fmaxf(gneg, -z);\n            b = fminf(b, z);\n          }\n        }\n      }\n    }\n    first = 0;"),
+    ("peels: cleared to (1, 0, 1, 0)", "  out[0] = 1.0f;\n  out[1] = 0.0f;\n  out[2] = 1.0f;\n  out[3] = 0.0f;\n  /* world-space ray",
+     "  out[0] = 1.0f;\n  out[1] = 0.0f;\n  out[2] = 0.0f;\n  out[3] = 0.0f;\n  /* world-space ray"),
+    # calibration_inverter.cpp (f-3)
+    ("inverter: weights are 1 / distance", "const float w = 1.0f / sqrtf(bd[k]);", "const float w = 1.0f / bd[k];"),
+    ("inverter: output is (index + 0.5) / dims", "o[1] = (wi[1] / tw + 0.5f) / (float)ry;", "o[1] = (wi[1] / tw) / (float)ry;"),
+    ("inverter: samples start half a voxel inside the box", "start[a] = bbox_min[a] + step[a] * 0.5f;", "start[a] = bbox_min[a];"),
+    ("inverter: points outside the frustum are -1", "o[0] = o[1] = o[2] = o[3] = -1.0f;", "o[0] = o[1] = o[2] = o[3] = 0.0f;"),
+    ("inverter: eight neighbours", "int k = n < 8 ? n : 7;", "int k = n < 8 ? n : 7; if (n >= 4 && !(d2 < bd[3])) continue; if (k > 3) k = 3;"),
 ]
 
 
