@@ -329,13 +329,15 @@ def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit
     return color, depth, ns
 
 
-def fill_colors(color, depth):
+def fill_colors(color, depth, return_atlas=False):
+    """-> (filled colour, depth) [, the native LOD atlas [H, 1.5 W, 4] after the inpaint pyramid]"""
     color, depth = f32(color), f32(depth)
     h, w = depth.shape
     oc = np.empty((h, w, 4), dtype=np.float32)
     od = np.empty((h, w), dtype=np.float32)
-    lib().orc_fill_colors(_p(color), _p(depth), w, h, _p(oc), _p(od), None)
-    return oc, od
+    atlas = np.empty((h, int(np.float32(w) * np.float32(1.5)), 4), dtype=np.float32) if return_atlas else None
+    lib().orc_fill_colors(_p(color), _p(depth), w, h, _p(oc), _p(od), _p(atlas) if return_atlas else None)
+    return (oc, od, atlas) if return_atlas else (oc, od)
 
 
 def fill_layout(w, h):

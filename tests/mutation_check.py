@@ -135,6 +135,17 @@ MUTANTS = [
     ("inverter: samples start half a voxel inside the box", "start[a] = bbox_min[a] + step[a] * 0.5f;", "start[a] = bbox_min[a];"),
     ("inverter: points outside the frustum are -1", "o[0] = o[1] = o[2] = o[3] = -1.0f;", "o[0] = o[1] = o[2] = o[3] = 0.0f;"),
     ("inverter: eight neighbours", "int k = n < 8 ? n : 7;", "int k = n < 8 ? n : 7; if (n >= 4 && !(d2 < bd[3])) continue; if (k > 3) k = 3;"),
+    # tsdf_inpaint.fs / tsdf_colorfill.fs / framebuffer_transfer.fs (f-2)
+    ("inpaint: only samples at or behind the mean depth", "if (samples[k][0] >= 0.0f && samples[k][3] >= depth_av) {", "if (samples[k][0] >= 0.0f && samples[k][3] <= depth_av) {"),
+    ("inpaint: reads the atlas squeezed to 2/3 in x", "const int pix = (int)((float)lx * (2.0f / 3.0f)), piy = (int)((float)ly * 1.0f);",
+     "const int pix = (int)((float)lx * 1.0f), piy = (int)((float)ly * 1.0f);"),
+    ("inpaint: alpha <= 0 is a hole", "          if (c[3] <= 0.0f) {\n            c[0] = -1.0f;", "          if (c[3] < 0.0f) {\n            c[0] = -1.0f;"),
+    ("inpaint: hole over a surface depth is marked alpha -1", "          oc[2] = 0.0f;\n          oc[3] = -1.0f;", "          oc[2] = 0.0f;\n          oc[3] = 0.0f;"),
+    ("inpaint: 4 x 4 taps from -1 to +2", "(int)((float)x - 4.0f * 0.5f + 1.0f), ty", "(int)((float)x - 4.0f * 0.5f), ty"),
+    ("colorfill: first LOD with alpha > 0", "        if (c[3] > 0.0f) break;", "        if (c[3] >= 0.0f) break;"),
+    ("colorfill: blends LOD + 1 and LOD + 2", "const int l = level + 1 + k; /* level+1 -> p1, level+2 -> p2 */", "const int l = level + k;"),
+    ("colorfill: depth comes from LOD 0", "out_dep[(size_t)py * L->W + px] = d0;", "out_dep[(size_t)py * L->W + px] = d;"),
+    ("lod atlas: 1.5 W wide", "L->FW = (int)((float)W * 1.5f);", "L->FW = (int)((float)W * 2.0f);"),
 ]
 
 

@@ -344,6 +344,23 @@ def test_fill_colors_prefers_far_samples(orc):
     assert np.all(np.isfinite(mid)) and np.all(mid[..., 2] > mid[..., 0])
 
 
+def test_inpaint_marks_colourless_surface_and_keeps_the_clear_colour(orc):
+    """tsdf_inpaint.fs:60-69: a 4 x 4 neighbourhood without a single alpha > 0 sample passes the depth on and writes
+    (0, 0, 0, -1) over a surface (depth < 1: the ray-marcher's fallback blend has alpha -1) and the clear colour
+    (0, 1, 0, 0) over background; LOD 1 of the 1.5 W x H atlas sits at (W, H - H/2) (ViewLod::setResolution)"""
+    W, H = 32, 16
+    color = np.zeros((H, W, 4), np.float32)
+    depth = np.ones((H, W), np.float32)
+    color[:, :16] = (0.3, 0.4, 0.5, -1.0)            # left half: a surface nobody coloured
+    depth[:, :16] = 0.5
+    color[:, 16:] = (0.0, 1.0, 0.0, 0.0)             # right half: cleared
+    _, od, atlas = orc.fill_colors(color, depth, return_atlas=True)
+    assert atlas.shape == (H, 48, 4) and np.array_equal(od, depth)
+    lod1 = atlas[H - H // 2:H, W:W + W // 2]          # 16 x 8 texels
+    assert np.all(lod1[2:6, 1:6] == np.array([0.0, 0.0, 0.0, -1.0], np.float32))
+    assert np.all(lod1[2:6, 10:15] == np.array([0.0, 1.0, 0.0, 0.0], np.float32))
+
+
 def test_oracle_is_clean_under_asan_and_ubsan():
     """the C restatement driven over every entry point (NaN / inf / invalid-LUT inputs
     included) under AddressSanitizer + UBSan; GPU sanitizers do not exist on the pool"""

@@ -45,6 +45,47 @@ CONSTANTS = [
     ("tsdf_integration.vs", r"if \(sdist <= -(limit) \)", "limit", r"sdist <= -limit"),
     ("tsdf_integration.vs", r"else if \(sdist >= (limit) \)", "limit", r"sdist >= limit"),
     ("tsdf_integration.vs", r"if \(weighted_tsd >= (limit)\)", "limit", r"tsd >= limit|weighted_tsd >= limit"),
+    # consumers of the volume (f-2, f-4)
+    ("tsdf_raymarch.fs", r"float sampleDistance = limit \* ([\d.]+)f;", 0.5, r"sd = limit \* 0\.5f"),
+    ("tsdf_raymarch.fs", r"const float IsoValue = ([\d.]+);", 0.0, r"if \(density > 0\.0f\)"),
+    ("tsdf_raymarch.fs", r"float prev_density = -(limit);", "limit", r"float prev = -limit;"),
+    ("tsdf_raymarch.fs", r"float samples = float\(num_samples\) \* ([\d.]+);", 0.0027, r"\(float\)num \* 0\.0027f"),
+    ("tsdf_raymarch.fs", r"total_color \+= colors\[i\] \* quality / \(distances\[i\] \+ ([\d.]+)\);", 0.01, r"col\[k\] \* q / \(dist \+ 0\.01f\)"),
+    ("tsdf_raymarch.fs", r"total_weight \+= quality / \(distances\[i\] \+ ([\d.]+)\);", 0.01, r"tw \+= q / \(dist \+ 0\.01f\)"),
+    ("tsdf_raymarch.fs", r"if\(distances\[i\] < (limit)\) \{\s+quality = texture\(kinect_qualities", "limit", r"if \(dist < limit\) tex2d_linear\(quality"),
+    ("tsdf_raymarch.fs", r"\) / -view_pos\.z \* ([\d.]+)f \+ 0\.5f;", 0.5, r"/ -vp\[2\] \* 0\.5f \+ 0\.5f"),
+    ("tsdf_raymarch.fs", r"if\(total_weight <= 0\.0\) total_color = vec3\(([\d.]+)\);", 1.0, r"\(cwt <= 0\.0f\) \? 1\.0f : cw\[k\] / cwt"),
+    ("tsdf_raymarch.fs", r"return vec4\(total_color2, (-[\d.]+)\);", -1.0, r"diff\[3\] = -1\.0f;"),
+    ("shading.glsl", r"LightPosition = vec3\(([\d.]+)f, 1\.0f, 1\.0f\)", 1.5, r"lp\[3\] = \{1\.5f, 1\.0f, 1\.0f\}"),
+    ("shading.glsl", r"LightDiffuse = vec3\(1\.0f, ([\d.]+)f, 0\.7f\)", 0.9, r"ld\[3\] = \{1\.0f, 0\.9f, 0\.7f\}"),
+    ("shading.glsl", r"LightAmbient = LightDiffuse \* ([\d.]+)f;", 0.2, r"\(ld\[k\] \* 0\.2f\) \* 0\.5f"),
+    ("shading.glsl", r"const float ks = ([\d.]+)f;", 0.5, r"1\.0f \* 0\.5f \* sl"),
+    ("shading.glsl", r"const float n = ([\d.]+)f;", 20.0, r"pow\(reflectedAngle, 20\)[^\n]*\n[^\n]*r16 = r8 \* r8;\n\s*sl = r16 \* r4;"),
+    ("shading.glsl", r"solid_diffuse = vec3\(([\d.]+)f\)", 0.5, r"\+ ld\[k\] \* 0\.5f \* dc"),
+    ("shading.glsl", r"vec3\((\d+),26,28\) / 255\.0f", 228, r"\{228, 26, 28\}"),
+    ("shading.glsl", r"vec3\(55,126,(\d+)\) / 255\.0f", 184, r"\{55, 126, 184\}"),
+    ("shading.glsl", r"vec3\(77,(\d+),74\) / 255\.0f", 175, r"\{77, 175, 74\}"),
+    ("shading.glsl", r"vec3\(152,78,(\d+)\) / 255\.0f", 163, r"\{152, 78, 163\}"),
+    ("shading.glsl", r"vec3\(255,(\d+),0\) / 255\.0f", 127, r"\{255, 127, 0\}"),
+    ("inc_bricks.glsl", r"return bricks\[index\] > (\d+)u;", 10, r"\]\] > 10u;"),
+    ("bricks.fs", r"gl_FrontFacing \? ([\d.]+) : gl_FragCoord\.z", 1.0, r"float r = 1\.0f, gneg = 0\.0f, b = 1\.0f;"),
+    ("tsdf_inpaint.fs", r"const int kernel_size = (\d+);", 4, r"for \(int x = 0; x < 4; \+\+x\)\n\s*for \(int y = 0; y < 4; \+\+y\) \{\n[^\n]*4\.0f \* 0\.5f \+ 1\.0f"),
+    ("tsdf_inpaint.fs", r"\* vec2\(([\d.]+) / 3\.0 , 1\.0\)\);", 2.0, r"\(float\)lx \* \(2\.0f / 3\.0f\)"),
+    ("tsdf_inpaint.fs", r"if \(color\.a <= ([\d.]+)\) \{\s+color\.r = -1\.0;", 0.0, r"if \(c\[3\] <= 0\.0f\) \{\n\s*c\[0\] = -1\.0f;"),
+    ("tsdf_inpaint.fs", r"out_FragColor = vec4\(0\.0, 0\.0, 0\.0, (-[\d.]+)\);", -1.0, r"oc\[3\] = -1\.0f;"),
+    ("tsdf_colorfill.fs", r"if \(out_FragColor\.a > ([\d.]+)\) break;", 0.0, r"if \(c\[3\] > 0\.0f\) break;"),
+    ("tsdf_colorfill.fs", r"vec2\(texture_offsets\[lod\]\) \+ ([\d.]+), vec2\(texture_offsets\[lod\] \+ texture_resolutions\[lod\]\) - 0\.5\)", 0.5,
+     r"fc_clampf\(ox \+ rx \* ptx, ox \+ 0\.5f, \(ox \+ rx\) - 0\.5f\)"),
+    # the offline inverter (f-3), C++
+    ("../framework/calibration/calibration_inverter.cpp", r"curr_calib_search\.search\(sample_pos, (\d+)\);", 8, r"float bd\[8\];\n\s*int bi\[8\]"),
+    ("../framework/calibration/calibration_inverter.cpp", r"sample_start = bbox_translation \+ sample_step \* ([\d.]+)f;", 0.5,
+     r"start\[a\] = bbox_min\[a\] \+ step\[a\] \* 0\.5f;"),
+    ("../framework/calibration/calibration_inverter.cpp", r"\(weighted_index \+ glm::fvec3\{([\d.]+)f\}\) / curr_calib_dims", 0.5,
+     r"o\[0\] = \(wi\[0\] / tw \+ 0\.5f\) / \(float\)rx;"),
+    ("../framework/calibration/calibration_inverter.cpp", r"float weight = ([\d.]+)f / glm::distance\(curr_point, sample\.pos\);", 1.0,
+     r"const float w = 1\.0f / sqrtf\(bd\[k\]\);"),
+    ("../framework/calibration/calibration_inverter.cpp", r"\] = glm::fvec4\{(-[\d.]+)f\};\s+continue;", -1.0,
+     r"o\[0\] = o\[1\] = o\[2\] = o\[3\] = -1\.0f;"),
 ]
 
 
