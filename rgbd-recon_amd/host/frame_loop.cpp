@@ -120,8 +120,14 @@ int main(int argc, char** argv)
     Backend be(cf, bbox, 0.01f, voxel, 8.0f * voxel);
     CalibVolumes cv(be, cf.filenames);
     cv.loadInverseCalibs(dir);
-    NetKinectArray nka(be);
-    ReconIntegration recon(be);
+    // kinect_client.cpp:240-255: the application's globals -- g_nka, g_recon_integration and the list of drawing
+    // modes it indexes with g_recon_mode, all through the reference's constructor signatures
+    NetKinectArray nka(&cf, &cv);
+    std::shared_ptr<ReconIntegration> recon_integration = std::make_shared<ReconIntegration>(cf, &cv, bbox, 0.01f, voxel);
+    std::vector<std::shared_ptr<Reconstruction>> recons;
+    recons.emplace_back(recon_integration);
+    const unsigned recon_mode = 0;
+    ReconIntegration& recon = *recon_integration;
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
     if (const char* msg = std::getenv("RGBDR_MESSAGE_FILE")) {  // one server message instead of the recordings
       std::vector<unsigned char> buf((colorsize + depthsize) * (size_t)n);
@@ -148,8 +154,13 @@ int main(int argc, char** argv)
       FILE* vf = std::fopen(argv[7], "rb");
       if (!vf || std::fread(&view, sizeof(view), 1, vf) != 1) return 5;
       std::fclose(vf);
-      ReconIntegration::Frame frame;
-      recon.drawF(view, frame);
+      // draw3d(), kinect_client.cpp:610-617: the camera is set, then g_recons.at(g_recon_mode)->drawF()
+      Reconstruction& mode = *recons.at(recon_mode);
+      mode.resize((std::size_t)view.width, (std::size_t)view.height);   // kinect_client.cpp:1003-1007
+      mode.setView(view);
+      mode.setViewportOffset(0.0f, 0.0f);
+      mode.drawF();
+      ReconIntegration::Frame const& frame = recon_integration->frame();
       FILE* ff = std::fopen((std::string(argv[6]) + ".frame").c_str(), "wb");
       if (!ff) return 3;
       std::fwrite(frame.color.data(), sizeof(float), frame.color.size(), ff);

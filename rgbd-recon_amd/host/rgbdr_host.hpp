@@ -4,6 +4,7 @@
 // The reference drives the path through three in-process classes
 //   kinect::CalibVolumes      framework/calibration/CalibVolumes.hpp:21-81
 //   kinect::NetKinectArray    framework/NetKinectArray.h:36-116
+//   kinect::Reconstruction    framework/reconstruction/reconstruction.hpp:11-37 (the base g_recons holds)
 //   kinect::ReconIntegration  framework/reconstruction/recon_integration.hpp:35-103
 // wired together in source/kinect_client.cpp:240-255 and called per frame in the
 // order of kinect_client.cpp:572-602.  The classes below keep those names, method
@@ -397,17 +398,68 @@ class NetKinectArray {
   double m_curr_frametime = 0.0;
 };
 
-// kinect::ReconIntegration
-class ReconIntegration {
+// kinect::Reconstruction (framework/reconstruction/reconstruction.hpp:11-37, reconstruction.cpp:14-62): the base the
+// application holds its drawing modes by -- std::vector<std::shared_ptr<Reconstruction>> g_recons and
+// g_recons.at(g_recon_mode)->drawF() (source/kinect_client.cpp:99, 251-255, 617).  Same virtuals, same
+// defaults (reload / resize do nothing, setViewportOffset complains on stderr).  The reference's draw() reads
+// its camera from OpenGL state (glGetFloatv(GL_MODELVIEW_MATRIX / GL_PROJECTION_MATRIX), glGetIntegerv(GL_VIEWPORT),
+// recon_integration.cpp:182-203); there is no GL state behind this backend, so the host states it with
+// setView() before drawF(): the one addition to the interface.
+class Reconstruction {
  public:
-  explicit ReconIntegration(Backend& be) : m_be(be) {}
+  Reconstruction(CalibrationFiles const& cfs, CalibVolumes const* cv, BoundingBox const& bbox)
+      : m_cv(cv), m_cf(&cfs), m_tex_width(cfs.getWidth()), m_tex_height(cfs.getHeight()), m_num_kinects(cfs.num()), m_bbox(bbox)
+  {
+  }
+  virtual ~Reconstruction() = default;
+
+  virtual void draw() = 0;
+  // reconstruction.cpp:35-39: TimerDatabase "draw" around draw() (the library brackets its launches itself)
+  virtual void drawF() { draw(); }
+  virtual void reload() {}
+  // "mustnt be implemented by children without fbos": the base ignores it
+  virtual void resize(std::size_t /*width*/, std::size_t /*height*/) {}
+  void setColorMaskMode(unsigned mode) { m_color_mask_mode = mode; }
+  virtual void setViewportOffset(float /*x*/, float /*y*/)
+  {
+    std::fprintf(stderr, "Reconstruction::setViewportOffset(float x, float y) -> implement me in derived class!\n");
+  }
+  // what the GL matrix stack and viewport hold when the reference's draw() runs (rgbdr_view: modelview, projection,
+  // NormalMatrix, img_to_eye ... exactly the uniforms ReconIntegration::draw derives from them, :177-241)
+  void setView(rgbdr_view const& view) { m_view = view; m_have_view = true; }
+  rgbdr_view const& view() const { return m_view; }
+
+ protected:
+  // Backend-only construction (no CalibrationFiles object at hand): sizes come from the backend's configuration
+  explicit Reconstruction(Backend const& be)
+      : m_cv(nullptr), m_cf(nullptr), m_tex_width((unsigned)be.config().depth_w), m_tex_height((unsigned)be.config().depth_h),
+        m_num_kinects(be.num())
+  {
+    for (int a = 0; a < 3; ++a) {
+      m_bbox.pmin[a] = be.config().bbox_min[a];
+      m_bbox.pmax[a] = be.config().bbox_max[a];
+    }
+  }
+  CalibVolumes const* m_cv;
+  CalibrationFiles const* m_cf;
+  unsigned m_tex_width, m_tex_height, m_num_kinects;
+  BoundingBox m_bbox;
+  unsigned m_color_mask_mode = 0;
+  rgbdr_view m_view{};
+  bool m_have_view = false;
+};
+
+// kinect::ReconIntegration : public Reconstruction (framework/reconstruction/recon_integration.hpp:35-103)
+class ReconIntegration : public Reconstruction {
+ public:
+  explicit ReconIntegration(Backend& be) : Reconstruction(be), m_be(be) {}
   // ReconIntegration(CalibrationFiles const&, CalibVolumes const*, gloost::BoundingBox const&, float limit,
   // float size), recon_integration.cpp:30, as kinect_client.cpp:252 calls it.  The volume lives in the
   // backend `cv` was built on, whose box must be `bbox`; limit and voxel size are applied like the
   // constructor's setTsdfLimit / setVoxelSize (a changed voxel size reallocates the grid: load the
   // inverse calibration volumes afterwards).
   ReconIntegration(CalibrationFiles const& cfs, CalibVolumes const* cv, BoundingBox const& bbox, float limit, float size)
-      : m_be(cv->backend())
+      : Reconstruction(cfs, cv, bbox), m_be(cv->backend())
   {
     if (cfs.num() != m_be.num()) throw std::invalid_argument("calibration files do not match the calibration volumes");
     for (int a = 0; a < 3; ++a)
@@ -430,16 +482,64 @@ class ReconIntegration {
   unsigned numBricks() const { return rgbdr_num_bricks(m_be.ctx()); }
   float occupiedRatio() const { return rgbdr_occupied_ratio(m_be.ctx()); }
   float getBrickSize() const { return rgbdr_get_brick_size(m_be.ctx()); }
-  // drawing.  The reference reads its uniforms from GL state; here
-  // the caller passes them as an rgbdr_view (modelview, projection, NormalMatrix, ... as
-  // ReconIntegration::draw computes them, recon_integration.cpp:177-241).
   void setColorFilling(bool active) { m_fill_holes = active; }
   void setSpaceSkip(bool active) { m_skip_space = active; }
+
+  // What the reference leaves in the framebuffer: RGBA32F colour, gl_FragDepth, the tex_num_samples image.
   struct Frame {
     int width = 0, height = 0;
-    std::vector<float> color, depth, num_samples;  // RGBA32F, gl_FragDepth, tex_num_samples
+    std::vector<float> color, depth, num_samples;
   };
-  // draw(): depth limits when m_skip_space && use_bricks, then the ray-march (:151-159, 177-241)
+  // ---- the Reconstruction interface (source/kinect_client.cpp:617: g_recons.at(g_recon_mode)->drawF()) ----
+  // draw(): the ray-march of recon_integration.cpp:177-241 for the view set with setView(), into frame().
+  // glColorMask of the anaglyph modes (:211-217, only without hole filling): mode 1 writes red only, mode 2
+  // green and blue only -- the other channels of frame() keep what the previous draw left there.
+  void draw() override
+  {
+    if (!m_have_view) throw std::invalid_argument("ReconIntegration::draw() before setView()");
+    if (m_color_mask_mode > 0 && !m_fill_holes && m_frame.width == m_view.width && m_frame.height == m_view.height) {
+      Frame now;
+      draw(m_view, now);
+      const size_t n = (size_t)now.width * now.height;
+      for (size_t i = 0; i < n; ++i) {
+        if (!(now.depth[i] < 1.0f)) continue;  // discarded fragment: nothing is written
+        if (m_color_mask_mode == 1) {
+          m_frame.color[4 * i] = now.color[4 * i];
+        } else {
+          m_frame.color[4 * i + 1] = now.color[4 * i + 1];
+          m_frame.color[4 * i + 2] = now.color[4 * i + 2];
+        }
+        m_frame.depth[i] = now.depth[i];
+      }
+      m_frame.num_samples = now.num_samples;
+      return;
+    }
+    draw(m_view, m_frame);
+  }
+  // drawF(), recon_integration.cpp:151-175: depth limits for space skipping when m_skip_space && m_use_bricks
+  // (inside the library's ray-march, from view.skip_space), Reconstruction::drawF(), fillColors() when m_fill_holes
+  void drawF() override
+  {
+    Reconstruction::drawF();
+    if (m_fill_holes) check(m_be.ctx(), rgbdr_fill_colors(m_be.ctx(), m_frame.color.data(), m_frame.depth.data()));
+  }
+  // resize(width, height), :494-512: the reference re-allocates its FBOs / LOD atlases for the new window; here
+  // the next draw renders that many pixels (the library sizes its buffers per call)
+  void resize(std::size_t width, std::size_t height) override
+  {
+    m_view.width = (int32_t)width;
+    m_view.height = (int32_t)height;
+  }
+  // :538-543: the uniform shifts gl_FragCoord to viewport-local pixels (tsdf_raymarch.fs:70,396-397); frame() is
+  // viewport-local already, so the offset is only kept
+  void setViewportOffset(float x, float y) override
+  {
+    m_viewport_offset[0] = x;
+    m_viewport_offset[1] = y;
+  }
+  Frame const& frame() const { return m_frame; }
+
+  // ---- the same with the uniforms passed in (no state) ----
   void draw(rgbdr_view view, Frame& f) const
   {
     view.skip_space = m_skip_space ? 1 : 0;
@@ -451,7 +551,6 @@ class ReconIntegration {
     f.num_samples.resize(n);
     check(m_be.ctx(), rgbdr_raymarch(m_be.ctx(), &view, f.color.data(), f.depth.data(), f.num_samples.data()));
   }
-  // drawF(): draw() and, when colour filling is on, fillColors() (:151-175)
   void drawF(rgbdr_view const& view, Frame& f) const
   {
     draw(view, f);
@@ -478,6 +577,8 @@ class ReconIntegration {
  private:
   Backend& m_be;
   bool m_fill_holes = true, m_skip_space = true;  // defaults of recon_integration.cpp:60-63
+  Frame m_frame;
+  float m_viewport_offset[2] = {0.0f, 0.0f};
 };
 
 // The per-step halo exchange of a host that splits the volume into Z slabs, one context per GPU

@@ -133,3 +133,36 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".cuh", ".h", "Makefile")):
                 text = open(os.path.join(dp, f)).read()
                 assert "pyoracle" not in text and "rgbdr_oracle" not in text and "load_oracle" not in text, f
+
+
+def test_host_mirror_has_the_reference_class_shape(tmp_path):
+    """kinect::Reconstruction is the abstract base the application holds its drawing modes by
+    (framework/reconstruction/reconstruction.hpp:11-37; std::vector<std::shared_ptr<Reconstruction>> g_recons,
+    source/kinect_client.cpp:99,251-255): the mirror keeps that shape.  Compile-time check, no GPU needed."""
+    import subprocess
+    src = tmp_path / "shape.cpp"
+    src.write_text('''
+#include <memory>
+#include <type_traits>
+#include <vector>
+#include "rgbdr_host.hpp"
+using namespace rgbdr::host;
+static_assert(std::is_abstract<Reconstruction>::value, "draw() is pure virtual");
+static_assert(std::has_virtual_destructor<Reconstruction>::value, "held by base pointer");
+static_assert(std::is_base_of<Reconstruction, ReconIntegration>::value, "ReconIntegration : public Reconstruction");
+static_assert(!std::is_abstract<ReconIntegration>::value, "ReconIntegration implements draw()");
+static_assert(std::is_constructible<ReconIntegration, CalibrationFiles const&, CalibVolumes const*, BoundingBox const&, float, float>::value,
+              "the reference's constructor signature (recon_integration.cpp:30)");
+// the members kinect_client.cpp calls through the base pointer
+void (Reconstruction::*p_draw)() = &Reconstruction::draw;
+void (Reconstruction::*p_drawF)() = &Reconstruction::drawF;
+void (Reconstruction::*p_reload)() = &Reconstruction::reload;
+void (Reconstruction::*p_resize)(std::size_t, std::size_t) = &Reconstruction::resize;
+void (Reconstruction::*p_mask)(unsigned) = &Reconstruction::setColorMaskMode;
+void (Reconstruction::*p_off)(float, float) = &Reconstruction::setViewportOffset;
+std::vector<std::shared_ptr<Reconstruction>> g_recons;
+int main() { return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off) ? 0 : 1; }
+''')
+    r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "rgbd-recon_amd", "host"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -64,6 +64,17 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
     ctx.close()
     assert same_bits(frame[: fc.size].reshape(fc.shape), fc) and same_bits(frame[fc.size:].reshape(fd.shape), fd)
     assert (fd < 1).mean() > 0.02
+    # ... and == the oracle end to end: g_recons.at(mode)->drawF() through the Reconstruction base pointer in
+    # frame_loop.cpp is depth peels -> getStartPos -> ray-march -> inpaint pyramid -> colorfill of the reference
+    gg = pkg.capi.compute_geometry(pkg.capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G))
+    ref_all = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=gg.brick_size,
+                               bv=gg.brick_voxels, res_bricks=tuple(gg.res_bricks))
+    peels = orc.depth_peels(bytes(view), synth.BBOX_MIN, gg.brick_size, tuple(gg.res_bricks), ref_all["counters"], ref_all["mask"])
+    oc, od, _ = orc.raymarch(bytes(view), ref_all["tsdf"], inv, scene.uv, [scene.color[i] for i in range(n)],
+                             ref_all["depth_b"], ref_all["quality"], peels=peels)
+    foc, fod = orc.fill_colors(oc, od)
+    assert same_bits(frame[: fc.size].reshape(fc.shape), foc), count_diff(frame[: fc.size].reshape(fc.shape), foc)
+    assert same_bits(frame[fc.size:].reshape(fd.shape), fod)
     g = pkg.capi.compute_geometry(pkg.capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G))
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
