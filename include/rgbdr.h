@@ -25,7 +25,11 @@
 extern "C" {
 #endif
 
-#define RGBDR_MAX_SENSORS 8 /* reference: 5 (sampler3D[5], glsl/tsdf_integration.vs:13) */
+/* The reference declares five sensor slots (sampler3D[5], glsl/tsdf_integration.vs:13; camera_positions[5],
+ * camera_colors[5]): its shaders define no behaviour for a sixth sensor.  Sensors 6-8 extend the same loops by
+ * their bound only and are checked against the oracle's loop bound alone -- there are no reference semantics to
+ * match for N > 5 (the ray-marcher's camera-influence mode gives sensors beyond the fifth no colour). */
+#define RGBDR_MAX_SENSORS 8
 #define RGBDR_TILE 8        /* storage tile edge in voxels (tile-linear TSDF / LUT layout) */
 
 typedef struct rgbdr_ctx rgbdr_ctx;
@@ -316,7 +320,9 @@ int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out);
  * A.4).  `ptr` is the dense row-major image of `sensor` ([height][width][channels], f32, or u8 for
  * RGBDR_IMG_COLOR) inside the context's allocation: the same memory rgbdr_readback_image copies from,
  * valid until the context is destroyed, rewritten by every rgbdr_process_textures (colour / raw depth:
- * by every upload).  The passes that write it run on `stream` (hipStream_t: the context's stream, or its
+ * by every upload -- DXT frames are kept in their blocks until somebody asks for RGBDR_IMG_COLOR; from the
+ * first such call on, every upload decodes them into this image on its own stream, so a view taken once
+ * stays current).  The passes that write it run on `stream` (hipStream_t: the context's stream, or its
  * internal second stream under RGBDR_FLAG_PIPELINE): order a consumer after them with an event recorded
  * on that stream, or call rgbdr_sync. */
 typedef struct {
@@ -428,9 +434,10 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the
  * driver placed that allocation (stable per allocation, several per cent apart), so the
- * library times the LUT stream on up to RGBDR_ARENA_TRIALS (environment, default 12, at most
- * 16, 1 = off) candidate allocations when the arena is created, stops at the first that streams
- * at the fast level and otherwise keeps the fastest.  Reports
+ * library can time the LUT stream on up to RGBDR_ARENA_TRIALS (environment; default 1 = OFF: the first
+ * allocation is taken and nothing is probed; at most 16) candidate allocations when the arena is created --
+ * held while probing, i.e. up to n x the arena of HBM transiently, at most about 1 s -- stop at the first that
+ * streams at the fast level and otherwise keep the fastest.  bench.py opts in and reports both.  Reports
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);

@@ -59,6 +59,9 @@ static void free_volume(rgbdr_ctx* c)
       c->d_stage[b][f] = nullptr;
     }
   c->stage_target = -1;
+  c->halo_begun = false;  // a resize between begin_step and exchange_async: the exchange has nothing to send
+  c->halo_done_rec[0] = c->halo_done_rec[1] = false;
+  c->halo_last = -1;
   (void)hipFree(c->d_tile_list);
   (void)hipFree(c->d_tile_state);
   c->d_tile_list = c->d_tile_state = nullptr;
@@ -326,20 +329,20 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
 
 void rgbdr_destroy(rgbdr_ctx* ctx)
 {
-  if (ctx) {
-    for (int b = 0; b < 2; ++b) {
-      if (ctx->h_depth[b]) (void)hipHostFree(ctx->h_depth[b]);
-      if (ctx->h_color[b]) (void)hipHostFree(ctx->h_color[b]);
-      if (b == 0 && ctx->h_skip_count) (void)hipHostFree(ctx->h_skip_count);
-      if (ctx->ev_mapped[b]) (void)hipEventDestroy(ctx->ev_mapped[b]);
-      ctx->h_depth[b] = ctx->h_color[b] = nullptr;
-      ctx->ev_mapped[b] = nullptr;
-    }
-  }
   if (!ctx) return;
+  // drain every stream first: queued kernels still write the mapped skip counter and read the page-locked frame buffers
   (void)hipSetDevice(ctx->device);
   if (ctx->pre_stream) (void)hipStreamSynchronize(ctx->pre_stream);
+  if (ctx->halo_stream) (void)hipStreamSynchronize(ctx->halo_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (int b = 0; b < 2; ++b) {
+    if (ctx->h_depth[b]) (void)hipHostFree(ctx->h_depth[b]);
+    if (ctx->h_color[b]) (void)hipHostFree(ctx->h_color[b]);
+    if (b == 0 && ctx->h_skip_count) (void)hipHostFree(ctx->h_skip_count);
+    if (ctx->ev_mapped[b]) (void)hipEventDestroy(ctx->ev_mapped[b]);
+    ctx->h_depth[b] = ctx->h_color[b] = nullptr;
+    ctx->ev_mapped[b] = nullptr;
+  }
   free_volume(ctx);
   for (int b = 0; b < 2; ++b) {
     if (ctx->ev_pre[b]) (void)hipEventDestroy(ctx->ev_pre[b]);
@@ -410,6 +413,14 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   if (!color_done) HIPCHK(hipMemcpyAsync(cdst, csrc, cbytes, kind, ps));
   ctx->color_decoded = !ctx->cfg.compress_rgb;
   ctx->frame_uploaded = true;
+  // a zero-copy view of the RGB8 frame is out (rgbdr_device_image(RGBDR_IMG_COLOR)): it is documented as rewritten
+  // by every upload, so the decode rides behind the copy on the same stream -- no host synchronisation
+  if (!ctx->color_decoded && ctx->color_view_out) {
+    launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
+                      color_frame_bytes(ctx->cfg), ctx->d_color, ps);
+    LAUNCHCHK("decode_dxt");
+    ctx->color_decoded = true;
+  }
   return RGBDR_OK;
 }
 
@@ -675,7 +686,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
     any_tiled = any_tiled || ctx->inv_tiled[i];
   }
   if (any_tiled && !all_tiled)
-    return ctx->fail(RGBDR_ERR_STATE, "inverse LUTs at 1:1 and at other resolutions cannot be mixed in one context yet");
+    // unreachable through the API: every call that sets an inverse LUT keeps the sensors of a context in one layout
+    // (any mix of LUT resolutions is fine in either layout)
+    return ctx->fail(RGBDR_ERR_STATE, "internal: sensors hold inverse LUTs in different layouts");
   const bool bricks = (ctx->cfg.flags & RGBDR_FLAG_USE_BRICKS) != 0;
   if (bricks && !ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "integrate with bricks before update_occupied_bricks");
   HIPCHK(hipSetDevice(ctx->device));
@@ -989,6 +1002,7 @@ int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device
     case RGBDR_IMG_QUALITY: f = ctx->d_quality; break;
     case RGBDR_IMG_COLOR:
       { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }
+      ctx->color_view_out = true;  // from now on every upload of DXT frames decodes them as well
       v.width = ctx->cfg.color_w;
       v.height = ctx->cfg.color_h;
       v.channels = 3;

@@ -155,6 +155,15 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
       nanosleep(&ts, nullptr);
     }
   }
+  // four planes: window origins, the tiles' smallest and largest projected depths, footprint size class
+  // (launch_tile_windows).  The arena is published only once they exist too: a failure here leaves no half-made state.
+  if (hipMalloc((void**)&ctx->d_win, 4 * ntiles * nsens(ctx) * sizeof(int32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->d_win = nullptr;
+    (void)hipFree(cand[best]);
+    ctx->arena_trials = ctx->arena_chosen = 0;
+    return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the per-tile window words failed: out of device memory");
+  }
   ctx->d_lut_tiled_base = cand[best];
   ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
   if (probed) {  // the replay stored into the volume: clear it again, forget recorded clears, nothing is integrated
@@ -162,8 +171,6 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     { int rc_ = bump_clear_epoch(ctx); if (rc_ != RGBDR_OK) return rc_; }
     ctx->integrated = false;
   }
-  // four planes: window origins, the tiles' smallest and largest projected depths, footprint size class (launch_tile_windows)
-  HIPCHK(hipMalloc((void**)&ctx->d_win, 4 * ntiles * nsens(ctx) * sizeof(int32_t)));
   HIPCHK(hipMemsetAsync(ctx->d_win, 0, 4 * ntiles * nsens(ctx) * sizeof(int32_t), ctx->stream));
   return RGBDR_OK;
 }
@@ -310,6 +317,8 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
   const uint32_t r[3] = {(uint32_t)g.res_volume[0], (uint32_t)g.res_volume[1], (uint32_t)g.res_volume[2]};
   if (!lut_is_one_to_one(r, g.res_volume))
     return ctx->fail(RGBDR_ERR_STATE, "synthetic inverse LUT needs a grid whose voxel centres hit texel centres exactly");
+  if (ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE)
+    return ctx->fail(RGBDR_ERR_STATE, "the synthetic (benchmark) inverse LUT is written in the grid layout only: not with RGBDR_FLAG_NO_RESAMPLE");
   int rc = ensure_tiled_lut(ctx);
   if (rc != RGBDR_OK) return rc;
   const LutExtent ext = lut_extent(ctx);
@@ -360,14 +369,44 @@ int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
   if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "compute_inverse_calibration before set_calibration");
   if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
   HIPCHK(hipSetDevice(ctx->device));
+  // every sensor of a context is resident in one layout (set_inverse_calibration): with RGBDR_FLAG_NO_RESAMPLE,
+  // or next to sensors that hold the file layout, the generated volume is kept as an x-fastest RGBA32F volume at
+  // the grid resolution (the rows this slab samples) and looked up per frame like an uploaded one
+  bool file_layout = (ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE) != 0;
   for (int i = 0; i < nsens(ctx); ++i)
-    if (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i])
-      return ctx->fail(RGBDR_ERR_STATE, "other sensors hold file-layout inverse LUTs (RGBDR_FLAG_NO_RESAMPLE)");
-  int rc = ensure_tiled_lut(ctx);
-  if (rc != RGBDR_OK) return rc;
+    if (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i]) file_layout = true;
   const rgbdr_geometry& g = ctx->geo;
   InvertParams p;
   fill_invert_params(ctx, sensor, g.res_volume, window, &p);
+  if (file_layout) {
+    for (int i = 0; i < nsens(ctx); ++i)
+      if (i != sensor && ctx->inv_set[i] && ctx->inv_tiled[i])
+        return ctx->fail(RGBDR_ERR_STATE, "other sensors hold grid-layout inverse LUTs generated on the device: set them again");
+    int lo, hi;
+    const LutExtent fext = lut_extent(ctx);
+    lut_z_range(g.res_volume[2], g.res_volume[2], fext.vz0, fext.vz1, &lo, &hi);
+    lo = (lo / kTile) * kTile;  // whole tiles from the volume's tile grid: the search is seeded per tile
+    const size_t frow = (size_t)g.res_volume[0] * g.res_volume[1];
+    (void)hipFree(ctx->d_lut_generic[sensor]);
+    ctx->d_lut_generic[sensor] = nullptr;
+    ctx->inv_set[sensor] = false;
+    HIPCHK(hipMalloc((void**)&ctx->d_lut_generic[sensor], frow * (size_t)(hi - lo + 1) * sizeof(float4)));
+    p.z0 = lo;
+    p.nz = hi - lo + 1;
+    p.out_linear = ctx->d_lut_generic[sensor];
+    p.out_tiled = nullptr;
+    launch_invert_lut(p, ctx->stream);
+    LAUNCHCHK("invert_lut");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = (uint32_t)g.res_volume[a];
+    ctx->zoff[sensor] = lo;
+    ctx->inv_tiled[sensor] = false;
+    ctx->inv_resampled[sensor] = false;
+    ctx->inv_set[sensor] = true;
+    return RGBDR_OK;
+  }
+  int rc = ensure_tiled_lut(ctx);
+  if (rc != RGBDR_OK) return rc;
   const LutExtent ext = lut_extent(ctx);
   p.z0 = ext.vz0;
   p.nz = ext.vz1 - ext.vz0;

@@ -180,6 +180,9 @@ int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int 
   if (!ctx->halo_begun) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_exchange_async before rgbdr_halo_begin_step + rgbdr_integrate");
   HIPCHK(hipSetDevice(ctx->device));
   const int b = ctx->halo_step & 1;
+  { int rc_ = check_slab(ctx, b); if (rc_ != RGBDR_OK) return rc_; }
+  if (ctx->stage_target != b || !ctx->integrated)
+    return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_exchange_async: no rgbdr_integrate has filled the staging set since rgbdr_halo_begin_step");
   ctx->halo_begun = false;
   ++ctx->halo_step;
   HIPCHK(hipEventRecord(ctx->ev_halo_staged[b], ctx->stream));

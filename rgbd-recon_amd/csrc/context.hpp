@@ -135,6 +135,7 @@ struct rgbdr_ctx {
   uint8_t* d_mask = nullptr;
   bool morph_current = false;       // d_depth_morph was written with the upload (k_upload_morph): the chain skips k_morph
   bool color_decoded = true;        // d_color holds the uploaded frame (false: only d_color_dxt does)
+  bool color_view_out = false;      // a device view of d_color was handed out: uploads keep it current
   bool mask_valid = false;
   // rgbdr_update_occupied_bricks only noted the threshold: mask_buf(rbuf) is to be rebuilt from the counters by
   // whoever needs it first -- the brick sweep's first kernel does it on the way (materialise_mask otherwise)

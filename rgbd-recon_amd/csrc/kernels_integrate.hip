@@ -255,17 +255,20 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
     launch_brick_sweep(p, ntiles, s);  // kernels_bricks.hip
     return;
   }
-  // developer A/B knob: RGBDR_INTEGRATE_GROUP=2 folds 3 or 4 sensors in two groups
+#ifdef RGBDR_DEV_KNOBS  // developer A/B builds only (make FLAGS+=-DRGBDR_DEV_KNOBS): the shipped launch path reads no environment
+  // RGBDR_INTEGRATE_GROUP=2 folds 3 or 4 sensors in two groups
   static const int maxg = getenv("RGBDR_INTEGRATE_GROUP") ? atoi(getenv("RGBDR_INTEGRATE_GROUP")) : 4;
   if (maxg == 2 && (N == 3 || N == 4)) {
     hipLaunchKernelGGL((k_integrate_tiled<N, 2>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
-  // developer A/B knob: RGBDR_NT=0 uses temporal loads/stores for the LUT / TSDF streams
-  if (getenv("RGBDR_NT") && !atoi(getenv("RGBDR_NT")) && N == 4) {
+  // RGBDR_NT=0 uses temporal loads/stores for the LUT / TSDF streams
+  static const bool temporal = getenv("RGBDR_NT") && !atoi(getenv("RGBDR_NT"));
+  if (temporal && N == 4) {
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, false>), dim3(ntiles), dim3(128), 0, s, p);
     return;
   }
+#endif
   if (p.elide_stores)
     hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
   else if (p.stage_lo || p.stage_hi)
@@ -279,8 +282,12 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
 bool integrate_stages_halo(const IntegrateParams& p, bool one_to_one)
 {
   if (!one_to_one || p.use_bricks || p.elide_stores || p.skip_background) return false;
+#ifdef RGBDR_DEV_KNOBS
   static const bool knobs = getenv("RGBDR_INTEGRATE_GROUP") || getenv("RGBDR_NT");
   return !knobs;
+#else
+  return true;
+#endif
 }
 
 void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t s)
@@ -290,9 +297,11 @@ void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t 
   // full sweep: chunk = one x-row of tiles when the grid divides evenly (measured
   // 3-8 % faster than identity / one contiguous run per XCD); brick-skipping sweep:
   // identity (most blocks only clear their tile; chunked order measured 40 % slower).
-  // RGBDR_TILE_CHUNK overrides (developer knob: 0 = identity, -1 = ntiles/8)
   unsigned chunk = p.use_bricks ? 0u : (unsigned)p.TX;
-  if (const char* e = getenv("RGBDR_TILE_CHUNK")) chunk = atoi(e) < 0 ? ntiles / 8 : (unsigned)atoi(e);
+#ifdef RGBDR_DEV_KNOBS  // RGBDR_TILE_CHUNK overrides (0 = identity, -1 = ntiles/8)
+  static const char* chunk_env = getenv("RGBDR_TILE_CHUNK");
+  if (chunk_env) chunk = atoi(chunk_env) < 0 ? ntiles / 8 : (unsigned)atoi(chunk_env);
+#endif
   p.order_chunk = (chunk && ntiles % (8 * chunk) == 0) ? chunk : 0;
   if (!one_to_one) {
     if (p.use_bricks)

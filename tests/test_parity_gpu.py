@@ -353,7 +353,6 @@ def test_halo_layers_alias_device_memory(pkg):
     """the halo views handed to torch.distributed alias the tile-linear slab"""
     import torch
 
-    from rgbd_recon_amd import dist as rdist
 
     scene, ctx, inv = build(pkg, slab_rank=1, slab_count=2)
     ctx.step(scene.depth, scene.color)
@@ -554,7 +553,6 @@ def test_device_images_alias_what_readback_returns(pkg):
     Reconstructions bind, recon_trigrid.cpp:30-33) -- every view is the memory rgbdr_readback_image copies from"""
     import torch
 
-    from rgbd_recon_amd import dist as rdist
 
     capi = pkg.capi
     scene, ctx, inv = build(pkg)
@@ -993,7 +991,6 @@ def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
     layers -- written by the full-sweep kernel itself, copied after the other sweeps"""
     import torch
 
-    from rgbd_recon_amd import dist as rdist
 
     dev = torch.device("cuda:0")
     scene, ctx, _ = build(pkg, G=64, tsdf_limit=0.1, slab_rank=rank, slab_count=count)      # 2 halo layers
@@ -1099,4 +1096,83 @@ def test_deferred_counter_clear(pkg):
     ctx.process_textures()
     ctx.update_occupied_bricks()
     assert np.array_equal(ctx.readback_brick_counters(), c1) and len(ctx.get_occupied()[0]) > 0
+    ctx.close()
+
+
+def test_colour_view_of_dxt_frames_follows_later_uploads(pkg, orc):
+    """rgbdr_device_image(RGBDR_IMG_COLOR) of DXT frames: the zero-copy view is documented as rewritten by every
+    upload.  The blocks are decoded lazily until a view is handed out; from then on every upload decodes as well, so
+    a consumer that kept the pointer of frame A sees frame B after B's upload (it used to see A's colours)."""
+    import torch
+    capi, synth = pkg.capi, pkg.synth
+    scene, ctx, inv = build(pkg, compress_rgb=1)
+    W, H = 128, 106
+    frame_a = np.stack([synth.encode_dxt(scene.color[i], 1) for i in range(2)])
+    frame_b = np.stack([synth.encode_dxt(np.ascontiguousarray(scene.color[i][::-1, ::-1]), 1) for i in range(2)])
+    assert not np.array_equal(frame_a, frame_b)
+    ctx.update(scene.depth, frame_a)
+    view = ctx.device_image(8, 1)
+
+    class _U8:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+    dev_view = torch.as_tensor(_U8(view.ptr, W * H * 3), device="cuda:0")          # what a device consumer keeps
+    ctx.sync()
+    assert np.array_equal(dev_view.cpu().numpy().reshape(H, W, 3), orc.decode_dxt(frame_a[1], W, H, 1))
+    ctx.update(scene.depth, frame_b)                                                 # no further rgbdr_device_image call
+    ctx.sync()
+    assert np.array_equal(dev_view.cpu().numpy().reshape(H, W, 3), orc.decode_dxt(frame_b[1], W, H, 1))
+    # and the passes still see the new frame
+    ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+
+    class Decoded:
+        pass
+
+    s2 = Decoded()
+    s2.__dict__.update(scene.__dict__)
+    s2.color = np.stack([orc.decode_dxt(frame_b[i], W, H, 1) for i in range(2)])
+    ref = oracle_run(orc, s2, ctx, inv)
+    check_images(ctx, ref, 2)
+    ctx.close()
+
+
+def test_generated_inverse_luts_keep_the_file_layout_under_no_resample(pkg, orc):
+    """RGBDR_FLAG_NO_RESAMPLE keeps every sensor's inverse LUT as the x-fastest RGBA32F volume, also the ones generated
+    on the device (rgbdr_compute_inverse_calibration) -- next to uploaded LUTs of any resolution (they used to be
+    refused as a mix of layouts).  On a power-of-two grid the per-frame lookup of a grid-resolution volume hits texel
+    centres exactly, so the volume equals the one of the default (grid-layout) context bit for bit."""
+    capi = pkg.capi
+    G = 32
+    vols = []
+    for flags in (15, 15 | capi.FLAG_NO_RESAMPLE):
+        scene, ctx, inv = build(pkg, G=G, inv_res=(45, 50, 45) if flags & capi.FLAG_NO_RESAMPLE else None, flags=flags)
+        ctx.compute_inverse_calibration(0, 3)                # sensor 0 generated, sensor 1 keeps its uploaded LUT
+        if flags & capi.FLAG_NO_RESAMPLE:
+            lut1 = scene.inverse((G, G, G))[1]               # same content as the default context's sensor 1
+            ctx.set_inverse_calibration(1, lut1, (G, G, G))
+        gen = ctx.readback_inverse_calibration(0, 0, G)
+        ctx.step(scene.depth, scene.color)
+        vols.append((gen, ctx.readback_tsdf()))
+        ctx.close()
+    assert same_bits(vols[0][0][..., :3], vols[1][0][..., :3])
+    assert same_bits(vols[0][1], vols[1][1]) and np.any(np.abs(vols[0][1]) < 0.01)
+
+
+def test_halo_exchange_after_a_resize_is_refused(pkg):
+    """a resize between rgbdr_halo_begin_step and rgbdr_halo_exchange_async frees the staging sets: the exchange
+    returns RGBDR_ERR_STATE instead of sending from a null buffer"""
+    capi = pkg.capi
+    scene = pkg.synth.Scene(2, 128, 106, lut_res=(32, 27, 32))
+    cfg = capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64, slab_rank=0, slab_count=2)
+    ctx = capi.Context(cfg, 0)
+    lib = capi.lib()
+    assert lib.rgbdr_halo_begin_step(ctx._h) == 0
+    ctx.set_voxel_size(2.0 / 32)
+    fake_comm = C.c_void_p(1)
+    rc = lib.rgbdr_halo_exchange_async(ctx._h, fake_comm, -1, 1)
+    assert rc == capi.ERR_STATE if hasattr(capi, "ERR_STATE") else rc == -6
+    # begin_step again but no integrate: still nothing to send
+    assert lib.rgbdr_halo_begin_step(ctx._h) == 0
+    assert lib.rgbdr_halo_exchange_async(ctx._h, fake_comm, -1, 1) == -6
     ctx.close()
