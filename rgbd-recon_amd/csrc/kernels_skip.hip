@@ -106,21 +106,36 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
 // every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
 // this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
 // Otherwise {tile, verdicts, window origins} goes on the list of k_integrate_tiled_listed.
-constexpr int kClassifyTiles = 256;
-__global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsigned ntiles)
+// One lane per (tile, sensor) pair takes that pair's verdict -- the four words of the pair are read coalesced, the three
+// bounds behind the window origin are one dependent round trip, every pair of the block in flight at once (round 2: one
+// lane per tile walked its sensors in turn, N x 2 dependent round trips at 4 wavefronts per SIMD: 94 % of the wave
+// cycles waiting, 50 us for 61 MB) -- then one lane per tile combines them from LDS.
+constexpr int kClassifyThreads = 256;
+__global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegrateParams p, unsigned ntiles, unsigned tiles_per_block)
 {
-  __shared__ unsigned todo[kClassifyTiles];  // tile | (value is +limit) << 31
+  __shared__ unsigned char verdict[kClassifyThreads];  // [tile in block][sensor]
+  __shared__ int origin[kClassifyThreads];             // the pair's window origin word (goes into the list entry)
+  __shared__ unsigned todo[kClassifyThreads];          // tile | (value is +limit) << 31
   __shared__ unsigned ntodo;
   if (threadIdx.x == 0) ntodo = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.skip_count_next = 0u;  // the counter the next sweep appends to
+  const unsigned N = (unsigned)p.N;
+  const unsigned tile0 = blockIdx.x * tiles_per_block;
+  {
+    const size_t pair = (size_t)tile0 * N + threadIdx.x;
+    if (threadIdx.x < tiles_per_block * N && pair < (size_t)ntiles * N) {
+      origin[threadIdx.x] = p.win[pair];
+      verdict[threadIdx.x] = (unsigned char)skip_verdict(p, pair, (int)(threadIdx.x % N));
+    }
+  }
   __syncthreads();
-  const unsigned tile = blockIdx.x * kClassifyTiles + threadIdx.x;
+  const unsigned tile = tile0 + threadIdx.x;
   bool listed = false, fill = false, positive = false;
   unsigned actions = 0u;
-  if (tile < ntiles) {
+  if (threadIdx.x < tiles_per_block && tile < ntiles) {
     bool all = true, negative = false;
-    for (int s = 0; s < p.N; ++s) {
-      const unsigned a = skip_verdict(p, (size_t)tile * p.N + s, s);
+    for (unsigned s = 0; s < N; ++s) {
+      const unsigned a = verdict[threadIdx.x * N + s];
       actions |= a << (2 * s);
       all = all && a != kSkipNone;
       negative = negative || a == kSkipCarve || a == kSkipFront;
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsign
       p.tile_state[tile] = 0u;  // about to hold integrated values
     }
   }
-  {
+  if (threadIdx.x < 64 || tiles_per_block > 64) {  // the wavefronts that hold tiles (wave-uniform condition)
     const unsigned long long m = __ballot(listed);
     const int lane = threadIdx.x & 63;
     unsigned base = 0;
@@ -142,10 +157,10 @@ __global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsign
       if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.skip_count, (unsigned)__popcll(m));
       base = __shfl(base, __ffsll((long long)m) - 1);
       if (listed) {  // entry: tile, verdicts, the N window origins (so that the sweep's window loads wait for one load, not two)
-        unsigned* e = p.skip_list + (size_t)(base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + p.N);
+        unsigned* e = p.skip_list + (size_t)(base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + N);
         e[0] = tile;
         e[1] = actions;
-        for (int s = 0; s < p.N; ++s) e[2 + s] = (unsigned)p.win[(size_t)tile * p.N + s];
+        for (unsigned s = 0; s < N; ++s) e[2 + s] = (unsigned)origin[threadIdx.x * N + s];
       }
     }
   }
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(256) void k_skip_classify(IntegrateParams p, unsign
   if (n == 0) return;
   typedef float v4f __attribute__((ext_vector_type(4)));
   v4f* out = reinterpret_cast<v4f*>(p.tsdf);
-  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += 256) {
+  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += kClassifyThreads) {
     const unsigned e = todo[i / (kTileVoxels / 4)];
     const float l = (e >> 31) ? p.limit : -p.limit;
     const v4f fillv = {l, l, l, l};
@@ -208,7 +223,8 @@ static void launch_listed_n(const IntegrateParams& p, unsigned blocks, hipStream
 void launch_skip_sweep(const IntegrateParams& p, unsigned blocks, hipStream_t s)
 {
   const unsigned ntiles = (unsigned)p.TX * p.TY * p.ntz;
-  hipLaunchKernelGGL(k_skip_classify, dim3((ntiles + kClassifyTiles - 1) / kClassifyTiles), dim3(256), 0, s, p, ntiles);
+  const unsigned tpb = (unsigned)kClassifyThreads / (unsigned)p.N;  // 64 tiles per block at 4 sensors
+  hipLaunchKernelGGL(k_skip_classify, dim3((ntiles + tpb - 1) / tpb), dim3(kClassifyThreads), 0, s, p, ntiles, tpb);
   switch (p.N) {
     case 1: launch_listed_n<1>(p, blocks, s); break;
     case 2: launch_listed_n<2>(p, blocks, s); break;

@@ -353,6 +353,7 @@ def test_halo_layers_alias_device_memory(pkg):
     """the halo views handed to torch.distributed alias the tile-linear slab"""
     import torch
 
+    from rgbd_recon_amd import dist as rdist
 
     scene, ctx, inv = build(pkg, slab_rank=1, slab_count=2)
     ctx.step(scene.depth, scene.color)
@@ -553,6 +554,7 @@ def test_device_images_alias_what_readback_returns(pkg):
     Reconstructions bind, recon_trigrid.cpp:30-33) -- every view is the memory rgbdr_readback_image copies from"""
     import torch
 
+    from rgbd_recon_amd import dist as rdist
 
     capi = pkg.capi
     scene, ctx, inv = build(pkg)
@@ -991,6 +993,7 @@ def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
     layers -- written by the full-sweep kernel itself, copied after the other sweeps"""
     import torch
 
+    from rgbd_recon_amd import dist as rdist
 
     dev = torch.device("cuda:0")
     scene, ctx, _ = build(pkg, G=64, tsdf_limit=0.1, slab_rank=rank, slab_count=count)      # 2 halo layers
