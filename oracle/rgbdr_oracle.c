@@ -172,6 +172,11 @@ ORC_API void orc_tex2d_linear(const float* img, int ch, int W, int H, float u, f
   tex2d_linear(img, ch, ch, W, H, u, v, out);
 }
 
+ORC_API void orc_tex2d_linear_rgb8(const uint8_t* img, int W, int H, float u, float v, float* out)
+{
+  tex2d_linear_rgb8(img, W, H, u, v, out);
+}
+
 ORC_API int orc_axis_nearest(float s, int n) { return axis_nearest(s, n); }
 
 /* ------------------------------------------------------------------------- */

@@ -1,0 +1,261 @@
+"""TEST INFRASTRUCTURE, build container only: drives oracle/_ref/libref_shaders.so -- the TEXT of the reference's
+pre_* and tsdf_integration shaders compiled as C++ by oracle/build_shader_ref.py -- through one frame in the
+reference's host order, binding every uniform and texture the way the reference's host code does:
+
+  NetKinectArray::processDepth       framework/NetKinectArray.cpp:251-290   morph, mode 0 then mode 1
+  NetKinectArray::processTextures    framework/NetKinectArray.cpp:311-428   filter / boundary / normal / quality loops
+  ReconIntegration::integrate        framework/reconstruction/recon_integration.cpp:243-270
+  texture filter state               NetKinectArray.cpp:182-190 (NEAREST: raw depth, depth, depth_b, depth2),
+                                     everything else LINEAR / CLAMP_TO_EDGE (globjects Texture::createDefault)
+
+The samplers and the driver-defined built-ins are stand-ins (oracle/glsl_runtime.hpp): this is not a run of the
+reference, it is the reference's arithmetic text between two fetches, compiled.  Used by tests/test_shader_ref.py and
+tests/golden/make_shader_golden.py; never by the product."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libref_shaders.so")
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        C.CDLL(os.path.join(HERE, "librgbdr_oracle.so"), mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(LIB_PATH)
+    return _lib
+
+
+class Sampler2DArray(C.Structure):
+    _fields_ = [("f32", C.c_void_p), ("u8", C.c_void_p), ("W", C.c_int), ("H", C.c_int), ("layers", C.c_int), ("ch", C.c_int),
+                ("linear", C.c_int)]
+
+
+class Sampler3D(C.Structure):
+    _fields_ = [("f32", C.c_void_p), ("rx", C.c_int), ("ry", C.c_int), ("rz", C.c_int), ("ch", C.c_int)]
+
+
+class Image3D(C.Structure):
+    _fields_ = [("f32", C.c_void_p), ("X", C.c_int), ("Y", C.c_int), ("Z", C.c_int)]
+
+
+class UintBuffer(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("out_of_range", C.c_size_t), ("scratch", C.c_uint)]
+
+
+class Shader:
+    def __init__(self, name):
+        self.name = name
+        l = lib()
+        self._set = getattr(l, "shref_%s_set" % name)
+        self._set.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_size_t]
+        self._bind_out = getattr(l, "shref_%s_bind_out" % name)
+        self._bind_out.argtypes = [C.c_char_p, C.c_void_p]
+        self._run = getattr(l, "shref_%s_run" % name)
+        self._oor = getattr(l, "shref_%s_buffer_out_of_range" % name)
+        self._oor.argtypes = [C.c_char_p]
+        self._oor.restype = C.c_size_t
+        self._off = getattr(l, "shref_%s_offcentre_lookups" % name)
+        self._off.restype = C.c_size_t
+        self._keep = []
+
+    def set(self, name, value, index=0):
+        if isinstance(value, C.Structure):
+            buf = value
+            n = C.sizeof(value)
+        else:
+            buf = np.ascontiguousarray(value)
+            n = buf.nbytes
+        self._keep.append(buf)
+        ptr = C.addressof(buf) if isinstance(buf, C.Structure) else buf.ctypes.data
+        rc = self._set(name.encode(), index, ptr, n)
+        assert rc == 0, "shader %s: uniform %s[%d] (%d bytes): rc %d" % (self.name, name, index, n, rc)
+
+    def f(self, name, v, index=0):
+        self.set(name, np.array(v, np.float32), index)
+
+    def u(self, name, v):
+        self.set(name, np.array(v, np.uint32))
+
+    def i(self, name, v):
+        self.set(name, np.array(v, np.int32))
+
+    def b(self, name, v):
+        self.set(name, np.array(1 if v else 0, np.uint8))
+
+    def array_f32(self, name, arr, linear, index=0):
+        """[layers, H, W(, ch)] float32 as a sampler2DArray"""
+        a = np.ascontiguousarray(arr, np.float32)
+        self._keep.append(a)
+        ch = a.shape[3] if a.ndim == 4 else 1
+        mode = {False: 0, True: 1, "centres": 2}[linear]
+        self.set(name, Sampler2DArray(a.ctypes.data, None, a.shape[2], a.shape[1], a.shape[0], ch, mode), index)
+
+    def array_rgb8(self, name, arr):
+        a = np.ascontiguousarray(arr, np.uint8)
+        self._keep.append(a)
+        self.set(name, Sampler2DArray(None, a.ctypes.data, a.shape[2], a.shape[1], a.shape[0], 3, 1))
+
+    def volume(self, name, vol, index):
+        """[rz, ry, rx, ch] float32 as element `index` of a sampler3D array"""
+        a = np.ascontiguousarray(vol, np.float32)
+        self._keep.append(a)
+        self.set(name, Sampler3D(a.ctypes.data, a.shape[2], a.shape[1], a.shape[0], a.shape[3]), index)
+
+    def out(self, name, arr):
+        assert arr.dtype == np.float32 and arr.flags.c_contiguous
+        self._keep.append(arr)
+        assert self._bind_out(name.encode(), arr.ctypes.data) == 0, name
+
+    def run(self, *dims):
+        self._run(*[C.c_int(int(d)) for d in dims])
+
+    def offcentre_lookups(self):
+        """lookups through a `linear="centres"` sampler that were not at a texel centre (must stay 0)"""
+        return int(self._off())
+
+    def buffer_out_of_range(self, name):
+        return int(self._oor(name.encode()))
+
+
+def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=None, res_bricks=None, limits=(0.5, 4.5),
+              filter_textures=True, processed=True, refine=True, near_far=(0.5, 4.5), compress=False):
+    """One frame through the compiled shader text; the keys of pyoracle.run_pipeline.  `scene`: rgbd_recon_amd.synth.Scene
+    (depth [N,H,W] f32, color [N,Hc,Wc,3] u8, xyz / uv forward LUTs [rz,ry,rx,3|2]); inv_luts [N][Z,Y,X,4]."""
+    n = scene.N
+    H, W = scene.depth.shape[1:3]
+    tsi = np.array([np.float32(1.0) / np.float32(W), np.float32(1.0) / np.float32(H)], np.float32)   # NetKinectArray.cpp:197
+    raw = np.ascontiguousarray(scene.depth, np.float32)
+
+    def common(sh, with_uv=False, with_xyz=True):
+        sh.set("texSizeInv", tsi)
+        if with_xyz:
+            for i in range(n):
+                sh.volume("cv_xyz", scene.xyz[i], i)
+        if with_uv:
+            for i in range(n):
+                sh.volume("cv_uv", scene.uv[i], i)
+        for nm in ("bbox_min", "bbox_max"):
+            try:
+                sh.f(nm, bbox_min if nm == "bbox_min" else bbox_max)
+            except AssertionError:
+                pass                                      # the shader does not include inc_bbox_test.glsl
+
+    # ---- processDepth: pre_morph.fs mode 0 into depth2.back, swap, mode 1, swap (:251-290) ----
+    morph = Shader("pre_morph")
+    common(morph)
+    back = np.zeros((n, H, W), np.float32)
+    morph.array_f32("kinect_depths", raw, linear=False)
+    morph.u("mode", 0)
+    for i in range(n):
+        morph.u("layer", i)
+        morph.out("out_Depth", back[i])
+        morph.run(W, H)
+    front, back = back, np.zeros((n, H, W), np.float32)
+    morph.array_f32("kinect_depths", front, linear=False)
+    morph.u("mode", 1)
+    for i in range(n):
+        morph.u("layer", i)
+        morph.out("out_Depth", back[i])
+        morph.run(W, H)
+    depth2 = back                                          # after the second swap: m_textures_depth2.front
+    src = depth2 if processed else raw                     # m_use_processed_depth rebinds unit "raw_depth" (:287-289)
+
+    # ---- filter loop: pre_depth.fs (:327-357) ----
+    flt = Shader("pre_depth")
+    common(flt, with_uv=True)
+    flt.array_f32("kinect_depths", src, linear=False)
+    flt.array_rgb8("kinect_colors", scene.color)
+    flt.b("filter_textures", filter_textures)
+    flt.b("processed_depth", processed)
+    depth_rg = np.zeros((n, H, W, 2), np.float32)
+    lab = np.zeros((n, H, W, 3), np.float32)
+    near, far = np.float32(near_far[0]), np.float32(near_far[1])
+    scale = np.float32(far - near)
+    for i in range(n):
+        flt.f("cv_min_ds", limits[0])
+        flt.f("cv_max_ds", limits[1])
+        flt.u("layer", i)
+        flt.b("compress", compress)
+        flt.f("scale", scale)
+        flt.f("near", near)
+        flt.f("scaled_near", scale / np.float32(255.0))
+        flt.out("out_Depth", depth_rg[i])
+        flt.out("out_Color", lab[i])
+        flt.run(W, H)
+
+    # ---- boundary loop: pre_boundary.fs (:359-377) ----
+    bnd = Shader("pre_boundary")
+    common(bnd, with_uv=True, with_xyz=False)
+    bnd.b("refine", refine)
+    bnd.array_f32("kinect_depths", depth_rg, linear=False)
+    bnd.array_f32("kinect_colors_lab", lab, linear="centres")
+    bnd.array_rgb8("kinect_colors", scene.color)
+    depth_b = np.zeros((n, H, W, 2), np.float32)
+    sil = np.zeros((n, H, W), np.float32)
+    for i in range(n):
+        bnd.u("layer", i)
+        bnd.out("out_Depth", depth_b[i])
+        bnd.out("out_Silhouette", sil[i])
+        bnd.run(W, H)
+
+    # ---- normal loop: pre_normal.fs + inc_bricks.glsl (:380-397); SSBO of recon_integration.cpp:389-401 ----
+    nb = int(res_bricks[0] * res_bricks[1] * res_bricks[2])
+    counters = np.zeros(nb, np.uint32)
+    nrm = Shader("pre_normal")
+    common(nrm, with_uv=True)
+    nrm.array_f32("kinect_depths", depth_b, linear=False)
+    nrm.f("brick_size", brick_size)
+    nrm.set("resolution", np.array(res_bricks, np.uint32))
+    nrm.set("bricks", UintBuffer(counters.ctypes.data, nb, 0, 0))
+    normals = np.zeros((n, H, W, 3), np.float32)
+    for i in range(n):
+        nrm.u("layer", i)
+        nrm.out("out_Normal", normals[i])
+        nrm.run(W, H)
+    oor = nrm.buffer_out_of_range("bricks")
+
+    # ---- quality loop: pre_quality.fs (:399-414) ----
+    import pyoracle                                   # camera positions: CalibVolumes.cpp:98-122 / frustum.cpp:21-33 (host code)
+    qua = Shader("pre_quality")
+    common(qua)
+    qua.array_f32("kinect_depths", depth_b, linear=False)
+    qua.array_f32("kinect_normals", normals, linear="centres")
+    qua.array_f32("kinect_colors_lab", lab, linear="centres")
+    qua.b("processed_depth", processed)
+    for i in range(n):
+        qua.f("camera_positions", pyoracle.camera_pos(scene.xyz[i]), i)
+    quality = np.zeros((n, H, W), np.float32)
+    for i in range(n):
+        qua.u("layer", i)
+        qua.out("out_Quality", quality[i])
+        qua.run(W, H)
+
+    out = {"raw": list(raw), "morph": list(depth2), "depth_rg": list(depth_rg), "lab": list(lab), "depth_b": list(depth_b),
+           "sil": list(sil), "normal": list(normals), "quality": list(quality), "counters": counters,
+           "bricks_out_of_range": oor, "offcentre_lookups": bnd.offcentre_lookups() + qua.offcentre_lookups()}
+
+    # ---- integrate: glClearTexImage(-limit) + tsdf_integration.vs over every voxel centre (:243-270) ----
+    if inv_luts is not None:
+        X, Y, Z = res
+        tsdf = np.full((Z, Y, X), -np.float32(limit), np.float32)
+        itg = Shader("tsdf_integration")
+        for i in range(n):
+            itg.volume("cv_xyz_inv", inv_luts[i], i)
+        itg.array_f32("kinect_silhouettes", sil, linear=True)
+        itg.array_f32("kinect_depths", depth_b, linear=False)
+        itg.array_f32("kinect_qualities", quality, linear=True)
+        itg.f("limit", limit)
+        itg.u("num_kinects", n)
+        itg.set("res_tsdf", np.array([X, Y, Z], np.uint32))
+        itg.set("volume_tsdf", Image3D(tsdf.ctypes.data, X, Y, Z))
+        itg.run(X, Y, Z, 0, Z)
+        out["tsdf"] = tsdf
+    return out

@@ -1,0 +1,34 @@
+"""The scenes behind tests/golden/shader_passes_*.npz (shared by make_shader_golden.py and tests/test_shader_ref.py).
+Deterministic from the seeds: the inputs are regenerated wherever the fixtures are used, and a digest of them is stored
+with the outputs so that a drift of the synthetic scene shows up as such."""
+import hashlib
+
+import numpy as np
+
+# name -> (sensors, (W, H), forward LUT res, grid G, inverse LUT res or None for 1:1, flags, seed)
+# flags: 1 filter_textures, 2 processed depth, 4 refine boundary (rgbdr_config.flags / NetKinectArray's toggles)
+CASES = {
+    "two_sensors_default": (2, (64, 53), (16, 14, 16), 32, None, 7, 1234),
+    "three_sensors_coarse_inverse_lut": (3, (64, 53), (16, 14, 16), 32, (23, 25, 22), 7, 77),
+    "no_filter_raw_depth_no_refine": (2, (48, 40), (12, 10, 12), 24, None, 0, 5),
+    "filter_only_fine_inverse_lut": (2, (48, 40), (12, 10, 12), 24, (30, 30, 30), 1, 9),
+    "four_sensors_128x106_into_64": (4, (128, 106), (32, 27, 32), 64, None, 7, 1234),
+}
+IMAGES = ("morph", "depth_rg", "lab", "depth_b", "sil", "normal", "quality")
+
+
+def build(pkg_synth, capi, name):
+    n, wh, lut_res, G, inv_res, flags, seed = CASES[name]
+    scene = pkg_synth.Scene(n, wh[0], wh[1], lut_res=lut_res, seed=seed)
+    cfg = capi.make_config(n, wh, voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags | 8)
+    geo = capi.compute_geometry(cfg)
+    inv_res = inv_res or (G, G, G)
+    inv = scene.inverse(inv_res)
+    return scene, cfg, geo, inv, inv_res
+
+
+def digest(scene, inv):
+    h = hashlib.sha256()
+    for a in (scene.depth, scene.color, *scene.xyz, *scene.uv, *inv):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
