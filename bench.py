@@ -319,6 +319,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         t0 = time.perf_counter()
         for _ in range(steps):
             step(bricks)
+        timed.host_enqueue_ms = (time.perf_counter() - t0) / steps * 1e3   # the host's share: enqueue time per step
         if sample_box is not None:       # the queue still holds most of the steps: clocks / power under load
             sample_box.update(gpu_state())
         barrier()
@@ -366,6 +367,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     replay_ms = ctx.settle(0.0)
     box_stream = V_local * (4 + 12 * N) / (replay_ms * 1e-3) if replay_ms > 0 else 0.0
     local_ms_per_step = timed.local_dt / args.steps * 1e3
+    host_enqueue_ms = timed.host_enqueue_ms
     halo_ms = exchanger.last_transfer_ms() if multi else None
     plain_ms = None
     if loop:
@@ -471,6 +473,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "frames_per_s": round(args.steps / dt, 2),
+        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),   # when this approaches ms_per_step the host loop is the limit
         "higher_is_better": True,
         "scaling": scaling if world > 1 else None,      # one GPU: nothing scales
         "vs_baseline": None,
@@ -525,6 +528,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                        "integrate_ms": round(int_s * 1e3, 4), "integrate_ms_without_staging": round(plain_ms[0], 4),
                        "staging_overhead_ms": round(int_s * 1e3 - plain_ms[0], 4),
                        "ms_per_step": round(ms_per_step, 4), "ms_per_step_without_halo": round(plain_ms[1], 4),
+                       "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
                        "roofline_frac": round(achieved / HBM_PEAK, 4), "halo_ms_to_self": halo_ms}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
