@@ -218,7 +218,7 @@ __global__ __launch_bounds__(128, 5) void k_integrate_tiled_list(IntegrateParams
   }
 }
 
-constexpr int kClearTiles = 256;
+
 // Brick-skipping sweep, first half (the clear of recon_integration.cpp:246-249 for everything
 // integrate will not touch).  One lane per tile: does the tile overlap an occupied brick?
 // Then it goes on the work list of k_integrate_tiled_list.  Otherwise it must hold -limit --
@@ -229,11 +229,13 @@ constexpr int kClearTiles = 256;
 // LAZY: updateOccupiedBricks' filter rides along (rgbdr_update_occupied_bricks only noted the threshold): the
 // decisions below read the counters themselves, and every lane also writes mask bytes for the sweep that follows
 // and for later consumers -- one launch less per frame.
-template <bool LAZY>
-__global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned ntiles)
+// kClearTiles lanes (= tiles) per block: 1024 for large grids (one list atomic per 1024 tiles), 256 for small ones
+// (a 200 x 221 x 200 grid has 17 500 tiles: 18 blocks of 1024 would leave most of the machine idle).
+template <bool LAZY, int kClearTiles>
+__global__ __launch_bounds__(kClearTiles) void k_brick_clear(IntegrateParams p, unsigned ntiles)
 {
   __shared__ unsigned todo[kClearTiles];
-  __shared__ unsigned ntodo;
+  __shared__ unsigned ntodo, wave_listed[kClearTiles / 64], list_base;
   if (threadIdx.x == 0) ntodo = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.tile_count_next = 0u;  // the counter the next sweep appends to
   __syncthreads();
@@ -271,26 +273,32 @@ __global__ __launch_bounds__(256) void k_brick_clear(IntegrateParams p, unsigned
     else if (clear)
       p.tile_state[tile] = p.epoch;
   }
-  // one atomic per wavefront for the list (thousands of lanes appending one entry each to one counter otherwise)
-  {
-    const unsigned long long m = __ballot(any);
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (m) {
-      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.tile_count, (unsigned)__popcll(m));
-      base = __shfl(base, __ffsll((long long)m) - 1);
-      if (any) p.tile_list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = tile | (whole ? 0x80000000u : 0u);
-    }
-  }
+  // one atomic per BLOCK for the list: same-address atomics serialise in the L2 (one per wavefront was measured as
+  // most of the classifier of the background-skip sweep, kernels_skip.hip)
+  const unsigned long long m = __ballot(any);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_listed[wave] = (unsigned)__popcll(m);
   if (clear) todo[atomicAdd(&ntodo, 1u)] = tile;
   __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (int w = 0; w < kClearTiles / 64; ++w) {
+      const unsigned c = wave_listed[w];
+      wave_listed[w] = total;  // exclusive prefix
+      total += c;
+    }
+    list_base = total ? atomicAdd(p.tile_count, total) : 0u;
+  }
+  __syncthreads();
+  if (any)
+    p.tile_list[list_base + wave_listed[wave] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = tile | (whole ? 0x80000000u : 0u);
   const unsigned n = ntodo;
   if (n == 0) return;
   typedef float v4f __attribute__((ext_vector_type(4)));
   const float l = -p.limit;
   const v4f fill = {l, l, l, l};
   v4f* out = reinterpret_cast<v4f*>(p.tsdf);
-  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += 256)
+  for (unsigned i = threadIdx.x; i < n * (kTileVoxels / 4); i += kClearTiles)
     __builtin_nontemporal_store(fill, out + (size_t)todo[i / (kTileVoxels / 4)] * (kTileVoxels / 4) + (i % (kTileVoxels / 4)));
 }
 
@@ -301,10 +309,15 @@ static void launch_list_n(const IntegrateParams& p, unsigned blocks, hipStream_t
 }
 void launch_brick_sweep(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
 {
-  if (p.brick_counters)
-    hipLaunchKernelGGL(k_brick_clear<true>, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
-  else
-    hipLaunchKernelGGL(k_brick_clear<false>, dim3((ntiles + kClearTiles - 1) / kClearTiles), dim3(256), 0, s, p, ntiles);
+  const bool big = ntiles > 65536u;
+  const unsigned t = big ? 1024u : 256u, grid = (ntiles + t - 1) / t;
+  if (p.brick_counters) {
+    if (big) hipLaunchKernelGGL((k_brick_clear<true, 1024>), dim3(grid), dim3(t), 0, s, p, ntiles);
+    else hipLaunchKernelGGL((k_brick_clear<true, 256>), dim3(grid), dim3(t), 0, s, p, ntiles);
+  } else {
+    if (big) hipLaunchKernelGGL((k_brick_clear<false, 1024>), dim3(grid), dim3(t), 0, s, p, ntiles);
+    else hipLaunchKernelGGL((k_brick_clear<false, 256>), dim3(grid), dim3(t), 0, s, p, ntiles);
+  }
   const unsigned blocks = ntiles < 2560u ? ntiles : 2560u;  // 10 resident blocks (5 wavefronts per SIMD) on each of the 256 CUs
   switch (p.N) {
     case 1: launch_list_n<1>(p, blocks, s); break;

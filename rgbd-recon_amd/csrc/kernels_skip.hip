@@ -107,16 +107,17 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
 // this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
 // Otherwise {tile, verdicts, window origins} goes on the list of k_integrate_tiled_listed.
 // One lane per (tile, sensor) pair takes that pair's verdict -- the four words of the pair are read coalesced, the three
-// bounds behind the window origin are one dependent round trip, every pair of the block in flight at once (round 2: one
-// lane per tile walked its sensors in turn, N x 2 dependent round trips at 4 wavefronts per SIMD: 94 % of the wave
-// cycles waiting, 50 us for 61 MB) -- then one lane per tile combines them from LDS.
-constexpr int kClassifyThreads = 256;
+// bounds behind the window origin are one dependent round trip, every pair of the block in flight at once -- then one
+// lane per tile combines them from LDS, and the block appends its listed tiles with ONE atomic on the list counter
+// (round 2: one lane per tile walked its sensors in turn and every wavefront took its own atomic on that one word:
+// 4096 same-address atomics were most of the kernel's 50 us).
+constexpr int kClassifyThreads = 1024;
 __global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegrateParams p, unsigned ntiles, unsigned tiles_per_block)
 {
   __shared__ unsigned char verdict[kClassifyThreads];  // [tile in block][sensor]
   __shared__ int origin[kClassifyThreads];             // the pair's window origin word (goes into the list entry)
   __shared__ unsigned todo[kClassifyThreads];          // tile | (value is +limit) << 31
-  __shared__ unsigned ntodo;
+  __shared__ unsigned ntodo, wave_listed[kClassifyThreads / 64], list_base;
   if (threadIdx.x == 0) ntodo = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.skip_count_next = 0u;  // the counter the next sweep appends to
   const unsigned N = (unsigned)p.N;
@@ -149,23 +150,27 @@ __global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegratePar
       p.tile_state[tile] = 0u;  // about to hold integrated values
     }
   }
-  if (threadIdx.x < 64 || tiles_per_block > 64) {  // the wavefronts that hold tiles (wave-uniform condition)
-    const unsigned long long m = __ballot(listed);
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (m) {
-      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(p.skip_count, (unsigned)__popcll(m));
-      base = __shfl(base, __ffsll((long long)m) - 1);
-      if (listed) {  // entry: tile, verdicts, the N window origins (so that the sweep's window loads wait for one load, not two)
-        unsigned* e = p.skip_list + (size_t)(base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + N);
-        e[0] = tile;
-        e[1] = actions;
-        for (unsigned s = 0; s < N; ++s) e[2 + s] = (unsigned)origin[threadIdx.x * N + s];
-      }
-    }
-  }
+  const unsigned long long m = __ballot(listed);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_listed[wave] = (unsigned)__popcll(m);
   if (fill) todo[atomicAdd(&ntodo, 1u)] = tile | (positive ? 0x80000000u : 0u);
   __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (int w = 0; w < kClassifyThreads / 64; ++w) {
+      const unsigned c = wave_listed[w];
+      wave_listed[w] = total;  // exclusive prefix
+      total += c;
+    }
+    list_base = total ? atomicAdd(p.skip_count, total) : 0u;
+  }
+  __syncthreads();
+  if (listed) {  // entry: tile, verdicts, the N window origins (so that the sweep's window loads wait for one load, not two)
+    unsigned* e = p.skip_list + (size_t)(list_base + wave_listed[wave] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + N);
+    e[0] = tile;
+    e[1] = actions;
+    for (unsigned s = 0; s < N; ++s) e[2 + s] = (unsigned)origin[threadIdx.x * N + s];
+  }
   const unsigned n = ntodo;
   if (n == 0) return;
   typedef float v4f __attribute__((ext_vector_type(4)));
