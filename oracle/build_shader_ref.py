@@ -29,10 +29,16 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # `#include </x>` names -> files: globjects::NamedString::create calls of framework/NetKinectArray.cpp:90,208-209
-INCLUDES = {"/inc_bbox_test.glsl": "inc_bbox_test.glsl", "/inc_color.glsl": "inc_color.glsl", "/bricks.glsl": "inc_bricks.glsl"}
+# ... and reconstruction.cpp:24 ("/shading.glsl")
+INCLUDES = {"/inc_bbox_test.glsl": "inc_bbox_test.glsl", "/inc_color.glsl": "inc_color.glsl", "/bricks.glsl": "inc_bricks.glsl",
+            "/shading.glsl": "shading.glsl"}
 SHADERS = {"pre_morph": "pre_morph.fs", "pre_depth": "pre_depth.fs", "pre_boundary": "pre_boundary.fs", "pre_normal": "pre_normal.fs",
-           "pre_quality": "pre_quality.fs", "tsdf_integration": "tsdf_integration.vs"}
-KIND = {"sampler2DArray": "s", "sampler3D": "t", "sampler2D": "x", "image3D": "i", "uint_buffer": "b"}
+           "pre_quality": "pre_quality.fs", "tsdf_integration": "tsdf_integration.vs",
+           # consumers of the volume: the ray-marcher and the screen-space hole filling
+           "tsdf_raymarch": "tsdf_raymarch.fs", "framebuffer_transfer": "framebuffer_transfer.fs", "tsdf_inpaint": "tsdf_inpaint.fs",
+           "tsdf_colorfill": "tsdf_colorfill.fs"}
+KIND = {"sampler2DArray": "s", "sampler3D": "t", "sampler2D": "x", "image3D": "i", "image2D": "i", "uint_buffer": "b"}
+SCALARS = r"(?:float|int|uint|bool|vec[234]|ivec[234]|uvec[234]|mat4)"
 FLOAT_LIT = re.compile(r"(?<![\w.])(\d+\.\d*|\.\d+)([eE][+-]?\d+)?(?![\w.])")
 SWIZZLE = re.compile(r"\.([xyzw]{2,4}|[rgba]{2,4}|[stpq]{2,4})\b(?!\s*\()")
 
@@ -79,6 +85,8 @@ def transform(text):
             raise SystemExit("interface block member not understood: %r" % line)
         # globals with storage qualifiers
         m = re.match(r"\s*(?:layout\s*\([^)]*\)\s*)?(?:noperspective\s+)?(uniform|in|out)\s+(\w+)\s*(?:\[\s*(\d+)\s*\])?\s+(\w+)\s*;", code)
+        if m and m.group(4).startswith("gl_") and m.group(1) != "uniform":
+            continue                                  # gl_FragCoord / gl_FragDepth belong to the runtime
         if m:
             role = {"uniform": "u", "in": "i", "out": "o"}[m.group(1)]
             cnt = int(m.group(3) or 1)
@@ -95,6 +103,8 @@ def transform(text):
     body = re.sub(r"([(,]\s*)in\s+(?=\w+\s+\w+\s*[,)])", r"\1", body)
     body = re.sub(r"([(,]\s*)out\s+(\w+)\s+(?=\w+\s*[,)])", r"\1\2& ", body)
     body = SWIZZLE.sub(lambda m: ".%s()" % m.group(1), body)
+    body = rewrite_arrays(body)
+    body, inits = hoist_global_initialisers(body)
     # float literals: outside of preprocessor lines and comments
     lines = []
     for line in body.splitlines():
@@ -104,7 +114,52 @@ def transform(text):
         parts = line.split("//", 1)
         parts[0] = FLOAT_LIT.sub(lambda m: m.group(0) + "f", parts[0])
         lines.append("//".join(parts))
-    return "\n".join(lines), slots
+    return "\n".join(lines) + "\nstatic void shader_globals_init()\n{\n" + "".join(
+        "  " + FLOAT_LIT.sub(lambda m: m.group(0) + "f", i) + "\n" for i in inits) + "}\n", slots
+
+
+def balanced(text, open_at):
+    """index just past the parenthesis that closes the one at text[open_at]"""
+    depth = 0
+    for i in range(open_at, len(text)):
+        depth += text[i] == "("
+        depth -= text[i] == ")"
+        if depth == 0:
+            return i + 1
+    raise SystemExit("unbalanced parentheses")
+
+
+def rewrite_arrays(body):
+    """GLSL array syntax C++ does not have: `T name[N] = T[N](a, b, ...)` (array constructor), `T[N] name` (array-typed
+    variable), `T[N] f(...)` (array-returning function) -> std::array<T, N>"""
+    out, pos = [], 0
+    for m in re.finditer(r"\b(const\s+)?(\w+)\s+(\w+)\s*\[\s*(\d+)\s*\]\s*=\s*(\w+)\s*\[\s*(\d+)\s*\]\s*\(", body):
+        if m.start() < pos or m.group(2) != m.group(5) or m.group(4) != m.group(6):
+            continue
+        end = balanced(body, m.end() - 1)
+        out.append(body[pos:m.start()])
+        out.append("%sstd::array<%s, %s> %s = {{%s}}" % (m.group(1) or "", m.group(2), m.group(4), m.group(3), body[m.end():end - 1]))
+        pos = end
+    out.append(body[pos:])
+    body = "".join(out)
+    return re.sub(r"\b(\w+)\s*\[\s*(\d+)\s*\]\s+(\w+)\b", lambda m: "std::array<%s, %s> %s" % m.groups(), body)
+
+
+def hoist_global_initialisers(body):
+    """A non-const global with an initialiser is initialised at the start of every shader invocation in GLSL (it may
+    depend on uniforms: `float sampleDistance = limit * 0.5f;`); a C++ global would be initialised once at load time.
+    Such declarations keep only `T name;` and the assignment moves into shader_globals_init(), run before main()."""
+    lines, inits, depth = [], [], 0
+    for line in body.splitlines():
+        code = line.split("//")[0]
+        m = re.match(r"^(\s*)(%s)\s+(\w+)\s*=\s*(.+);\s*$" % SCALARS, code) if depth == 0 else None
+        if m:
+            lines.append("%s%s %s;" % (m.group(1), m.group(2), m.group(3)))
+            inits.append("%s = %s;" % (m.group(3), m.group(4)))
+        else:
+            lines.append(line)
+        depth += code.count("{") - code.count("}")
+    return "\n".join(lines), inits
 
 
 HARNESS = r'''
@@ -168,6 +223,7 @@ __attribute__((visibility("default"))) void shref_%(name)s_run(int W, int H)
   for (int py = 0; py < H; ++py)
     for (int px = 0; px < W; ++px) {
       pass_TexCoord = vec2(((float)px + 0.5f) / (float)W, ((float)py + 0.5f) / (float)H);
+      shader_globals_init();
       shader_main();
       store_outputs((size_t)py * W + px);
     }
@@ -182,8 +238,81 @@ __attribute__((visibility("default"))) void shref_%(name)s_run(int X, int Y, int
     for (int y = 0; y < Y; ++y)
       for (int x = 0; x < X; ++x) {
         in_Position = vec3((x + 0.5f) * stepX, (y + 0.5f) * stepY, (z + 0.5f) * stepZ);
+        shader_globals_init();
         shader_main();
       }
+}
+'''
+
+
+RUN_RAYMARCH = r'''
+// tsdf_raymarch.fs over a W x H viewport.  Stand-ins for the fixed-function parts (as in the oracle): the unit cube is
+// "rasterised" onto a pixel when the ray through its centre meets the cube in front of the camera (the shader's own
+// intersectBox decides), pass_Position is the volume-space far-plane point of that ray (screenToVol with the host's
+// inverses), the framebuffer starts cleared to (0,1,0,0) / depth 1 (ViewLod::enable), gl_FragDepth is clamped and
+// tested GL_LESS.  inverse(mat4) inside the shader returns the host's inverses (registered pairs).
+__attribute__((visibility("default"))) void shref_%(name)s_add_inverse(const float* m, const float* inv)
+{
+  InversePair p;
+  std::memcpy(&p.m, m, sizeof(mat4));
+  std::memcpy(&p.inv, inv, sizeof(mat4));
+  g_inverses.push_back(p);
+}
+__attribute__((visibility("default"))) void shref_%(name)s_run(int W, int H, const float* modelview_inv, const float* vol_to_world_inv,
+                                                               float* out_color, float* out_depth)
+{
+  mat4 mvi, v2wi;
+  std::memcpy(&mvi, modelview_inv, sizeof(mat4));
+  std::memcpy(&v2wi, vol_to_world_inv, sizeof(mat4));
+  for (int py = 0; py < H; ++py)
+    for (int px = 0; px < W; ++px) {
+      const size_t o = (size_t)py * W + px;
+      out_color[o * 4 + 0] = 0.0f;
+      out_color[o * 4 + 1] = 1.0f;
+      out_color[o * 4 + 2] = 0.0f;
+      out_color[o * 4 + 3] = 0.0f;
+      out_depth[o] = 1.0f;
+      shader_globals_init();
+      const vec4 pc = img_to_eye_curr * vec4((float)px + 0.5f, (float)py + 0.5f, 1.0f, 1.0f);
+      const vec4 es = vec4(pc.x / pc.w, pc.y / pc.w, pc.z / pc.w, 1.0f);
+      const vec4 tv = v2wi * (mvi * es);
+      pass_Position = vec3(tv.x, tv.y, tv.z);
+      float t0 = 0.0f, t1 = 0.0f;
+      const bool is_t0 = intersectBox(CameraPos, normalize(pass_Position - CameraPos) * sampleDistance, t0, t1);
+      if (!is_t0 || !(t1 > 0.0f)) continue;  // no fragment
+      gl_FragCoord = vec4((float)px + 0.5f, (float)py + 0.5f, 0.0f, 1.0f);
+      gl_FragDepth = 0.0f;
+      g_discarded = false;
+      shader_main();
+      if (g_discarded) continue;
+      const float d = gl_FragDepth < 0.0f ? 0.0f : (gl_FragDepth > 1.0f ? 1.0f : gl_FragDepth);
+      if (!(d < 1.0f)) continue;
+      std::memcpy(out_color + o * 4, &out_Color, 16);
+      out_depth[o] = d;
+    }
+}
+'''
+RUN_VIEWPORT = r'''
+// a ScreenQuad::draw into the viewport (x0, y0, w, h) of an FW-wide RGBA32F + depth atlas (ViewLod::enable,
+// view_lod.cpp:73-92) with glDepthFunc(GL_ALWAYS) (recon_integration.cpp:281): every fragment writes out_FragColor and
+// gl_FragDepth.  pass_TexCoord runs over the quad, gl_FragCoord is the window pixel (integer centres where the shader
+// declares layout(pixel_center_integer)).
+__attribute__((visibility("default"))) void shref_%(name)s_run(int x0, int y0, int w, int h, int integer_centres, float* color, float* depth,
+                                                               int FW)
+{
+  for (int py = 0; py < h; ++py)
+    for (int px = 0; px < w; ++px) {
+      const float c = integer_centres ? 0.0f : 0.5f;
+      gl_FragCoord = vec4((float)(x0 + px) + c, (float)(y0 + py) + c, 0.0f, 1.0f);
+      pass_TexCoord = vec2(((float)px + 0.5f) / (float)w, ((float)py + 0.5f) / (float)h);
+      gl_FragDepth = 0.0f;
+      g_discarded = false;
+      shader_globals_init();
+      shader_main();
+      const size_t o = (size_t)(y0 + py) * FW + (x0 + px);
+      std::memcpy(color + o * 4, &out_FragColor, 16);
+      depth[o] = gl_FragDepth;
+    }
 }
 '''
 
@@ -195,7 +324,8 @@ def generate(name, glsl_dir):
     for (n, t, cnt, role) in slots:
         kind = KIND.get(t, "o" if role == "o" else "u")
         reg.append('    r["%s"] = Slot{(void*)&%s, sizeof(%s), %d, \'%s\'};' % (n, n + ("[0]" if cnt > 1 else ""), t, cnt, kind))
-    run = (RUN_VERTEX if name == "tsdf_integration" else RUN_FRAGMENT) % {"name": name}
+    run = {"tsdf_integration": RUN_VERTEX, "tsdf_raymarch": RUN_RAYMARCH, "framebuffer_transfer": RUN_VIEWPORT,
+           "tsdf_inpaint": RUN_VIEWPORT, "tsdf_colorfill": RUN_VIEWPORT}.get(name, RUN_FRAGMENT) % {"name": name}
     return ('// GENERATED from the reference\'s glsl/%s by oracle/build_shader_ref.py -- scratch file, never committed\n'
             '#include "glsl_runtime.hpp"\nnamespace glslrt {\nnamespace shader_%s {\n' % (SHADERS[name], name)
             + body + "\n" + HARNESS % {"name": name, "reg": "\n".join(reg), "run": run})

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <array>
 #include <map>
 #include <string>
 #include <vector>
@@ -31,6 +32,7 @@ void orc_tex3d_linear(const float* vol, int ch, int rx, int ry, int rz, float u,
 void orc_tex2d_linear(const float* img, int ch, int W, int H, float u, float v, float* out);
 void orc_tex2d_linear_rgb8(const uint8_t* img, int W, int H, float u, float v, float* out);
 int orc_axis_nearest(float s, int n);
+void orc_tex2d_linear_mirrored_rgba(const float* col, int FW, int H, float u, float v, float* out);
 }
 
 namespace glslrt {
@@ -41,7 +43,22 @@ using glm::uvec3;
 using glm::vec2;
 using glm::vec3;
 using glm::vec4;
+using glm::mat4;
 typedef unsigned int uint;
+
+// ---- fragment state the fixed-function pipeline owns ------------------------------------------------------------
+static vec4 gl_FragCoord;
+static float gl_FragDepth;
+static bool g_discarded;
+struct DepthRange {
+  float near = 0.0f, far = 1.0f;  // glDepthRange is never changed by the reference
+};
+static DepthRange gl_DepthRange;
+#define discard          \
+  do {                   \
+    g_discarded = true;  \
+    return;              \
+  } while (0)
 
 // ---- samplers ----------------------------------------------------------------------------------------------
 struct sampler2DArray {  // [layers][H][W][ch] f32, or RGB8 when u8 is set; LINEAR or NEAREST, CLAMP_TO_EDGE
@@ -67,8 +84,14 @@ struct sampler3D {  // [rz][ry][rx][ch] f32, LINEAR, CLAMP_TO_EDGE
   const float* f32 = nullptr;
   int rx = 0, ry = 0, rz = 0, ch = 0;
 };
-struct sampler2D {
-  int unused = 0;
+struct sampler2D {  // [H][W][ch] f32; mode 0 NEAREST / CLAMP_TO_EDGE, 1 LINEAR / MIRRORED_REPEAT (the ViewLod colour atlas)
+  const float* f32 = nullptr;
+  int W = 0, H = 0, ch = 0;
+  int mode = 0;
+};
+struct image2D {  // r32f, write only
+  float* f32 = nullptr;
+  int W = 0, H = 0;
 };
 struct image3D {  // r32f, write only: x fastest
   float* f32 = nullptr;
@@ -102,6 +125,31 @@ inline vec4 texture(const sampler3D& s, const vec3& c)
   float out[4] = {0.0f, 0.0f, 0.0f, 1.0f};
   orc_tex3d_linear(s.f32, s.ch, s.rx, s.ry, s.rz, c.x, c.y, c.z, out);
   return vec4(out[0], out[1], out[2], out[3]);
+}
+// texelFetch outside the texture is undefined in GL; the oracle's convention (zeros) -- tsdf_inpaint.fs reaches
+// outside at the atlas borders
+inline vec4 texelFetch(const sampler2D& s, const ivec2& p, int /*lod*/)
+{
+  float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (p.x >= 0 && p.y >= 0 && p.x < s.W && p.y < s.H)
+    for (int k = 0; k < s.ch; ++k) out[k] = s.f32[((size_t)p.y * s.W + p.x) * s.ch + k];
+  return vec4(out[0], out[1], out[2], out[3]);
+}
+inline vec4 texture(const sampler2D& s, const vec2& c)
+{
+  float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (s.mode == 1 && s.ch == 4) {
+    orc_tex2d_linear_mirrored_rgba(s.f32, s.W, s.H, c.x, c.y, out);
+  } else {
+    const int ix = orc_axis_nearest(c.x, s.W), iy = orc_axis_nearest(c.y, s.H);
+    for (int k = 0; k < s.ch; ++k) out[k] = s.f32[((size_t)iy * s.W + ix) * s.ch + k];
+  }
+  return vec4(out[0], out[1], out[2], out[3]);
+}
+inline void imageStore(image2D& img, const ivec2& p, const vec4& v)
+{
+  if (p.x < 0 || p.y < 0 || p.x >= img.W || p.y >= img.H) return;
+  img.f32[(size_t)p.y * img.W + p.x] = v.x;
 }
 inline void imageStore(image3D& img, const ivec3& p, const vec4& v)
 {
@@ -153,11 +201,32 @@ inline vec3 cross(const vec3& x, const vec3& y)
 {
   return vec3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
+inline float ceil(float x) { return ceilf(x); }
+inline vec2 min(const vec2& a, const vec2& b) { return vec2(min(a.x, b.x), min(a.y, b.y)); }
+inline vec2 max(const vec2& a, const vec2& b) { return vec2(max(a.x, b.x), max(a.y, b.y)); }
+inline vec3 min(const vec3& a, const vec3& b) { return vec3(min(a.x, b.x), min(a.y, b.y), min(a.z, b.z)); }
+inline vec3 max(const vec3& a, const vec3& b) { return vec3(max(a.x, b.x), max(a.y, b.y), max(a.z, b.z)); }
+inline vec2 floor(const vec2& v) { return vec2(floorf(v.x), floorf(v.y)); }
+// clamp(x, lo, hi) = min(max(x, lo), hi), also where lo > hi (tsdf_colorfill.fs:33 beyond the last LOD; GL: undefined)
+inline vec2 clamp(const vec2& v, const vec2& lo, const vec2& hi) { return min(max(v, lo), hi); }
+// inverse(mat4) is evaluated by the GPU in the reference (tsdf_raymarch.fs:387-388); the oracle takes the inverses the
+// host computed (rgbdr_view: modelview_inv, vol_to_world_inv).  The harness registers those pairs here.
+struct InversePair {
+  mat4 m, inv;
+};
+static std::vector<InversePair> g_inverses;
+inline mat4 inverse(const mat4& m)
+{
+  for (const InversePair& p : g_inverses)
+    if (std::memcmp(&p.m, &m, sizeof(mat4)) == 0) return p.inv;
+  return glm::inverse(m);
+}
 // driver-defined in GLSL; the oracle's conventions (DESIGN.md section 2 "Numeric conventions")
 inline float length(const vec2& v) { return sqrtf(dot(v, v)); }
 inline float length(const vec3& v) { return sqrtf(dot(v, v)); }
 inline float distance(float a, float b) { return fabsf(a - b); }
 inline float distance(const vec3& a, const vec3& b) { return length(vec3(a.x - b.x, a.y - b.y, a.z - b.z)); }
+inline float distance(const vec2& a, const vec2& b) { return length(vec2(a.x - b.x, a.y - b.y)); }
 inline vec3 normalize(const vec3& v)
 {
   const float l = sqrtf(dot(v, v));
@@ -170,18 +239,26 @@ inline float pow(float x, float y)
     const float x2 = x * x, x4 = x2 * x2;
     return x4 * x2;
   }
+  if (y == 20.0f) {  // shading.glsl:45
+    const float r2 = x * x, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+    return r16 * r4;
+  }
   return powf(x, y);
 }
 
-// GLSL lets vec3 * uvec3 convert implicitly (tsdf_integration.vs:57 `position * res_tsdf`); glm has no mixed operator
+// GLSL converts integer vectors to float vectors implicitly (tsdf_integration.vs:57 `position * res_tsdf`,
+// framebuffer_transfer.fs:14 `pass_TexCoord * resolution_tex`, tsdf_colorfill.fs:24 `ivec2(...) + vec2(...) * pos`);
+// glm has no mixed operators
 inline vec3 operator*(const vec3& a, const uvec3& b) { return vec3(a.x * (float)b.x, a.y * (float)b.y, a.z * (float)b.z); }
+inline vec2 operator*(const vec2& a, const uvec2& b) { return vec2(a.x * (float)b.x, a.y * (float)b.y); }
+inline vec2 operator+(const ivec2& a, const vec2& b) { return vec2((float)a.x + b.x, (float)a.y + b.y); }
 
 // ---- registry: uniforms / samplers / outputs by name, filled by the generated code ---------------------------
 struct Slot {
   void* ptr;
   size_t bytes;  // of one element
   int count;     // array length (1 for scalars)
-  char kind;     // 'u' plain data, 's' sampler2DArray, 't' sampler3D, 'i' image3D, 'b' uint_buffer
+  char kind;     // 'u' plain data, 's' sampler2DArray, 't' sampler3D, 'i' image, 'b' uint_buffer, 'o' output
 };
 typedef std::map<std::string, Slot> Registry;
 }  // namespace glslrt

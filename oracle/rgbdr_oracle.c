@@ -1321,6 +1321,16 @@ static void fc_texture(const float* col, const fc_layout* L, float u, float v, f
   }
 }
 
+/* the sampler above for the shader-text harness (oracle/glsl_runtime.hpp): an FW x H RGBA32F texture */
+ORC_API void orc_tex2d_linear_mirrored_rgba(const float* col, int FW, int H, float u, float v, float* out)
+{
+  fc_layout L;
+  memset(&L, 0, sizeof(L));
+  L.FW = FW;
+  L.H = H;
+  fc_texture(col, &L, u, v, out);
+}
+
 static void fc_clear(float* col, float* dep, const fc_layout* L)
 {
   for (size_t i = 0; i < (size_t)L->FW * L->H; ++i) {

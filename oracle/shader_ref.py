@@ -259,3 +259,132 @@ def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=N
         itg.run(X, Y, Z, 0, Z)
         out["tsdf"] = tsdf
     return out
+
+
+# ---- consumers of the volume: tsdf_raymarch.fs + shading.glsl, and the hole filling of fillColors -----
+class Sampler2D(C.Structure):
+    _fields_ = [("f32", C.c_void_p), ("W", C.c_int), ("H", C.c_int), ("ch", C.c_int), ("mode", C.c_int)]
+
+
+class Image2D(C.Structure):
+    _fields_ = [("f32", C.c_void_p), ("W", C.c_int), ("H", C.c_int)]
+
+
+def raymarch(view_bytes, tsdf, inv_luts, uv_luts, colors, depth_bs, quals, limit=0.01, peels=None):
+    """tsdf_raymarch.fs compiled, with the uniforms ReconIntegration::draw sets (recon_integration.cpp:74-87,177-206);
+    the arguments and results of pyoracle.raymarch."""
+    import pyoracle
+    v = pyoracle.View.from_buffer_copy(view_bytes)
+    n = len(inv_luts)
+    W, H = v.width, v.height
+    sh = Shader("tsdf_raymarch")
+    keep = []
+
+    def mat(field):
+        a = np.array(list(getattr(v, field)), np.float32)
+        keep.append(a)
+        return a
+
+    mv, proj, v2w = mat("modelview"), mat("projection"), mat("vol_to_world")
+    # gl_NormalMatrix = inverseTranspose(modelview) (the compatibility-profile built-in); only its inverse is used
+    glnm = np.ascontiguousarray(np.linalg.inv(mv.reshape(4, 4).T.astype(np.float64)).T.T.reshape(-1).astype(np.float32))
+    sh.set("gl_ModelViewMatrix", mv)
+    sh.set("gl_ProjectionMatrix", proj)
+    sh.set("gl_NormalMatrix", glnm)
+    sh.set("NormalMatrix", mat("normal_matrix"))
+    sh.set("vol_to_world", v2w)
+    sh.set("img_to_eye_curr", mat("img_to_eye"))
+    sh.f("CameraPos", list(v.camera_pos))
+    add_inverse = getattr(lib(), "shref_tsdf_raymarch_add_inverse")
+    add_inverse.argtypes = [C.c_void_p, C.c_void_p]
+    for m, inv in ((mv, mat("modelview_inv")), (v2w, mat("vol_to_world_inv")), (glnm, mat("gl_normal_matrix_inv"))):
+        add_inverse(m.ctypes.data, inv.ctypes.data)
+    sh.u("num_kinects", n)
+    sh.f("limit", limit)
+    sh.b("skipSpace", bool(v.skip_space))
+    sh.f("viewport_offset", [0.0, 0.0])
+    sh.i("g_shade_mode", v.shade_mode)
+    for i in range(n):
+        sh.volume("cv_xyz_inv", inv_luts[i], i)
+        sh.volume("cv_uv", uv_luts[i], i)
+    t = np.ascontiguousarray(tsdf, np.float32)
+    sh.volume("volume_tsdf", t.reshape(t.shape + (1,)), 0)
+    sh.array_rgb8("kinect_colors", np.stack(colors))
+    sh.array_f32("kinect_depths", np.stack(depth_bs), linear=False)
+    sh.array_f32("kinect_qualities", np.stack(quals), linear=True)
+    sh.array_f32("kinect_normals", np.zeros((n,) + np.asarray(quals[0]).shape + (3,), np.float32), linear=True)   # unused by main()
+    pk = np.ascontiguousarray(peels if peels is not None else np.zeros((H, W, 4)), np.float32)
+    sh.set("depth_peels", Sampler2D(pk.ctypes.data, W, H, 4, 0))
+    ns = np.zeros((H, W), np.float32)                       # m_tex_num_samples->clearImage(0), :207-208
+    sh.set("tex_num_samples", Image2D(ns.ctypes.data, W, H))
+    color = np.empty((H, W, 4), np.float32)
+    depth = np.empty((H, W), np.float32)
+    run = getattr(lib(), "shref_tsdf_raymarch_run")
+    run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    run(W, H, keep[-3].ctypes.data, keep[-2].ctypes.data, color.ctypes.data, depth.ctypes.data)
+    del pk
+    return color, depth, ns
+
+
+def fill_colors(color, depth):
+    """ReconIntegration::fillColors (recon_integration.cpp:280-339) with framebuffer_transfer.fs, tsdf_inpaint.fs and
+    tsdf_colorfill.fs compiled; the atlas layout is ViewLod::setResolution (view_lod.cpp:24-61) through the oracle's
+    fill_layout (host code).  -> (filled colour [H,W,4], depth [H,W])"""
+    import pyoracle
+    color, depth = np.ascontiguousarray(color, np.float32), np.ascontiguousarray(depth, np.float32)
+    H, W = depth.shape
+    nl, FW, off, res = pyoracle.fill_layout(W, H)
+    off = np.ascontiguousarray(off, np.uint32).reshape(20, 2)
+    res = np.ascontiguousarray(res, np.uint32).reshape(20, 2)
+
+    def cleared():                                          # ViewLod::enable: glClearColor(0,1,0,0), depth 1
+        c = np.zeros((H, FW, 4), np.float32)
+        c[..., 1] = 1.0
+        return c, np.ones((H, FW), np.float32)
+
+    def bind(sh, c, d):
+        sh.set("texture_color", Sampler2D(c.ctypes.data, FW, H, 4, 1))       # LINEAR, MIRRORED_REPEAT (view_lod.cpp:52-53)
+        sh.set("texture_depth", Sampler2D(d.ctypes.data, FW, H, 1, 0))       # NEAREST
+
+    def viewport_run(sh, lod, c, d, integer_centres):
+        fn = getattr(lib(), "shref_%s_run" % sh.name)
+        fn.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int]
+        fn(int(off[lod][0]), int(off[lod][1]), int(res[lod][0]), int(res[lod][1]), integer_centres, c.ctypes.data, d.ctypes.data, FW)
+
+    transfer, inpaint, colorfill = Shader("framebuffer_transfer"), Shader("tsdf_inpaint"), Shader("tsdf_colorfill")
+    rinv = np.array([np.float32(1.0) / np.float32(FW), np.float32(1.0) / np.float32(H)], np.float32)
+    for sh in (inpaint, colorfill):
+        for i in range(20):
+            sh.set("texture_offsets", off[i].copy(), i)
+            sh.set("texture_resolutions", res[i].copy(), i)
+        sh.set("resolution_inv", rinv)
+        sh.f("viewport_offset", [0.0, 0.0])
+    transfer.set("resolution_tex", np.array([FW, H], np.uint32))          # ReconIntegration::resize: resolution_full()
+    transfer.i("lod", 0)
+    # m_view_inpaint after draw(): the ray-marched frame in LOD 0 of a cleared atlas
+    a_col, a_dep = cleared()
+    a_col[:, :W], a_dep[:, :W] = color, depth
+    b_col, b_dep = cleared()
+
+    def do_transfer():
+        nonlocal a_col, a_dep, b_col, b_dep
+        bind(transfer, a_col, a_dep)
+        b_col, b_dep = cleared()                             # enable(0): clears colour and depth
+        viewport_run(transfer, 0, b_col, b_dep, 0)
+        a_col, a_dep, b_col, b_dep = b_col, b_dep, a_col, a_dep
+
+    do_transfer()
+    for i in range(1, nl):
+        bind(inpaint, a_col, a_dep)
+        inpaint.i("lod", i - 1)
+        viewport_run(inpaint, i, b_col, b_dep, 1)            # enable(i, false, false): no clear
+        a_col, a_dep, b_col, b_dep = b_col, b_dep, a_col, a_dep
+        do_transfer()
+    # colorfill samples m_view_inpaint2 (the native atlas) into the default framebuffer
+    bind(colorfill, b_col, b_dep)
+    colorfill.i("num_lods", nl)
+    oc, od = np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.float32)
+    fn = getattr(lib(), "shref_tsdf_colorfill_run")
+    fn.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int]
+    fn(0, 0, W, H, 1, oc.ctypes.data, od.ctypes.data, W)
+    return oc, od

@@ -36,6 +36,27 @@ def run_case(name):
     return scene, inv, out
 
 
+def run_views(name, scene, inv, frame):
+    """the frame's volume and images through tsdf_raymarch.fs (+ depth peels from the ORACLE for skip_space: the
+    instanced brick cubes of bricks.{vs,gs,fs} need a rasteriser and are not compiled) and the fill shaders"""
+    import pyoracle
+    n = scene.N
+    scn, cfg, geo, _, _ = shader_cases.build(synth, capi, name)
+    ids, ratio = pyoracle.update_occupied(frame["counters"], cfg.min_voxels_per_brick)
+    mask = np.zeros(frame["counters"].shape, np.uint8)
+    mask[ids] = 1
+    out = {}
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(capi, synth, eye, mode, skip)
+        peels = pyoracle.depth_peels(bytes(view), synth.BBOX_MIN, geo.brick_size, tuple(geo.res_bricks), frame["counters"], mask) if skip else None
+        col, dep, ns = shader_ref.raymarch(bytes(view), frame["tsdf"], inv, scene.uv, [scene.color[i] for i in range(n)],
+                                           frame["depth_b"], frame["quality"], limit=cfg.tsdf_limit, peels=peels)
+        out[key + "_color"], out[key + "_depth"], out[key + "_samples"] = col, dep, ns
+        if fill:
+            out[key + "_filled_color"], out[key + "_filled_depth"] = shader_ref.fill_colors(col, dep)
+    return out
+
+
 def main():
     assert shader_ref.available(), "oracle/_ref/libref_shaders.so is missing: make -C oracle shaders"
     for name in shader_cases.CASES:
@@ -48,6 +69,12 @@ def main():
         np.savez_compressed(path, **arrays)
         print("%-40s %7.1f KiB  surface voxels %d  counted %d" % (name, os.path.getsize(path) / 1024,
               int(np.sum(np.abs(out["tsdf"]) < 0.01)), int(out["counters"].sum())))
+        if name in shader_cases.VIEW_CASES:            # tsdf_raymarch.fs / the hole-filling shaders on that frame
+            views = run_views(name, scene, inv, out)
+            path = os.path.join(HERE, "shader_views_%s.npz" % name)
+            np.savez_compressed(path, **views)
+            print("%-40s %7.1f KiB  %s" % ("  views", os.path.getsize(path) / 1024,
+                  ", ".join("%s: %d px hit" % (k[:-6], int((v < 1).sum())) for k, v in views.items() if k.endswith("_depth"))))
 
 
 if __name__ == "__main__":

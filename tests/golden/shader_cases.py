@@ -32,3 +32,20 @@ def digest(scene, inv):
     for a in (scene.depth, scene.color, *scene.xyz, *scene.uv, *inv):
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+# ---- consumers of the volume: views ray-marched (and hole-filled) from the frames of the cases above -----------------
+# case -> [(key, eye, shade mode, skip_space, hole filling)]; viewport 48 x 36, target (0, 0.9, 0), fov 50
+VIEW_CASES = {
+    "two_sensors_default": [("outside_m0", (2.2, 1.6, 1.9), 0, 0, False), ("outside_m1", (2.2, 1.6, 1.9), 1, 0, False),
+                            ("outside_m2", (2.2, 1.6, 1.9), 2, 0, False), ("outside_m3", (2.2, 1.6, 1.9), 3, 0, False),
+                            ("inside_m0", (0.85, 1.7, 0.8), 0, 0, True), ("outside_skip_fill", (2.2, 1.6, 1.9), 0, 1, True)],
+    "four_sensors_128x106_into_64": [("outside_skip_fill", (2.2, 1.6, 1.9), 0, 1, True), ("inside_m1", (0.85, 1.7, 0.8), 1, 0, False)],
+}
+VIEWPORT = (48, 36)
+
+
+def make_view(capi, synth, eye, mode, skip):
+    v = capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, VIEWPORT[0], VIEWPORT[1], synth.BBOX_MIN, synth.BBOX_MAX, shade_mode=mode)
+    v.skip_space = skip
+    return v

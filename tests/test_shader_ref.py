@@ -120,3 +120,81 @@ def test_hip_path_equals_the_shader_fixtures(pkg, name):
     got = ctx.readback_tsdf()
     assert same_bits(got, fx["tsdf"]), "%d voxels differ" % count_diff(got, fx["tsdf"])
     ctx.close()
+
+
+# ---- consumers of the volume: tsdf_raymarch.fs + shading.glsl, framebuffer_transfer.fs / tsdf_inpaint.fs / tsdf_colorfill.fs ----
+def view_fixture(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", "shader_views_%s.npz" % name))
+
+
+def frame_inputs(pkg, name):
+    """the frame the views are rendered from: the committed pass fixture (what the compiled pass shaders produced)"""
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, pkg.capi, name)
+    fx = fixture(name)
+    return scene, cfg, geo, inv, fx
+
+
+def occupied_mask(orc, counters, min_voxels):
+    ids, _ = orc.update_occupied(counters, min_voxels)
+    mask = np.zeros(counters.shape, np.uint8)
+    mask[ids] = 1
+    return mask
+
+
+@pytest.mark.parametrize("name", sorted(shader_cases.VIEW_CASES))
+def test_oracle_ray_march_and_hole_filling_equal_the_compiled_shader_text(orc, pkg, name):
+    """every view of the case: oracle == compiled tsdf_raymarch.fs (+ shading.glsl) == committed fixture, and for the
+    filled ones oracle == compiled transfer / inpaint / colorfill == fixture.  (Depth peels for space skipping come
+    from the oracle in both: bricks.{vs,gs,fs} draw instanced cubes through a rasteriser, which is not compiled.)"""
+    scene, cfg, geo, inv, fx = frame_inputs(pkg, name)
+    vf = view_fixture(name)
+    n = scene.N
+    have_lib = True
+    try:
+        shader_ref = shader_lib()
+    except pytest.skip.Exception:
+        have_lib = False
+    mask = occupied_mask(orc, fx["counters"], cfg.min_voxels_per_brick)
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(pkg.capi, pkg.synth, eye, mode, skip)
+        peels = orc.depth_peels(bytes(view), pkg.synth.BBOX_MIN, geo.brick_size, tuple(geo.res_bricks), fx["counters"], mask) if skip else None
+        args = (bytes(view), fx["tsdf"], inv, scene.uv, [scene.color[i] for i in range(n)], list(fx["depth_b"]), list(fx["quality"]))
+        oc, od, on = orc.raymarch(*args, limit=cfg.tsdf_limit, peels=peels)
+        for what, got in (("color", oc), ("depth", od), ("samples", on)):
+            assert same_bits(got, vf["%s_%s" % (key, what)]), "oracle vs fixture: %s %s: %d differ" % (key, what, count_diff(got, vf["%s_%s" % (key, what)]))
+        assert 0.02 < (od < 1).mean() < 0.98
+        if fill:
+            fc, fd = orc.fill_colors(oc, od)
+            assert same_bits(fc, vf[key + "_filled_color"]) and same_bits(fd, vf[key + "_filled_depth"])
+        if have_lib:
+            sc, sd, sn = shader_ref.raymarch(*args, limit=cfg.tsdf_limit, peels=peels)
+            assert same_bits(sc, oc) and same_bits(sd, od) and same_bits(sn, on), "compiled shader text vs oracle: %s" % key
+            if fill:
+                gc, gd = shader_ref.fill_colors(sc, sd)
+                assert same_bits(gc, fc) and same_bits(gd, fd), "compiled hole-filling text vs oracle: %s" % key
+    if not have_lib:
+        pytest.skip("oracle == fixtures checked; the compiled shader text exists in the build container only")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(shader_cases.VIEW_CASES))
+def test_hip_ray_march_and_hole_filling_equal_the_shader_fixtures(pkg, name):
+    capi = pkg.capi
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, capi, name)
+    vf = view_fixture(name)
+    n = scene.N
+    ctx = capi.Context(cfg, 0)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(capi, pkg.synth, eye, mode, skip)
+        color, depth, ns = ctx.raymarch(view)
+        for what, got in (("color", color), ("depth", depth), ("samples", ns)):
+            assert same_bits(got, vf["%s_%s" % (key, what)]), "%s %s: %d differ" % (key, what, count_diff(got, vf["%s_%s" % (key, what)]))
+        if fill:
+            fc, fd = ctx.fill_colors(view.width, view.height)
+            assert same_bits(fc, vf[key + "_filled_color"]) and same_bits(fd, vf[key + "_filled_depth"])
+    ctx.close()
