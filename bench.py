@@ -843,14 +843,70 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
                                          ctx.readback_brick_counters(), 10)
     except MemoryError:
         ref_cpu = None
+    ref_text = reference_text_baseline(ctx, scene, capi, synth, hip, sil, db, q, N)
     what = "all %d z rows" % Z if done == Z else "%d of %d z rows, extrapolated to the grid" % (done, Z)
-    return {"reference_cpu_work": ref_cpu, "value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads,
+    return {"reference_cpu_work": ref_cpu, "reference_shader_text": ref_text,
+            "value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads,
             "kind": "port",
             "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota) on the benchmark workload: full "
                       "pre_* chain of the %d-sensor frame (median of 3: %.2f s) + integrate of %s (%.2f s)"
                       % (threads, N, t_pre, what, t_int),
             "integrate_mvoxels_per_s": round(g.res_volume[0] * g.res_volume[1] * done / t_int / 1e6, 2),
             "parity_rows_bit_exact": parity, "parity_rows": done}
+
+
+def reference_text_baseline(ctx, scene, capi, synth, hip, sil, db, q, N, rows=32):
+    """The TEXT of the reference's own shaders compiled as C++ (oracle/_ref/libref_shaders.so, built in the build
+    container by oracle/build_shader_ref.py; samplers are stand-ins, see oracle/glsl_runtime.hpp), one thread, on a
+    bounded sample of the benchmark workload: the pre_* chain of sensor 0 and tsdf_integration.vs on `rows` z rows in
+    the middle of the volume -- timed, and compared bit for bit with the HIP images / volume rows.  None where the
+    library did not travel (it exists only where /root/reference was present at build time)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import shader_ref
+        if not shader_ref.available():
+            return None
+        g = ctx.geo
+        X, Y, Z = g.res_volume
+        z0 = (Z // 2 // 8) * 8
+        inv = [ctx.readback_inverse_calibration(i, z0, z0 + rows) for i in range(N)]
+        # tsdf_integration.vs over the rows: a 1:1 LUT is looked up at texel centres, so the rows are a volume of their own
+        tsdf = np.full((rows, Y, X), -np.float32(0.01), np.float32)
+        itg = shader_ref.Shader("tsdf_integration")
+        for i in range(N):
+            itg.volume("cv_xyz_inv", inv[i], i)
+        itg.array_f32("kinect_silhouettes", np.stack(sil), linear=True)
+        itg.array_f32("kinect_depths", np.stack(db), linear=False)
+        itg.array_f32("kinect_qualities", np.stack(q), linear=True)
+        itg.f("limit", 0.01)
+        itg.u("num_kinects", N)
+        itg.set("res_tsdf", np.array([X, Y, rows], np.uint32))
+        itg.set("volume_tsdf", shader_ref.Image3D(tsdf.ctypes.data, X, Y, rows))
+        t0 = time.perf_counter()
+        itg.run(X, Y, rows, 0, rows)
+        t_int = time.perf_counter() - t0
+        got = hip[z0:z0 + rows]
+        same_vol = bool(np.all((tsdf == got) | (np.isnan(tsdf) & np.isnan(got))))
+
+        class One:                                     # sensor 0 alone through the pre_* shader text
+            pass
+
+        one = One()
+        one.N, one.depth, one.color, one.xyz, one.uv = 1, scene.depth[:1], scene.color[:1], scene.xyz[:1], scene.uv[:1]
+        t0 = time.perf_counter()
+        frame = shader_ref.run_frame(one, synth.BBOX_MIN, synth.BBOX_MAX, (X, Y, Z), None, brick_size=g.brick_size,
+                                     res_bricks=tuple(g.res_bricks))
+        t_pre = time.perf_counter() - t0
+        same_img = all(bool(np.all((frame[k][0] == ctx.readback_image(w, 0)) | (np.isnan(frame[k][0]) & np.isnan(ctx.readback_image(w, 0)))))
+                       for k, w in (("depth_b", capi.IMG_DEPTH_B_RG), ("sil", capi.IMG_SILHOUETTE), ("quality", capi.IMG_QUALITY),
+                                    ("normal", capi.IMG_NORMAL), ("lab", capi.IMG_LAB)))
+        return {"what": "the reference's shader text compiled as C++ (stand-in samplers), 1 thread: tsdf_integration.vs on %d of %d "
+                        "z rows, pre_* chain of 1 of %d sensors" % (rows, Z, N),
+                "integrate_mvoxels_per_s": round(X * Y * rows / t_int / 1e6, 2), "integrate_s": round(t_int, 2),
+                "pre_chain_one_sensor_s": round(t_pre, 2),
+                "hip_rows_bit_identical": same_vol, "hip_images_bit_identical": same_img, "rows": rows}
+    except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 if __name__ == "__main__":
