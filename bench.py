@@ -227,7 +227,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
 
     # several ranks on one GPU (--backend gloo, debugging): no placement shopping, it would hold world x 10 arenas
     trials = 1 if (args.backend == "gloo" and world > 1) else max(1, args.arena_trials)
-    os.environ["RGBDR_ARENA_TRIALS"] = os.environ.get("RGBDR_ARENA_TRIALS_FORCE", str(trials))
+    os.environ["RGBDR_ARENA_TRIALS"] = str(trials)     # read by the library when the LUT arena is created
     load_package()
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
