@@ -30,7 +30,7 @@ def run_case(name):
     G = shader_cases.CASES[name][3]
     out = shader_ref.run_frame(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit,
                                brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), filter_textures=bool(flags & 1),
-                               processed=bool(flags & 2), refine=bool(flags & 4))
+                               processed=bool(flags & 2), refine=bool(flags & 4), compress=name in shader_cases.COMPRESSED_DEPTH)
     assert out["bricks_out_of_range"] == 0, "a marked position left the brick grid: undefined in the shader"
     assert out["offcentre_lookups"] == 0, "a texel-centre sampler was used off centre"
     return scene, inv, out

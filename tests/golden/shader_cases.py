@@ -13,14 +13,22 @@ CASES = {
     "no_filter_raw_depth_no_refine": (2, (48, 40), (12, 10, 12), 24, None, 0, 5),
     "filter_only_fine_inverse_lut": (2, (48, 40), (12, 10, 12), 24, (30, 30, 30), 1, 9),
     "four_sensors_128x106_into_64": (4, (128, 106), (32, 27, 32), 64, None, 7, 1234),
+    # u8 depth frames (compress_depth: pre_depth.fs un-compresses; the reference's u8 + morph combination is incoherent,
+    # SURVEY A.5, so raw depth) and a grid that is not a power of two (voxel centres are not texel centres of a 1:1 LUT)
+    "u8_depth_raw_non_pow2_grid": (2, (64, 53), (16, 14, 16), 40, None, 5, 21),
 }
+COMPRESSED_DEPTH = {"u8_depth_raw_non_pow2_grid"}
 IMAGES = ("morph", "depth_rg", "lab", "depth_b", "sil", "normal", "quality")
 
 
 def build(pkg_synth, capi, name):
     n, wh, lut_res, G, inv_res, flags, seed = CASES[name]
     scene = pkg_synth.Scene(n, wh[0], wh[1], lut_res=lut_res, seed=seed)
-    cfg = capi.make_config(n, wh, voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags | 8)
+    compress = name in COMPRESSED_DEPTH
+    if compress:                   # the frames as the server sends them (u8) and as the raw-depth texture holds them ([0, 1])
+        scene.depth_u8 = pkg_synth.compress_depth_u8(scene.depth)
+        scene.depth = (scene.depth_u8.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    cfg = capi.make_config(n, wh, voxel_size=2.0 / G, brick_size=8 * 2.0 / G, flags=flags | 8, compress_depth=1 if compress else 0)
     geo = capi.compute_geometry(cfg)
     inv_res = inv_res or (G, G, G)
     inv = scene.inverse(inv_res)

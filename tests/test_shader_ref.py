@@ -44,7 +44,8 @@ def oracle_frame(orc, pkg, name):
     flags, G = shader_cases.CASES[name][5], shader_cases.CASES[name][3]
     ref = orc.run_pipeline(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit,
                            brick_size=geo.brick_size, bv=geo.brick_voxels, res_bricks=tuple(geo.res_bricks),
-                           filter_textures=bool(flags & 1), processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=False)
+                           filter_textures=bool(flags & 1), processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=False,
+                           compress=name in shader_cases.COMPRESSED_DEPTH)
     return scene, inv, ref
 
 
@@ -65,7 +66,7 @@ def test_oracle_equals_the_compiled_shader_text(orc, pkg, name):
     geo = pkg.capi.compute_geometry(cfg)
     got = shader_ref.run_frame(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit,
                                brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), filter_textures=bool(flags & 1),
-                               processed=bool(flags & 2), refine=bool(flags & 4))
+                               processed=bool(flags & 2), refine=bool(flags & 4), compress=name in shader_cases.COMPRESSED_DEPTH)
     assert got["bricks_out_of_range"] == 0 and got["offcentre_lookups"] == 0
     compare(got, ref, n, "compiled shader text vs oracle")
     # and the committed fixture is what the compiled text produces today
@@ -111,7 +112,7 @@ def test_hip_path_equals_the_shader_fixtures(pkg, name):
         ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
         ctx.set_inverse_calibration(i, inv[i], inv_res)
     ctx.set_use_bricks(False)
-    ctx.step(scene.depth, scene.color)
+    ctx.step(scene.depth_u8 if name in shader_cases.COMPRESSED_DEPTH else scene.depth, scene.color)
     for k, which in IMG.items():
         for i in range(n):
             got = ctx.readback_image(which, i)
@@ -198,3 +199,32 @@ def test_hip_ray_march_and_hole_filling_equal_the_shader_fixtures(pkg, name):
             fc, fd = ctx.fill_colors(view.width, view.height)
             assert same_bits(fc, vf[key + "_filled_color"]) and same_bits(fd, vf[key + "_filled_depth"])
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_small_scenes_oracle_equals_the_compiled_shader_text(orc, pkg, seed):
+    """beyond the committed cases: random sensor counts, image / LUT / grid sizes (mostly not powers of two), host
+    toggles and limits -- build container only (needs the compiled shader text)"""
+    shader_ref = shader_lib()
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 4))
+    wh = (int(rng.integers(24, 49)), int(rng.integers(20, 41)))
+    lut_res = tuple(int(v) for v in rng.integers(8, 15, 3))
+    G = int(rng.choice([16, 20, 24, 27, 32]))
+    inv_res = None if rng.random() < 0.4 else tuple(int(v) for v in rng.integers(12, 40, 3))
+    flags = int(rng.integers(0, 8))
+    limit = float(rng.choice([0.01, 0.02, 0.035]))
+    scene = pkg.synth.Scene(n, wh[0], wh[1], lut_res=lut_res, seed=int(rng.integers(1, 10000)))
+    cfg = pkg.capi.make_config(n, wh, voxel_size=2.0 / G, brick_size=8 * 2.0 / G, tsdf_limit=limit)
+    geo = pkg.capi.compute_geometry(cfg)
+    res = tuple(geo.res_volume)
+    inv = scene.inverse(inv_res or res)
+    kw = dict(filter_textures=bool(flags & 1), processed=bool(flags & 2), refine=bool(flags & 4))
+    ref = orc.run_pipeline(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, res, inv, limit=cfg.tsdf_limit, brick_size=geo.brick_size,
+                           bv=geo.brick_voxels, res_bricks=tuple(geo.res_bricks), use_bricks=False, **kw)
+    got = shader_ref.run_frame(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, res, inv, limit=cfg.tsdf_limit,
+                               brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), **kw)
+    assert got["offcentre_lookups"] == 0
+    if got["bricks_out_of_range"]:
+        pytest.skip("a marked position left the brick grid: undefined in the shader (the oracle skips it)")
+    compare(got, ref, n, "compiled shader text vs oracle (seed %d)" % seed)
