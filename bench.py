@@ -522,6 +522,11 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         out["roofline"]["avg_launch_ms_first_placement"] = out["roofline"]["avg_launch_ms"]
     if per_rank is not None:
         out["per_rank"] = per_rank
+        # BASELINE.json's multi-GPU configs name 8 sensors, its single-GPU config 4: a voxel of the N > 1 runs costs
+        # twice the LUT bytes of a voxel of the N = 1 run, so `value` (Mvoxels/s) is not comparable across that step
+        out["scaling_note"] = ("N = 1 runs configs[2] (4 sensors), N = 2 / 4 configs[3] (8 sensors, 512^3), N = 8 configs[4] (8 sensors, "
+                               "1024^3): compare voxel_sensor_updates_per_s across N, not value; --weak runs the fixed-sensor weak-"
+                               "scaling grids (4 sensors, 134 M voxels per GPU) instead")
     if loop:
         out["slab"] = {"rank": slab_rank, "of": slab_count, "owned_z_rows": int(g.slab_voxel_z1 - g.slab_voxel_z0),
                        "faces_staged": int(slab_rank > 0) + int(slab_rank < slab_count - 1),

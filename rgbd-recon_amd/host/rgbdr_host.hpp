@@ -381,6 +381,9 @@ class NetKinectArray {
     return updateFromMapped();
   }
   double getCurrentFrameTime() const { return m_curr_frametime; }
+  // glm::uvec2 NetKinectArray::getDepthResolution() / getColorResolution() (NetKinectArray.h:61-62)
+  std::array<unsigned, 2> getDepthResolution() const { return {{(unsigned)m_be.config().depth_w, (unsigned)m_be.config().depth_h}}; }
+  std::array<unsigned, 2> getColorResolution() const { return {{(unsigned)m_be.config().color_w, (unsigned)m_be.config().color_h}}; }
 
   // NetKinectArray::readFromFiles (NetKinectArray.cpp:724-764): one ".stream" file
   // per sensor, frames of [colorsize bytes][depthsize bytes]; reads frame `index`
