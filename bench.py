@@ -694,14 +694,34 @@ def run_rank(args, slab=None, quiet=False, shared=None):
             ctx.enable_timers(False)
         except Exception as e:  # noqa: BLE001 -- extra keys must never cost the headline line
             out["post_pass"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    if rank == 0 and not quiet:
-        emit(out)
     ctx.close()
     if multi:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))
-        if not shared.get("keep_pg"):
-            dist.destroy_process_group()
-            shared["pg"] = False
+    # The same job at fixed work per GPU (extra key): BASELINE.json's metric names 4 sensors into 512^3 on one GPU, its
+    # multi-GPU configs 8 sensors -- so next to configs[3] / configs[4] the run also times the weak-scaling grid with the
+    # N = 1 sensor count (134 M voxels and 4 sensors per GPU: 512x512x1024 / 512x1024x1024 / 1024^3), whose value is
+    # directly comparable with N times the N = 1 value.
+    if world > 1 and not loop and not args.weak and not lean and not args.sensors and not args.grid:
+        try:
+            a2 = argparse.Namespace(**vars(args))
+            a2.weak = True
+            sub = dict(shared)
+            sub.update(lean=True, keep_pg=True)
+            w = run_rank(a2, quiet=True, shared=sub)
+            for k in ("scene", "scene_n", "d_depth", "d_color"):
+                shared.pop(k, None)
+            out["weak_scaling_4_sensors"] = {"grid": w["config"]["grid"], "sensors": w["config"]["sensors"], "value": w["value"],
+                                             "ms_per_step": w["ms_per_step"], "frames_per_s": w["frames_per_s"],
+                                             "voxel_sensor_updates_per_s": w["voxel_sensor_updates_per_s"],
+                                             "per_rank": w.get("per_rank"), "roofline_frac_slowest_rank": w["roofline"]["frac"],
+                                             "comparable_with": "N x the value of the N = 1 run (same sensors, same voxels per GPU)"}
+        except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
+            out["weak_scaling_4_sensors"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if rank == 0 and not quiet:
+        emit(out)
+    if multi and not shared.get("keep_pg"):
+        dist.destroy_process_group()
+        shared["pg"] = False
     return out
 
 

@@ -83,6 +83,12 @@ def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
     assert j["ms_per_step"] >= max(pr["ms_per_step"]) * 0.999
     assert "host-staged" in j["config"]["halo_transport"] and j["halo"]["transfer_ms_max"] > 0
+    # the fixed-work-per-GPU twin of the run: 4 sensors, 134 M voxels per rank -- comparable with N x the N = 1 value
+    w = j["weak_scaling_4_sensors"]
+    assert "error" not in w, w
+    assert w["grid"] == [512, 512, 1024] and w["sensors"] == 4 and w["value"] > 0 and len(w["per_rank"]["integrate_ms"]) == 2
+    assert abs(w["value"] - 512 * 512 * 1024 / (w["ms_per_step"] * 1e-3) / 1e6) < 0.01 * w["value"]
+    assert "voxel_sensor_updates_per_s" in j["scaling_note"]
 
 
 def test_one_slab_of_config_3_as_its_rank_would_run_it():
