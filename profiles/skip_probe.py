@@ -37,6 +37,8 @@ org, dmin, dmax, ext = c.readback_skip_tables(1)
 bounds = c.readback_skip_tables(2)
 print("verdicts", {k: int((v == k).sum()) for k in range(4)}, "tiles with every sensor decided", int((v != 0).all(axis=1).sum()), "of", v.shape[0])
 und = v == 0
+live = und.sum(axis=1)
+print("listed tiles by undecided sensors", {int(k): int((live == k).sum()) for k in range(1, N + 1)})
 notcont = und & ~np.isfinite(dmin)
 ox = (org & 0xffff).astype(np.int16).astype(int) + 1
 oy = (org >> 16).astype(np.int16).astype(int) + 1
