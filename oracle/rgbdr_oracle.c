@@ -23,6 +23,13 @@
  *     (external/squish, the decoder of NetKinectArray.cpp:633).
  * The same shim also pins the C++ host mirror's sensor-yml scanner and .stream reader against
  * kinect::CalibrationFiles / sys::FileBuffer (tests/test_oracle_ref.py).
+ * CHECKED, NOT PINNED (round 3): the TEXT of the reference's shaders -- pre_morph / pre_depth / pre_boundary /
+ * pre_normal / pre_quality .fs, tsdf_integration.vs, tsdf_raymarch.fs + shading.glsl, framebuffer_transfer / tsdf_inpaint /
+ * tsdf_colorfill .fs and their includes -- is compiled as C++ from /root/reference where it lies (oracle/build_shader_ref.py,
+ * against the reference's vendored glm) and run against the functions below on synthetic scenes: bit-identical in every
+ * image, counter, volume and frame (tests/test_shader_ref.py).  The texture samplers and the driver-defined built-ins of
+ * that harness are stand-ins bound to THIS file's conventions (oracle/glsl_runtime.hpp), so it is not a run of the reference
+ * and the pass arithmetic stays "parity unpinned"; it shows that no statement of a shader was mis-read.
  *
  * NUMERIC CONVENTIONS (decisions where GLSL / GL leave the result to the driver):
  *   - all arithmetic is IEEE-754 binary32, no FMA contraction (-ffp-contract=off),
