@@ -100,8 +100,8 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
   if (i < npairs) mask[i] = (uint8_t)skip_verdict(p, i, (int)(i % (unsigned)p.N));
 }
 
-// First half of the RGBDR_FLAG_SKIP_BACKGROUND sweep (the role k_brick_clear has for bricks): one lane per tile
-// takes the verdicts of its N sensors.  If every sensor has one, the tile's 512 voxels all end as the same value --
+// First half of the RGBDR_FLAG_SKIP_BACKGROUND sweep (the role k_brick_clear has for bricks): the verdicts of a
+// tile's N sensors for the current frame.  If every sensor has one, the tile's 512 voxels all end as the same value --
 // over tsd = limit the first carve or in-front verdict makes -limit and nothing after it changes that; hidden from
 // every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
 // this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
