@@ -204,7 +204,8 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv
  * (window <= 0 selects the default 2).
  *   compute_inverse_calibration: directly at this context's grid resolution into the
  *     resident grid layout (what `calib_inverter` + loadInverseCalibs would produce
- *     for a LUT at 1:1);
+ *     for a LUT at 1:1); with RGBDR_FLAG_NO_RESAMPLE -- every sensor of a context is resident in
+ *     one layout -- as an x-fastest RGBA32F volume at the grid resolution instead, looked up per frame;
  *   generate_inverse_lut: a volume of any resolution as x-fastest RGBA32F records in
  *     host memory, ready to be written as a `.cv_xyz_inv` file. */
 int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window);
