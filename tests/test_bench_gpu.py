@@ -99,3 +99,18 @@ def test_one_slab_of_config_3_as_its_rank_would_run_it():
     assert j["config"]["baseline_config"].startswith("configs[3]") and j["config"]["sensors"] == 8
     assert j["roofline"]["bytes_per_launch"] == 512 * 512 * 128 * (4 + 12 * 8) + 8 * 512 * 424 * 8
     assert "true>" in j["roofline"]["kernel"] and j["config"]["halo_transport"] == "rccl"
+
+
+def test_eight_ranks_run_config_4_end_to_end_on_one_gpu():
+    """`python3 bench.py --gpus 8`, the driver's command for BASELINE configs[4] (8 sensors, 1024^3, eight Z slabs with two
+    halo tile layers per face, slab ray-march + hole filling, the weak-scaling twin), with every rank on the one GPU of
+    the box and the halos through the host (gloo): the numbers mean nothing, the whole multi-rank code path runs"""
+    j = run_bench("--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1")
+    assert j["n_gpus"] == 8 and j["config"]["baseline_config"].startswith("configs[4]") and j["config"]["grid"] == [1024, 1024, 1024]
+    pr = j["per_rank"]
+    assert len(pr["integrate_ms"]) == 8 and all(v > 0 for v in pr["integrate_ms"]) and all(v is not None for v in pr["halo_ms"])
+    assert j["halo"]["layers_per_face"] == 2 and j["halo"]["bytes_per_face"] == 2 * 128 * 128 * 2048
+    assert j["roofline"]["bytes_per_launch"] == 1024 * 1024 * 128 * (4 + 12 * 8) + 8 * 512 * 424 * 8
+    assert "error" not in j["post_pass"] and j["post_pass"]["slab_raymarch_composited_ms"] > 0 and j["post_pass"]["surface_pixels"] > 0.05
+    w = j["weak_scaling_4_sensors"]
+    assert "error" not in w and w["grid"] == [1024, 1024, 1024] and w["sensors"] == 4 and len(w["per_rank"]["integrate_ms"]) == 8
