@@ -319,6 +319,9 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
     return ctx->fail(RGBDR_ERR_STATE, "synthetic inverse LUT needs a grid whose voxel centres hit texel centres exactly");
   if (ctx->cfg.flags & RGBDR_FLAG_NO_RESAMPLE)
     return ctx->fail(RGBDR_ERR_STATE, "the synthetic (benchmark) inverse LUT is written in the grid layout only: not with RGBDR_FLAG_NO_RESAMPLE");
+  for (int i = 0; i < nsens(ctx); ++i)
+    if (i != sensor && ctx->inv_set[i] && !ctx->inv_tiled[i])
+      return ctx->fail(RGBDR_ERR_STATE, "other sensors hold file-layout inverse LUTs (the grid-layout arena did not fit when they were set)");
   int rc = ensure_tiled_lut(ctx);
   if (rc != RGBDR_OK) return rc;
   const LutExtent ext = lut_extent(ctx);
