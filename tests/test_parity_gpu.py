@@ -800,7 +800,8 @@ def test_settle_leaves_a_usable_context(pkg, orc):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,G,wh", [(2, 64, (128, 106)), (5, 64, (128, 106)), (3, 96, (200, 150)), (1, 32, (64, 53))])
+@pytest.mark.parametrize("n,G,wh", [(2, 64, (128, 106)), (5, 64, (128, 106)), (3, 96, (200, 150)), (1, 32, (64, 53)),
+                                    (4, 64, (128, 106)), (8, 64, (128, 106)), (7, 40, (96, 80))])
 def test_full_sweep_background_skip(pkg, orc, n, G, wh):
     """RGBDR_FLAG_SKIP_BACKGROUND leaves the LUT planes of (tile, sensor) pairs unread whose window shows only
     background; the volume is the oracle's bit for bit, with and without the flag, also next to store elision,
