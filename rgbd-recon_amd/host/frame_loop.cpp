@@ -14,6 +14,7 @@
 // directory (NetKinectArray.cpp:727-731).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <string>
 
@@ -166,6 +167,37 @@ int main(int argc, char** argv)
       std::fwrite(frame.color.data(), sizeof(float), frame.color.size(), ff);
       std::fwrite(frame.depth.data(), sizeof(float), frame.depth.size(), ff);
       std::fclose(ff);
+      // the anaglyph path of draw3d() (kinect_client.cpp:620-640): without hole filling the left eye is drawn with
+      // glColorMask(red) and the right eye with glColorMask(green, blue) into the same framebuffer
+      recon_integration->setColorFilling(false);
+      mode.setColorMaskMode(0);
+      mode.drawF();                                   // what a plain draw leaves
+      const std::vector<float> plain = recon_integration->frame().color;
+      view.shade_mode = 2;                            // another image (normals) through the masks
+      mode.setView(view);
+      mode.setColorMaskMode(1);
+      mode.drawF();
+      const std::vector<float> red = recon_integration->frame().color;
+      mode.setColorMaskMode(2);
+      mode.drawF();
+      const std::vector<float> both = recon_integration->frame().color;
+      mode.setColorMaskMode(0);
+      mode.drawF();
+      const std::vector<float> normals = recon_integration->frame().color;
+      size_t wrong = 0, hit = 0;
+      const std::vector<float>& depth = recon_integration->frame().depth;
+      for (size_t i = 0; i < depth.size(); ++i) {
+        const bool h = depth[i] < 1.0f;
+        hit += h;
+        for (int c = 0; c < 4; ++c) {
+          const float want_red = (h && c == 0) ? normals[4 * i + c] : plain[4 * i + c];       // only red of hit pixels changed
+          const float want_both = (h && c < 3) ? normals[4 * i + c] : plain[4 * i + c];       // then green and blue; alpha never
+          wrong += std::memcmp(&red[4 * i + c], &want_red, 4) != 0;
+          wrong += std::memcmp(&both[4 * i + c], &want_both, 4) != 0;
+        }
+      }
+      std::printf("color masks: %zu pixels hit, %zu channel values wrong\n", hit, wrong);
+      if (wrong) return 7;
     }
     // error behaviour mirrors the reference's exception types
     try {

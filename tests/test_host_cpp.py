@@ -50,6 +50,10 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
                        text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("res 32 32 32 bricks 64")
+    # Reconstruction::setColorMaskMode through the base pointer (anaglyph path: red, then green + blue of the same pixels)
+    import re
+    m = re.search(r"color masks: (\d+) pixels hit, (\d+) channel values wrong", r.stdout)
+    assert m and int(m.group(1)) > 30 and int(m.group(2)) == 0, r.stdout
     got = np.fromfile(out, dtype=np.float32).reshape(G, G, G)
     # ReconIntegration::drawF through the C++ mirror == the same calls through the ctypes harness
     frame = np.fromfile(out + ".frame", dtype=np.float32)
