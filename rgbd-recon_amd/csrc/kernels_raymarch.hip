@@ -414,11 +414,25 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       }
     }
     bool prev_in_grid = false, first = true;
+    // one mask byte per cell, loaded one cell ahead: the walk itself needs no loads, so the next cell is known before
+    // this cell's faces are looked at and its byte is in flight meanwhile
+    bool last_list = false;                 // was the cell the ray just left on the list?
+    bool cur_list = peel_listed(p, cell);
     float tcur = t0;
     for (int iter = 0; iter < 4096; ++iter) {
+      int a = 0;
+      if (tmax[1] < tmax[a]) a = 1;
+      if (tmax[2] < tmax[a]) a = 2;
+      const float tnext = tmax[a];
+      const bool leaving = !(tnext < t1);
+      int ncell[3] = {cell[0], cell[1], cell[2]};
+      if (a == 0) ncell[0] += stepi[0];
+      else if (a == 1) ncell[1] += stepi[1];
+      else ncell[2] += stepi[2];
+      const bool next_in_grid = !leaving && peel_in_grid(p, ncell);
+      const bool next_list = next_in_grid && p.mask[((size_t)ncell[2] * p.res_bricks[1] + ncell[1]) * p.res_bricks[0] + ncell[0]] != 0;
       if (!(first && !(t0 > 0.0f))) {
-        const bool cur_list = peel_listed(p, cell);
-        const bool prev_list = prev_in_grid && peel_listed(p, prev);
+        const bool prev_list = prev_in_grid && last_list;
         if (cur_list || prev_list) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
@@ -435,12 +449,8 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
         }
       }
       first = false;
-      int a = 0;
-      if (tmax[1] < tmax[a]) a = 1;
-      if (tmax[2] < tmax[a]) a = 2;
-      const float tnext = tmax[a];
-      if (!(tnext < t1)) {
-        if (peel_listed(p, cell)) {
+      if (leaving) {
+        if (cur_list) {
           const float z = peel_z(p, o, d, t1);
           if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);
@@ -454,20 +464,17 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       prev[1] = cell[1];
       prev[2] = cell[2];
       prev_in_grid = true;
+      last_list = cur_list;
+      cell[0] = ncell[0];
+      cell[1] = ncell[1];
+      cell[2] = ncell[2];
       // no runtime-indexed register arrays: step the selected axis explicitly
-      if (a == 0) {
-        cell[0] += stepi[0];
-        tmax[0] += tdelta[0];
-      } else if (a == 1) {
-        cell[1] += stepi[1];
-        tmax[1] += tdelta[1];
-      } else {
-        cell[2] += stepi[2];
-        tmax[2] += tdelta[2];
-      }
+      if (a == 0) tmax[0] += tdelta[0];
+      else if (a == 1) tmax[1] += tdelta[1];
+      else tmax[2] += tdelta[2];
       tcur = tnext;
-      if (!peel_in_grid(p, cell)) {
-        if (peel_listed(p, prev)) {
+      if (!next_in_grid) {
+        if (last_list) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
         }
         break;
       }
+      cur_list = next_list;
     }
   } while (false);
   p.out[(size_t)py * p.width + px] = make_float4(r, gneg, b, 0.0f);
