@@ -20,9 +20,14 @@ ctx.step(scene.depth, scene.color)
 ctx.set_timer_detail(2)
 ctx.enable_timers(True)
 view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX)
+import statistics  # noqa: E402
 for skip in (0, 1):
     view.skip_space = skip
-    for _ in range(3):
+    draw, peel = [], []
+    for _ in range(25):
         ctx.raymarch(view)
-    print("skip_space %d: draw %.4f ms, brickdraw %.4f ms" % (skip, ctx.timer_ns("draw") * 1e-6, ctx.timer_ns("brickdraw") * 1e-6 if skip else 0.0))
+        draw.append(ctx.timer_ns("draw") * 1e-6)
+        peel.append(ctx.timer_ns("brickdraw") * 1e-6 if skip else 0.0)
+    print("skip_space %d: draw %.4f ms (median of 25; min %.4f), brickdraw %.4f ms, march alone %.4f ms"
+          % (skip, statistics.median(draw), min(draw), statistics.median(peel), statistics.median(d - b for d, b in zip(draw, peel))))
 ctx.close()
