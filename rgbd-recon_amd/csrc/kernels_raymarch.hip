@@ -330,13 +330,23 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
       fsamples = (float)num * 0.0027f;
       if (hit) shade_fragment(p, sp, rgba, fdepth);
     } else if (MODE == 1) {
-      for (unsigned k = 0; k < r.max_num; ++k) {
-        if (sample_owned(p, sp[2]) && tsdf_sample(p, sp[0], sp[1], sp[2]) > 0.0f) {
-          khit = (int)k;
-          break;
+      // as in march_ahead: AHEAD samples in flight, looked at in order (a sample this slab does not own is fetched from the
+      // nearest resident rows and not looked at)
+      for (unsigned k0 = 0; k0 < r.max_num && khit == kNoHit; k0 += AHEAD) {
+        float pos[AHEAD][3], dens[AHEAD];
+#pragma unroll
+        for (int j = 0; j < AHEAD; ++j) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) pos[j][a] = j == 0 ? sp[a] : pos[j - 1][a] + r.step[a];
+          dens[j] = tsdf_sample(p, pos[j][0], pos[j][1], pos[j][2]);
         }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) sp[a] += r.step[a];
+        for (int j = 0; j < AHEAD; ++j) {
+          if (khit != kNoHit || !(k0 + j < r.max_num)) break;
+          if (sample_owned(p, pos[j][2]) && dens[j] > 0.0f) khit = (int)(k0 + j);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) sp[a] = pos[j][a] + r.step[a];
+        }
       }
     } else {
       const int kmin = p.khit[o];
@@ -534,7 +544,10 @@ void launch_raymarch(const RaymarchParams& p, int mode, hipStream_t s)
     else
       hipLaunchKernelGGL((k_raymarch<0, RGBDR_AHEAD_FULL>), grid, dim3(16, 16), 0, s, p);
   else if (mode == 1)
-    hipLaunchKernelGGL(k_raymarch<1>, grid, dim3(16, 16), 0, s, p);
+    if (p.skip_space)
+      hipLaunchKernelGGL((k_raymarch<1, RGBDR_AHEAD_SKIP>), grid, dim3(16, 16), 0, s, p);
+    else
+      hipLaunchKernelGGL((k_raymarch<1, RGBDR_AHEAD_FULL>), grid, dim3(16, 16), 0, s, p);
   else
     hipLaunchKernelGGL(k_raymarch<2>, grid, dim3(16, 16), 0, s, p);
 }
