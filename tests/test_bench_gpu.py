@@ -37,6 +37,12 @@ def test_bench_line_contract():
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mvoxels/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert c["parity_rows_bit_exact"] is True and c["parity_rows"] == 64
+    # the reference's own shader text, compiled (it travels as oracle/_ref/libref_shaders.so where the build container had
+    # /root/reference): timed on a bounded sample and bit-identical to the HIP rows / images at the benchmark size
+    rt = c["reference_shader_text"]
+    if rt is not None:
+        assert "error" not in rt, rt
+        assert rt["hip_rows_bit_identical"] is True and rt["hip_images_bit_identical"] is True and rt["integrate_mvoxels_per_s"] > 0
     # box calibration: a replay of the kernel's memory streams on the same box, and the GPU state beside it
     assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
     assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
