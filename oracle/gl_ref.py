@@ -1,0 +1,584 @@
+"""TEST INFRASTRUCTURE, build container only: RUNS the reference's GLSL -- the files where they lie under
+/root/reference/glsl, compiled by Mesa's GLSL compiler and executed by llvmpipe (Mesa 23.2.1, OpenGL 4.5 compatibility
+profile, no X server: oracle/gl_context.c) -- through one frame in the reference's host order and returns what the
+textures hold afterwards.  tests/golden/make_gl_golden.py freezes these results as tests/golden/gl_*.npz; the oracle
+(CPU suite) and the HIP path (GPU suite) are compared with them.
+
+Unlike oracle/shader_ref.py (the shader text compiled as C++ against stand-in samplers) nothing of the GL machine is
+restated here: texture filtering, texel addressing, float formats, the rasteriser's pixel centres, imageStore, SSBO
+atomics, blending and the depth test are Mesa's.  What this file does restate is the reference's HOST code, i.e. which
+texture is created with which format / filter and bound where, and which uniforms are set per pass:
+
+  NetKinectArray::init / ctor         framework/NetKinectArray.cpp:42-214     formats, NEAREST filters, programs
+  NetKinectArray::processDepth        framework/NetKinectArray.cpp:250-290    pre_morph.fs, mode 0 then 1 (ping-pong)
+  NetKinectArray::processTextures     framework/NetKinectArray.cpp:311-428    filter / boundary / normal / quality loops
+  TextureArray                        framework/rendering/TextureArray.cpp:18-36
+  CalibVolumes                        framework/calibration/CalibVolumes.cpp:45-49 (BBox UBO), :76-77, :135-141 (3-D textures)
+  ScreenQuad                          framework/rendering/screen_quad.cpp:8-37
+  VolumeSampler                       framework/rendering/volume_sampler.cpp:9-50,86-91
+  ReconIntegration                    framework/reconstruction/recon_integration.cpp:61-128 (uniforms), :243-270 (integrate),
+                                      :389-404 (brick SSBO), :150-241 (draw), :280-339 (fillColors), :406-425 (depth limits)
+  texture units                       source/kinect_client.cpp:245-249 (nka 1.., calibration volumes 9.., inverse 30..)
+
+The text is compiled as it is, with two exceptions applied in memory (nothing of it is stored in this repository):
+  * the shaders' helper function `sample(...)` is renamed `sample_(...)`: Mesa reserves `sample` once
+    ARB_gpu_shader5 is on, and ARB_gpu_shader5 must be on for `cv_xyz[layer]` (a sampler array indexed by a uniform
+    under `#version 130`, which NVIDIA's compiler takes as written);
+  * `uniform mat4 gl_NormalMatrix` (tsdf_raymarch.fs:19, used by shade mode 2 only) is renamed `ref_NormalMatrix`
+    and set to inverseTranspose(modelview): the built-in of that name is a mat3, so what NVIDIA binds to a mat4 of
+    that name is driver-defined -- shade mode 2 of the GL run carries that assumption, the other modes do not.
+Mesa's driconf switches in minigl.MESA_ENV (+ force_glsl_extensions_warn, force_compat_shaders) make its compiler
+accept the remaining NVIDIA-isms without touching the text.
+
+Never imported by the product; needs /root/reference, so it cannot run on the GPU box."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+import minigl as m
+
+REF_GLSL = os.environ.get("RGBDR_REFERENCE", "/root/reference") + "/glsl/"
+NKA_UNIT = 1          # kinect_client.cpp:245
+CV_UNIT = 9           # :247
+CV_INV_UNIT = 30      # :249
+IMAGE_UNIT = 3        # recon_integration.cpp:28
+UNITS = {"color": NKA_UNIT, "depth": NKA_UNIT + 1, "quality": NKA_UNIT + 2, "normal": NKA_UNIT + 3, "silhouette": NKA_UNIT + 4,
+         "morph_depth": NKA_UNIT + 5, "color_lab": NKA_UNIT + 6, "raw_depth": 40, "morph_input": 42}    # NetKinectArray.cpp:191-192,430-440
+
+_gl = None
+_quad = None
+_programs = {}
+
+
+def available():
+    return os.path.exists(m.LIB_PATH) and os.path.isdir(REF_GLSL)
+
+
+def _text(name):
+    t = open(REF_GLSL + name).read()
+    t = re.sub(r"\bsample\(", "sample_(", t)
+    return t.replace("gl_NormalMatrix", "ref_NormalMatrix")
+
+
+def gl():
+    """the context, the named strings of Reconstruction / NetKinectArray and the screen triangle"""
+    global _gl, _quad
+    if _gl is None:
+        os.environ.setdefault("force_glsl_extensions_warn", "true")
+        os.environ.setdefault("force_compat_shaders", "true")
+        g = m.GL(compat=True, version=(4, 4))
+        # NetKinectArray.cpp:76,200-201; reconstruction.cpp (shading.glsl)
+        for name, f in (("/bricks.glsl", "inc_bricks.glsl"), ("/inc_bbox_test.glsl", "inc_bbox_test.glsl"),
+                        ("/inc_color.glsl", "inc_color.glsl"), ("/shading.glsl", "shading.glsl")):
+            g.named_string(name, _text(f))
+        # ScreenQuad: one triangle covering the viewport, position + texcoord interleaved
+        data = np.array([-1, -1, 0, 0, 3, -1, 2, 0, -1, 3, 0, 2], np.float32)
+        vao, vbo = g.gen("VertexArrays"), g.gen("Buffers")
+        g.glBindVertexArray(vao)
+        g.glBindBuffer(m.ARRAY_BUFFER, vbo)
+        g.glBufferData(m.ARRAY_BUFFER, data.nbytes, data.ctypes.data, m.STATIC_DRAW)
+        g.glEnableVertexAttribArray(0)
+        g.glVertexAttribPointer(0, 2, m.FLOAT, 0, 16, C.c_void_p(0))
+        g.glEnableVertexAttribArray(1)
+        g.glVertexAttribPointer(1, 2, m.FLOAT, 0, 16, C.c_void_p(8))
+        g.glBindVertexArray(0)
+        _gl, _quad = g, vao
+    return _gl
+
+
+def info():
+    return gl().info()
+
+
+def program(name, files):
+    g = gl()
+    if name not in _programs:
+        kinds = {"vs": m.VERTEX_SHADER, "fs": m.FRAGMENT_SHADER, "gs": m.GEOMETRY_SHADER}
+        _programs[name] = g.program([g.shader(kinds[f[-2:]], _text(f), f) for f in files], name)
+    return _programs[name]
+
+
+class Prog:
+    """uniform setters by name (globjects Program::setUniform: silently ignores inactive uniforms)"""
+
+    def __init__(self, name, files):
+        self.g, self.id, self.name = gl(), program(name, files), name
+
+    def use(self):
+        self.g.glUseProgram(self.id)
+
+    def _loc(self, name):
+        return self.g.loc(self.id, name)
+
+    def i(self, name, v):
+        l = self._loc(name)
+        if l >= 0:
+            self.g.glUniform1i(l, int(v))
+
+    def u(self, name, v):
+        l = self._loc(name)
+        if l >= 0:
+            self.g.glUniform1ui(l, int(v))
+
+    def f(self, name, v):
+        l = self._loc(name)
+        if l >= 0:
+            self.g.glUniform1f(l, float(np.float32(v)))
+
+    def b(self, name, v):
+        self.i(name, 1 if v else 0)
+
+    def iv(self, name, vals):
+        a = np.ascontiguousarray(vals, np.int32)
+        l = self._loc(name)
+        if l >= 0:
+            self.g.glUniform1iv(l, a.size, a.ctypes.data)
+
+    def fv(self, name, vals, n):
+        a = np.ascontiguousarray(vals, np.float32).reshape(-1, n)
+        l = self._loc(name)
+        if l >= 0:
+            getattr(self.g, "glUniform%dfv" % n)(l, a.shape[0], a.ctypes.data)
+
+    def uv(self, name, vals, n):
+        a = np.ascontiguousarray(vals, np.uint32).reshape(-1, n)
+        l = self._loc(name)
+        if l >= 0:
+            getattr(self.g, "glUniform%duiv" % n)(l, a.shape[0], a.ctypes.data)
+
+    def mat4(self, name, cols):
+        """16 floats, column major (glm / gloost layout)"""
+        a = np.ascontiguousarray(cols, np.float32).reshape(16)
+        l = self._loc(name)
+        if l >= 0:
+            self.g.glUniformMatrix4fv(l, 1, 0, a.ctypes.data)
+
+
+def draw_quad():
+    g = gl()
+    g.glBindVertexArray(_quad)
+    g.glDrawArrays(m.TRIANGLES, 0, 3)
+    g.glBindVertexArray(0)
+
+
+def array_texture(internal, fmt, typ, W, H, layers, data=None, filt=m.LINEAR):
+    g = gl()
+    t = g.texture(m.TEXTURE_2D_ARRAY, filt)
+    g.glPixelStorei(m.UNPACK_ALIGNMENT, 1)
+    if data is not None:
+        data = np.ascontiguousarray(data)
+    g.glTexImage3D(m.TEXTURE_2D_ARRAY, 0, internal, W, H, layers, 0, fmt, typ, data.ctypes.data if data is not None else None)
+    return t
+
+
+def volume_texture(internal, fmt, vol):
+    """[rz, ry, rx, ch] float32 (x fastest: calibration_volume.hpp:57-59) as a LINEAR / CLAMP_TO_EDGE 3-D texture"""
+    g = gl()
+    a = np.ascontiguousarray(vol, np.float32)
+    t = g.texture(m.TEXTURE_3D, m.LINEAR)
+    g.glPixelStorei(m.UNPACK_ALIGNMENT, 1)
+    g.glTexImage3D(m.TEXTURE_3D, 0, internal, a.shape[2], a.shape[1], a.shape[0], 0, fmt, m.FLOAT, a.ctypes.data)
+    return t
+
+
+def bind(unit, target, tex):
+    g = gl()
+    g.glActiveTexture(m.TEXTURE0 + unit)
+    g.glBindTexture(target, tex)
+
+
+def buffer(target, data, usage=m.STATIC_DRAW):
+    g = gl()
+    b = g.gen("Buffers")
+    a = np.ascontiguousarray(data)
+    g.glBindBuffer(target, b)
+    g.glBufferData(target, a.nbytes, a.ctypes.data, usage)
+    return b
+
+
+def check_fbo(what):
+    st = gl().glCheckFramebufferStatus(m.FRAMEBUFFER)
+    if st != m.FRAMEBUFFER_COMPLETE:
+        raise RuntimeError("framebuffer incomplete (0x%04x) while attaching %s" % (st, what))
+
+
+def draw_buffers(n):
+    a = (C.c_uint * n)(*[m.COLOR_ATTACHMENT0 + i for i in range(n)])
+    gl().glDrawBuffers(n, a)
+
+
+def delete_textures(texs):
+    a = (C.c_uint * len(texs))(*texs)
+    gl().glDeleteTextures(len(texs), a)
+
+
+class Calib:
+    """CalibVolumes: BBox UBO at binding 2, forward volumes on units 9 + 2 i / 10 + 2 i, inverse on 30 + i"""
+
+    def __init__(self, scene, bbox_min, bbox_max, inv_luts):
+        g = gl()
+        self.n = scene.N
+        ext = np.array([list(bbox_min) + [1.0], list(bbox_max) + [1.0]], np.float32)           # CalibVolumes.cpp:45-49
+        self.ubo = buffer(m.UNIFORM_BUFFER, ext)
+        g.glBindBufferBase(m.UNIFORM_BUFFER, 2, self.ubo)
+        self.xyz = [volume_texture(m.RGB32F, m.RGB, scene.xyz[i]) for i in range(self.n)]       # :135-136
+        self.uv = [volume_texture(m.RG32F, m.RG, scene.uv[i]) for i in range(self.n)]           # :140-141
+        self.inv = [volume_texture(m.RGBA32F, m.RGBA, v) for v in (inv_luts or [])]             # :76-77
+        for i in range(self.n):                                                                  # :162-175
+            bind(CV_UNIT + 2 * i, m.TEXTURE_3D, self.xyz[i])
+            bind(CV_UNIT + 2 * i + 1, m.TEXTURE_3D, self.uv[i])
+        for i, t in enumerate(self.inv):
+            bind(CV_INV_UNIT + i, m.TEXTURE_3D, t)
+        self.units_xyz = [CV_UNIT + 2 * i for i in range(self.n)]
+        self.units_uv = [CV_UNIT + 2 * i + 1 for i in range(self.n)]
+        self.units_inv = [CV_INV_UNIT + i for i in range(len(self.inv))]
+
+    def free(self):
+        delete_textures(self.xyz + self.uv + self.inv)
+
+
+def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=None, res_bricks=None, limits=(0.5, 4.5),
+              filter_textures=True, processed=True, refine=True, near_far=(0.5, 4.5), compress=False, keep=False):
+    """One frame through the reference's shaders on Mesa; the keys of pyoracle.run_pipeline / shader_ref.run_frame.
+    `scene`: rgbd_recon_amd.synth.Scene (depth [N,H,W] f32 or depth_u8, color [N,Hc,Wc,3] u8, xyz / uv forward LUTs);
+    inv_luts [N][Z,Y,X,4]."""
+    g = gl()
+    n = scene.N
+    H, W = scene.depth.shape[1:3]
+    Hc, Wc = scene.color.shape[1:3]
+    cal = Calib(scene, bbox_min, bbox_max, inv_luts)
+    vs = "texture_passthrough.vs"
+    prog = {k: Prog(k, [vs, f]) for k, f in (("morph", "pre_morph.fs"), ("filter", "pre_depth.fs"), ("boundary", "pre_boundary.fs"),
+                                                ("normal", "pre_normal.fs"), ("quality", "pre_quality.fs"))}
+
+    # ---- NetKinectArray::init: textures (formats :139-172, filters :174-186) ----
+    tex_color = array_texture(m.RGB, m.RGB, m.UNSIGNED_BYTE, Wc, Hc, n, scene.color)                       # m_colorArray :157
+    if compress:                                                                                           # :166-168
+        tex_raw = array_texture(m.LUMINANCE, m.RED, m.UNSIGNED_BYTE, W, H, n, scene.depth_u8, filt=m.NEAREST)
+    else:
+        tex_raw = array_texture(m.LUMINANCE32F_ARB, m.RED, m.FLOAT, W, H, n, np.ascontiguousarray(scene.depth, np.float32), filt=m.NEAREST)
+    tex_lab = array_texture(m.RGB32F, m.RGB, m.FLOAT, W, H, n)                                             # m_textures_color
+    tex_quality = array_texture(m.LUMINANCE32F_ARB, m.RED, m.FLOAT, W, H, n)
+    tex_normal = array_texture(m.RGB32F, m.RGB, m.FLOAT, W, H, n)
+    tex_sil = array_texture(m.R32F, m.RED, m.FLOAT, W, H, n)
+    tex_depth = array_texture(m.RG32F, m.RG, m.FLOAT, W, H, n, filt=m.NEAREST)
+    tex_depth_b = array_texture(m.RG32F, m.RG, m.FLOAT, W, H, n, filt=m.NEAREST)
+    depth2 = [array_texture(m.LUMINANCE32F_ARB, m.RED, m.FLOAT, W, H, n, filt=m.NEAREST) for _ in range(2)]   # front, back
+
+    tsi = np.array([np.float32(1.0) / np.float32(W), np.float32(1.0) / np.float32(H)], np.float32)          # :195
+    for k in ("filter", "normal", "quality", "morph", "boundary"):
+        prog[k].use()
+        prog[k].fv("texSizeInv", tsi, 2)
+    import pyoracle                                    # camera positions: CalibVolumes.cpp:98-122 / frustum.cpp:21-33 (host code)
+    prog["quality"].use()
+    prog["quality"].fv("camera_positions", np.stack([pyoracle.camera_pos(scene.xyz[i]) for i in range(n)]), 3)
+    prog["filter"].use()
+    prog["filter"].i("kinect_depths", UNITS["raw_depth"])
+    prog["morph"].use()
+    prog["morph"].i("kinect_depths", UNITS["morph_input"])
+    # setStartTextureUnit (:430-452)
+    for k, names in (("filter", {"kinect_colors": "color"}), ("normal", {"kinect_depths": "depth"}),
+                     ("quality", {"kinect_depths": "depth", "kinect_normals": "normal", "kinect_colors_lab": "color_lab"}),
+                     ("boundary", {"kinect_colors_lab": "color_lab", "kinect_depths": "depth", "kinect_colors": "color"})):
+        prog[k].use()
+        for uni, unit in names.items():
+            prog[k].i(uni, UNITS[unit])
+    # bindToTextureUnits (:454-465)
+    bind(UNITS["color"], m.TEXTURE_2D_ARRAY, tex_color)
+    bind(UNITS["quality"], m.TEXTURE_2D_ARRAY, tex_quality)
+    bind(UNITS["normal"], m.TEXTURE_2D_ARRAY, tex_normal)
+    bind(UNITS["silhouette"], m.TEXTURE_2D_ARRAY, tex_sil)
+    bind(UNITS["morph_depth"], m.TEXTURE_2D_ARRAY, depth2[0])
+    bind(UNITS["color_lab"], m.TEXTURE_2D_ARRAY, tex_lab)
+    bind(UNITS["raw_depth"], m.TEXTURE_2D_ARRAY, tex_raw)
+
+    # ---- brick SSBO (recon_integration.cpp:389-401): float brick_size, pad, uvec3 resolution, pad, counters ----
+    nb = int(res_bricks[0] * res_bricks[1] * res_bricks[2])
+    head = np.zeros(8 + nb, np.uint32)
+    head[0] = np.array([brick_size], np.float32).view(np.uint32)[0]
+    head[4:7] = np.array(res_bricks, np.uint32)
+    ssbo = buffer(m.SHADER_STORAGE_BUFFER, head, m.DYNAMIC_COPY)
+    g.glBindBufferRange(m.SHADER_STORAGE_BUFFER, 3, ssbo, 0, head.nbytes)
+
+    # ---- processTextures (:311-428) ----
+    fbo = g.gen("Framebuffers")
+    g.glDisable(m.DEPTH_TEST)
+    g.glDisable(m.BLEND)
+    g.glDisable(m.CULL_FACE)
+    g.glViewport(0, 0, W, H)
+    bind(UNITS["raw_depth"], m.TEXTURE_2D_ARRAY, tex_raw)
+    g.glBindFramebuffer(m.FRAMEBUFFER, fbo)
+
+    def attach(i, tex, layer):
+        g.glFramebufferTextureLayer(m.FRAMEBUFFER, m.COLOR_ATTACHMENT0 + i, tex, 0, layer)
+
+    # processDepth (:250-290)
+    draw_buffers(1)
+    bind(UNITS["morph_input"], m.TEXTURE_2D_ARRAY, tex_raw)
+    pm = prog["morph"]
+    pm.use()
+    pm.iv("cv_xyz", cal.units_xyz)
+    for mode in (0, 1):
+        pm.u("mode", mode)
+        if mode == 1:
+            depth2.reverse()                                           # swapBuffers
+            bind(UNITS["morph_input"], m.TEXTURE_2D_ARRAY, depth2[0])
+        for i in range(n):
+            attach(0, depth2[1], i)
+            if i == 0:
+                check_fbo("depth2.back (GL_LUMINANCE32F_ARB)")
+            pm.u("layer", i)
+            draw_quad()
+    bind(UNITS["morph_input"], m.TEXTURE_2D_ARRAY, 0)
+    depth2.reverse()
+    bind(UNITS["morph_depth"], m.TEXTURE_2D_ARRAY, depth2[0])
+    if processed:
+        bind(UNITS["raw_depth"], m.TEXTURE_2D_ARRAY, depth2[0])
+
+    # filter loop (:327-357)
+    draw_buffers(2)
+    pf = prog["filter"]
+    pf.use()
+    pf.b("filter_textures", filter_textures)
+    pf.b("processed_depth", processed)
+    pf.iv("cv_xyz", cal.units_xyz)
+    pf.iv("cv_uv", cal.units_uv)
+    near, far = np.float32(near_far[0]), np.float32(near_far[1])
+    scale = np.float32(far - near)
+    for i in range(n):
+        pf.f("cv_min_ds", limits[0])
+        pf.f("cv_max_ds", limits[1])
+        attach(0, tex_depth, i)
+        attach(1, tex_lab, i)
+        if i == 0:
+            check_fbo("depth (RG32F) + colour (RGB32F)")
+        pf.u("layer", i)
+        pf.b("compress", compress)
+        pf.f("scale", scale)
+        pf.f("near", near)
+        pf.f("scaled_near", scale / np.float32(255.0))
+        draw_quad()
+
+    # boundary loop (:359-377)
+    pb = prog["boundary"]
+    pb.use()
+    pb.iv("cv_uv", cal.units_uv)
+    pb.b("refine", refine)
+    bind(UNITS["depth"], m.TEXTURE_2D_ARRAY, tex_depth)
+    for i in range(n):
+        attach(0, tex_depth_b, i)
+        attach(1, tex_sil, i)
+        if i == 0:
+            check_fbo("depth_b (RG32F) + silhouette (R32F)")
+        pb.u("layer", i)
+        draw_quad()
+    bind(UNITS["depth"], m.TEXTURE_2D_ARRAY, tex_depth_b)
+
+    # normal loop (:380-397)
+    pn = prog["normal"]
+    pn.use()
+    pn.iv("cv_xyz", cal.units_xyz)
+    pn.iv("cv_uv", cal.units_uv)
+    draw_buffers(1)
+    attach(1, 0, 0)
+    for i in range(n):
+        attach(0, tex_normal, i)
+        if i == 0:
+            check_fbo("normal (RGB32F)")
+        pn.u("layer", i)
+        draw_quad()
+    g.glMemoryBarrier(m.ALL_BARRIER_BITS)
+
+    # quality loop (:399-414)
+    pq = prog["quality"]
+    pq.use()
+    pq.iv("cv_xyz", cal.units_xyz)
+    pq.b("processed_depth", processed)
+    for i in range(n):
+        attach(0, tex_quality, i)
+        if i == 0:
+            check_fbo("quality (GL_LUMINANCE32F_ARB)")
+        pq.u("layer", i)
+        draw_quad()
+    g.glBindFramebuffer(m.FRAMEBUFFER, 0)
+    g.glUseProgram(0)
+    g.glFinish()
+
+    rd = g.read_texture
+    T = m.TEXTURE_2D_ARRAY
+    out = {
+        "raw": list(np.ascontiguousarray(scene.depth, np.float32)),
+        "morph": list(rd(T, depth2[0], m.RED, (n, H, W))),
+        "depth_rg": list(rd(T, tex_depth, m.RG, (n, H, W, 2))),
+        "lab": list(rd(T, tex_lab, m.RGB, (n, H, W, 3))),
+        "depth_b": list(rd(T, tex_depth_b, m.RG, (n, H, W, 2))),
+        "sil": list(rd(T, tex_sil, m.RED, (n, H, W))),
+        "normal": list(rd(T, tex_normal, m.RGB, (n, H, W, 3))),
+        "quality": list(rd(T, tex_quality, m.RED, (n, H, W))),
+    }
+    counters = np.zeros(8 + nb, np.uint32)
+    g.glBindBuffer(m.SHADER_STORAGE_BUFFER, ssbo)
+    g.glGetBufferSubData(m.SHADER_STORAGE_BUFFER, 0, counters.nbytes, counters.ctypes.data)
+    out["counters"] = counters[8:].copy()
+
+    # ---- ReconIntegration::integrate (:243-270), full sweep: VolumeSampler::sample() ----
+    frame_tex = {"color": tex_color, "depth_b": tex_depth_b, "quality": tex_quality, "normal": tex_normal, "sil": tex_sil}
+    if inv_luts is not None:
+        X, Y, Z = res
+        out["tsdf"] = integrate(cal, frame_tex, n, (X, Y, Z), limit, (W, H))
+    if keep:
+        out["_gl"] = {"cal": cal, "tex": frame_tex}
+        return out
+    delete_textures([tex_color, tex_raw, tex_lab, tex_quality, tex_normal, tex_sil, tex_depth, tex_depth_b] + depth2)
+    cal.free()
+    return out
+
+
+def bind_frame(tex):
+    """what NetKinectArray::bindToTextureUnits leaves bound for ReconIntegration's programs (units 1-5)"""
+    bind(UNITS["color"], m.TEXTURE_2D_ARRAY, tex["color"])
+    bind(UNITS["depth"], m.TEXTURE_2D_ARRAY, tex["depth_b"])
+    bind(UNITS["quality"], m.TEXTURE_2D_ARRAY, tex["quality"])
+    bind(UNITS["normal"], m.TEXTURE_2D_ARRAY, tex["normal"])
+    bind(UNITS["silhouette"], m.TEXTURE_2D_ARRAY, tex["sil"])
+
+
+VS_PAD = 8
+
+
+def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=None):
+    """glClearTexImage(-limit) + tsdf_integration.vs over the voxel centres of VolumeSampler (all of them, or the
+    index lists of the occupied bricks) with rasteriser discard; -> [Z, Y, X] float32
+
+    `pad`: llvmpipe's vertex-shader path (Mesa 23.2.1 draw module) returns 0 from the texture fetch that FOLLOWS a
+    fetch through a dynamically indexed sampler array (`cv_xyz_inv[i]`) in every vertex whose position in the vertex
+    stream is not a multiple of 8 -- the same fetch with a constant index, and the same shader in the first lane, are
+    right (vs_sampler_array_bug() shows it on Mesa alone, no oracle involved).  So the voxel centres are drawn one per
+    group of 8: every centre is followed by pad - 1 vertices at (2, 2, 2), whose imageStore falls outside the volume and
+    is discarded (GL 4.4 section 8.26).  The shader text and the centres are unchanged; make_gl_golden.py also checks
+    that pad = 8 and pad = 16 give the same volume."""
+    pad = pad or VS_PAD
+    g = gl()
+    X, Y, Z = res
+    p = Prog("integration", ["tsdf_integration.vs"])
+    assert g.glGetAttribLocation(p.id, b"in_Position") == 0
+    p.use()
+    p.iv("cv_xyz_inv", cal.units_inv)                                   # :92
+    p.i("volume_tsdf", IMAGE_UNIT)                                      # :95
+    p.i("kinect_colors", 1)
+    p.i("kinect_depths", 2)
+    p.i("kinect_qualities", 3)
+    p.i("kinect_normals", 4)
+    p.i("kinect_silhouettes", 5)
+    p.u("num_kinects", n)
+    p.uv("res_depth", np.array(depth_wh, np.uint32), 2)
+    p.f("limit", limit)
+    p.uv("res_tsdf", np.array([X, Y, Z], np.uint32), 3)                 # setVoxelSize :346
+    bind_frame(tex)
+    # VolumeSampler: (x + .5) * step, x fastest (volume_sampler.cpp:14-24)
+    sx, sy, sz = np.float32(1.0) / np.float32(X), np.float32(1.0) / np.float32(Y), np.float32(1.0) / np.float32(Z)
+    pos = np.empty((Z, Y, X, 3), np.float32)
+    pos[..., 0] = ((np.arange(X, dtype=np.float32) + np.float32(0.5)) * sx)[None, None, :]
+    pos[..., 1] = ((np.arange(Y, dtype=np.float32) + np.float32(0.5)) * sy)[None, :, None]
+    pos[..., 2] = ((np.arange(Z, dtype=np.float32) + np.float32(0.5)) * sz)[:, None, None]
+    if pad > 1:
+        padded = np.full((X * Y * Z, pad, 3), 2.0, np.float32)
+        padded[:, 0] = pos.reshape(-1, 3)
+        pos = padded
+    vao = g.gen("VertexArrays")
+    g.glBindVertexArray(vao)
+    vbo = buffer(m.ARRAY_BUFFER, pos)
+    g.glEnableVertexAttribArray(0)
+    g.glVertexAttribPointer(0, 3, m.FLOAT, 0, 12, C.c_void_p(0))
+    vol = volume
+    if vol is None:
+        vol = g.texture(m.TEXTURE_3D, m.LINEAR)
+        g.glTexImage3D(m.TEXTURE_3D, 0, m.R32F, X, Y, Z, 0, m.RED, m.FLOAT, None)                 # :347
+    g.glEnable(m.RASTERIZER_DISCARD)
+    neg = C.c_float(-float(np.float32(limit)))
+    g.glClearTexImage(vol, 0, m.RED, m.FLOAT, C.byref(neg))
+    g.glBindImageTexture(IMAGE_UNIT, vol, 0, 1, 0, m.WRITE_ONLY, m.R32F)
+    if indices is None:
+        g.glDrawArrays(m.POINTS, 0, X * Y * Z * pad)
+    else:
+        for idx in indices:                                             # m_sampler.sample(m_bricks[index].indices), :258-260
+            a = (np.asarray(idx, np.uint32)[:, None] * np.uint32(pad) + np.arange(pad, dtype=np.uint32)[None, :]).reshape(-1)
+            a = np.ascontiguousarray(a, np.uint32)
+            g.glDrawElements(m.POINTS, a.size, m.UNSIGNED_INT, a.ctypes.data)
+    g.glMemoryBarrier(m.ALL_BARRIER_BITS)
+    g.glDisable(m.RASTERIZER_DISCARD)
+    g.glUseProgram(0)
+    g.glBindVertexArray(0)
+    g.glFinish()
+    tsdf = g.read_texture(m.TEXTURE_3D, vol, m.RED, (Z, Y, X))
+    if volume is None:
+        delete_textures([vol])
+    b = (C.c_uint * 1)(vbo)
+    g.glBindBuffer(m.ARRAY_BUFFER, 0)
+    C.CFUNCTYPE(None, C.c_int, C.c_void_p)(g._lib.glctx_proc(b"glDeleteBuffers"))(1, b)
+    return tsdf
+
+
+def release(out):
+    """frees what run_frame(keep=True) left alive"""
+    st = out.pop("_gl", None)
+    if st:
+        delete_textures(list(st["tex"].values()))
+        st["cal"].free()
+
+
+_TF_BUFFER, _INTERLEAVED = 0x8C8E, 0x8C8C
+
+
+def vs_sampler_array_bug(count=64):
+    """Mesa against itself, no reference text and no oracle involved: a vertex shader of this file's own fetches a
+    coordinate from a sampler3D array -- once with a uniform index, once with the constant 0 (the uniform IS 0) -- and
+    uses it for a second fetch from an all-ones LINEAR array texture.  On llvmpipe 23.2.1 the uniform-index variant
+    returns 0 for every vertex that is not the first of a group of 8.  -> list of the vertex numbers that are wrong
+    ([] on a correct implementation); integrate() pads its vertex stream accordingly."""
+    g = gl()
+    vol = volume_texture(m.RGBA32F, m.RGBA, np.full((4, 4, 4, 4), 0.5, np.float32))
+    ones = array_texture(m.R32F, m.RED, m.FLOAT, 8, 8, 2, np.ones((2, 8, 8), np.float32))
+    res = []
+    for index in ("k", "0"):
+        src = ("#version 430\nin vec3 p; uniform sampler3D[5] vols; uniform sampler2DArray img; uniform uint k; out float v;\n"
+               "void main() { vec3 c = texture(vols[%s], p).xyz; v = texture(img, vec3(c.xy, 0.0)).r; gl_Position = vec4(0.0, 0.0, 0.0, 1.0); }" % index)
+        prog = g.glCreateProgram()
+        g.glAttachShader(prog, g.shader(m.VERTEX_SHADER, src, "probe"))
+        names = (C.c_char_p * 1)(b"v")
+        C.CFUNCTYPE(None, C.c_uint, C.c_int, C.c_void_p, C.c_uint)(g._lib.glctx_proc(b"glTransformFeedbackVaryings"))(prog, 1, names, _INTERLEAVED)
+        g.glLinkProgram(prog)
+        g.glUseProgram(prog)
+        bind(CV_INV_UNIT, m.TEXTURE_3D, vol)
+        bind(UNITS["silhouette"], m.TEXTURE_2D_ARRAY, ones)
+        units = np.full(5, CV_INV_UNIT, np.int32)
+        g.glUniform1iv(g.loc(prog, "vols"), 5, units.ctypes.data)
+        g.glUniform1i(g.loc(prog, "img"), UNITS["silhouette"])
+        if g.loc(prog, "k") >= 0:
+            g.glUniform1ui(g.loc(prog, "k"), 0)
+        pts = np.random.default_rng(5).random((count, 3), dtype=np.float32)
+        vao = g.gen("VertexArrays")
+        g.glBindVertexArray(vao)
+        buffer(m.ARRAY_BUFFER, pts)
+        g.glEnableVertexAttribArray(0)
+        g.glVertexAttribPointer(0, 3, m.FLOAT, 0, 12, C.c_void_p(0))
+        out = np.zeros(count, np.float32)
+        tfb = buffer(_TF_BUFFER, out, m.DYNAMIC_COPY)
+        g.glBindBufferBase(_TF_BUFFER, 0, tfb)
+        g.glEnable(m.RASTERIZER_DISCARD)
+        C.CFUNCTYPE(None, C.c_uint)(g._lib.glctx_proc(b"glBeginTransformFeedback"))(m.POINTS)
+        g.glDrawArrays(m.POINTS, 0, count)
+        C.CFUNCTYPE(None)(g._lib.glctx_proc(b"glEndTransformFeedback"))()
+        g.glDisable(m.RASTERIZER_DISCARD)
+        g.glFinish()
+        g.glBindBuffer(_TF_BUFFER, tfb)
+        g.glGetBufferSubData(_TF_BUFFER, 0, out.nbytes, out.ctypes.data)
+        g.glBindBufferBase(_TF_BUFFER, 0, 0)
+        g.glUseProgram(0)
+        g.glBindVertexArray(0)
+        res.append(out)
+    delete_textures([vol, ones])
+    assert np.all(res[1] == 1.0), "the constant-index variant is wrong too"
+    return [int(i) for i in np.nonzero(res[0] != res[1])[0]]

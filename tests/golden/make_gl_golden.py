@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/gl_passes_<case>.npz (and gl_views_<case>.npz): what the reference's GLSL -- glsl/pre_*.fs,
+tsdf_integration.vs, ... read where they lie under /root/reference and RUN by Mesa llvmpipe (oracle/gl_ref.py,
+oracle/gl_context.c; build container only) -- produces for the scenes of shader_cases.py.  The fixtures are data
+(images, counters, volumes, frames); no reference text is stored.
+
+These are outputs of the reference's own shader code executed by a real OpenGL implementation (compiler, texture units,
+rasteriser, image stores, atomics), with the reference's host-side GL state restated by gl_ref.py.  They are what pins
+the oracle's pass arithmetic (tests/test_gl_ref.py: oracle vs these fixtures on CPU, HIP path vs these fixtures on GPU).
+
+    make -C oracle glctx && python tests/golden/make_gl_golden.py [case ...]"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), HERE]
+from __graft_entry__ import load_oracle, load_package  # noqa: E402
+
+load_oracle()
+load_package()
+import gl_ref  # noqa: E402
+import shader_cases  # noqa: E402
+from rgbd_recon_amd import capi, synth  # noqa: E402
+
+
+def frame_kwargs(name, cfg, geo):
+    flags = shader_cases.CASES[name][5]
+    return dict(limit=cfg.tsdf_limit, brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), filter_textures=bool(flags & 1),
+                processed=bool(flags & 2), refine=bool(flags & 4), compress=name in shader_cases.COMPRESSED_DEPTH)
+
+
+def run_case(name, keep=False):
+    scene, cfg, geo, inv, inv_res = shader_cases.build(synth, capi, name)
+    G = shader_cases.CASES[name][3]
+    out = gl_ref.run_frame(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, keep=keep, **frame_kwargs(name, cfg, geo))
+    return scene, cfg, geo, inv, out
+
+
+def main(argv):
+    assert gl_ref.available(), "oracle/_ref/libglctx.so or /root/reference/glsl is missing: make -C oracle glctx"
+    names = argv or list(shader_cases.CASES)
+    info = gl_ref.info()
+    print("running the reference's GLSL on", info["renderer"], "/", info["version"])
+    bug = gl_ref.vs_sampler_array_bug()
+    print("llvmpipe vertex-shader sampler-array defect present:", bug)
+    for name in names:
+        scene, cfg, geo, inv, out = run_case(name, keep=True)
+        n = scene.N
+        G = shader_cases.CASES[name][3]
+        # the padding that works around llvmpipe's vertex-shader defect must not matter: one centre per 8 == one per 16
+        again = gl_ref.integrate(out["_gl"]["cal"], out["_gl"]["tex"], n, (G, G, G), cfg.tsdf_limit, shader_cases.CASES[name][1], pad=16)
+        assert np.array_equal(again.view(np.uint32), out["tsdf"].view(np.uint32)), "padding 8 and 16 disagree"
+        arrays = {k: np.stack(out[k]) for k in shader_cases.IMAGES}
+        arrays["counters"] = out["counters"]
+        arrays["tsdf"] = out["tsdf"]
+        arrays["inputs_sha256"] = np.frombuffer(shader_cases.digest(scene, inv).encode(), dtype=np.uint8)
+        arrays["gl_renderer"] = np.frombuffer((info["renderer"] + " / " + info["version"]).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, "gl_passes_%s.npz" % name)
+        np.savez_compressed(path, **arrays)
+        print("%-40s %7.1f KiB  surface voxels %d  counted %d  NaN qualities %d" % (
+            name, os.path.getsize(path) / 1024, int(np.sum(np.abs(out["tsdf"]) < cfg.tsdf_limit)), int(out["counters"].sum()),
+            int(np.isnan(arrays["quality"]).sum())))
+        if hasattr(gl_ref, "run_views") and name in shader_cases.VIEW_CASES:
+            views = gl_ref.run_views(name, scene, cfg, geo, inv, out)
+            path = os.path.join(HERE, "gl_views_%s.npz" % name)
+            np.savez_compressed(path, **views)
+            print("%-40s %7.1f KiB  %s" % ("  views", os.path.getsize(path) / 1024,
+                  ", ".join("%s: %d px hit" % (k[:-6], int((v < 1).sum())) for k, v in views.items() if k.endswith("_depth") and "filled" not in k)))
+        gl_ref.release(out)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,182 @@
+"""The reference's GLSL RUN -- the files under /root/reference/glsl compiled by Mesa's GLSL compiler and executed by
+llvmpipe in the build container (oracle/gl_ref.py, oracle/gl_context.c) -- against the oracle and the HIP path, through
+committed fixtures (tests/golden/gl_passes_*.npz, gl_views_*.npz: data only, made by tests/golden/make_gl_golden.py).
+
+This is what pins the oracle's pass arithmetic: the expected values are outputs of the reference's own shader code on a
+real OpenGL implementation (texture units, rasteriser, image stores, atomics included), not of a restatement.
+
+  CPU, build container:  Mesa runs the shaders again and reproduces the committed fixtures bit for bit
+  CPU, anywhere:         oracle  vs fixtures, within the tolerances below
+  GPU:                   HIP path vs fixtures, same tolerances (the HIP path is bit-identical to the oracle)
+
+Tolerances (absolute; what is observed is in DESIGN.md section 2).  They are llvmpipe-against-IEEE differences, not
+slack for the algorithm: llvmpipe evaluates pow / exp / inversesqrt / normalize with its own polynomial and Newton
+approximations and filters 8-bit textures with 8-bit weights, the oracle uses libm and float weights.
+  morph, depth_rg (float depth frames), depth_b, silhouette, brick counters     bit-exact
+  morph, depth_rg of u8 depth frames                                            1e-6   (unorm8 -> float: x * (1/255) vs x / 255)
+  Lab colour                                                                    4e-3   (pow(x, 1/3), 8-bit bilinear weights)
+  normals                                                                       1e-5
+  quality                                                                       2e-6; excluded: texels where llvmpipe's
+                                                                                pow(angle < 0, 2) is NaN (undefined in GLSL) or
+                                                                                a NaN normal is a bilinear neighbour (weight 0)
+  TSDF                                                                          1e-7, same class (-limit / +limit / surface)
+                                                                                everywhere, voxels fed by such a NaN excluded"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import count_diff, same_bits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden")]
+import shader_cases  # noqa: E402
+
+IMG = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
+EXACT = ("morph", "depth_rg", "depth_b", "sil")
+TOL = {"lab": 4e-3, "normal": 1e-5, "quality": 2e-6}
+TOL_U8_DEPTH = 1e-6
+TOL_TSDF = 1e-7
+MAX_NAN_FRACTION = 5e-3          # texels whose quality is NaN on llvmpipe only; each one must have a negative angle
+
+
+def fixture(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", "gl_passes_%s.npz" % name))
+
+
+def gl_lib():
+    import gl_ref
+    if not gl_ref.available():
+        # in the build container the context library is part of build(): missing means the pin silently vanished
+        assert not os.path.isdir("/root/reference/glsl"), \
+            "oracle/_ref/libglctx.so is missing although /root/reference is present: run `make -C oracle glctx`"
+        pytest.skip("reference checkout absent: the shaders run in the build container only")
+    return gl_ref
+
+
+def within(got, want, tol, what, allow_nan_in_want=False, excuse=None):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    assert got.shape == want.shape, what
+    skip = np.isnan(want) & ~np.isnan(got) if allow_nan_in_want else np.zeros(got.shape, bool)
+    assert skip.mean() <= MAX_NAN_FRACTION, "%s: %d values are NaN on llvmpipe only" % (what, int(skip.sum()))
+    if excuse is not None:
+        for idx in np.argwhere(skip):
+            assert excuse(tuple(int(v) for v in idx)), "%s: NaN on llvmpipe at %s without a negative angle" % (what, tuple(idx))
+    same_nan = np.isnan(got) == np.isnan(want)
+    assert np.all(same_nan | skip), "%s: %d NaN mismatches" % (what, int((~(same_nan | skip)).sum()))
+    fin = np.isfinite(got) & np.isfinite(want)
+    inf_ok = (got == want) | ~(np.isinf(got) | np.isinf(want))
+    assert np.all(inf_ok | skip), "%s: infinities differ" % what
+    d = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64))
+    assert d.size == 0 or d.max() <= tol, "%s: max |difference| %.3g > %.3g (%d values beyond)" % (what, d.max(), tol, int((d > tol).sum()))
+    return int(skip.sum())
+
+
+def negative_angle(scene, i, depth_b, normal):
+    """The two situations in which llvmpipe's quality is NaN and the oracle's is not, checked per texel:
+    (a) pre_quality.fs:43-48 in float64: dot(normalize(camera - world_pos), normal) < 0, so pow(angle, 2.0) (:104) is
+        undefined in GLSL -- llvmpipe returns NaN, libm's powf the square;
+    (b) a NaN normal among the 8 neighbours: `kinect_normals` is LINEAR and sampled at the texel centre, llvmpipe
+        evaluates a + w * (b - a) with w = 0 (or 1e-7 for sizes that are not powers of two) in float, which is NaN for
+        b = NaN; the oracle reads the texel itself (a texture unit's 8-bit weight is 0 there)."""
+    import pyoracle
+    H, W = depth_b.shape[:2]
+    cam = np.asarray(pyoracle.camera_pos(scene.xyz[i]), np.float64)
+
+    def check(idx):
+        y, x = idx
+        if np.isnan(normal[max(y - 1, 0):y + 2, max(x - 1, 0):x + 2]).any():
+            return True
+        pos = np.asarray(pyoracle.tex3d(scene.xyz[i], (x + 0.5) / W, (y + 0.5) / H, float(depth_b[y, x, 0])), np.float64)[:3]
+        d = cam - pos
+        return float(np.dot(d / np.linalg.norm(d), np.asarray(normal[y, x], np.float64))) < 1e-6
+    return check
+
+
+def compare(got, fx, name, what, scene):
+    """`got`: images per sensor + counters + tsdf of the oracle or the HIP path; `fx`: the Mesa run"""
+    n = shader_cases.CASES[name][0]
+    limit = np.float32(0.01)
+    u8 = name in shader_cases.COMPRESSED_DEPTH
+    for k in shader_cases.IMAGES:
+        for i in range(n):
+            w = "%s vs Mesa: %s sensor %d" % (what, k, i)
+            if k in EXACT and not (u8 and k in ("morph", "depth_rg")):
+                assert same_bits(got[k][i], fx[k][i]), "%s: %d texels differ" % (w, count_diff(got[k][i], fx[k][i]))
+            elif k in EXACT:
+                within(got[k][i], fx[k][i], TOL_U8_DEPTH, w)
+            else:
+                within(got[k][i], fx[k][i], TOL[k], w, allow_nan_in_want=(k == "quality"),
+                       excuse=negative_angle(scene, i, got["depth_b"][i], got["normal"][i]) if k == "quality" else None)
+    assert np.array_equal(got["counters"], fx["counters"]), "%s vs Mesa: brick counters differ" % what
+    t, r = np.asarray(got["tsdf"], np.float32), fx["tsdf"]
+    skipped = within(t, r, TOL_TSDF, "%s vs Mesa: TSDF" % what, allow_nan_in_want=True)
+    ok = ~(np.isnan(r) | np.isnan(t))
+
+    def cls(v):
+        return np.where(v <= -limit, -1, np.where(v >= limit, 1, 0))
+    assert np.array_equal(cls(t)[ok], cls(r)[ok]), "%s vs Mesa: %d voxels change class" % (what, int((cls(t)[ok] != cls(r)[ok]).sum()))
+    return skipped
+
+
+def oracle_frame(orc, pkg, name):
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, pkg.capi, name)
+    flags, G = shader_cases.CASES[name][5], shader_cases.CASES[name][3]
+    ref = orc.run_pipeline(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit,
+                           brick_size=geo.brick_size, bv=geo.brick_voxels, res_bricks=tuple(geo.res_bricks),
+                           filter_textures=bool(flags & 1), processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=False,
+                           compress=name in shader_cases.COMPRESSED_DEPTH)
+    return scene, inv, ref
+
+
+def test_the_vertex_stage_defect_of_llvmpipe_is_what_the_harness_pads_for():
+    """Mesa against itself (a probe shader of the harness, no reference text, no oracle): after a fetch through a
+    uniform-indexed sampler array the next fetch returns 0 in every vertex that is not the first of 8 -- the reason
+    gl_ref.integrate draws one voxel centre per group of 8.  If a future Mesa fixes it the padding is merely unnecessary."""
+    gl_ref = gl_lib()
+    wrong = gl_ref.vs_sampler_array_bug(64)
+    assert all(i % 8 != 0 for i in wrong), "a first-of-8 vertex is wrong as well: the padding does not cover this Mesa"
+
+
+@pytest.mark.parametrize("name", sorted(shader_cases.CASES))
+def test_mesa_runs_the_reference_glsl_and_reproduces_the_fixtures(pkg, name):
+    gl_ref = gl_lib()
+    import make_gl_golden
+    scene, cfg, geo, inv, out = make_gl_golden.run_case(name)
+    fx = fixture(name)
+    assert bytes(fx["inputs_sha256"]).decode() == shader_cases.digest(scene, inv), "the synthetic scene drifted: regenerate the fixtures"
+    for k in shader_cases.IMAGES:
+        assert same_bits(np.stack(out[k]), fx[k]), "%s: Mesa no longer reproduces the committed fixture (%d differ)" % (k, count_diff(np.stack(out[k]), fx[k]))
+    assert np.array_equal(out["counters"], fx["counters"])
+    assert same_bits(out["tsdf"], fx["tsdf"])
+
+
+@pytest.mark.parametrize("name", sorted(shader_cases.CASES))
+def test_oracle_matches_the_reference_glsl_run(orc, pkg, name):
+    scene, inv, ref = oracle_frame(orc, pkg, name)
+    fx = fixture(name)
+    assert bytes(fx["inputs_sha256"]).decode() == shader_cases.digest(scene, inv), "the synthetic scene drifted: regenerate the fixtures"
+    compare(ref, fx, name, "oracle", scene)
+    assert np.any(np.abs(fx["tsdf"]) < 0.01) and fx["counters"].sum() > 0          # the fixtures are not trivial
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(shader_cases.CASES))
+def test_hip_path_matches_the_reference_glsl_run(pkg, name):
+    capi = pkg.capi
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, capi, name)
+    n = shader_cases.CASES[name][0]
+    fx = fixture(name)
+    assert bytes(fx["inputs_sha256"]).decode() == shader_cases.digest(scene, inv)
+    ctx = capi.Context(cfg, 0)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth_u8 if name in shader_cases.COMPRESSED_DEPTH else scene.depth, scene.color)
+    got = {k: [ctx.readback_image(which, i) for i in range(n)] for k, which in IMG.items()}
+    got["counters"] = ctx.readback_brick_counters()
+    got["tsdf"] = ctx.readback_tsdf()
+    ctx.close()
+    compare(got, fx, name, "HIP path", scene)
