@@ -425,12 +425,18 @@ def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=N
 
     # ---- ReconIntegration::integrate (:243-270), full sweep: VolumeSampler::sample() ----
     frame_tex = {"color": tex_color, "depth_b": tex_depth_b, "quality": tex_quality, "normal": tex_normal, "sil": tex_sil}
+    vol = None
     if inv_luts is not None:
         X, Y, Z = res
-        out["tsdf"] = integrate(cal, frame_tex, n, (X, Y, Z), limit, (W, H))
+        vol = g.texture(m.TEXTURE_3D, m.LINEAR)                                                    # m_volume_tsdf, :52, :347
+        g.glTexImage3D(m.TEXTURE_3D, 0, m.R32F, X, Y, Z, 0, m.RED, m.FLOAT, None)
+        out["tsdf"] = integrate(cal, frame_tex, n, (X, Y, Z), limit, (W, H), volume=vol)
     if keep:
-        out["_gl"] = {"cal": cal, "tex": frame_tex}
+        out["_gl"] = {"cal": cal, "tex": frame_tex, "volume": vol}
+        delete_textures([tex_raw, tex_lab, tex_depth] + depth2)
         return out
+    if vol is not None:
+        delete_textures([vol])
     delete_textures([tex_color, tex_raw, tex_lab, tex_quality, tex_normal, tex_sil, tex_depth, tex_depth_b] + depth2)
     cal.free()
     return out
@@ -525,7 +531,7 @@ def release(out):
     """frees what run_frame(keep=True) left alive"""
     st = out.pop("_gl", None)
     if st:
-        delete_textures(list(st["tex"].values()))
+        delete_textures(list(st["tex"].values()) + ([st["volume"]] if st["volume"] else []))
         st["cal"].free()
 
 
@@ -582,3 +588,310 @@ def vs_sampler_array_bug(count=64):
     delete_textures([vol, ones])
     assert np.all(res[1] == 1.0), "the constant-index variant is wrong too"
     return [int(i) for i in np.nonzero(res[0] != res[1])[0]]
+
+
+# ---- consumers of the volume: ReconIntegration::drawF = drawDepthLimits + draw + fillColors --------------
+CUBE = np.array([1, 1, 1, 0, 1, 1, 1, 1, 0, 0, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0, 0, 1, 0, 0], np.float32)     # unit_cube.cpp:20-29
+CUBE_STRIP = np.array([3, 2, 6, 7, 4, 2, 0, 3, 1, 6, 5, 4, 1, 0], np.uint8)                               # :45-48
+_cube_vao = None
+
+
+def cube_vao():
+    global _cube_vao
+    if _cube_vao is None:
+        g = gl()
+        _cube_vao = g.gen("VertexArrays")
+        g.glBindVertexArray(_cube_vao)
+        buffer(m.ARRAY_BUFFER, CUBE)
+        g.glEnableVertexAttribArray(0)
+        g.glVertexAttribPointer(0, 3, m.FLOAT, 0, 12, C.c_void_p(0))
+        g.glBindVertexArray(0)
+    return _cube_vao
+
+
+def lod_layout(W, H):
+    """ViewLod::setResolution (view_lod.cpp:24-48): -> (full width, offsets [n,2], resolutions [n,2])"""
+    n = 1 + int(np.floor(np.log2(np.float32(min(W, H)))))
+    FW = int(np.float32(W) * np.float32(1.5))
+    off, res = np.zeros((n, 2), np.uint32), np.zeros((n, 2), np.uint32)
+    ox, oy = W, H
+    for i in range(n):
+        p = np.power(np.float32(2.0), np.float32(i))
+        res[i] = (int(np.floor(np.float32(W) / p)), int(np.floor(np.float32(H) / p)))
+        if i > 0:
+            oy -= int(res[i][1])
+            off[i] = (ox, oy)
+    return FW, off, res
+
+
+class ViewLod:
+    """view_lod.cpp: one RGBA32F colour atlas (LINEAR, MIRRORED_REPEAT s/t) + DEPTH_COMPONENT32 (NEAREST), 1.5 W x H"""
+
+    def __init__(self, W, H):
+        g = gl()
+        self.W, self.H = W, H
+        self.FW, self.off, self.res = lod_layout(W, H)
+        half = np.full((H, self.FW, 4), 0.5, np.float32)
+        self.color = g.texture(m.TEXTURE_2D, m.LINEAR)
+        g.glTexImage2D(m.TEXTURE_2D, 0, m.RGBA32F, self.FW, H, 0, m.RGBA, m.FLOAT, half.ctypes.data)
+        g.glTexParameteri(m.TEXTURE_2D, m.TEXTURE_WRAP_S, m.MIRRORED_REPEAT)
+        g.glTexParameteri(m.TEXTURE_2D, m.TEXTURE_WRAP_T, m.MIRRORED_REPEAT)
+        self.depth = g.texture(m.TEXTURE_2D, m.NEAREST)
+        g.glTexImage2D(m.TEXTURE_2D, 0, m.DEPTH_COMPONENT32, self.FW, H, 0, m.DEPTH_COMPONENT, m.FLOAT, half[..., 0].copy().ctypes.data)
+        self.fbo = g.gen("Framebuffers")
+        g.glBindFramebuffer(m.FRAMEBUFFER, self.fbo)
+        g.glFramebufferTexture2D(m.FRAMEBUFFER, m.COLOR_ATTACHMENT0, m.TEXTURE_2D, self.color, 0)
+        g.glFramebufferTexture2D(m.FRAMEBUFFER, m.DEPTH_ATTACHMENT, m.TEXTURE_2D, self.depth, 0)
+        draw_buffers(1)
+        check_fbo("ViewLod (RGBA32F + DEPTH_COMPONENT32)")
+        g.glBindFramebuffer(m.FRAMEBUFFER, 0)
+
+    def enable(self, lod=0, clear_color=True, clear_depth=True):
+        g = gl()
+        g.glBindFramebuffer(m.FRAMEBUFFER, self.fbo)
+        g.glViewport(int(self.off[lod][0]), int(self.off[lod][1]), int(self.res[lod][0]), int(self.res[lod][1]))
+        if clear_color:
+            g.glClearColor(0.0, 1.0, 0.0, 0.0)
+            g.glClear(m.COLOR_BUFFER_BIT)
+        if clear_depth:
+            g.glClear(m.DEPTH_BUFFER_BIT)
+
+    def disable(self):
+        gl().glBindFramebuffer(m.FRAMEBUFFER, 0)
+
+    def bind_units(self, start):
+        bind(start, m.TEXTURE_2D, self.color)
+        bind(start + 1, m.TEXTURE_2D, self.depth)
+
+    def read(self, full=False):
+        g = gl()
+        c = g.read_texture(m.TEXTURE_2D, self.color, m.RGBA, (self.H, self.FW, 4))
+        d = g.read_texture(m.TEXTURE_2D, self.depth, m.DEPTH_COMPONENT, (self.H, self.FW))
+        return (c, d) if full else (c[:, :self.W].copy(), d[:, :self.W].copy())
+
+    def free(self):
+        delete_textures([self.color, self.depth])
+
+
+def set_matrices(view):
+    """g_camera.set() / update_model_matrix(): the fixed-function matrix stacks the shaders read as gl_ModelViewMatrix /
+    gl_ProjectionMatrix (compatibility profile)"""
+    g = gl()
+    pr = np.array(list(view.projection), np.float32)
+    mv = np.array(list(view.modelview), np.float32)
+    g.glMatrixMode(m.PROJECTION)
+    g.glLoadMatrixf(pr.ctypes.data)
+    g.glMatrixMode(m.MODELVIEW)
+    g.glLoadMatrixf(mv.ctypes.data)
+    return mv, pr
+
+
+def brick_buffers(brick_size, res_bricks, counters, min_voxels):
+    """SSBO 3 as divideBox lays it out with the frame's counters in it, SSBO 4 = updateOccupiedBricks' id list
+    (recon_integration.cpp:389-401, :428-446) -> (ssbo3, ssbo4, occupied ids)"""
+    g = gl()
+    nb = int(np.prod(res_bricks))
+    head = np.zeros(8 + nb, np.uint32)
+    head[0] = np.array([brick_size], np.float32).view(np.uint32)[0]
+    head[4:7] = np.array(res_bricks, np.uint32)
+    head[8:] = counters
+    b3 = buffer(m.SHADER_STORAGE_BUFFER, head, m.DYNAMIC_COPY)
+    g.glBindBufferRange(m.SHADER_STORAGE_BUFFER, 3, b3, 0, head.nbytes)
+    ids = np.nonzero(np.asarray(counters) >= min_voxels)[0].astype(np.uint32)
+    occ = np.zeros(8 + nb, np.uint32)
+    occ[:ids.size] = ids
+    b4 = buffer(m.SHADER_STORAGE_BUFFER, occ, m.DYNAMIC_DRAW)
+    if ids.size:
+        g.glBindBufferRange(m.SHADER_STORAGE_BUFFER, 4, b4, 0, 4 * ids.size)
+    return b3, b4, ids
+
+
+def depth_limits(view, brick_size, res_bricks, counters, min_voxels):
+    """ReconIntegration::drawDepthLimits (:406-425): the occupied bricks as instanced unit cubes through bricks.{vs,gs,fs}
+    into an RGBA32F target without depth buffer, cleared to (1, 0, 1, 0), MIN blending -> [H, W, 4]"""
+    g = gl()
+    W, H = view.width, view.height
+    tex = g.texture(m.TEXTURE_2D, m.LINEAR)
+    g.glTexImage2D(m.TEXTURE_2D, 0, m.RGBA32F, W, H, 0, m.RGBA, m.UNSIGNED_BYTE, None)                 # view.cpp:41
+    fbo = g.gen("Framebuffers")
+    g.glBindFramebuffer(m.FRAMEBUFFER, fbo)
+    g.glFramebufferTexture2D(m.FRAMEBUFFER, m.COLOR_ATTACHMENT0, m.TEXTURE_2D, tex, 0)
+    draw_buffers(1)
+    check_fbo("depth-limit view (RGBA32F)")
+    g.glViewport(0, 0, W, H)
+    g.glClearColor(1.0, 0.0, 1.0, 0.0)                                                                 # :144
+    g.glClear(m.COLOR_BUFFER_BIT)
+    b3, b4, ids = brick_buffers(brick_size, res_bricks, counters, min_voxels)
+    p = Prog("bricks", ["bricks.vs", "bricks.fs", "bricks.gs"])
+    assert g.glGetAttribLocation(p.id, b"in_Position") == 0
+    p.use()
+    set_matrices(view)
+    g.glEnable(m.DEPTH_TEST)
+    g.glDepthFunc(m.LESS)
+    g.glDisable(m.CULL_FACE)
+    g.glEnable(m.BLEND)
+    g.glBlendEquation(m.MIN)
+    if ids.size:
+        g.glBindVertexArray(cube_vao())
+        g.glDrawElementsInstanced(m.TRIANGLE_STRIP, CUBE_STRIP.size, m.UNSIGNED_BYTE, CUBE_STRIP.ctypes.data, int(ids.size))
+        g.glBindVertexArray(0)
+    g.glUseProgram(0)
+    g.glDisable(m.BLEND)
+    g.glBlendEquation(m.FUNC_ADD)
+    g.glBindFramebuffer(m.FRAMEBUFFER, 0)
+    g.glFinish()
+    out = g.read_texture(m.TEXTURE_2D, tex, m.RGBA, (H, W, 4))
+    return out, tex
+
+
+def raymarch(view, cal, tex, volume, n, limit, peels_tex=None, target=None):
+    """ReconIntegration::draw (:170-241) into a ViewLod (what m_fill_holes = true renders to; the same shader output
+    the default framebuffer would quantise to RGBA8): tsdf_raymarch.{vs,fs} over UnitCube::draw
+    -> (colour [H,W,4], depth [H,W], sample counts [H,W], the ViewLod)"""
+    g = gl()
+    W, H = view.width, view.height
+    p = Prog("raymarch", ["tsdf_raymarch.vs", "tsdf_raymarch.fs"])
+    p.use()
+    mv, pr = set_matrices(view)
+    # ctor (:61-87)
+    p.mat4("vol_to_world", list(view.vol_to_world))
+    p.i("kinect_colors", 1)
+    p.i("kinect_depths", 2)
+    p.i("kinect_qualities", 3)
+    p.i("kinect_normals", 4)
+    p.iv("cv_xyz_inv", cal.units_inv)
+    p.iv("cv_uv", cal.units_uv)
+    p.u("num_kinects", n)
+    p.f("limit", limit)
+    p.i("depth_peels", 17)
+    p.b("skipSpace", bool(view.skip_space))
+    p.i("tex_num_samples", IMAGE_UNIT + 1)
+    p.fv("viewport_offset", [0.0, 0.0], 2)
+    p.i("volume_tsdf", 29)
+    # draw (:177-209)
+    p.mat4("img_to_eye_curr", list(view.img_to_eye))
+    p.mat4("NormalMatrix", list(view.normal_matrix))
+    p.fv("CameraPos", list(view.camera_pos), 3)
+    # the mat4 the text declares as gl_NormalMatrix (see the header of this file): inverseTranspose(modelview)
+    nm = np.linalg.inv(mv.reshape(4, 4).T.astype(np.float64)).T                   # row-major maths on M = mv^T-of-columns
+    p.mat4("ref_NormalMatrix", np.ascontiguousarray(nm.T.reshape(-1), np.float32))
+    settings = buffer(m.UNIFORM_BUFFER, np.array([view.shade_mode, 0, 0, 0], np.int32))     # kinect_client.cpp:262-266
+    g.glBindBufferBase(m.UNIFORM_BUFFER, 1, settings)
+    bind_frame(tex)
+    bind(29, m.TEXTURE_3D, volume)                                                           # :348
+    if peels_tex is not None:
+        bind(17, m.TEXTURE_2D, peels_tex)
+    ns = g.texture(m.TEXTURE_2D, m.LINEAR)
+    g.glTexImage2D(m.TEXTURE_2D, 0, m.R32F, W, H, 0, m.RED, m.FLOAT, None)                   # resize :498
+    zero = C.c_float(0.0)
+    g.glClearTexImage(ns, 0, m.RED, m.FLOAT, C.byref(zero))
+    g.glBindImageTexture(IMAGE_UNIT + 1, ns, 0, 0, 0, m.WRITE_ONLY, m.R32F)
+    t = target or ViewLod(W, H)
+    g.glEnable(m.DEPTH_TEST)
+    g.glDepthFunc(m.LESS)
+    t.enable()
+    g.glDisable(m.CULL_FACE)
+    g.glBindVertexArray(cube_vao())
+    g.glDrawElements(m.TRIANGLE_STRIP, CUBE_STRIP.size, m.UNSIGNED_BYTE, CUBE_STRIP.ctypes.data)
+    g.glBindVertexArray(0)
+    g.glMemoryBarrier(m.ALL_BARRIER_BITS)
+    g.glUseProgram(0)
+    t.disable()
+    g.glFinish()
+    color, depth = t.read()
+    samples = g.read_texture(m.TEXTURE_2D, ns, m.RED, (H, W))
+    delete_textures([ns])
+    return color, depth, samples, t
+
+
+def fill_colors(a, W, H):
+    """ReconIntegration::fillColors (:280-339) on the ViewLod `a` the ray-march rendered into; the last pass goes to an
+    RGBA32F + DEPTH_COMPONENT32 target of this file instead of the window.  -> (filled colour [H,W,4], depth [H,W])"""
+    g = gl()
+    b = ViewLod(W, H)
+    nl = a.off.shape[0]
+    vs = "texture_passthrough.vs"
+    transfer, inpaint, colorfill = Prog("transfer", [vs, "framebuffer_transfer.fs"]), Prog("inpaint", [vs, "tsdf_inpaint.fs"]), Prog("colorfill", [vs, "tsdf_colorfill.fs"])
+    rinv = np.array([np.float32(1.0) / np.float32(a.FW), np.float32(1.0) / np.float32(H)], np.float32)
+    for p in (inpaint, colorfill):                                                             # ctor :103-128, resize :502-510
+        p.use()
+        p.i("texture_color", 15)
+        p.i("texture_depth", 16)
+        p.fv("viewport_offset", [0.0, 0.0], 2)
+        p.uv("texture_offsets", a.off, 2)
+        p.uv("texture_resolutions", a.res, 2)
+        p.fv("resolution_inv", rinv, 2)
+    colorfill.i("num_lods", nl)
+    transfer.use()
+    transfer.i("texture_color", 15)
+    transfer.i("texture_depth", 16)
+    transfer.uv("resolution_tex", np.array([a.FW, H], np.uint32), 2)
+    g.glEnable(m.DEPTH_TEST)
+    g.glDepthFunc(m.ALWAYS)
+
+    def do_transfer():
+        nonlocal a, b
+        a.bind_units(15)
+        b.enable(0)
+        transfer.use()
+        transfer.i("lod", 0)
+        draw_quad()
+        b.disable()
+        a, b = b, a
+
+    do_transfer()
+    for i in range(1, nl):
+        a.bind_units(15)
+        b.enable(i, False, False)
+        inpaint.use()
+        inpaint.i("lod", i - 1)
+        draw_quad()
+        b.disable()
+        a, b = b, a
+        do_transfer()
+    g.glDepthFunc(m.LESS)
+    b.bind_units(15)                                       # m_view_inpaint2 (:316)
+    win = ViewLod(W, H)                                    # stands for the window: only its LOD-0 rectangle is used
+    win.enable(0)
+    g.glClearColor(0.0, 0.0, 0.0, 0.0)
+    g.glClear(m.COLOR_BUFFER_BIT | m.DEPTH_BUFFER_BIT)     # kinect_client.cpp:614
+    colorfill.use()
+    colorfill.uv("resolution_tex", a.res[0], 2)
+    colorfill.i("lod", 0)
+    draw_quad()
+    win.disable()
+    g.glUseProgram(0)
+    g.glFinish()
+    oc, od = win.read()
+    atlas = b.read(full=True)[0]
+    win.free()
+    a.free()
+    b.free()
+    return oc, od, atlas
+
+
+def run_views(name, scene, cfg, geo, inv, out):
+    """every view of shader_cases.VIEW_CASES[name] from the frame run_frame(keep=True) left in GL"""
+    import pyoracle
+    import shader_cases
+    from rgbd_recon_amd import capi, synth
+    st = out["_gl"]
+    n = scene.N
+    res = {}
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(capi, synth, eye, mode, skip)
+        v = pyoracle.View.from_buffer_copy(bytes(view))
+        peels_tex = None
+        if skip:
+            peels, peels_tex = depth_limits(v, geo.brick_size, tuple(geo.res_bricks), out["counters"], cfg.min_voxels_per_brick)
+            res[key + "_peels"] = peels
+        color, depth, ns, target = raymarch(v, st["cal"], st["tex"], st["volume"], n, cfg.tsdf_limit, peels_tex)
+        res[key + "_color"], res[key + "_depth"], res[key + "_samples"] = color, depth, ns
+        if fill:
+            fc, fd, atlas = fill_colors(target, v.width, v.height)
+            res[key + "_filled_color"], res[key + "_filled_depth"] = fc, fd
+        else:
+            target.free()
+        if peels_tex is not None:
+            delete_textures([peels_tex])
+    return res

@@ -233,6 +233,7 @@ class GL:
     def texture(self, target, filt=LINEAR, wrap=CLAMP_TO_EDGE):
         """globjects Texture::createDefault: LINEAR min/mag, CLAMP_TO_EDGE s/t/r (globjects-0.5.0 Texture.cpp)"""
         t = self.gen("Textures")
+        self.glActiveTexture(TEXTURE0)          # unit 0 is this harness's scratch unit: the reference binds nothing to it
         self.glBindTexture(target, t)
         self.glTexParameteri(target, TEXTURE_MIN_FILTER, filt)
         self.glTexParameteri(target, TEXTURE_MAG_FILTER, filt)
@@ -244,6 +245,7 @@ class GL:
     def read_texture(self, target, tex, fmt, shape, dtype=np.float32, gltype=FLOAT):
         out = np.empty(shape, dtype)
         self.glPixelStorei(PACK_ALIGNMENT, 1)
+        self.glActiveTexture(TEXTURE0)
         self.glBindTexture(target, tex)
         self.glGetTexImage(target, 0, fmt, gltype, out.ctypes.data)
         return out

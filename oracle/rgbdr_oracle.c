@@ -850,8 +850,14 @@ static inline void mat4_mul_vec4(const float* m, const float* v, float* o)
  * that is: r = nearest emitted face, -g = farthest, b = nearest back face.  Restated per
  * ray: walk the brick grid along the pixel's ray; entering an occupied brick is a front
  * face, leaving one a back face (the unit-cube strip is wound counter-clockwise seen from
- * outside); faces outside the depth range [0,1] are clipped.  A neighbour outside the
- * grid counts as not occupied (the shader indexes out of range there). */
+ * outside); faces outside the depth range [0,1] are clipped.  The neighbour across a face on
+ * the grid's boundary: the shader adds ivec3(+-1) to the uvec3 brick index and linearises it
+ * (bricks.gs:28-43, inc_bricks.glsl:25-27), so x = -1 wraps to the linear id before (the last
+ * brick of the previous row), x = res.x to the id after, y = -1 / res.y to the ids res.x before /
+ * after -- an ALIASED brick inside the buffer whose counter decides the cull; only ids before
+ * the first or past the last brick are out of the buffer's range (robust access: 0 -> not
+ * occupied).  Seen in the run of the shaders on Mesa (tests/test_gl_ref.py): whole boundary
+ * faces are culled by the counter of the aliased brick. */
 
 typedef struct {
   float bbox_min[3];
@@ -869,8 +875,11 @@ static inline float peel_z(const float* pmv, const float* o, const float* d, flo
 
 static inline int grid_counter_gt10(const orc_brick_grid* g, const uint32_t* counters, const int* c)
 {
-  if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->res_bricks[0] || c[1] >= g->res_bricks[1] || c[2] >= g->res_bricks[2]) return 0;
-  return counters[((size_t)c[2] * g->res_bricks[1] + c[1]) * g->res_bricks[0] + c[0]] > 10u;
+  /* `c` may lie one cell outside the grid along one axis: the shader's uint arithmetic wraps to the same linear id */
+  const long nb = (long)g->res_bricks[0] * g->res_bricks[1] * g->res_bricks[2];
+  const long id = ((long)c[2] * g->res_bricks[1] + c[1]) * g->res_bricks[0] + c[0];
+  if (id < 0 || id >= nb) return 0;
+  return counters[id] > 10u;
 }
 static inline int grid_in_list(const orc_brick_grid* g, const uint8_t* mask, const int* c)
 {
@@ -901,11 +910,16 @@ static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_bri
   const float d[3] = {f4[0] - o4[0], f4[1] - o4[1], f4[2] - o4[2]};
   /* clip the segment t in [0,1] against the brick grid's box */
   float t0 = 0.0f, t1 = 1.0f;
+  int entry_axis = -1; /* the axis of the box face the ray enters the grid through (when it starts outside) */
   for (int a = 0; a < 3; ++a) {
     const float lo = g->bbox_min[a], hi = g->bbox_min[a] + g->brick_size * (float)g->res_bricks[a];
     const float inv = 1.0f / d[a];
     const float ta = (lo - o[a]) * inv, tb = (hi - o[a]) * inv;
-    t0 = fmaxf(t0, fminf(ta, tb));
+    const float tin = fminf(ta, tb);
+    if (tin > t0) {
+      t0 = tin;
+      entry_axis = a;
+    }
     t1 = fminf(t1, fmaxf(ta, tb));
   }
   if (!(t0 < t1)) return;
@@ -935,7 +949,8 @@ static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_bri
   }
   float r = 1.0f, gneg = 0.0f, b = 1.0f;
   /* entry into the grid from outside (t0 > 0): previous cell is outside the grid */
-  int prev_in_grid = 0, prev[3] = {-1, -1, -1};
+  int prev_in_grid = 0, prev[3] = {cell[0], cell[1], cell[2]};
+  if (entry_axis >= 0) prev[entry_axis] -= stepi[entry_axis]; /* the cell outside the grid the ray comes from */
   float tcur = t0;
   int first = 1;
   for (int iter = 0; iter < 4096; ++iter) {
@@ -946,7 +961,7 @@ static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_bri
       if (cur_list || prev_list) {
         const float z = peel_z(pmv, o, d, tcur);
         if (z >= 0.0f && z <= 1.0f) {
-          if (cur_list && !(prev_in_grid && grid_counter_gt10(g, counters, prev))) { /* front face of `cell` */
+          if (cur_list && !grid_counter_gt10(g, counters, prev)) { /* front face of `cell` */
             r = fminf(r, z);
             gneg = fminf(gneg, -z);
           }
@@ -966,7 +981,9 @@ static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_bri
     const float tnext = tmax[a];
     if (!(tnext < t1)) {
       /* leaving through the grid's outer box at t1: back face of the last cell */
-      if (grid_in_list(g, mask, cell)) {
+      int beyond[3] = {cell[0], cell[1], cell[2]};
+      beyond[a] += stepi[a];
+      if (grid_in_list(g, mask, cell) && !grid_counter_gt10(g, counters, beyond)) {
         const float z = peel_z(pmv, o, d, t1);
         if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
           r = fminf(r, z);
@@ -985,7 +1002,7 @@ static void depth_peel_pixel(const orc_view* vw, const float* pmv, const orc_bri
     tcur = tnext;
     if (cell[a] < 0 || cell[a] >= g->res_bricks[a]) {
       /* stepped out of the grid: back face of prev */
-      if (grid_in_list(g, mask, prev)) {
+      if (grid_in_list(g, mask, prev) && !grid_counter_gt10(g, counters, cell)) {
         const float z = peel_z(pmv, o, d, tcur);
         if (z >= 0.0f && z <= 1.0f) {
           r = fminf(r, z);

@@ -391,6 +391,10 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
 // neighbour with counter > 10 dropped by the geometry shader.  Per pixel: walk the
 // brick grid along the ray (Amanatides-Woo); entering an occupied brick is a front
 // face, leaving one a back face; faces outside the depth range are clipped.
+// Across a face on the grid's boundary the shader's "neighbour" is the brick its uint index
+// arithmetic wraps to (bricks.gs:28-43, inc_bricks.glsl:25-27): the linear id one before / after
+// (x), res.x before / after (y), res.x * res.y before / after (z) -- an aliased brick of the buffer
+// unless that id falls before the first or past the last brick (then: not occupied).
 __device__ __forceinline__ float peel_z(const PeelParams& p, const float* o, const float* d, float t)
 {
   const float4 c = mat4_mul(p.pmv, o[0] + d[0] * t, o[1] + d[1] * t, o[2] + d[2] * t, 1.0f);
@@ -402,7 +406,10 @@ __device__ __forceinline__ bool peel_in_grid(const PeelParams& p, const int* c)
 }
 __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
 {
-  return peel_in_grid(p, c) && p.counters[((size_t)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0]] > 10u;
+  // c may lie one cell outside the grid along one axis (see above): linear id with the shader's wrap-around
+  const long long nb = (long long)p.res_bricks[0] * p.res_bricks[1] * p.res_bricks[2];
+  const long long id = ((long long)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0];
+  return id >= 0 && id < nb && p.counters[id] > 10u;
 }
 __device__ __forceinline__ bool peel_listed(const PeelParams& p, const int* c)
 {
@@ -421,16 +428,21 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
     const float o[3] = {o4.x, o4.y, o4.z};
     const float d[3] = {f4.x - o4.x, f4.y - o4.y, f4.z - o4.z};
     float t0 = 0.0f, t1 = 1.0f;
+    int entry_axis = -1;                    // the box face the ray enters the grid through, if it starts outside
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float lo = p.bbox_min[a], hi = p.bbox_min[a] + p.brick_size * (float)p.res_bricks[a];
       const float inv = 1.0f / d[a];
       const float ta = (lo - o[a]) * inv, tb = (hi - o[a]) * inv;
-      t0 = fmaxf(t0, fminf(ta, tb));
+      const float tin = fminf(ta, tb);
+      if (tin > t0) {
+        t0 = tin;
+        entry_axis = a;
+      }
       t1 = fminf(t1, fmaxf(ta, tb));
     }
     if (!(t0 < t1)) break;
-    int cell[3], stepi[3], prev[3] = {-1, -1, -1};
+    int cell[3], stepi[3], prev[3];
     float tmax[3], tdelta[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -452,6 +464,10 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
         tdelta[a] = __builtin_inff();
       }
     }
+    // the cell outside the grid the ray comes from (its aliased brick decides the cull of the first front face)
+    prev[0] = cell[0] - (entry_axis == 0 ? stepi[0] : 0);
+    prev[1] = cell[1] - (entry_axis == 1 ? stepi[1] : 0);
+    prev[2] = cell[2] - (entry_axis == 2 ? stepi[2] : 0);
     bool prev_in_grid = false, first = true;
     // one mask byte per cell, loaded one cell ahead: the walk itself needs no loads, so the next cell is known before
     // this cell's faces are looked at and its byte is in flight meanwhile
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
         if (cur_list || prev_list) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
-            if (cur_list && !(prev_in_grid && peel_gt10(p, prev))) {
+            if (cur_list && !peel_gt10(p, prev)) {
               r = fminf(r, z);
               gneg = fminf(gneg, -z);
             }
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       }
       first = false;
       if (leaving) {
-        if (cur_list) {
+        if (cur_list && !peel_gt10(p, ncell)) {
           const float z = peel_z(p, o, d, t1);
           if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);
@@ -513,7 +529,7 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       else tmax[2] += tdelta[2];
       tcur = tnext;
       if (!next_in_grid) {
-        if (last_list) {
+        if (last_list && !peel_gt10(p, cell)) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);

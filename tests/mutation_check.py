@@ -122,7 +122,10 @@ MUTANTS = [
     ("start pos: the back face depth is -g", "k == 0 ? dr : -dg, 1.0f};", "k == 0 ? dr : dg, 1.0f};"),
     ("start pos: no face at all means no samples", "        if (dr >= 1.0f) {\n          pb[0] = pf[0];", "        if (0) {\n          pb[0] = pf[0];"),
     # bricks.{gs,fs}
-    ("peels: neighbour culls a face when its counter > 10", "]] > 10u;", "]] >= 10u;"),
+    ("peels: neighbour culls a face when its counter > 10", "return counters[id] > 10u;", "return counters[id] >= 10u;"),
+    ("peels: across the grid's boundary the neighbour is the brick the uint index wraps to",
+     "  if (id < 0 || id >= nb) return 0;\n  return counters[id] > 10u;",
+     "  if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= g->res_bricks[0] || c[1] >= g->res_bricks[1] || c[2] >= g->res_bricks[2]) return 0;\n  return counters[id] > 10u;"),
     ("peels: blue keeps the nearest BACK face only", "            r = fminf(r, z);\n            gneg = fminf(gneg, -z);\n          }\n          if (prev_list",
      "            r = fminf(r, z);\n            gneg = fminf(gneg, -z);\n            b = fminf(b, z);\n          }\n          if (prev_list"),
     ("peels: green is MIN of -z (the farthest face)", "            gneg = fminf(gneg, -z);\n            b = fminf(b, z);\n          }\n        }\n      }\n    }\n    first = 0;",

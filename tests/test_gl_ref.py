@@ -180,3 +180,117 @@ def test_hip_path_matches_the_reference_glsl_run(pkg, name):
     got["tsdf"] = ctx.readback_tsdf()
     ctx.close()
     compare(got, fx, name, "HIP path", scene)
+
+
+# ---- consumers of the volume on Mesa: bricks.{vs,gs,fs} through the rasteriser with MIN blending (drawDepthLimits),
+# ---- tsdf_raymarch.{vs,fs} over the unit cube with the depth test, framebuffer_transfer / tsdf_inpaint / tsdf_colorfill ----
+TOL_PEEL = 1e-6            # rasterised gl_FragCoord.z against the analytic face depth
+MAX_PEEL_EDGE = 2e-3       # fraction of peel values on a face edge where the rasteriser's fill rule decides
+TOL_VIEW_DEPTH = 2e-5
+TOL_VIEW_COLOR = 1e-2      # 8-bit bilinear weights of the colour frames, pow() of the Phong term on llvmpipe
+TOL_FILL_COLOR = 2e-3
+
+
+def view_fixture(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", "gl_views_%s.npz" % name))
+
+
+def occupied_mask(orc, counters, min_voxels):
+    ids, _ = orc.update_occupied(counters, min_voxels)
+    mask = np.zeros(counters.shape, np.uint8)
+    mask[ids] = 1
+    return mask
+
+
+def max_abs(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max()) if a.size else 0.0
+
+
+@pytest.mark.parametrize("name", sorted(shader_cases.VIEW_CASES))
+def test_mesa_reproduces_the_view_fixtures(pkg, name):
+    gl_ref = gl_lib()
+    import make_gl_golden
+    scene, cfg, geo, inv, out = make_gl_golden.run_case(name, keep=True)
+    views = gl_ref.run_views(name, scene, cfg, geo, inv, out)
+    gl_ref.release(out)
+    vf = view_fixture(name)
+    assert sorted(views) == sorted(vf.files)
+    for k in views:
+        assert same_bits(views[k], vf[k]), "%s: Mesa no longer reproduces the committed fixture (%d differ)" % (k, count_diff(views[k], vf[k]))
+
+
+@pytest.mark.parametrize("name", sorted(shader_cases.VIEW_CASES))
+def test_oracle_views_match_the_reference_glsl_run(orc, pkg, name):
+    """The oracle works on the frame Mesa produced (gl_passes fixture: volume, depth, quality, counters) and, for the
+    space-skipping views, marches from Mesa's peel image, so every stage is compared on identical inputs:
+      peels      oracle's per-ray grid walk == the rasterised, MIN-blended cube faces (incl. the geometry shader's cull)
+      ray-march  same pixels hit, same number of samples per pixel, depth and colour within tolerance
+      filling    the oracle fills Mesa's ray-marched frame; colours compared where the window's depth test (LESS
+                 against the cleared 1.0, recon_integration.cpp:314 + kinect_client.cpp:614,994) lets the fragment
+                 through, i.e. depth < 1 -- elsewhere the window keeps its clear colour"""
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, pkg.capi, name)
+    fx, vf = fixture(name), view_fixture(name)
+    n = scene.N
+    mask = occupied_mask(orc, fx["counters"], cfg.min_voxels_per_brick)
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(pkg.capi, pkg.synth, eye, mode, skip)
+        peels = None
+        if skip:
+            peels = vf[key + "_peels"]
+            op = orc.depth_peels(bytes(view), pkg.synth.BBOX_MIN, geo.brick_size, tuple(geo.res_bricks), fx["counters"], mask)
+            d = np.abs(op.astype(np.float64) - peels)
+            assert (d > TOL_PEEL).mean() <= MAX_PEEL_EDGE, "%s: %d peel values differ from the rasteriser's" % (key, int((d > TOL_PEEL).sum()))
+            assert np.array_equal(op[..., 0] < 1, peels[..., 0] < 1), "%s: peel coverage differs" % key
+            assert 0.02 < (peels[..., 0] < 1).mean() < 0.98
+        oc, od, on = orc.raymarch(bytes(view), fx["tsdf"], inv, scene.uv, [scene.color[i] for i in range(n)], list(fx["depth_b"]),
+                                  list(fx["quality"]), limit=cfg.tsdf_limit, peels=peels)
+        gc, gd, gn = vf[key + "_color"], vf[key + "_depth"], vf[key + "_samples"]
+        assert np.array_equal(od < 1, gd < 1), "%s: %d pixels hit in one frame only" % (key, int(((od < 1) != (gd < 1)).sum()))
+        assert 0.02 < (gd < 1).mean() < 0.98
+        assert same_bits(on, gn), "%s: sample counts differ at %d pixels" % (key, count_diff(on, gn))
+        assert max_abs(od, gd) <= TOL_VIEW_DEPTH, "%s: depth differs by %.3g" % (key, max_abs(od, gd))
+        assert max_abs(oc, gc) <= TOL_VIEW_COLOR, "%s: colour differs by %.3g" % (key, max_abs(oc, gc))
+        if fill:
+            fc, fd = orc.fill_colors(gc, gd)
+            gfc, gfd = vf[key + "_filled_color"], vf[key + "_filled_depth"]
+            assert max_abs(fd, gfd) <= 1e-6
+            shown = fd < 1
+            assert np.all(gfc[~shown] == 0.0), "%s: a fragment with depth 1 passed the window's depth test" % key
+            assert max_abs(fc[shown], gfc[shown]) <= TOL_FILL_COLOR, "%s: filled colour differs by %.3g" % (key, max_abs(fc[shown], gfc[shown]))
+            assert (shown & (gc[..., 3] <= 0)).sum() > 0            # pixels were actually filled
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(shader_cases.VIEW_CASES))
+def test_hip_views_match_the_reference_glsl_run(pkg, name):
+    """The HIP path renders from its OWN frame (bit-identical to the oracle's, i.e. ulps away from Mesa's) and its own
+    peels, so a ray may stop one sample earlier or later than on Mesa at a grazing pixel: the pixelwise comparisons
+    allow 2 % of the pixels to differ, everything else is held to the tolerances of the oracle test."""
+    capi = pkg.capi
+    scene, cfg, geo, inv, inv_res = shader_cases.build(pkg.synth, capi, name)
+    vf = view_fixture(name)
+    n = scene.N
+    ctx = capi.Context(cfg, 0)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    for key, eye, mode, skip, fill in shader_cases.VIEW_CASES[name]:
+        view = shader_cases.make_view(capi, pkg.synth, eye, mode, skip)
+        color, depth, ns = ctx.raymarch(view)
+        gc, gd, gn = vf[key + "_color"], vf[key + "_depth"], vf[key + "_samples"]
+        npx = gd.size
+        assert ((depth < 1) != (gd < 1)).sum() <= 0.02 * npx, "%s: coverage" % key
+        assert (ns != gn).sum() <= 0.02 * npx, "%s: %d sample counts differ" % (key, int((ns != gn).sum()))
+        both = (depth < 1) & (gd < 1)
+        assert (np.abs(depth - gd)[both] > TOL_VIEW_DEPTH).sum() <= 0.02 * npx, "%s: depth" % key
+        assert (np.abs(color - gc)[both].max(axis=-1) > TOL_VIEW_COLOR).sum() <= 0.02 * npx, "%s: colour" % key
+        if fill:
+            fc, fd = ctx.fill_colors(view.width, view.height)
+            gfc, gfd = vf[key + "_filled_color"], vf[key + "_filled_depth"]
+            shown = (fd < 1) & (gfd < 1)
+            assert ((fd < 1) != (gfd < 1)).sum() <= 0.02 * npx
+            assert (np.abs(fc - gfc)[shown].max(axis=-1) > TOL_VIEW_COLOR).sum() <= 0.03 * npx, "%s: filled colour" % key
+    ctx.close()

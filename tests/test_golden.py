@@ -10,8 +10,8 @@ import pytest
 from conftest import count_diff, same_bits
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (tests/golden/shader_*.npz are the fixtures of tests/test_shader_ref.py)
-FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith("shader_"))
+# (tests/golden/shader_*.npz are the fixtures of tests/test_shader_ref.py, gl_*.npz those of tests/test_gl_ref.py)
+FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith(("shader_", "gl_")))
 IMG = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
 FLAGS = {"two_sensors_1to1": 15, "two_sensors_generic": 15, "three_sensors_nobricks": 7}

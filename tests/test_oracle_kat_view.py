@@ -274,6 +274,38 @@ def test_depth_peels_cull_faces_towards_a_full_neighbour(orc, pkg):
     assert abs(p[C, C, 0] - window_depth(0.8)) < 2e-6 and p[C, C, 2] == 1.0 and abs(p[C, C, 1] + window_depth(0.8)) < 2e-6
 
 
+def test_depth_peels_boundary_face_is_culled_by_the_brick_the_index_wraps_to(orc, pkg):
+    """bricks.gs:28-43 adds ivec3(-1, 0, 0) to the uvec3 index of brick (0, 2, 2) and linearises it (inc_bricks.glsl:25-27):
+    uint arithmetic wraps to the linear id before, 59 = brick (4, 1, 2) of the 5^3 grid -- its counter decides whether
+    the face on the grid's boundary is drawn.  (Seen first in the run of the shaders on Mesa, tests/test_gl_ref.py.)
+    Camera on the -x side, looking along +x: the brick's x = 0 face is 2.0 from the eye, its x = 0.2 face 2.2."""
+    rb = GRID[2]
+    v = pkg.capi.make_view((-2.0, 0.5, 0.5), (0.5, 0.5, 0.5), (0, 1, 0), 20.0, 5, 5, (0, 0, 0), (1, 1, 1), near=NEAR, far=FAR)
+
+    def wd(dist):
+        p22, p32 = (FAR + NEAR) / (NEAR - FAR), 2 * FAR * NEAR / (NEAR - FAR)
+        return (p22 * -dist + p32) / dist * 0.5 + 0.5
+
+    def run(alias_count):
+        mask = np.zeros(125, np.uint8)
+        cnt = np.zeros(125, np.uint32)
+        mask[(2 * rb[1] + 2) * rb[0] + 0] = 1
+        cnt[(2 * rb[1] + 2) * rb[0] + 0] = 50
+        assert (2 * rb[1] + 2) * rb[0] + 0 - 1 == (2 * rb[1] + 1) * rb[0] + 4 == 59
+        cnt[59] = alias_count                                      # brick (4, 1, 2): not drawn, far from the ray
+        return orc.depth_peels(bytes(v), GRID[0], GRID[1], rb, cnt, mask)[C, C]
+
+    p = run(0)
+    assert abs(p[0] - wd(2.0)) < 2e-6 and abs(p[1] + wd(2.2)) < 2e-6 and abs(p[2] - wd(2.2)) < 2e-6
+    p = run(10)                                                    # > 10, not >= 10
+    assert abs(p[0] - wd(2.0)) < 2e-6
+    p = run(11)                                                    # the front face is gone: only the back face is left
+    assert abs(p[0] - wd(2.2)) < 2e-6 and abs(p[1] + wd(2.2)) < 2e-6 and abs(p[2] - wd(2.2)) < 2e-6
+    # an id outside the buffer (brick (2, 2, 4) towards +z: 137 >= 125) never culls: one brick seen from +z as before
+    q = peels_of(orc, pkg, [(2, 2, 4)], counters={(2, 2, 3): 0})
+    assert abs(q[C, C, 0] - window_depth(1.0)) < 2e-6 and abs(q[C, C, 2] - window_depth(0.8)) < 2e-6
+
+
 # ---- CalibrationInverter::calculateInverseVolumes (calibration_inverter.cpp:99-155) -------------------------
 def grid_lut(R=4):
     """forward LUT whose sample (sx, sy, sz) sits at ((s + 0.5) / R) of the unit box.  With the corner order of
