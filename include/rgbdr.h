@@ -430,7 +430,12 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels
 /* ReconIntegration::fillColors (recon_integration.cpp:280-339): screen-space hole
  * filling of the frame the last rgbdr_raymarch produced -- the tsdf_inpaint.fs pyramid
  * over the ViewLod atlas, then tsdf_colorfill.fs (first LOD with alpha > 0, blended
- * with the next two).  color = height*width RGBA32F, depth = height*width. */
+ * with the next two).  color = height*width RGBA32F, depth = height*width.
+ * These are the fragment shader's OUTPUTS for every pixel.  The reference draws that pass into its window with
+ * GL_LESS against the cleared depth (recon_integration.cpp:314, kinect_client.cpp:614,994): a fragment whose depth is
+ * exactly 1 -- a ray that hit nothing -- fails the test and the window keeps its clear colour there (seen in the run
+ * of the shaders on Mesa, tests/test_gl_ref.py).  A consumer that wants the reference's window takes
+ * depth < 1 ? color : its clear colour. */
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the

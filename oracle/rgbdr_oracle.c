@@ -8,10 +8,27 @@
  * (rgbd-recon_amd/csrc) never links, loads or calls anything in oracle/.
  *
  * PARITY PINNING.  The reference ships no tests, golden vectors or recordings
- *  and its arithmetic runs inside a GL driver that is not
- * available here, so the pass arithmetic below is pinned only by reading the
- * shader source ("parity unpinned" for those functions).  What IS
- * pinned against reference code compiled from /root/reference (oracle/_ref, see
+ * (SURVEY.md section 4).  Since round 3 the pass arithmetic below is pinned against
+ * OUTPUTS OF THE REFERENCE'S OWN SHADERS RUN IN THE BUILD CONTAINER: the GLSL files where
+ * they lie under /root/reference/glsl are compiled by Mesa's GLSL compiler and executed by
+ * llvmpipe (Mesa 23.2.1, OpenGL 4.5 compatibility profile, reached without an X server
+ * through the image's own swrast_dri.so: oracle/gl_context.c, oracle/gl_ref.py), through
+ * one frame in the reference's host order -- pre_morph, pre_depth, pre_boundary, pre_normal
+ * (+ mark_brick's SSBO atomics), pre_quality, tsdf_integration.vs (points + imageStore),
+ * bricks.{vs,gs,fs} (rasteriser + MIN blending), tsdf_raymarch.{vs,fs}, framebuffer_transfer /
+ * tsdf_inpaint / tsdf_colorfill -- and frozen as tests/golden/gl_passes_*.npz / gl_views_*.npz.
+ * tests/test_gl_ref.py holds this file to them (and the HIP path, on the GPU box): depth,
+ * filtered depth, boundary classes, silhouettes and brick counters bit for bit; normals,
+ * quality, Lab and the TSDF within the ulp-level tolerances stated there (TSDF: <= 2e-9
+ * observed, 1e-7 allowed, no voxel changes class); peels, ray-march and hole filling per
+ * pixel.  What that run does NOT pin: the reference's HOST code is restated by gl_ref.py
+ * (texture formats / filters / bindings / uniforms, read from NetKinectArray.cpp,
+ * recon_integration.cpp, CalibVolumes.cpp), and llvmpipe is not the NVIDIA driver the
+ * reference was developed on (filter weights are float, not 8-bit fixed point; pow / exp /
+ * inversesqrt are llvmpipe's approximations; pow(x < 0, y) is NaN there).  Two in-memory
+ * edits of the text and the one vertex-stage defect of llvmpipe the harness pads around
+ * are listed at the top of oracle/gl_ref.py.
+ * Also pinned, against reference C++ compiled from /root/reference (oracle/_ref, see
  * oracle/Makefile and oracle/ref_shim.cpp):
  *   - the calibration-volume file format (orc_lut_write / orc_lut_read versus
  *     framework/calibration/calibration_volume.hpp:30-79),
@@ -23,13 +40,13 @@
  *     (external/squish, the decoder of NetKinectArray.cpp:633).
  * The same shim also pins the C++ host mirror's sensor-yml scanner and .stream reader against
  * kinect::CalibrationFiles / sys::FileBuffer (tests/test_oracle_ref.py).
- * CHECKED, NOT PINNED (round 3): the TEXT of the reference's shaders -- pre_morph / pre_depth / pre_boundary /
+ * ALSO CHECKED (round 3, before the Mesa run existed): the TEXT of the reference's shaders -- pre_morph / pre_depth / pre_boundary /
  * pre_normal / pre_quality .fs, tsdf_integration.vs, tsdf_raymarch.fs + shading.glsl, framebuffer_transfer / tsdf_inpaint /
  * tsdf_colorfill .fs and their includes -- is compiled as C++ from /root/reference where it lies (oracle/build_shader_ref.py,
  * against the reference's vendored glm) and run against the functions below on synthetic scenes: bit-identical in every
  * image, counter, volume and frame (tests/test_shader_ref.py).  The texture samplers and the driver-defined built-ins of
- * that harness are stand-ins bound to THIS file's conventions (oracle/glsl_runtime.hpp), so it is not a run of the reference
- * and the pass arithmetic stays "parity unpinned"; it shows that no statement of a shader was mis-read.
+ * that harness are stand-ins bound to THIS file's conventions (oracle/glsl_runtime.hpp), so it is not a run of the reference;
+ * it shows that no statement of a shader was mis-read, bit for bit, where the Mesa run can only say "within llvmpipe's ulps".
  *
  * NUMERIC CONVENTIONS (decisions where GLSL / GL leave the result to the driver):
  *   - all arithmetic is IEEE-754 binary32, no FMA contraction (-ffp-contract=off),

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Mutation check of the oracle's known-answer tests (TEST INFRASTRUCTURE).
 
-The pass arithmetic of the oracle is pinned only by reading the shaders ("parity unpinned", DESIGN.md
-section 2): a transcription slip in oracle/rgbdr_oracle.c would be mirrored by the kernels and pass every
-HIP-vs-oracle test.  The analytic KATs (tests/test_oracle_kat.py, tests/test_oracle_kat_passes.py,
+Until round 3 the pass arithmetic of the oracle was pinned only by reading the shaders; now the reference's GLSL runs
+on Mesa in the build container (tests/test_gl_ref.py) -- within llvmpipe's ulps.  The KATs below remain
+the exact, driver-independent check: a transcription slip in oracle/rgbdr_oracle.c would be mirrored by the kernels and pass
+every HIP-vs-oracle test.  The analytic KATs (tests/test_oracle_kat.py, tests/test_oracle_kat_passes.py,
 tests/test_bricks_cpu.py) are the independent check -- this script shows they have teeth: each entry of
 MUTANTS flips one detail of the reference (a quirk, a constant, a comparison) in a scratch copy of the
 oracle source, builds it, and runs the KATs against it through RGBDR_ORACLE_LIB; the mutant must make at

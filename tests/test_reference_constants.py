@@ -67,7 +67,7 @@ CONSTANTS = [
     ("shading.glsl", r"vec3\(77,(\d+),74\) / 255\.0f", 175, r"\{77, 175, 74\}"),
     ("shading.glsl", r"vec3\(152,78,(\d+)\) / 255\.0f", 163, r"\{152, 78, 163\}"),
     ("shading.glsl", r"vec3\(255,(\d+),0\) / 255\.0f", 127, r"\{255, 127, 0\}"),
-    ("inc_bricks.glsl", r"return bricks\[index\] > (\d+)u;", 10, r"\]\] > 10u;"),
+    ("inc_bricks.glsl", r"return bricks\[index\] > (\d+)u;", 10, r"return counters\[id\] > 10u;"),
     ("bricks.fs", r"gl_FrontFacing \? ([\d.]+) : gl_FragCoord\.z", 1.0, r"float r = 1\.0f, gneg = 0\.0f, b = 1\.0f;"),
     ("tsdf_inpaint.fs", r"const int kernel_size = (\d+);", 4, r"for \(int x = 0; x < 4; \+\+x\)\n\s*for \(int y = 0; y < 4; \+\+y\) \{\n[^\n]*4\.0f \* 0\.5f \+ 1\.0f"),
     ("tsdf_inpaint.fs", r"\* vec2\(([\d.]+) / 3\.0 , 1\.0\)\);", 2.0, r"\(float\)lx \* \(2\.0f / 3\.0f\)"),
