@@ -15,8 +15,8 @@ approximations and filters 8-bit textures with 8-bit weights, the oracle uses li
   morph, depth_rg (float depth frames), depth_b, silhouette, brick counters     bit-exact
   morph, depth_rg of u8 depth frames                                            1e-6   (unorm8 -> float: x * (1/255) vs x / 255)
   Lab colour                                                                    4e-3   (pow(x, 1/3), 8-bit bilinear weights)
-  normals                                                                       1e-5
-  quality                                                                       2e-6; excluded: texels where llvmpipe's
+  normals                                                                       5e-5   (1.3e-5 seen at 512 x 424, where the differenced positions are closest)
+  quality                                                                       2e-6 + 2e-5 relative; excluded: texels where llvmpipe's
                                                                                 pow(angle < 0, 2) is NaN (undefined in GLSL) or
                                                                                 a NaN normal is a bilinear neighbour (weight 0)
   TSDF                                                                          1e-7, same class (-limit / +limit / surface)
@@ -35,7 +35,8 @@ import shader_cases  # noqa: E402
 
 IMG = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
 EXACT = ("morph", "depth_rg", "depth_b", "sil")
-TOL = {"lab": 4e-3, "normal": 1e-5, "quality": 2e-6}
+TOL = {"lab": 4e-3, "normal": 5e-5, "quality": 2e-6}
+RTOL = {"quality": 2e-5}         # two pow(x, 6.0) and a pow(x, 2.0) of llvmpipe's exp2(y * log2(x)) in one product
 TOL_U8_DEPTH = 1e-6
 TOL_TSDF = 1e-7
 MAX_NAN_FRACTION = 5e-3          # texels whose quality is NaN on llvmpipe only; each one must have a negative angle
@@ -55,7 +56,7 @@ def gl_lib():
     return gl_ref
 
 
-def within(got, want, tol, what, allow_nan_in_want=False, excuse=None):
+def within(got, want, tol, what, allow_nan_in_want=False, excuse=None, rtol=0.0):
     got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
     assert got.shape == want.shape, what
     skip = np.isnan(want) & ~np.isnan(got) if allow_nan_in_want else np.zeros(got.shape, bool)
@@ -68,7 +69,7 @@ def within(got, want, tol, what, allow_nan_in_want=False, excuse=None):
     fin = np.isfinite(got) & np.isfinite(want)
     inf_ok = (got == want) | ~(np.isinf(got) | np.isinf(want))
     assert np.all(inf_ok | skip), "%s: infinities differ" % what
-    d = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64))
+    d = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64)) - rtol * np.abs(want[fin].astype(np.float64))
     assert d.size == 0 or d.max() <= tol, "%s: max |difference| %.3g > %.3g (%d values beyond)" % (what, d.max(), tol, int((d > tol).sum()))
     return int(skip.sum())
 
@@ -94,10 +95,10 @@ def negative_angle(scene, i, depth_b, normal):
     return check
 
 
-def compare(got, fx, name, what, scene):
+def compare(got, fx, name, what, scene, limit=0.01, counter_slack=0.0):
     """`got`: images per sensor + counters + tsdf of the oracle or the HIP path; `fx`: the Mesa run"""
     n = shader_cases.CASES[name][0]
-    limit = np.float32(0.01)
+    limit = np.float32(limit)
     u8 = name in shader_cases.COMPRESSED_DEPTH
     for k in shader_cases.IMAGES:
         for i in range(n):
@@ -107,9 +108,10 @@ def compare(got, fx, name, what, scene):
             elif k in EXACT:
                 within(got[k][i], fx[k][i], TOL_U8_DEPTH, w)
             else:
-                within(got[k][i], fx[k][i], TOL[k], w, allow_nan_in_want=(k == "quality"),
+                within(got[k][i], fx[k][i], TOL[k], w, allow_nan_in_want=(k == "quality"), rtol=RTOL.get(k, 0.0),
                        excuse=negative_angle(scene, i, got["depth_b"][i], got["normal"][i]) if k == "quality" else None)
-    assert np.array_equal(got["counters"], fx["counters"]), "%s vs Mesa: brick counters differ" % what
+    dc = np.abs(got["counters"].astype(np.int64) - fx["counters"].astype(np.int64)).sum()
+    assert dc <= counter_slack * fx["counters"].sum(), "%s vs Mesa: brick counters differ by %d in total" % (what, dc)
     t, r = np.asarray(got["tsdf"], np.float32), fx["tsdf"]
     skipped = within(t, r, TOL_TSDF, "%s vs Mesa: TSDF" % what, allow_nan_in_want=True)
     ok = ~(np.isnan(r) | np.isnan(t))
@@ -294,3 +296,74 @@ def test_hip_views_match_the_reference_glsl_run(pkg, name):
             assert ((fd < 1) != (gfd < 1)).sum() <= 0.02 * npx
             assert (np.abs(fc - gfc)[shown].max(axis=-1) > TOL_VIEW_COLOR).sum() <= 0.03 * npx, "%s: filled colour" % key
     ctx.close()
+
+
+# ---- beyond the committed cases (build container only: Mesa runs live) -----------------------------------------------
+def live_compare(orc, pkg, gl_ref, scene, cfg, geo, res, inv, what, bricks=False, counter_slack=0.0, **kw):
+    """Mesa and the oracle on the same scene; the tolerances of `compare`.  With bricks=True the integration draws the
+    index lists of the occupied bricks (ReconIntegration::integrate with m_use_bricks, the reference's default;
+    recon_integration.cpp:255-261) instead of every voxel."""
+    n = scene.N
+    args = (scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, res, inv)
+    common = dict(limit=cfg.tsdf_limit, brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), **kw)
+    got = gl_ref.run_frame(*args, keep=bricks, **common)
+    ref = orc.run_pipeline(*args, bv=geo.brick_voxels, use_bricks=bricks, **common)
+    if bricks:
+        # the voxels of the occupied bricks: divideBox + containedVoxels (host code) on MESA's counters
+        ids, _ = orc.update_occupied(got["counters"], cfg.min_voxels_per_brick)
+        occ = np.zeros(got["counters"].shape, np.uint8)
+        occ[ids] = 1
+        vmask, _, _ = orc.brick_voxel_mask(pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, geo.brick_size, res, occ)
+        st = got["_gl"]
+        H, W = scene.depth.shape[1:3]
+        got["tsdf"] = gl_ref.integrate(st["cal"], st["tex"], n, res, cfg.tsdf_limit, (W, H), indices=[np.nonzero(vmask.ravel())[0]])
+        gl_ref.release(got)
+    fx = {k: np.stack(got[k]) for k in shader_cases.IMAGES}
+    fx["counters"], fx["tsdf"] = got["counters"], got["tsdf"]
+
+    name = "__live__"
+    shader_cases.CASES[name] = (n,)
+    try:
+        compare(ref, fx, name, what, scene, limit=cfg.tsdf_limit, counter_slack=counter_slack)
+    finally:
+        del shader_cases.CASES[name]
+    return fx, ref
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_scenes_oracle_matches_mesa(orc, pkg, seed):
+    """random sensor counts, image / LUT / grid sizes (mostly not powers of two), host toggles and limits; every
+    second seed integrates through the occupied bricks' index lists like the reference's default mode"""
+    gl_ref = gl_lib()
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(1, 5))
+    wh = (int(rng.integers(24, 49)), int(rng.integers(20, 41)))
+    lut_res = tuple(int(v) for v in rng.integers(8, 15, 3))
+    G = int(rng.choice([16, 20, 24, 27, 32]))
+    inv_res = None if rng.random() < 0.4 else tuple(int(v) for v in rng.integers(12, 40, 3))
+    flags = int(rng.integers(0, 8))
+    limit = float(rng.choice([0.01, 0.02, 0.035]))
+    scene = pkg.synth.Scene(n, wh[0], wh[1], lut_res=lut_res, seed=int(rng.integers(1, 10000)))
+    cfg = pkg.capi.make_config(n, wh, voxel_size=2.0 / G, brick_size=8 * 2.0 / G, tsdf_limit=limit)
+    geo = pkg.capi.compute_geometry(cfg)
+    res = tuple(geo.res_volume)
+    inv = scene.inverse(inv_res or res)
+    live_compare(orc, pkg, gl_ref, scene, cfg, geo, res, inv, "oracle (seed %d)" % seed, bricks=bool(seed % 2),
+                 filter_textures=bool(flags & 1), processed=bool(flags & 2), refine=bool(flags & 4))
+
+
+def test_full_sensor_resolution_oracle_matches_mesa(orc, pkg):
+    """BASELINE's sensor size: two 512 x 424 sensors (13 x 13 bilateral over 217 088 pixels each, the scene's 0.5 m sphere)
+    into a 64^3 volume, every pass on Mesa against the oracle"""
+    gl_ref = gl_lib()
+    G = 64
+    scene = pkg.synth.Scene(2, 512, 424, lut_res=(32, 27, 32), seed=4321)
+    cfg = pkg.capi.make_config(2, (512, 424), voxel_size=2.0 / G, brick_size=8 * 2.0 / G)
+    geo = pkg.capi.compute_geometry(cfg)
+    inv = scene.inverse((G, G, G))
+    # 434 176 marked positions, some on the scene's floor plane = the box's y = 0 face: a last-bit difference of the
+    # LINEAR position fetch moves such a point across a brick boundary or out of the grid (where the shader converts a
+    # negative float to uvec3 -- undefined; the oracle skips the point, llvmpipe counts it somewhere): 76 of 194 114 counts
+    fx, ref = live_compare(orc, pkg, gl_ref, scene, cfg, geo, (G, G, G), inv, "oracle (512 x 424)", counter_slack=1e-3,
+                           filter_textures=True, processed=True, refine=True)
+    assert (np.abs(fx["tsdf"]) < cfg.tsdf_limit).sum() > 1000 and fx["counters"].sum() > 10000
