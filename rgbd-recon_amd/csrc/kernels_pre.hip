@@ -106,17 +106,27 @@ __device__ __forceinline__ void dxt_palette(const uint8_t* src, int mode, int co
   }
 }
 
-// one texel of a DXT1 / DXT5 layer: what k_decode_dxt stores at (x, y)
-__device__ __forceinline__ void dxt_texel(const uint8_t* __restrict__ layer, int W, int mode, int x, int y, int* rgb)
+// The colour half of one 4 x 4 block as two words -- x: the two 565 end points, y: sixteen 2-bit indices, row by
+// row -- and one texel of it: what k_decode_dxt stores at (x, y), with squish's integer arithmetic (dxt_palette).
+// k_pre_depth's bilinear lookup fetches each block it touches once (one 8-byte load; the four taps lie in one
+// block for 9 of 16 positions) instead of six byte loads per tap.
+__device__ __forceinline__ uint2 dxt_block(const uint8_t* __restrict__ layer, int bw, int mode, int bx, int by)
 {
-  const int bw = (W + 3) / 4;
-  const uint8_t* src = layer + (size_t)((y >> 2) * bw + (x >> 2)) * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8);
-  int codes[4][3];
-  dxt_palette(src, mode, codes);
-  const int idx = (src[4 + (y & 3)] >> (2 * (x & 3))) & 3;
-  rgb[0] = codes[idx][0];
-  rgb[1] = codes[idx][1];
-  rgb[2] = codes[idx][2];
+  return *reinterpret_cast<const uint2*>(layer + (size_t)(by * bw + bx) * (mode == 1 ? 8 : 16) + (mode == 1 ? 0 : 8));
+}
+__device__ __forceinline__ void dxt_texel(uint2 blk, int mode, int x, int y, int* rgb)
+{
+  const int a = (int)(blk.x & 0xffffu), bb = (int)(blk.x >> 16);
+  const int idx = (int)(blk.y >> (8 * (y & 3) + 2 * (x & 3))) & 3;
+  const bool three = mode == 1 && a <= bb;  // DXT1 block with a transparent fourth colour
+  const int ca[3] = {(a >> 11) & 0x1f, (a >> 5) & 0x3f, a & 0x1f}, cb[3] = {(bb >> 11) & 0x1f, (bb >> 5) & 0x3f, bb & 0x1f};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = i == 1 ? ((ca[i] << 2) | (ca[i] >> 4)) : ((ca[i] << 3) | (ca[i] >> 2));
+    const int d = i == 1 ? ((cb[i] << 2) | (cb[i] >> 4)) : ((cb[i] << 3) | (cb[i] >> 2));
+    const int m2 = three ? (c + d) / 2 : (2 * c + d) / 3, m3 = three ? 0 : (c + 2 * d) / 3;
+    rgb[i] = idx == 0 ? c : (idx == 1 ? d : (idx == 2 ? m2 : m3));
+  }
 }
 
 __global__ void k_decode_dxt(const uint8_t* __restrict__ blocks_all, int W, int H, int mode, size_t layer_bytes,
@@ -329,11 +339,17 @@ __device__ __forceinline__ float3 color_bilinear_dxt(const uint8_t* __restrict__
                                                      float v, const float* unorm)
 {
   const Axis X = axis_linear(u, W), Y = axis_linear(v, H);
+  const int bw = (W + 3) / 4;
+  const int bx0 = X.i0 >> 2, bx1 = X.i1 >> 2, by0 = Y.i0 >> 2, by1 = Y.i1 >> 2;
+  const uint2 b00 = dxt_block(layer, bw, mode, bx0, by0);
+  const uint2 b10 = bx1 == bx0 ? b00 : dxt_block(layer, bw, mode, bx1, by0);
+  const uint2 b01 = by1 == by0 ? b00 : dxt_block(layer, bw, mode, bx0, by1);
+  const uint2 b11 = by1 == by0 ? b10 : (bx1 == bx0 ? b01 : dxt_block(layer, bw, mode, bx1, by1));
   int p00[3], p10[3], p01[3], p11[3];
-  dxt_texel(layer, W, mode, X.i0, Y.i0, p00);
-  dxt_texel(layer, W, mode, X.i1, Y.i0, p10);
-  dxt_texel(layer, W, mode, X.i0, Y.i1, p01);
-  dxt_texel(layer, W, mode, X.i1, Y.i1, p11);
+  dxt_texel(b00, mode, X.i0, Y.i0, p00);
+  dxt_texel(b10, mode, X.i1, Y.i0, p10);
+  dxt_texel(b01, mode, X.i0, Y.i1, p01);
+  dxt_texel(b11, mode, X.i1, Y.i1, p11);
   float c[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
