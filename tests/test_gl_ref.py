@@ -15,7 +15,8 @@ approximations and filters 8-bit textures with 8-bit weights, the oracle uses li
   morph, depth_rg (float depth frames), depth_b, silhouette, brick counters     bit-exact
   morph, depth_rg of u8 depth frames                                            1e-6   (unorm8 -> float: x * (1/255) vs x / 255)
   Lab colour                                                                    4e-3   (pow(x, 1/3), 8-bit bilinear weights)
-  normals                                                                       5e-5   (1.3e-5 seen at 512 x 424, where the differenced positions are closest)
+  normals                                                                       5e-5   (1.3e-5 seen at 512 x 424, where the differenced positions are closest);
+                                                                                0.1 % of the components up to 1e-3 (near-degenerate cross products)
   quality                                                                       2e-6 + 2e-5 relative; excluded: texels where llvmpipe's
                                                                                 pow(angle < 0, 2) is NaN (undefined in GLSL) or
                                                                                 a NaN normal is a bilinear neighbour (weight 0)
@@ -36,6 +37,7 @@ import shader_cases  # noqa: E402
 IMG = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
 EXACT = ("morph", "depth_rg", "depth_b", "sil")
 TOL = {"lab": 4e-3, "normal": 5e-5, "quality": 2e-6}
+LOOSE = {"normal": (1e-3, 1e-3)}  # a normal is normalize(cross(a, b)) of differenced positions: ill-conditioned where a x b is tiny
 RTOL = {"quality": 2e-5}         # two pow(x, 6.0) and a pow(x, 2.0) of llvmpipe's exp2(y * log2(x)) in one product
 TOL_U8_DEPTH = 1e-6
 TOL_TSDF = 1e-7
@@ -56,7 +58,8 @@ def gl_lib():
     return gl_ref
 
 
-def within(got, want, tol, what, allow_nan_in_want=False, excuse=None, rtol=0.0):
+def within(got, want, tol, what, allow_nan_in_want=False, excuse=None, rtol=0.0, loose=None):
+    """`loose` = (fraction, tolerance): that share of the values may exceed `tol`, up to the second tolerance"""
     got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
     assert got.shape == want.shape, what
     skip = np.isnan(want) & ~np.isnan(got) if allow_nan_in_want else np.zeros(got.shape, bool)
@@ -70,6 +73,9 @@ def within(got, want, tol, what, allow_nan_in_want=False, excuse=None, rtol=0.0)
     inf_ok = (got == want) | ~(np.isinf(got) | np.isinf(want))
     assert np.all(inf_ok | skip), "%s: infinities differ" % what
     d = np.abs(got[fin].astype(np.float64) - want[fin].astype(np.float64)) - rtol * np.abs(want[fin].astype(np.float64))
+    if loose is not None and d.size and d.max() > tol:
+        assert (d > tol).mean() <= loose[0] and d.max() <= loose[1], "%s: %d values beyond %.3g, max %.3g" % (what, int((d > tol).sum()), tol, d.max())
+        return int(skip.sum())
     assert d.size == 0 or d.max() <= tol, "%s: max |difference| %.3g > %.3g (%d values beyond)" % (what, d.max(), tol, int((d > tol).sum()))
     return int(skip.sum())
 
@@ -108,7 +114,7 @@ def compare(got, fx, name, what, scene, limit=0.01, counter_slack=0.0):
             elif k in EXACT:
                 within(got[k][i], fx[k][i], TOL_U8_DEPTH, w)
             else:
-                within(got[k][i], fx[k][i], TOL[k], w, allow_nan_in_want=(k == "quality"), rtol=RTOL.get(k, 0.0),
+                within(got[k][i], fx[k][i], TOL[k], w, allow_nan_in_want=(k == "quality"), rtol=RTOL.get(k, 0.0), loose=LOOSE.get(k),
                        excuse=negative_angle(scene, i, got["depth_b"][i], got["normal"][i]) if k == "quality" else None)
     dc = np.abs(got["counters"].astype(np.int64) - fx["counters"].astype(np.int64)).sum()
     assert dc <= counter_slack * fx["counters"].sum(), "%s vs Mesa: brick counters differ by %d in total" % (what, dc)
@@ -332,11 +338,11 @@ def live_compare(orc, pkg, gl_ref, scene, cfg, geo, res, inv, what, bricks=False
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_small_scenes_oracle_matches_mesa(orc, pkg, seed):
-    """random sensor counts, image / LUT / grid sizes (mostly not powers of two), host toggles and limits; every
+    """random sensor counts (1-5), image / LUT / grid sizes (mostly not powers of two), host toggles and limits; every
     second seed integrates through the occupied bricks' index lists like the reference's default mode"""
     gl_ref = gl_lib()
     rng = np.random.default_rng(2000 + seed)
-    n = int(rng.integers(1, 5))
+    n = int(rng.integers(1, 5)) if seed else 5       # seed 0: all five slots of the shaders' sampler3D[5] arrays
     wh = (int(rng.integers(24, 49)), int(rng.integers(20, 41)))
     lut_res = tuple(int(v) for v in rng.integers(8, 15, 3))
     G = int(rng.choice([16, 20, 24, 27, 32]))
