@@ -895,3 +895,18 @@ def run_views(name, scene, cfg, geo, inv, out):
         if peels_tex is not None:
             delete_textures([peels_tex])
     return res
+
+
+def decode_dxt(blocks, W, H, mode):
+    """What the GL driver makes of a DXT1 / DXT5 colour frame -- the reference uploads the server's blocks as
+    GL_COMPRESSED_RGBA_S3TC_DXT{1,5}_EXT layers of m_colorArray (NetKinectArray.cpp:149-156, TextureArray.cpp:30-32)
+    and lets the texture unit decode them.  blocks: the block stream of one layer -> [H, W, 4] u8 as Mesa decodes it."""
+    g = gl()
+    b = np.ascontiguousarray(blocks, np.uint8).reshape(-1)
+    fmt = m.COMPRESSED_RGBA_S3TC_DXT1_EXT if mode == 1 else m.COMPRESSED_RGBA_S3TC_DXT5_EXT
+    t = g.texture(m.TEXTURE_2D_ARRAY, m.LINEAR)
+    g.glPixelStorei(m.UNPACK_ALIGNMENT, 1)
+    g.glCompressedTexImage3D(m.TEXTURE_2D_ARRAY, 0, fmt, W, H, 1, 0, b.size, b.ctypes.data)
+    out = g.read_texture(m.TEXTURE_2D_ARRAY, t, m.RGBA, (1, H, W, 4), dtype=np.uint8, gltype=m.UNSIGNED_BYTE)
+    delete_textures([t])
+    return out[0]

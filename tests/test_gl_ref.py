@@ -373,3 +373,35 @@ def test_full_sensor_resolution_oracle_matches_mesa(orc, pkg):
     fx, ref = live_compare(orc, pkg, gl_ref, scene, cfg, geo, (G, G, G), inv, "oracle (512 x 424)", counter_slack=1e-3,
                            filter_textures=True, processed=True, refine=True)
     assert (np.abs(fx["tsdf"]) < cfg.tsdf_limit).sum() > 1000 and fx["counters"].sum() > 10000
+
+
+@pytest.mark.parametrize("mode", [1, 5])
+def test_dxt_blocks_decode_within_one_step_of_the_gl_drivers_decode(orc, pkg, mode):
+    """The reference hands its DXT colour frames to the GL driver (GL_COMPRESSED_RGBA_S3TC_DXT1 / DXT5 layers); the
+    library and the oracle decode them with squish's integer arithmetic -- the reference's own CPU decoder of the same
+    frames (NetKinectArray.cpp:633).  EXT_texture_compression_s3tc leaves the rounding of the two interpolated palette
+    entries to the implementation: llvmpipe evaluates (2 a + b) / 3 as a + ((b - a) * 85 >> 8) and the DXT1 midpoint as
+    (a + b + 1) >> 1, squish truncates the exact quotient.  So, on random blocks (both end-point orders) and on an
+    encoded picture: the end-point colours (indices 0 and 1) and transparent black are identical, the interpolated
+    entries within one step of 255."""
+    gl_ref = gl_lib()
+    rng = np.random.default_rng(77 + mode)
+    W, H = 64, 40
+    nb = (W // 4) * (H // 4)
+    blocks = rng.integers(0, 256, (nb, 8 if mode == 1 else 16), dtype=np.uint8)
+    blocks[: nb // 8, 2:4] = blocks[: nb // 8, 0:2]                    # some blocks with equal end points
+    o = 0 if mode == 1 else 8
+    for blk in (blocks, pkg.synth.encode_dxt(rng.integers(0, 256, (H, W, 3), dtype=np.uint8), mode)):
+        blk = np.ascontiguousarray(blk, np.uint8).reshape(nb, -1)
+        want = gl_ref.decode_dxt(blk, W, H, mode)[..., :3].astype(np.int32)
+        got = orc.decode_dxt(blk, W, H, mode).astype(np.int32)
+        assert np.abs(got - want).max() <= 1, "more than one step from Mesa's S3TC decode"
+        yy, xx = np.mgrid[0:H, 0:W]
+        b = blk[(yy // 4) * (W // 4) + xx // 4].astype(np.int32)                          # [H, W, bytes]
+        rows = np.take_along_axis(b[..., o + 4:o + 8], (yy & 3)[..., None], axis=-1)[..., 0]   # the texel's index byte
+        idx = (rows >> (2 * (xx & 3))) & 3
+        c0 = b[..., o] | (b[..., o + 1] << 8)
+        c1 = b[..., o + 2] | (b[..., o + 3] << 8)
+        exact = (idx < 2) | ((mode == 1) & (c0 <= c1) & (idx == 3))                      # end points, transparent black
+        assert np.array_equal(got[exact], want[exact]), "an end-point colour differs from Mesa's decode"
+        assert exact.any() and (~exact).any()
