@@ -521,10 +521,22 @@ class ReconIntegration : public Reconstruction {
   }
   // drawF(), recon_integration.cpp:151-175: depth limits for space skipping when m_skip_space && m_use_bricks
   // (inside the library's ray-march, from view.skip_space), Reconstruction::drawF(), fillColors() when m_fill_holes
+  // The last pass of fillColors draws into the WINDOW with GL_LESS against its cleared depth (:314, kinect_client.cpp:
+  // 605-614,994): a fragment of depth exactly 1 -- a ray that hit nothing -- fails the test, the window keeps its clear
+  // colour (g_clear_color, kinect_client.cpp:55: zeros unless `-c` is given).  frame() is that window.
   void drawF() override
   {
     Reconstruction::drawF();
-    if (m_fill_holes) check(m_be.ctx(), rgbdr_fill_colors(m_be.ctx(), m_frame.color.data(), m_frame.depth.data()));
+    if (!m_fill_holes) return;
+    check(m_be.ctx(), rgbdr_fill_colors(m_be.ctx(), m_frame.color.data(), m_frame.depth.data()));
+    const size_t n = m_frame.depth.size();
+    for (size_t i = 0; i < n; ++i)
+      if (!(m_frame.depth[i] < 1.0f))
+        for (int c = 0; c < 4; ++c) m_frame.color[4 * i + c] = m_clear_color[c];
+  }
+  void setClearColor(float r, float g, float b, float a)
+  {
+    m_clear_color[0] = r, m_clear_color[1] = g, m_clear_color[2] = b, m_clear_color[3] = a;
   }
   // resize(width, height), :494-512: the reference re-allocates its FBOs / LOD atlases for the new window; here
   // the next draw renders that many pixels (the library sizes its buffers per call)
@@ -580,6 +592,7 @@ class ReconIntegration : public Reconstruction {
  private:
   Backend& m_be;
   bool m_fill_holes = true, m_skip_space = true;  // defaults of recon_integration.cpp:60-63
+  float m_clear_color[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // g_clear_color
   Frame m_frame;
   float m_viewport_offset[2] = {0.0f, 0.0f};
 };
