@@ -405,3 +405,24 @@ def test_dxt_blocks_decode_within_one_step_of_the_gl_drivers_decode(orc, pkg, mo
         exact = (idx < 2) | ((mode == 1) & (c0 <= c1) & (idx == 3))                      # end points, transparent black
         assert np.array_equal(got[exact], want[exact]), "an end-point colour differs from Mesa's decode"
         assert exact.any() and (~exact).any()
+
+
+def test_u8_depth_through_the_morph_pass_oracle_matches_mesa(orc, pkg):
+    """The combination SURVEY A.5 calls incoherent -- u8 depth frames AND processed depth: pre_morph.fs tests
+    0.5 < d < 4.5 on the raw [0, 1] values (:19-26), pre_depth.fs un-compresses the morph output (:63-72) -- is still
+    defined behaviour; Mesa and the oracle agree on it"""
+    gl_ref = gl_lib()
+    G = 32
+    scene = pkg.synth.Scene(2, 64, 53, lut_res=(16, 14, 16), seed=21)
+    scene.depth_u8 = pkg.synth.compress_depth_u8(scene.depth)
+    scene.depth = (scene.depth_u8.astype(np.float32) / np.float32(255.0)).astype(np.float32)
+    cfg = pkg.capi.make_config(2, (64, 53), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, compress_depth=1)
+    geo = pkg.capi.compute_geometry(cfg)
+    inv = scene.inverse((G, G, G))
+    shader_cases.COMPRESSED_DEPTH.add("__live__")
+    try:
+        fx, ref = live_compare(orc, pkg, gl_ref, scene, cfg, geo, (G, G, G), inv, "oracle (u8 + morph)", compress=True,
+                               filter_textures=True, processed=True, refine=True)
+    finally:
+        shader_cases.COMPRESSED_DEPTH.discard("__live__")
+    assert fx["counters"].sum() > 0 and (fx["morph"] != 0).sum() > 1000
