@@ -869,8 +869,9 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
     except MemoryError:
         ref_cpu = None
     ref_text = reference_text_baseline(ctx, scene, capi, synth, hip, sil, db, q, N)
+    ref_glsl = reference_glsl_fixture_check(capi, synth)
     what = "all %d z rows" % Z if done == Z else "%d of %d z rows, extrapolated to the grid" % (done, Z)
-    return {"reference_cpu_work": ref_cpu, "reference_shader_text": ref_text,
+    return {"reference_cpu_work": ref_cpu, "reference_shader_text": ref_text, "reference_glsl_on_mesa": ref_glsl,
             "value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads,
             "kind": "port",
             "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota) on the benchmark workload: full "
@@ -878,6 +879,55 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
                       % (threads, N, t_pre, what, t_int),
             "integrate_mvoxels_per_s": round(g.res_volume[0] * g.res_volume[1] * done / t_int / 1e6, 2),
             "parity_rows_bit_exact": parity, "parity_rows": done}
+
+
+def reference_glsl_fixture_check(capi, synth, name="four_sensors_128x106_into_64"):
+    """The HIP path against what the reference's OWN GLSL produced when Mesa llvmpipe ran it in the build container
+    (tests/golden/gl_passes_<name>.npz: data, made by tests/golden/make_gl_golden.py; tolerances and caveats in
+    tests/test_gl_ref.py / DESIGN.md section 2): the fixture's scene (4 sensors 128 x 106 into 64^3) through the
+    library, largest absolute differences per output, and whether any voxel changes class.  Not timed, not the
+    benchmark workload: it puts the parity against the reference's shaders into the bench record."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import shader_cases
+        path = os.path.join(ROOT, "tests", "golden", "gl_passes_%s.npz" % name)
+        if not os.path.exists(path):
+            return None
+        fx = np.load(path)
+        scene, cfg, geo, inv, inv_res = shader_cases.build(synth, capi, name)
+        if bytes(fx["inputs_sha256"]).decode() != shader_cases.digest(scene, inv):
+            return {"error": "the synthetic scene drifted from the fixture's"}
+        n = shader_cases.CASES[name][0]
+        c = capi.Context(cfg, 0)
+        for i in range(n):
+            c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+            c.set_inverse_calibration(i, inv[i], inv_res)
+        c.set_use_bricks(False)
+        c.step(scene.depth, scene.color)
+        imgs = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
+        out = {}
+        for k, which in imgs.items():
+            got = np.stack([c.readback_image(which, i) for i in range(n)]).astype(np.float64)
+            want = fx[k].astype(np.float64)
+            fin = np.isfinite(got) & np.isfinite(want)
+            out[k] = float(np.abs(got - want)[fin].max())
+        counters_equal = bool(np.array_equal(c.readback_brick_counters(), fx["counters"]))
+        t, r = c.readback_tsdf(), fx["tsdf"]
+        c.close()
+        ok = ~(np.isnan(t) | np.isnan(r))
+        lim = np.float32(cfg.tsdf_limit)
+
+        def cls(v):
+            return np.where(v <= -lim, -1, np.where(v >= lim, 1, 0))
+        return {"what": "HIP path vs the reference's GLSL run on Mesa llvmpipe (committed fixture gl_passes_%s.npz)" % name,
+                "max_abs_diff": {k: float("%.3g" % v) for k, v in out.items()}, "brick_counters_equal": counters_equal,
+                "tsdf_max_abs_diff": float("%.3g" % np.abs(t.astype(np.float64) - r)[ok].max()),
+                "tsdf_voxels_differing": int((t != r)[ok].sum()), "tsdf_voxels": int(t.size),
+                "tsdf_voxels_changing_class": int((cls(t) != cls(r))[ok].sum()),
+                "voxels_masked_nan_on_llvmpipe_only": int((np.isnan(r) & ~np.isnan(t)).sum()),
+                "renderer": bytes(fx["gl_renderer"]).decode()}
+    except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def reference_text_baseline(ctx, scene, capi, synth, hip, sil, db, q, N, rows=32):
