@@ -599,19 +599,22 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   launch_pre_depth(p, zero, (unsigned)ctx->geo.num_bricks, ps);
   ctx->clear_pending = false;
   tend(ctx, "bilateral", ps);
-  tbegin(ctx, "boundary", ps);
-  launch_boundary(p, ps);
-  tend(ctx, "boundary", ps);
-  // the normal and quality passes run as one launch unless the host asked for the per-pass timers
-  // ("normal" / "quality" of NetKinectArray.cpp:381-414), which need the two separate ones
+  // the boundary, normal and quality passes run as one launch unless the host asked for the per-pass timers
+  // ("boundary" / "normal" / "quality" of NetKinectArray.cpp:359-414), which need the separate ones
   if ((ctx->timers && ctx->timer_detail >= 2) || ctx->separate_passes) {
+    tbegin(ctx, "boundary", ps);
+    launch_boundary(p, ps);
+    tend(ctx, "boundary", ps);
     tbegin(ctx, "normal", ps);
     launch_normal(p, ps);
     tend(ctx, "normal", ps);
     tbegin(ctx, "quality", ps);
     launch_quality(p, ps);
     tend(ctx, "quality", ps);
+  } else if (ctx->fuse_boundary) {
+    launch_boundary_normal_quality(p, ps);
   } else {
+    launch_boundary(p, ps);
     launch_normal_quality(p, ps);
   }
   tend(ctx, "1preprocess", ps);

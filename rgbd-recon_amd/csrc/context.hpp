@@ -150,6 +150,7 @@ struct rgbdr_ctx {
   bool timers = false, accumulate = false;
   // developer A/B knob, read when the context is created
   bool separate_passes = getenv("RGBDR_SEPARATE_PASSES") != nullptr;
+  bool fuse_boundary = getenv("RGBDR_NO_BOUNDARY_FUSION") == nullptr;  // A/B switch of the three-pass kernel (read once, here)
   int timer_detail = 2;  // 1: only "1preprocess" / "2integrate" / "bricks" ...; 2: also the five pre_* passes
   std::map<std::string, rgbdr::Timer> tm;
 

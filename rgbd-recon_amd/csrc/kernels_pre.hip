@@ -797,11 +797,15 @@ __device__ __forceinline__ float quality_angle(const PreParams& p, int l, float3
 // quality image + the packed 8-B texel the integration kernel samples: depth_b.r and the quality
 // with "silhouette == 0" folded into its sign bit.  quality is a product of
 // non-negative factors (or NaN), so the sign bit is free; |NaN| stays NaN.
-__device__ __forceinline__ void store_quality(const PreParams& p, size_t i, float depth, float q)
+__device__ __forceinline__ void store_quality_sil(const PreParams& p, size_t i, float depth, float q, float sil)
 {
   p.quality[i] = q;
-  const unsigned qbits = (__float_as_uint(q) & 0x7fffffffu) | (p.silhouette[i] < 1.0f ? 0x80000000u : 0u);
+  const unsigned qbits = (__float_as_uint(q) & 0x7fffffffu) | (sil < 1.0f ? 0x80000000u : 0u);
   p.frame[i] = make_uint2(__float_as_uint(depth), qbits);
+}
+__device__ __forceinline__ void store_quality(const PreParams& p, size_t i, float depth, float q)
+{
+  store_quality_sil(p, i, depth, q, p.silhouette[i]);
 }
 
 __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
@@ -886,6 +890,150 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_normal_quality(PreParams p)
     wave_add(p.brick_counters, nb_id, nb_inc);
     wave_add(p.brick_counters, home_id, 1u);
   }
+}
+
+// ---------------------------------------------------------------------------
+// pre_boundary.fs + pre_normal.fs + pre_quality.fs in one launch (the default of process_textures; the separate
+// kernels above run when a host asks for the per-pass timers).  The boundary pass only changes the depth of a
+// pixel that is an edge candidate (depth > 0 and range weight <= 0.65: a few per cent of the pixels), from a 5 x 5
+// neighbourhood of (depth, weight, Lab); everything else is a function of the pixel itself.  So the block stages
+// the (depth, weight) window of its 28 x 28 depth_b window plus the 2-texel rim those neighbourhoods reach, the Lab
+// window only when the depth_b window holds a candidate, and derives the depth_b window from them -- each value is
+// what k_boundary writes at the clamped image position, computed with the same expressions in the same order.
+// Its own 16 x 16 pixels' depth_b / silhouette are written from the same function.  One launch and one round trip
+// of depth_b through memory less per frame.
+constexpr int BR = R13 + 2;        // rim of the staged (depth, weight) / Lab windows
+constexpr int BW = BX + 2 * BR;    // 32
+constexpr int BP = BW + 1;         // LDS pitch in texels
+
+// pre_boundary.fs:90-113 for the texel at LDS position (cy, cx)
+__device__ __forceinline__ void boundary_texel(const float2 (*rg)[BP], const float (*lab)[BP][3], int cy, int cx, bool refine,
+                                               float& dx, float& dy, float& sil)
+{
+  const float2 c = rg[cy][cx];
+  dx = c.x;
+  dy = c.y;
+  sil = 1.0f;
+  if (dx <= 0.0f) {
+    dy = 0.0f;
+    sil = 0.0f;
+  } else if (!(dy > 0.65f)) {
+    sil = 0.0f;
+    const float* color = lab[cy][cx];
+    float total = 0.0f, num = 0.0f;
+    for (int y = 0; y < 5; ++y)
+#pragma unroll
+      for (int x = 0; x < 5; ++x) {
+        const float2 t = rg[cy - 2 + y][cx - 2 + x];
+        if (t.x > 0.0f && t.y > 0.65f) {
+          num += 1.0f;
+          total += distance3(color, lab[cy - 2 + y][cx - 2 + x]);
+        }
+      }
+    const float color_dist = (num < 16.0f * 0.5f) ? 1.0f : total / num;
+    if (color_dist > 0.5f || !refine) {
+      dx = -1.0f;
+      dy = 0.1f;
+    } else {
+      dy = 1.0f;
+    }
+  } else {
+    dy = 0.0f;
+  }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PreParams p)
+{
+  __shared__ float tile[TH][TPITCH];
+  __shared__ float2 w_rg[BW][BP];
+  __shared__ float w_lab[BW][BP][3];
+  const BlockPos bp = block_pos(p.N);
+  const int l = bp.l;
+  const int W = p.W, H = p.H;
+  const size_t lo = (size_t)l * W * H;
+  const float* drg = p.depth_rg + lo * 2;
+  const float* lab = p.lab + lo * 3;
+  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const bool inside = px < W && py < H;
+  const size_t o = inside ? (size_t)py * W + px : 0;
+  const float dx0 = inside ? drg[o * 2] : 0.0f, dy0 = inside ? drg[o * 2 + 1] : 1.0f;
+  const bool cand0 = inside && !(dx0 <= 0.0f) && !(dy0 > 0.65f);
+  // no pixel of the block is an edge candidate or keeps a depth in (0,1): depth_b = (depth, 0), the silhouette follows
+  // the sign of the depth, normals and quality are zero -- nothing to stage
+  if (!__syncthreads_or(inside && (cand0 || !unit_outside(dx0)))) {
+    if (!inside) return;
+    const float sil = dx0 <= 0.0f ? 0.0f : 1.0f;
+    p.depth_b_rg[(lo + o) * 2] = dx0;
+    p.depth_b_rg[(lo + o) * 2 + 1] = 0.0f;
+    p.silhouette[lo + o] = sil;
+    p.normal[(lo + o) * 3 + 0] = 0.0f;
+    p.normal[(lo + o) * 3 + 1] = 0.0f;
+    p.normal[(lo + o) * 3 + 2] = 0.0f;
+    store_quality_sil(p, lo + o, dx0, 0.0f, sil);
+    return;
+  }
+  const int bx0 = bp.bx * BX - BR, by0 = blockIdx.y * BY - BR;
+  const int tid = threadIdx.y * BX + threadIdx.x;
+  bool cand = false;
+  for (int i = tid; i < BW * BW; i += BX * BY) {
+    const int ty = i / BW, tx = i - ty * BW;
+    const size_t os = (size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1);
+    const float2 v = make_float2(drg[os * 2], drg[os * 2 + 1]);
+    w_rg[ty][tx] = v;
+    cand |= ty >= 2 && ty < BW - 2 && tx >= 2 && tx < BW - 2 && !(v.x <= 0.0f) && !(v.y > 0.65f);
+  }
+  if (__syncthreads_or(cand)) {  // (also the barrier behind the staging above)
+    for (int i = tid; i < BW * BW; i += BX * BY) {
+      const int ty = i / BW, tx = i - ty * BW;
+      const size_t os = (size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1);
+      w_lab[ty][tx][0] = lab[os * 3];
+      w_lab[ty][tx][1] = lab[os * 3 + 1];
+      w_lab[ty][tx][2] = lab[os * 3 + 2];
+    }
+    __syncthreads();
+  }
+  // depth_b.r over the 28 x 28 window: the value at the CLAMPED image position (what stage_depth_b reads), whose
+  // 5 x 5 neighbourhood is staged around it (positions beyond the image repeat the edge texels, as k_boundary stages them)
+  for (int i = tid; i < TW * TH; i += BX * BY) {
+    const int ty = i / TW, tx = i - ty * TW;
+    const int cy = clampi(by0 + 2 + ty, 0, H - 1) - by0, cx = clampi(bx0 + 2 + tx, 0, W - 1) - bx0;
+    float dx, dy, sil;
+    boundary_texel(w_rg, w_lab, cy, cx, p.refine != 0, dx, dy, sil);
+    tile[ty][tx] = unit_outside(dx) ? __builtin_inff() : dx;
+  }
+  __syncthreads();
+  if (!inside) return;
+  float depth, dyb, sil;
+  boundary_texel(w_rg, w_lab, threadIdx.y + BR, threadIdx.x + BR, p.refine != 0, depth, dyb, sil);
+  p.depth_b_rg[(lo + o) * 2] = depth;
+  p.depth_b_rg[(lo + o) * 2 + 1] = dyb;
+  p.silhouette[lo + o] = sil;
+  float3 n = make_float3(0.0f, 0.0f, 0.0f);
+  float q = 0.0f;
+  int home_id = -1, nb_id = -1;
+  unsigned nb_inc = 0u;
+  if (!unit_outside(depth)) {
+    const int cy = threadIdx.y + R13, cx = threadIdx.x + R13;
+    const float3 world = world_at(p, l, px, py, depth);
+    if (p.brick_counters) mark_brick(p, world, home_id, nb_id, nb_inc);
+    n = normal_at<true>(p, l, px, py, depth, tile[cy + 1][cx], tile[cy - 1][cx], tile[cy][cx - 1], tile[cy][cx + 1]);
+    q = quality_taps(tile, depth);
+    q *= quality_angle(p, l, world, n);
+  }
+  p.normal[(lo + o) * 3 + 0] = n.x;
+  p.normal[(lo + o) * 3 + 1] = n.y;
+  p.normal[(lo + o) * 3 + 2] = n.z;
+  store_quality_sil(p, lo + o, depth, q, sil);
+  if (p.brick_counters) {  // reconverged: every live lane of the wavefront takes part
+    wave_add(p.brick_counters, nb_id, nb_inc);
+    wave_add(p.brick_counters, home_id, 1u);
+  }
+}
+
+void launch_boundary_normal_quality(const PreParams& p, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_boundary_normal_quality<4>, pass_grid(p), dim3(BX, BY), 0, s, p);
 }
 
 void launch_normal_quality(const PreParams& p, hipStream_t s)

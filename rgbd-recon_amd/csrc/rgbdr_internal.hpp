@@ -220,6 +220,7 @@ void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
 void launch_quality(const PreParams& p, hipStream_t s);
 void launch_normal_quality(const PreParams& p, hipStream_t s);  // both passes in one launch
+void launch_boundary_normal_quality(const PreParams& p, hipStream_t s);  // pre_boundary + pre_normal + pre_quality
 void launch_update_occupied(const uint32_t* counters, uint32_t n, uint32_t min_voxels, uint8_t* mask,
                             uint32_t* count, hipStream_t s);
 void launch_compact_occupied(const uint8_t* mask, uint32_t n, uint32_t* ids, uint32_t* count, hipStream_t s);
