@@ -957,7 +957,9 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PrePa
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   const bool inside = px < W && py < H;
   const size_t o = inside ? (size_t)py * W + px : 0;
-  const float dx0 = inside ? drg[o * 2] : 0.0f, dy0 = inside ? drg[o * 2 + 1] : 1.0f;
+  const float2* drg2 = reinterpret_cast<const float2*>(drg);  // (depth, weight) pairs: 8-byte aligned (hipMalloc + a whole layer)
+  const float2 own = inside ? drg2[o] : make_float2(0.0f, 1.0f);
+  const float dx0 = own.x, dy0 = own.y;
   const bool cand0 = inside && !(dx0 <= 0.0f) && !(dy0 > 0.65f);
   // no pixel of the block is an edge candidate or keeps a depth in (0,1): depth_b = (depth, 0), the silhouette follows
   // the sign of the depth, normals and quality are zero -- nothing to stage
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PrePa
   for (int i = tid; i < BW * BW; i += BX * BY) {
     const int ty = i / BW, tx = i - ty * BW;
     const size_t os = (size_t)clampi(by0 + ty, 0, H - 1) * W + clampi(bx0 + tx, 0, W - 1);
-    const float2 v = make_float2(drg[os * 2], drg[os * 2 + 1]);
+    const float2 v = drg2[os];
     w_rg[ty][tx] = v;
     cand |= ty >= 2 && ty < BW - 2 && tx >= 2 && tx < BW - 2 && !(v.x <= 0.0f) && !(v.y > 0.65f);
   }
