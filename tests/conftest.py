@@ -13,6 +13,14 @@ from __graft_entry__ import load_oracle, load_package  # noqa: E402
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Where the reference checkout exists (the build container) the libraries compiled from it / for running it are part
+    # of build(); a fresh clone that runs the tests first gets them built here, once.  A failing build leaves them
+    # missing and the tests that need them FAIL (they only skip where the checkout is absent, i.e. on the GPU box).
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.isdir("/root/reference/glsl") and not all(
+            os.path.exists(os.path.join(ref_dir, f)) for f in ("libref_shim.so", "libref_shaders.so", "libglctx.so")):
+        import subprocess
+        subprocess.call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "portable", "ref", "shaders", "glctx"])
 
 
 @pytest.fixture(scope="session")
