@@ -80,7 +80,7 @@ def main():
                     help="one GPU, real RCCL: run an inner Z slab (rank 1 of 4) whose two neighbours are this process "
                          "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
     ap.add_argument("--arena-trials", type=int, default=10,
-                    help="RGBDR_ARENA_TRIALS for this run (the library's default is 1 = off): within one box the sweep "
+                    help="RGBDR_ARENA_TRIALS for this run (the library's default is 3): within one box the sweep "
                          "time differs by up to 12 %% between processes with where hipMalloc placed the LUT arena; the "
                          "library times up to this many candidate placements (about 5 ms each, at most 1 s) and keeps the "
                          "fastest; the candidates' times are reported in roofline.arena_placement_probe_ms")
@@ -496,7 +496,8 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                      "box_stream_GBps": round(box_stream / 1e9, 1), "box_stream_replay_ms": round(replay_ms, 4),
                      "frac_of_box_stream": round(achieved / box_stream, 4) if box_stream > 0 else None,
                      "box": box,
-                     "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1]},
+                     "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1],
+                     "arena_contiguous": ctx.arena_contiguous()},
         "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
         "bricked": None if lean else {"ms_per_step": round(dtb / bsteps * 1e3, 4),
                                       "value": round(V_total / (dtb / bsteps) / 1e6, 1),
@@ -506,19 +507,23 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         "full_sweep_store_elision": elided,
         "full_sweep_background_skip": skipbg,
     }
-    # What a default library user gets (RGBDR_ARENA_TRIALS unset = 1: the first hipMalloc result, no probing): the
-    # stream replay of candidate 0, priced like the kernel (which runs at frac_of_box_stream of its replay).
+    # What the first placement gives (RGBDR_ARENA_TRIALS=1: no probing) and what the library's default gives (unset: the
+    # best of the first three candidates): the stream replay of those candidates, priced like the kernel (which runs at
+    # frac_of_box_stream of its replay).
     probe_ms, kept = ctx.arena_probe()
     if len(probe_ms) > 1 and probe_ms[0] > 0 and probe_ms[kept] > 0 and world == 1:
         first_ms = int_s * 1e3 * probe_ms[0] / probe_ms[kept]
         out["roofline"]["avg_launch_ms_first_placement"] = round(first_ms, 4)
         out["roofline"]["frac_first_placement"] = round(bytes_launch / (first_ms * 1e-3) / HBM_PEAK, 4)
-        out["roofline"]["placement_note"] = ("bench.py opts into RGBDR_ARENA_TRIALS=%d (library default 1 = off; %d placements were "
-                                             "probed): `frac` is on the fastest of the probed placements of the LUT arena, "
-                                             "frac_first_placement scales the measured launch time by replay(candidate 0) / "
-                                             "replay(kept)" % (trials, len(probe_ms)))
+        dflt_ms = int_s * 1e3 * min(m for m in probe_ms[:3] if m > 0) / probe_ms[kept]
+        out["roofline"]["frac_library_default"] = round(bytes_launch / (dflt_ms * 1e-3) / HBM_PEAK, 4)
+        out["roofline"]["placement_note"] = ("bench.py asks for RGBDR_ARENA_TRIALS=%d (library default 3; %d placements were "
+                                             "probed; the library asks for physically contiguous arenas first): `frac` is on the fastest of the probed placements of the LUT arena, "
+                                             "frac_first_placement / frac_library_default scale the measured launch time by replay(candidate 0) / "
+                                             "replay(kept) and by replay(best of the first three) / replay(kept)" % (trials, len(probe_ms)))
     elif world == 1:
         out["roofline"]["frac_first_placement"] = out["roofline"]["frac"]       # a single placement was looked at
+        out["roofline"]["frac_library_default"] = out["roofline"]["frac"]
         out["roofline"]["avg_launch_ms_first_placement"] = out["roofline"]["avg_launch_ms"]
     if per_rank is not None:
         out["per_rank"] = per_rank

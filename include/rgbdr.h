@@ -439,14 +439,21 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the
- * driver placed that allocation (stable per allocation, several per cent apart), so the
- * library can time the LUT stream on up to RGBDR_ARENA_TRIALS (environment; default 1 = OFF: the first
- * allocation is taken and nothing is probed; at most 16) candidate allocations when the arena is created --
- * held while probing, i.e. up to n x the arena of HBM transiently, at most about 1 s -- stop at the first that
- * streams at the fast level and otherwise keep the fastest.  bench.py opts in and reports both.  Reports
+ * driver placed that allocation (stable per allocation, up to 12 % apart: a zone of 13-19 GB of the device memory,
+ * usually where the first large allocation of a process lands, streams slower than the rest), so the
+ * library times the LUT stream on up to RGBDR_ARENA_TRIALS candidate allocations when the arena is created
+ * (environment; 1..16; default 3 for arenas of 1 GiB and more, 1 = the first allocation is taken and nothing is
+ * probed for smaller ones) -- held while probing, i.e. up to n x the arena of HBM transiently and never more than
+ * what leaves 4 GiB free, at most about 1 s -- stops at the first that streams at the fast level and otherwise
+ * keeps the fastest.  bench.py asks for 10 and reports every candidate.  Reports
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);
+/* The arena is requested as physically contiguous device memory first (hipExtMallocWithFlags with
+ * hipDeviceMallocContiguous; plain hipMalloc when that fails or RGBDR_ARENA_PLAIN is set): contiguous arenas stream at
+ * the fast level wherever they land, except the first ~13 GB a process obtains that way.  Reports
+ * whether the kept arena is contiguous.  No counterpart in the reference (its LUTs are GL textures). */
+int rgbdr_get_arena_contiguous(const rgbdr_ctx* ctx, int* contiguous);
 /* Device memory released shortly before (by this or by an earlier process) is wiped by the
  * driver in the background and slows every stream for a moment.  rgbdr_settle replays the
  * integrate kernel's LUT-read + TSDF-store stream (the volume's contents are undefined
