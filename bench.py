@@ -496,8 +496,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                      "box_stream_GBps": round(box_stream / 1e9, 1), "box_stream_replay_ms": round(replay_ms, 4),
                      "frac_of_box_stream": round(achieved / box_stream, 4) if box_stream > 0 else None,
                      "box": box,
-                     "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1],
-                     "arena_contiguous": ctx.arena_contiguous()},
+                     "arena_placement_probe_ms": ctx.arena_probe()[0], "arena_kept": ctx.arena_probe()[1]},
         "passes_ms": {k: round(v[0] / max(v[1], 1) * 1e-6, 4) for k, v in stats.items()},
         "bricked": None if lean else {"ms_per_step": round(dtb / bsteps * 1e3, 4),
                                       "value": round(V_total / (dtb / bsteps) / 1e6, 1),
@@ -518,7 +517,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         dflt_ms = int_s * 1e3 * min(m for m in probe_ms[:3] if m > 0) / probe_ms[kept]
         out["roofline"]["frac_library_default"] = round(bytes_launch / (dflt_ms * 1e-3) / HBM_PEAK, 4)
         out["roofline"]["placement_note"] = ("bench.py asks for RGBDR_ARENA_TRIALS=%d (library default 3; %d placements were "
-                                             "probed; the library asks for physically contiguous arenas first): `frac` is on the fastest of the probed placements of the LUT arena, "
+                                             "probed): `frac` is on the fastest of the probed placements of the LUT arena, "
                                              "frac_first_placement / frac_library_default scale the measured launch time by replay(candidate 0) / "
                                              "replay(kept) and by replay(best of the first three) / replay(kept)" % (trials, len(probe_ms)))
     elif world == 1:

@@ -449,11 +449,6 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);
-/* The arena is requested as physically contiguous device memory first (hipExtMallocWithFlags with
- * hipDeviceMallocContiguous; plain hipMalloc when that fails or RGBDR_ARENA_PLAIN is set): contiguous arenas stream at
- * the fast level wherever they land, except the first ~13 GB a process obtains that way.  Reports
- * whether the kept arena is contiguous.  No counterpart in the reference (its LUTs are GL textures). */
-int rgbdr_get_arena_contiguous(const rgbdr_ctx* ctx, int* contiguous);
 /* Device memory released shortly before (by this or by an earlier process) is wiped by the
  * driver in the background and slows every stream for a moment.  rgbdr_settle replays the
  * integrate kernel's LUT-read + TSDF-store stream (the volume's contents are undefined

@@ -81,25 +81,6 @@ LutExtent rgbdr::lut_extent(const rgbdr_ctx* ctx)
   e.dst = ctx->d_lut_tiled + (ptrdiff_t)(e.t0 - g.slab_tile_z0) * layer;
   return e;
 }
-// The LUT arena is requested as PHYSICALLY CONTIGUOUS device memory (hipDeviceMallocContiguous) and only then as a
-// plain hipMalloc: plain allocations of this size come in three streaming levels on MI355X (1.05 / 1.10-1.14 /
-// 1.17-1.18 ms for the benchmark sweep, the level a property of where the pieces landed), contiguous ones stream at the
-// fast level -- except the first ~13 GB a process obtains that way, which sit at the slow one
-// (profiles/probes_src/contig_probe.hip, profiles/r03_notes).  RGBDR_ARENA_PLAIN=1 restores plain hipMalloc (A/B).
-static hipError_t arena_alloc(float** p, size_t bytes, bool* contiguous)
-{
-  static const bool plain = std::getenv("RGBDR_ARENA_PLAIN") != nullptr;
-  *contiguous = false;
-  if (!plain) {
-    if (hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocContiguous) == hipSuccess) {
-      *contiguous = true;
-      return hipSuccess;
-    }
-    (void)hipGetLastError();
-  }
-  return hipMalloc((void**)p, bytes);
-}
-
 extern "C" {
 
 static int ensure_tiled_lut(rgbdr_ctx* ctx)
@@ -122,7 +103,6 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   if (trials > 16) trials = 16;
   if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain
   float* cand[16] = {nullptr};
-  bool cand_contig[16] = {false};
   float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too: the volume is invalidated below
   float best_ms = 0.0f;
   int best = -1, got = 0;
@@ -132,14 +112,15 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   for (int t = 0; t < trials; ++t) {
     size_t free_b = 0, total_b = 0;
     if (t > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)4 << 30))) break;
-    bool contiguous = false;
-    if (arena_alloc(&cand[t], bytes, &contiguous) != hipSuccess) {
+    // (plain hipMalloc on purpose: physically contiguous arenas -- hipExtMallocWithFlags + hipDeviceMallocContiguous --
+    // stream at two levels instead of three, but allocating and freeing them next to live buffers made parity tests
+    // fail intermittently and once hung a process for 15 minutes: profiles/r03_notes)
+    if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) {
       (void)hipGetLastError();
       cand[t] = nullptr;
       if (t == 0) return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed: out of device memory");
       break;
     }
-    cand_contig[t] = contiguous;
     got = t + 1;
     if (trials == 1) {
       best = 0;
@@ -162,7 +143,6 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   if (best < 0) best = 0;
   ctx->arena_trials = got;
   ctx->arena_chosen = best;
-  ctx->arena_contiguous = cand_contig[best];
   int freed = 0;
   for (int t = 0; t < got; ++t)
     if (t != best) {
@@ -544,13 +524,6 @@ int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
     nanosleep(&ts, nullptr);
   }
   if (stream_ms) *stream_ms = cur;
-  return RGBDR_OK;
-}
-
-int rgbdr_get_arena_contiguous(const rgbdr_ctx* ctx, int* contiguous)
-{
-  if (!ctx || !contiguous) return RGBDR_ERR_INVALID_ARGUMENT;
-  *contiguous = ctx->arena_contiguous ? 1 : 0;
   return RGBDR_OK;
 }
 

@@ -95,7 +95,6 @@ struct rgbdr_ctx {
   int bgmax_for = -1;        // frame buffer d_bgmax was computed from since the last process_textures (-1: stale)
   float arena_probe_ms[16] = {0};  // LUT-stream time of each candidate placement of the arena
   int arena_trials = 0, arena_chosen = 0;
-  bool arena_contiguous = false;   // the kept arena came from hipExtMallocWithFlags(hipDeviceMallocContiguous)
   float4* d_lut_generic[rgbdr::kMaxSensors] = {};
   int zoff[rgbdr::kMaxSensors] = {};
 
