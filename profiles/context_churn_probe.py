@@ -1,3 +1,7 @@
+"""Creates and destroys N small contexts (1 / 3 / 5 / 8 sensors in turn), runs one frame in each and compares every image
+with the oracle: the loop that exposed the intermittent corruption / hang with physically contiguous LUT arenas
+(profiles/r03_notes).  Test infrastructure (loads the oracle); run on the GPU box under `timeout`:
+    timeout 200 python3 profiles/context_churn_probe.py 40"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
