@@ -16,13 +16,7 @@ LIB_PATH = os.path.join(HERE, "_ref", "libglctx.so")
 MESA_ENV = {
     "allow_glsl_builtin_variable_redeclaration": "true",
     "allow_glsl_extension_directive_midshader": "true",
-    "allow_glsl_builtin_const_expression": "true",
-    "allow_glsl_relaxed_es": "false",
-    "allow_higher_compat_version": "true",
-    "allow_glsl_compat_shaders": "true",
-    "glsl_zero_init": "false",
     "LP_NUM_THREADS": "8",
-    "MESA_NO_ERROR": "0",
 }
 
 # enums (GL/glcorearb.h)
