@@ -72,5 +72,58 @@ def main(argv):
         gl_ref.release(out)
 
 
+
+
+# ---- BASELINE's sensor size: four 512 x 424 sensors into 128^3, frozen as a SAMPLE (the full frame would be 60 MB) ----
+SAMPLE_NAME = "four_sensors_512x424_into_128"
+SAMPLE_G = 128
+SAMPLE_TEXELS, SAMPLE_VOXELS = 20000, 60000
+
+
+def sample_scene():
+    G = SAMPLE_G
+    scene = synth.Scene(4, 512, 424, lut_res=(32, 27, 32), seed=1234)
+    cfg = capi.make_config(4, (512, 424), voxel_size=2.0 / G, brick_size=8 * 2.0 / G)
+    geo = capi.compute_geometry(cfg)
+    inv = scene.inverse((G, G, G))
+    return scene, cfg, geo, inv
+
+
+def make_sample():
+    """the Mesa run of the whole frame; stored: every brick counter, SAMPLE_TEXELS texels of every image and SAMPLE_VOXELS
+    voxels (half of them drawn from the surface band) at seeded positions"""
+    scene, cfg, geo, inv = sample_scene()
+    G = SAMPLE_G
+    out = gl_ref.run_frame(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit, brick_size=geo.brick_size,
+                           res_bricks=tuple(geo.res_bricks), filter_textures=True, processed=True, refine=True)
+    rng = np.random.default_rng(4242)
+    n, H, W = 4, 424, 512
+    arrays = {"counters": out["counters"], "inputs_sha256": np.frombuffer(shader_cases.digest(scene, inv).encode(), dtype=np.uint8)}
+    # texels: half uniformly, half where the sensor saw something (depth_b.r in (0, 1))
+    db = np.stack(out["depth_b"])[..., 0]
+    seen = np.flatnonzero((db > 0) & (db < 1))
+    tex = np.unique(np.concatenate([rng.integers(0, n * H * W, SAMPLE_TEXELS // 2), rng.choice(seen, SAMPLE_TEXELS // 2, replace=False)]))
+    arrays["texels"] = tex.astype(np.uint32)
+    for k in shader_cases.IMAGES:
+        a = np.stack(out[k])
+        arrays[k] = a.reshape(n * H * W, -1)[tex]
+    t = out["tsdf"].reshape(-1)
+    band = np.flatnonzero(np.abs(t) < cfg.tsdf_limit)
+    vox = np.unique(np.concatenate([rng.integers(0, t.size, SAMPLE_VOXELS // 2), rng.choice(band, min(SAMPLE_VOXELS // 2, band.size), replace=False)]))
+    arrays["voxels"] = vox.astype(np.uint32)
+    arrays["tsdf"] = t[vox]
+    info = gl_ref.info()
+    arrays["gl_renderer"] = np.frombuffer((info["renderer"] + " / " + info["version"]).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "gl_sample_%s.npz" % SAMPLE_NAME)
+    np.savez_compressed(path, **arrays)
+    print("%-40s %7.1f KiB  %d texels, %d voxels (%d in the band of %d), counted %d" % (
+        SAMPLE_NAME, os.path.getsize(path) / 1024, tex.size, vox.size, int((np.abs(t[vox]) < cfg.tsdf_limit).sum()), band.size, int(out["counters"].sum())))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if sys.argv[1:] == ["sample"]:
+        make_sample()
+    else:
+        main(sys.argv[1:])
+        if not sys.argv[1:]:
+            make_sample()

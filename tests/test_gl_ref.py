@@ -20,7 +20,8 @@ approximations and filters 8-bit textures with 8-bit weights, the oracle uses li
   quality                                                                       2e-6 + 2e-5 relative; excluded: texels where llvmpipe's
                                                                                 pow(angle < 0, 2) is NaN (undefined in GLSL) or
                                                                                 a NaN normal is a bilinear neighbour (weight 0)
-  TSDF                                                                          1e-7, same class (-limit / +limit / surface)
+  TSDF                                                                          5e-7 (2.3e-7 seen with four 512 x 424 sensors, <= 2e-9 on
+                                                                                the small scenes), same class (-limit / +limit / surface)
                                                                                 everywhere, voxels fed by such a NaN excluded"""
 import os
 import sys
@@ -40,7 +41,7 @@ TOL = {"lab": 4e-3, "normal": 5e-5, "quality": 2e-6}
 LOOSE = {"normal": (1e-3, 1e-3)}  # a normal is normalize(cross(a, b)) of differenced positions: ill-conditioned where a x b is tiny
 RTOL = {"quality": 2e-5}         # two pow(x, 6.0) and a pow(x, 2.0) of llvmpipe's exp2(y * log2(x)) in one product
 TOL_U8_DEPTH = 1e-6
-TOL_TSDF = 1e-7
+TOL_TSDF = 5e-7          # 5e-5 of the band's half-width: the weighted mean inherits the relative error of llvmpipe's quality (pow)
 MAX_NAN_FRACTION = 5e-3          # texels whose quality is NaN on llvmpipe only; each one must have a negative angle
 
 
@@ -102,6 +103,20 @@ def negative_angle(scene, i, depth_b, normal):
     return check
 
 
+def class_flips(t, r, ok, limit):
+    """voxels whose class (-limit / inside the band / +limit) differs between the two volumes -- not counting a voxel
+    where both values lie within 1e-6 of the same boundary (tsdf_integration.vs:41-46 compares sdist with +-limit: a
+    last-bit difference of sdist turns exactly -limit into a weighted mean a hair above it; the values still agree
+    to the TSDF tolerance, which is checked separately)"""
+    limit = np.float32(limit)
+
+    def cls(v):
+        return np.where(v <= -limit, -1, np.where(v >= limit, 1, 0))
+    d = (cls(t) != cls(r)) & ok
+    at_boundary = (np.abs(np.abs(t) - limit) <= 1e-6) & (np.abs(np.abs(r) - limit) <= 1e-6) & (np.sign(t) == np.sign(r))
+    return int((d & ~at_boundary).sum())
+
+
 def compare(got, fx, name, what, scene, limit=0.01, counter_slack=0.0):
     """`got`: images per sensor + counters + tsdf of the oracle or the HIP path; `fx`: the Mesa run"""
     n = shader_cases.CASES[name][0]
@@ -123,9 +138,8 @@ def compare(got, fx, name, what, scene, limit=0.01, counter_slack=0.0):
     skipped = within(t, r, TOL_TSDF, "%s vs Mesa: TSDF" % what, allow_nan_in_want=True)
     ok = ~(np.isnan(r) | np.isnan(t))
 
-    def cls(v):
-        return np.where(v <= -limit, -1, np.where(v >= limit, 1, 0))
-    assert np.array_equal(cls(t)[ok], cls(r)[ok]), "%s vs Mesa: %d voxels change class" % (what, int((cls(t)[ok] != cls(r)[ok]).sum()))
+    flips = class_flips(t, r, ok, limit)
+    assert flips == 0, "%s vs Mesa: %d voxels change class" % (what, flips)
     return skipped
 
 
@@ -431,3 +445,83 @@ def test_u8_depth_through_the_morph_pass_oracle_matches_mesa(orc, pkg):
     finally:
         shader_cases.COMPRESSED_DEPTH.discard("__live__")
     assert fx["counters"].sum() > 0 and (fx["morph"] != 0).sum() > 1000
+
+
+# ---- BASELINE's sensor size, committed as a sample: four 512 x 424 sensors into 128^3 on Mesa ------------------------
+def sample_fixture():
+    return np.load(os.path.join(ROOT, "tests", "golden", "gl_sample_four_sensors_512x424_into_128.npz"))
+
+
+def sample_scene(pkg):
+    G = 128
+    scene = pkg.synth.Scene(4, 512, 424, lut_res=(32, 27, 32), seed=1234)
+    cfg = pkg.capi.make_config(4, (512, 424), voxel_size=2.0 / G, brick_size=8 * 2.0 / G)
+    geo = pkg.capi.compute_geometry(cfg)
+    inv = scene.inverse((G, G, G))
+    return scene, cfg, geo, inv, G
+
+
+def compare_sample(got, fx, scene, limit, what):
+    """`got`: full images per sensor, counters and volume of the oracle / the HIP path; `fx`: the sampled Mesa run
+    (tests/golden/make_gl_golden.py: 19 814 texels of every image, 59 413 voxels -- half of them in the surface band)"""
+    n, H, W = 4, 424, 512
+    tex = fx["texels"].astype(np.int64)
+    si, rem = np.divmod(tex, H * W)
+    ty, tx = np.divmod(rem, W)
+    full = {k: np.stack([np.asarray(a, np.float32) for a in got[k]]) for k in shader_cases.IMAGES}
+    for k in shader_cases.IMAGES:
+        g = full[k].reshape(n * H * W, -1)[tex]
+        w = "%s vs Mesa (4 x 512 x 424): %s" % (what, k)
+        if k in EXACT:
+            assert same_bits(g, fx[k]), "%s: %d sampled values differ" % (w, count_diff(g, fx[k]))
+        elif k == "quality":
+            want = fx[k]
+            llvm_nan = np.isnan(want) & ~np.isnan(g)
+            assert llvm_nan.mean() <= MAX_NAN_FRACTION
+            for j in np.flatnonzero(llvm_nan.reshape(-1)):
+                i = int(si[j])
+                assert negative_angle(scene, i, full["depth_b"][i], full["normal"][i])((int(ty[j]), int(tx[j]))), \
+                    "%s: NaN on llvmpipe at sensor %d (%d, %d) without a negative angle or a NaN neighbour" % (w, i, ty[j], tx[j])
+            ok = ~llvm_nan
+            within(g[ok], want[ok], TOL[k], w, rtol=RTOL[k])
+        else:
+            within(g, fx[k], TOL[k], w, loose=LOOSE.get(k))
+    dc = np.abs(np.asarray(got["counters"]).astype(np.int64) - fx["counters"].astype(np.int64)).sum()
+    assert dc <= 1e-3 * fx["counters"].sum(), "%s: brick counters differ by %d of %d" % (what, dc, fx["counters"].sum())
+    t = np.asarray(got["tsdf"], np.float32).reshape(-1)[fx["voxels"].astype(np.int64)]
+    r = fx["tsdf"]
+    within(t, r, TOL_TSDF, "%s vs Mesa (4 x 512 x 424): TSDF" % what, allow_nan_in_want=True)
+    ok = ~(np.isnan(r) | np.isnan(t))
+    lim = np.float32(limit)
+
+    flips = class_flips(t, r, ok, lim)
+    assert flips == 0, "%s: %d sampled voxels change class" % (what, flips)
+    assert (np.abs(r[ok]) < lim).sum() > 20000
+
+
+def test_oracle_matches_the_mesa_sample_at_baseline_sensor_size(orc, pkg):
+    scene, cfg, geo, inv, G = sample_scene(pkg)
+    fx = sample_fixture()
+    assert bytes(fx["inputs_sha256"]).decode() == shader_cases.digest(scene, inv), "the synthetic scene drifted: regenerate the fixture"
+    ref = orc.run_pipeline(scene, pkg.synth.BBOX_MIN, pkg.synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit, brick_size=geo.brick_size,
+                           bv=geo.brick_voxels, res_bricks=tuple(geo.res_bricks), use_bricks=False)
+    compare_sample(ref, fx, scene, cfg.tsdf_limit, "oracle")
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_the_mesa_sample_at_baseline_sensor_size(pkg):
+    capi = pkg.capi
+    scene, cfg, geo, inv, G = sample_scene(pkg)
+    fx = sample_fixture()
+    assert bytes(fx["inputs_sha256"]).decode() == shader_cases.digest(scene, inv)
+    ctx = capi.Context(cfg, 0)
+    for i in range(4):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    got = {k: [ctx.readback_image(which, i) for i in range(4)] for k, which in IMG.items()}
+    got["counters"] = ctx.readback_brick_counters()
+    got["tsdf"] = ctx.readback_tsdf()
+    ctx.close()
+    compare_sample(got, fx, scene, cfg.tsdf_limit, "HIP path")
