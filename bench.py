@@ -874,6 +874,8 @@ def cpu_baseline(ctx, scene, capi, synth, G, N, W, H, rows, V_total):
         ref_cpu = None
     ref_text = reference_text_baseline(ctx, scene, capi, synth, hip, sil, db, q, N)
     ref_glsl = reference_glsl_fixture_check(capi, synth)
+    if isinstance(ref_glsl, dict) and "error" not in ref_glsl:
+        ref_glsl["baseline_sensor_size"] = reference_glsl_sample_check(capi, synth)
     what = "all %d z rows" % Z if done == Z else "%d of %d z rows, extrapolated to the grid" % (done, Z)
     return {"reference_cpu_work": ref_cpu, "reference_shader_text": ref_text, "reference_glsl_on_mesa": ref_glsl,
             "value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads,
@@ -930,6 +932,47 @@ def reference_glsl_fixture_check(capi, synth, name="four_sensors_128x106_into_64
                 "tsdf_voxels_changing_class": int((cls(t) != cls(r))[ok].sum()),
                 "voxels_masked_nan_on_llvmpipe_only": int((np.isnan(r) & ~np.isnan(t)).sum()),
                 "renderer": bytes(fx["gl_renderer"]).decode()}
+    except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+
+def reference_glsl_sample_check(capi, synth, name="four_sensors_512x424_into_128"):
+    """the same at BASELINE's sensor size: four 512 x 424 sensors into 128^3, against the committed SAMPLE of the Mesa run
+    (tests/golden/gl_sample_<name>.npz: 19 814 texels of every image, 59 413 voxels, every brick counter)"""
+    try:
+        path = os.path.join(ROOT, "tests", "golden", "gl_sample_%s.npz" % name)
+        if not os.path.exists(path):
+            return None
+        fx = np.load(path)
+        G, n, H, W = 128, 4, 424, 512
+        scene = synth.Scene(n, W, H, lut_res=(32, 27, 32), seed=1234)
+        cfg = capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G)
+        inv = scene.inverse((G, G, G))
+        c = capi.Context(cfg, 0)
+        for i in range(n):
+            c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+            c.set_inverse_calibration(i, inv[i], (G, G, G))
+        c.set_use_bricks(False)
+        c.step(scene.depth, scene.color)
+        tex = fx["texels"].astype(np.int64)
+        out = {}
+        for k, which in {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}.items():
+            got = np.stack([c.readback_image(which, i) for i in range(n)]).reshape(n * H * W, -1)[tex].astype(np.float64)
+            want = fx[k].astype(np.float64)
+            fin = np.isfinite(got) & np.isfinite(want)
+            out[k] = float("%.3g" % np.abs(got - want)[fin].max())
+        cnt = c.readback_brick_counters().astype(np.int64)
+        t = c.readback_tsdf().reshape(-1)[fx["voxels"].astype(np.int64)]
+        c.close()
+        r = fx["tsdf"]
+        ok = ~(np.isnan(t) | np.isnan(r))
+        lim = np.float32(cfg.tsdf_limit)
+        return {"what": "4 sensors 512 x 424 into 128^3, %d sampled texels per image, %d sampled voxels (%d in the band)"
+                        % (tex.size, t.size, int((np.abs(r[ok]) < lim).sum())),
+                "max_abs_diff": out, "brick_counts_differing": int(np.abs(cnt - fx["counters"].astype(np.int64)).sum()),
+                "brick_counts": int(fx["counters"].sum()),
+                "tsdf_max_abs_diff": float("%.3g" % np.abs(t.astype(np.float64) - r)[ok].max()),
+                "tsdf_voxels_beyond_1e-6": int((np.abs(t.astype(np.float64) - r)[ok] > 1e-6).sum())}
     except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 

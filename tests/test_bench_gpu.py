@@ -48,6 +48,10 @@ def test_bench_line_contract():
     assert rg is not None and "error" not in rg, rg
     assert rg["tsdf_max_abs_diff"] <= 5e-7 and rg["tsdf_voxels_changing_class"] == 0 and rg["brick_counters_equal"] is True
     assert rg["max_abs_diff"]["depth_rg"] == 0.0 and rg["max_abs_diff"]["depth_b"] == 0.0 and rg["max_abs_diff"]["sil"] == 0.0
+    big = rg["baseline_sensor_size"]
+    assert big is not None and "error" not in big, big
+    assert big["tsdf_max_abs_diff"] <= 5e-7 and big["tsdf_voxels_beyond_1e-6"] == 0 and big["max_abs_diff"]["depth_rg"] == 0.0
+    assert big["brick_counts_differing"] <= 1e-3 * big["brick_counts"]
     # box calibration: a replay of the kernel's memory streams on the same box, and the GPU state beside it
     assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
     assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
