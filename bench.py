@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--loopback", action="store_true",
                     help="one GPU, real RCCL: run an inner Z slab (rank 1 of 4) whose two neighbours are this process "
                          "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
-    ap.add_argument("--arena-trials", type=int, default=10,
+    ap.add_argument("--arena-trials", type=int, default=16,
                     help="RGBDR_ARENA_TRIALS for this run (the library's default is 3): within one box the sweep "
                          "time differs by up to 12 %% between processes with where hipMalloc placed the LUT arena; the "
                          "library times up to this many candidate placements (about 5 ms each, at most 1 s) and keeps the "
