@@ -17,7 +17,10 @@ texture is created with which format / filter and bound where, and which uniform
   ScreenQuad                          framework/rendering/screen_quad.cpp:8-37
   VolumeSampler                       framework/rendering/volume_sampler.cpp:9-50,86-91
   ReconIntegration                    framework/reconstruction/recon_integration.cpp:61-128 (uniforms), :243-270 (integrate),
-                                      :389-404 (brick SSBO), :150-241 (draw), :280-339 (fillColors), :406-425 (depth limits)
+                                      :389-404 (brick SSBO), :150-241 (draw), :280-339 (fillColors), :406-425 (depth limits),
+                                      :341-354 (setVoxelSize), :474-484 (setBrickSize), :361-388 (divideBox),
+                                      :431-446 (updateOccupiedBricks) -- host_grid() / occupied_bricks() below
+  VolumeSampler::containedVoxels      framework/rendering/volume_sampler.cpp:50-62 (the index list of a brick)
   texture units                       source/kinect_client.cpp:245-249 (nka 1.., calibration volumes 9.., inverse 30..)
 
 The text is compiled as it is, with two exceptions applied in memory (nothing of it is stored in this repository):
@@ -217,7 +220,7 @@ def delete_textures(texs):
 class Calib:
     """CalibVolumes: BBox UBO at binding 2, forward volumes on units 9 + 2 i / 10 + 2 i, inverse on 30 + i"""
 
-    def __init__(self, scene, bbox_min, bbox_max, inv_luts):
+    def __init__(self, scene, bbox_min, bbox_max, inv_luts, inv_rgb_only=False):
         g = gl()
         self.n = scene.N
         ext = np.array([list(bbox_min) + [1.0], list(bbox_max) + [1.0]], np.float32)           # CalibVolumes.cpp:45-49
@@ -225,7 +228,13 @@ class Calib:
         g.glBindBufferBase(m.UNIFORM_BUFFER, 2, self.ubo)
         self.xyz = [volume_texture(m.RGB32F, m.RGB, scene.xyz[i]) for i in range(self.n)]       # :135-136
         self.uv = [volume_texture(m.RG32F, m.RG, scene.uv[i]) for i in range(self.n)]           # :140-141
-        self.inv = [volume_texture(m.RGBA32F, m.RGBA, v) for v in (inv_luts or [])]             # :76-77
+        # :76-77 creates RGBA32F; inv_rgb_only (the 512^3 sample only, make_gl_golden.py) stores the same texels without
+        # the fourth component, which no shader reads (tsdf_integration.vs:31 and tsdf_raymarch.fs take .xyz):
+        # llvmpipe refuses a 512^3 RGBA32F texture (2 GiB), and takes the 1.5 GiB RGB32F one
+        if inv_rgb_only:
+            self.inv = [volume_texture(m.RGB32F, m.RGB, np.ascontiguousarray(v[..., :3])) for v in (inv_luts or [])]
+        else:
+            self.inv = [volume_texture(m.RGBA32F, m.RGBA, v) for v in (inv_luts or [])]
         for i in range(self.n):                                                                  # :162-175
             bind(CV_UNIT + 2 * i, m.TEXTURE_3D, self.xyz[i])
             bind(CV_UNIT + 2 * i + 1, m.TEXTURE_3D, self.uv[i])
@@ -240,21 +249,35 @@ class Calib:
 
 
 def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=None, res_bricks=None, limits=(0.5, 4.5),
-              filter_textures=True, processed=True, refine=True, near_far=(0.5, 4.5), compress=False, keep=False):
+              filter_textures=True, processed=True, refine=True, near_far=(0.5, 4.5), compress=False, keep=False,
+              compress_rgb=0, use_bricks=False, min_voxels=10, inv_rgb_only=False, integrate_voxels=None):
     """One frame through the reference's shaders on Mesa; the keys of pyoracle.run_pipeline / shader_ref.run_frame.
     `scene`: rgbd_recon_amd.synth.Scene (depth [N,H,W] f32 or depth_u8, color [N,Hc,Wc,3] u8, xyz / uv forward LUTs);
-    inv_luts [N][Z,Y,X,4]."""
+    inv_luts [N][Z,Y,X,4].
+    compress_rgb 1 / 5: the colour frames are scene.color_blocks [N][bytes] (DXT1 / DXT5 block streams as the server sends
+    them) in GL_COMPRESSED_RGBA_S3TC_DXT{1,5}_EXT layers, decoded by the GL implementation (NetKinectArray.cpp:149-156).
+    use_bricks: ReconIntegration's default mode (m_use_bricks, recon_integration.cpp:255-261): updateOccupiedBricks on
+    the counters of THIS run, then one indexed draw per occupied brick with the brick's containedVoxels list.
+    integrate_voxels: linear voxel ids to run tsdf_integration.vs for instead of the whole VolumeSampler (samples of grids
+    too large to sweep on llvmpipe; the rest of the volume keeps the cleared -limit)."""
     g = gl()
     n = scene.N
     H, W = scene.depth.shape[1:3]
     Hc, Wc = scene.color.shape[1:3]
-    cal = Calib(scene, bbox_min, bbox_max, inv_luts)
+    cal = Calib(scene, bbox_min, bbox_max, inv_luts, inv_rgb_only=inv_rgb_only)
     vs = "texture_passthrough.vs"
     prog = {k: Prog(k, [vs, f]) for k, f in (("morph", "pre_morph.fs"), ("filter", "pre_depth.fs"), ("boundary", "pre_boundary.fs"),
                                                 ("normal", "pre_normal.fs"), ("quality", "pre_quality.fs"))}
 
     # ---- NetKinectArray::init: textures (formats :139-172, filters :174-186) ----
-    tex_color = array_texture(m.RGB, m.RGB, m.UNSIGNED_BYTE, Wc, Hc, n, scene.color)                       # m_colorArray :157
+    if compress_rgb:                                                                                       # m_colorArray :149-156
+        blocks = np.ascontiguousarray(np.stack([np.asarray(b, np.uint8).reshape(-1) for b in scene.color_blocks]))
+        fmt = m.COMPRESSED_RGBA_S3TC_DXT1_EXT if compress_rgb == 1 else m.COMPRESSED_RGBA_S3TC_DXT5_EXT
+        tex_color = g.texture(m.TEXTURE_2D_ARRAY, m.LINEAR)                                                # TextureArray.cpp:27-32
+        g.glPixelStorei(m.UNPACK_ALIGNMENT, 1)
+        g.glCompressedTexImage3D(m.TEXTURE_2D_ARRAY, 0, fmt, Wc, Hc, n, 0, blocks.size, blocks.ctypes.data)
+    else:
+        tex_color = array_texture(m.RGB, m.RGB, m.UNSIGNED_BYTE, Wc, Hc, n, scene.color)                   # m_colorArray :157
     if compress:                                                                                           # :166-168
         tex_raw = array_texture(m.LUMINANCE, m.RED, m.UNSIGNED_BYTE, W, H, n, scene.depth_u8, filt=m.NEAREST)
     else:
@@ -430,7 +453,17 @@ def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=N
         X, Y, Z = res
         vol = g.texture(m.TEXTURE_3D, m.LINEAR)                                                    # m_volume_tsdf, :52, :347
         g.glTexImage3D(m.TEXTURE_3D, 0, m.R32F, X, Y, Z, 0, m.RED, m.FLOAT, None)
-        out["tsdf"] = integrate(cal, frame_tex, n, (X, Y, Z), limit, (W, H), volume=vol)
+        indices = None
+        if use_bricks:                      # updateOccupiedBricks (:431-446) + the occupied bricks' lists (:255-261)
+            grid = host_grid(bbox_min, bbox_max, None, brick_size, res=(X, Y, Z))
+            assert grid["res_bricks"] == tuple(int(v) for v in res_bricks), (grid["res_bricks"], res_bricks)
+            occ = occupied_bricks(out["counters"], min_voxels)
+            out["occupied"] = occ
+            indices = [brick_indices(grid, int(b)) for b in occ]
+        elif integrate_voxels is not None:
+            indices = [np.asarray(integrate_voxels, np.uint32)]
+        out["tsdf"] = integrate(cal, frame_tex, n, (X, Y, Z), limit, (W, H), volume=vol, indices=indices,
+                                compact=integrate_voxels is not None)
     if keep:
         out["_gl"] = {"cal": cal, "tex": frame_tex, "volume": vol}
         delete_textures([tex_raw, tex_lab, tex_depth] + depth2)
@@ -454,7 +487,7 @@ def bind_frame(tex):
 VS_PAD = 8
 
 
-def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=None):
+def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=None, compact=False):
     """glClearTexImage(-limit) + tsdf_integration.vs over the voxel centres of VolumeSampler (all of them, or the
     index lists of the occupied bricks) with rasteriser discard; -> [Z, Y, X] float32
 
@@ -464,7 +497,13 @@ def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=
     right (vs_sampler_array_bug() shows it on Mesa alone, no oracle involved).  So the voxel centres are drawn one per
     group of 8: every centre is followed by pad - 1 vertices at (2, 2, 2), whose imageStore falls outside the volume and
     is discarded (GL 4.4 section 8.26).  The shader text and the centres are unchanged; make_gl_golden.py also checks
-    that pad = 8 and pad = 16 give the same volume."""
+    that pad = 8 and pad = 16 give the same volume.
+
+    Index lists: an index past the end of the vertex buffer (a brick whose containedVoxels range leaves the z end of the
+    grid) is undefined in GL without robust buffer access; the harness drops it.  Indices past the x / y end alias a
+    voxel of the next row / slice through z*X*Y + y*X + x and are drawn like any other (that IS what the reference draws).
+    `compact`: the vertex buffer holds only the listed voxels' centres (same floats), drawn with glDrawArrays -- for
+    samples of grids whose whole VolumeSampler buffer (12 B x pad per voxel) would not fit."""
     pad = pad or VS_PAD
     g = gl()
     X, Y, Z = res
@@ -485,12 +524,22 @@ def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=
     bind_frame(tex)
     # VolumeSampler: (x + .5) * step, x fastest (volume_sampler.cpp:14-24)
     sx, sy, sz = np.float32(1.0) / np.float32(X), np.float32(1.0) / np.float32(Y), np.float32(1.0) / np.float32(Z)
-    pos = np.empty((Z, Y, X, 3), np.float32)
-    pos[..., 0] = ((np.arange(X, dtype=np.float32) + np.float32(0.5)) * sx)[None, None, :]
-    pos[..., 1] = ((np.arange(Y, dtype=np.float32) + np.float32(0.5)) * sy)[None, :, None]
-    pos[..., 2] = ((np.arange(Z, dtype=np.float32) + np.float32(0.5)) * sz)[:, None, None]
+    if compact:
+        ids = np.concatenate([np.asarray(i, np.int64) for i in indices])
+        ids = ids[ids < X * Y * Z]
+        zz, rem = np.divmod(ids, X * Y)
+        yy, xx = np.divmod(rem, X)
+        pos = np.stack([(xx.astype(np.float32) + np.float32(0.5)) * sx, (yy.astype(np.float32) + np.float32(0.5)) * sy,
+                        (zz.astype(np.float32) + np.float32(0.5)) * sz], axis=-1).astype(np.float32)
+        nvert = ids.size
+    else:
+        pos = np.empty((Z, Y, X, 3), np.float32)
+        pos[..., 0] = ((np.arange(X, dtype=np.float32) + np.float32(0.5)) * sx)[None, None, :]
+        pos[..., 1] = ((np.arange(Y, dtype=np.float32) + np.float32(0.5)) * sy)[None, :, None]
+        pos[..., 2] = ((np.arange(Z, dtype=np.float32) + np.float32(0.5)) * sz)[:, None, None]
+        nvert = X * Y * Z
     if pad > 1:
-        padded = np.full((X * Y * Z, pad, 3), 2.0, np.float32)
+        padded = np.full((nvert, pad, 3), 2.0, np.float32)
         padded[:, 0] = pos.reshape(-1, 3)
         pos = padded
     vao = g.gen("VertexArrays")
@@ -506,11 +555,15 @@ def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=
     neg = C.c_float(-float(np.float32(limit)))
     g.glClearTexImage(vol, 0, m.RED, m.FLOAT, C.byref(neg))
     g.glBindImageTexture(IMAGE_UNIT, vol, 0, 1, 0, m.WRITE_ONLY, m.R32F)
-    if indices is None:
-        g.glDrawArrays(m.POINTS, 0, X * Y * Z * pad)
+    if indices is None or compact:
+        g.glDrawArrays(m.POINTS, 0, nvert * pad)
     else:
         for idx in indices:                                             # m_sampler.sample(m_bricks[index].indices), :258-260
-            a = (np.asarray(idx, np.uint32)[:, None] * np.uint32(pad) + np.arange(pad, dtype=np.uint32)[None, :]).reshape(-1)
+            idx = np.asarray(idx, np.uint32)
+            idx = idx[idx < np.uint32(X * Y * Z)]
+            if idx.size == 0:
+                continue
+            a = (idx[:, None] * np.uint32(pad) + np.arange(pad, dtype=np.uint32)[None, :]).reshape(-1)
             a = np.ascontiguousarray(a, np.uint32)
             g.glDrawElements(m.POINTS, a.size, m.UNSIGNED_INT, a.ctypes.data)
     g.glMemoryBarrier(m.ALL_BARRIER_BITS)
@@ -525,6 +578,63 @@ def integrate(cal, tex, n, res, limit, depth_wh, indices=None, volume=None, pad=
     g.glBindBuffer(m.ARRAY_BUFFER, 0)
     C.CFUNCTYPE(None, C.c_int, C.c_void_p)(g._lib.glctx_proc(b"glDeleteBuffers"))(1, b)
     return tsdf
+
+
+# ---- ReconIntegration's grid and bricks: HOST code of the reference, restated in binary32 like glm::fvec3 does it ----
+_F = np.float32
+
+
+def host_grid(bbox_min, bbox_max, voxel_size, brick_size, res=None):
+    """setVoxelSize (recon_integration.cpp:341-354): m_res_volume = ceil(extent / voxel);  setBrickSize (:474-484):
+    m_brick_size = voxel * round(size / voxel);  divideBox (:361-388): bricks x-fastest from bbox.min in steps of
+    m_brick_size accumulated in float, the last one per axis clipped, each with the index list of
+    VolumeSampler::containedVoxels (volume_sampler.cpp:50-62).  Membership is separable, so per axis the bricks'
+    (first voxel, bound) pairs are kept and a brick's list is built from them in the reference's loop order.
+    voxel_size None: `brick_size` is already the adjusted m_brick_size and `res` the volume resolution."""
+    mn = [_F(v) for v in bbox_min]
+    ext = [_F(_F(bbox_max[a]) - mn[a]) for a in range(3)]                  # getPMax()[a] - getPMin()[a], mathType = float
+    if voxel_size is not None:
+        vs = _F(voxel_size)
+        res = tuple(int(np.ceil(_F(ext[a] / vs))) for a in range(3))
+        q = _F(_F(brick_size) / vs)
+        bs = _F(vs * _F(np.floor(np.abs(q) + _F(0.5)) * np.sign(q)))      # glm::round: half away from zero
+    else:
+        bs = _F(brick_size)
+    axes = []
+    for a in range(3):
+        size, lo0 = ext[a], mn[a]
+        step = _F(_F(1.0) / _F(res[a]))                                    # glm::fvec3 step{1.0f / fvec3{m_dimensions}}
+        start, rng = lo0, []
+        while _F(_F(size - start) + lo0) > _F(0.0):                        # while(size.x - start.x + min.x > 0.0f)
+            bsz = min(bs, _F(_F(size - start) + lo0))                      # glm::min(fvec3{m_brick_size}, size - start + min)
+            pos_n = _F(_F(start - lo0) / size)                             # (curr_brick.pos - min) / size
+            size_n = _F(bsz / size)                                        # curr_brick.size / size
+            first = int(_F(pos_n / step))                                  # unsigned x = pos.x / step.x
+            bound = _F(_F(pos_n + size_n) / step)                          # x < (pos.x + size.x) / step.x
+            last = first
+            while _F(last) < bound:
+                last += 1
+            rng.append((first, last))                                      # voxels first .. last - 1
+            start = _F(start + bs)                                         # start.x += m_brick_size
+        axes.append(rng)
+    return {"res": tuple(res), "brick_size": float(bs), "res_bricks": tuple(len(r) for r in axes), "axes": axes}
+
+
+def brick_indices(grid, brick):
+    """m_bricks[brick].indices: for y, for x, for z: z * X * Y + y * X + x  (volume_sampler.cpp:53-58; unsigned arithmetic)"""
+    X, Y, Z = grid["res"]
+    rx, ry, rz = grid["res_bricks"]
+    bx, by, bz = brick % rx, (brick // rx) % ry, brick // (rx * ry)
+    xs = np.arange(*grid["axes"][0][bx], dtype=np.uint64)
+    ys = np.arange(*grid["axes"][1][by], dtype=np.uint64)
+    zs = np.arange(*grid["axes"][2][bz], dtype=np.uint64)
+    ids = zs[None, None, :] * np.uint64(X * Y) + ys[:, None, None] * np.uint64(X) + xs[None, :, None]
+    return (ids.reshape(-1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def occupied_bricks(counters, min_voxels):
+    """updateOccupiedBricks (:436-440): ids with m_active_bricks[i] >= m_min_voxels_per_brick, ascending"""
+    return np.nonzero(np.asarray(counters, np.uint32) >= np.uint32(min_voxels))[0].astype(np.uint32)
 
 
 def release(out):

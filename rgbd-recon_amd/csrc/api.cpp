@@ -163,6 +163,7 @@ static int alloc_volume(rgbdr_ctx* ctx)
 int sync_all(rgbdr_ctx* ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->copy_stream) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   if (ctx->pre_stream) HIPCHK(hipStreamSynchronize(ctx->pre_stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->halo_stream) HIPCHK(hipStreamSynchronize(ctx->halo_stream));
@@ -282,8 +283,14 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
       return cleanup(RGBDR_ERR_HIP);
     }
   }
+  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    ctx->err = "hipStreamCreate failed";
+    return cleanup(RGBDR_ERR_HIP);
+  }
   for (int b = 0; b < 2; ++b)
     if (hipEventCreateWithFlags(&ctx->ev_pre[b], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_in_read[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_int[b], hipEventDisableTiming) != hipSuccess) {
       ctx->err = "hipEventCreate failed";
       return cleanup(RGBDR_ERR_HIP);
@@ -298,7 +305,7 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
                 {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
                 {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol},
-                {(void**)&ctx->d_depth_u8, n},        {(void**)&ctx->d_count, 32},
+                {(void**)&ctx->d_count, 32},
                 {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors},
                 {(void**)&ctx->d_cc_far, n * 8},         {(void**)&ctx->d_box_flags, n}};
   for (auto& a : allocs) {
@@ -332,10 +339,15 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   if (!ctx) return;
   // drain every stream first: queued kernels still write the mapped skip counter and read the page-locked frame buffers
   (void)hipSetDevice(ctx->device);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->pre_stream) (void)hipStreamSynchronize(ctx->pre_stream);
   if (ctx->halo_stream) (void)hipStreamSynchronize(ctx->halo_stream);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (int b = 0; b < 2; ++b) {
+    (void)hipFree(ctx->d_in_depth[b]);
+    (void)hipFree(ctx->d_in_color[b]);
+    if (ctx->ev_h2d[b]) (void)hipEventDestroy(ctx->ev_h2d[b]);
+    if (ctx->ev_in_read[b]) (void)hipEventDestroy(ctx->ev_in_read[b]);
     if (ctx->h_depth[b]) (void)hipHostFree(ctx->h_depth[b]);
     if (ctx->h_color[b]) (void)hipHostFree(ctx->h_color[b]);
     if (b == 0 && ctx->h_skip_count) (void)hipHostFree(ctx->h_skip_count);
@@ -349,6 +361,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     if (ctx->ev_int[b]) (void)hipEventDestroy(ctx->ev_int[b]);
   }
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->halo_stream) {
     (void)hipStreamSynchronize(ctx->halo_stream);
     (void)hipStreamDestroy(ctx->halo_stream);
@@ -358,7 +371,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     if (ctx->ev_halo_done[b]) (void)hipEventDestroy(ctx->ev_halo_done[b]);
   }
   void* ptrs[] = {ctx->d_depth_raw, ctx->d_depth_morph, ctx->d_depth_rg, ctx->d_lab,   ctx->d_depth_b, ctx->d_sil,
-                  ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_depth_u8, ctx->d_count,
+                  ctx->d_normal,    ctx->d_quality,     ctx->d_frame,    ctx->d_color, ctx->d_count,
                   ctx->d_color_dxt, ctx->d_cc_far,    ctx->d_box_flags};
   for (void* p : ptrs) (void)hipFree(p);
   for (int i = 0; i < kMaxSensors; ++i) {
@@ -371,16 +384,19 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
 }
 
 // ---------------------------------------------------------------------------
-static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, hipMemcpyKind kind)
+static size_t depth_frame_bytes_all(const rgbdr_ctx* ctx) { return npx(ctx) * (ctx->cfg.compress_depth ? 1 : 4); }
+static size_t color_frame_bytes_all(const rgbdr_ctx* ctx) { return color_frame_bytes(ctx->cfg) * (size_t)nsens(ctx); }
+
+// The frame set is on the device (the caller's buffers, or a staging set a host upload filled): raw depth (or u8
+// depth), the pre_morph image and the colour frame / blocks in as few launches as the pointers allow, on the stream
+// that runs the pre_* chain.
+static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
 {
-  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
-  HIPCHK(hipSetDevice(ctx->device));
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
   ctx->morph_current = false;
-  if (kind == hipMemcpyDeviceToDevice && !ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
+  if (!ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
       launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw, ctx->d_depth_morph, color,
                           ctx->d_color, ncol, ps)) {
     LAUNCHCHK("upload_morph");
@@ -390,27 +406,22 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
     return RGBDR_OK;
   }
   // Compressed colour stays in its DXT blocks: pre_depth decodes the four taps of its bilinear lookup itself, and the
-  // whole frame is only decoded when a consumer of the RGB8 image asks (ensure_color_decoded).  Frames that are
-  // already on the device: depth (or u8 depth) and the colour blocks / RGB8 frame move in one launch where the
-  // pointers allow it.
-  const bool dev = kind == hipMemcpyDeviceToDevice;
+  // whole frame is only decoded when a consumer of the RGB8 image asks (ensure_color_decoded).
   const size_t layer = color_frame_bytes(ctx->cfg);
-  const void* csrc = color;
   void* cdst = ctx->cfg.compress_rgb ? (void*)ctx->d_color_dxt : (void*)ctx->d_color;
   const size_t cbytes = ctx->cfg.compress_rgb ? layer * nsens(ctx) : ncol;
   bool color_done = false;
   if (ctx->cfg.compress_depth) {
-    if (!dev) HIPCHK(hipMemcpyAsync(ctx->d_depth_u8, depth, n, kind, ps));
-    launch_u8_to_unit(dev ? (const uint8_t*)depth : ctx->d_depth_u8, ctx->d_depth_raw, n, ps);
+    launch_u8_to_unit((const uint8_t*)depth, ctx->d_depth_raw, n, ps);
     LAUNCHCHK("u8_to_unit");
-  } else if (dev && launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw,
-                                        ctx->d_depth_morph, csrc, cdst, cbytes, ps)) {
+  } else if (launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw, ctx->d_depth_morph,
+                                 color, cdst, cbytes, ps)) {
     color_done = true;
     ctx->morph_current = true;
   } else {
-    HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, kind, ps));
+    HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, hipMemcpyDeviceToDevice, ps));
   }
-  if (!color_done) HIPCHK(hipMemcpyAsync(cdst, csrc, cbytes, kind, ps));
+  if (!color_done) HIPCHK(hipMemcpyAsync(cdst, color, cbytes, hipMemcpyDeviceToDevice, ps));
   ctx->color_decoded = !ctx->cfg.compress_rgb;
   ctx->frame_uploaded = true;
   // a zero-copy view of the RGB8 frame is out (rgbdr_device_image(RGBDR_IMG_COLOR)): it is documented as rewritten
@@ -424,6 +435,42 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
   return RGBDR_OK;
 }
 
+// NetKinectArray::update (NetKinectArray.cpp:226-238: PBO -> texture arrays) for frames in HOST memory.  The copy has
+// its own stream and lands in a staging set, so the DMA of frame k+1 runs while the sweep of frame k still occupies
+// the compute stream; the chain's stream only waits for the event behind the copy and then runs the same launch a
+// device-resident frame takes.  Page-locked sources (the double frame buffer) are true asynchronous DMA; a pageable
+// source is staged by the runtime before hipMemcpyAsync returns, so the caller may reuse its buffer at once either way.
+static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color)
+{
+  const size_t dbytes = depth_frame_bytes_all(ctx), cbytes = color_frame_bytes_all(ctx);
+  const int s = ctx->in_set;
+  if (!ctx->d_in_depth[s]) {
+    HIPCHK(hipMalloc(&ctx->d_in_depth[s], dbytes));
+    HIPCHK(hipMalloc(&ctx->d_in_color[s], cbytes));
+  }
+  hipStream_t cs = ctx->copy_stream;
+  if (ctx->ev_in_read_rec[s]) HIPCHK(hipStreamWaitEvent(cs, ctx->ev_in_read[s], 0));  // its last reader: two uploads ago
+  HIPCHK(hipMemcpyAsync(ctx->d_in_depth[s], depth, dbytes, hipMemcpyHostToDevice, cs));
+  HIPCHK(hipMemcpyAsync(ctx->d_in_color[s], color, cbytes, hipMemcpyHostToDevice, cs));
+  HIPCHK(hipEventRecord(ctx->ev_h2d[s], cs));
+  hipStream_t ps = ctx->pstream();
+  HIPCHK(hipStreamWaitEvent(ps, ctx->ev_h2d[s], 0));
+  int rc = upload_device(ctx, ctx->d_in_depth[s], ctx->d_in_color[s]);
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->ev_in_read[s], ps));
+  ctx->ev_in_read_rec[s] = true;
+  ctx->in_set = 1 - s;
+  return RGBDR_OK;
+}
+
+static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, hipMemcpyKind kind)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  return kind == hipMemcpyDeviceToDevice ? upload_device(ctx, depth, color) : upload_host(ctx, depth, color);
+}
+
 int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color)
 {
   return upload_common(ctx, depth, color, hipMemcpyHostToDevice);
@@ -432,9 +479,6 @@ int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth, const void* col
 {
   return upload_common(ctx, depth, color, hipMemcpyDeviceToDevice);
 }
-
-static size_t depth_frame_bytes_all(const rgbdr_ctx* ctx) { return npx(ctx) * (ctx->cfg.compress_depth ? 1 : 4); }
-static size_t color_frame_bytes_all(const rgbdr_ctx* ctx) { return color_frame_bytes(ctx->cfg) * (size_t)nsens(ctx); }
 
 int rgbdr_map_frame_buffer(rgbdr_ctx* ctx, void** depth, void** color, size_t* depth_bytes, size_t* color_bytes)
 {
@@ -463,7 +507,7 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
   if (!ctx->h_depth[b]) return ctx->fail(RGBDR_ERR_STATE, "upload_mapped_frame before map_frame_buffer");
   int rc = upload_common(ctx, ctx->h_depth[b], ctx->h_color[b], hipMemcpyHostToDevice);  // page-locked: true async DMA
   if (rc != RGBDR_OK) return rc;
-  HIPCHK(hipEventRecord(ctx->ev_mapped[b], ctx->pstream()));
+  HIPCHK(hipEventRecord(ctx->ev_mapped[b], ctx->copy_stream));  // the DMA out of this buffer has drained
   ctx->ev_mapped_rec[b] = true;
   ctx->mapped_back = 1 - b;  // swapBuffers
   return RGBDR_OK;

@@ -56,7 +56,7 @@ struct rgbdr_ctx {
   uint2* d_frame = nullptr;
   float2* d_cc_far = nullptr;            // per pixel: frame-independent lookups of pre_depth.fs (k_pre_cache, set_calibration)
   unsigned char* d_box_flags = nullptr;
-  uint8_t *d_color = nullptr, *d_depth_u8 = nullptr, *d_color_dxt = nullptr;
+  uint8_t *d_color = nullptr, *d_color_dxt = nullptr;
   bool frame_uploaded = false, textures_processed = false;
 
   // forward calibration
@@ -82,6 +82,17 @@ struct rgbdr_ctx {
   hipEvent_t ev_mapped[2] = {nullptr, nullptr};
   bool ev_mapped_rec[2] = {false, false};
   int mapped_back = 0;
+  // Host-fed frames (rgbdr_upload_frame / rgbdr_upload_mapped_frame): the host -> device copy of frame k+1 runs on
+  // copy_stream into one of two device staging sets while the passes of frame k still run; the stream that runs the
+  // pre_* chain then takes the frame from the staging set with the device-resident upload (k_upload_morph: raw
+  // depth + pre_morph + colour in one launch).  ev_h2d[s]: the copies into set s have landed; ev_in_read[s]: the
+  // upload kernel that read set s has run (the next copy into s waits for it).
+  hipStream_t copy_stream = nullptr;
+  void* d_in_depth[2] = {nullptr, nullptr};
+  void* d_in_color[2] = {nullptr, nullptr};
+  hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_in_read[2] = {nullptr, nullptr};
+  bool ev_in_read_rec[2] = {false, false};
+  int in_set = 0;                    // staging set the next host upload fills
   int32_t* d_win = nullptr;  // per (tile, sensor) frame-window origin; second plane: smallest projected depth
   uint8_t* d_skip_mask = nullptr;  // ... and per (tile, sensor) pair 1 = skipped; [ntiles * N] bytes + a 4-B counter behind them
   float* d_bgmax = nullptr;  // RGBDR_FLAG_SKIP_BACKGROUND: [N][(H+1)][(W+1)] window bounds of the current frame

@@ -74,6 +74,43 @@ def main(argv):
 
 
 
+# ---- the reference's default mode and its limits: bricks-on index lists, DXT1 colour layers, five sensors ----------------
+def mode_kwargs(name, cfg, geo):
+    c = shader_cases.MODE_CASES[name]
+    f = c["flags"]
+    return dict(limit=cfg.tsdf_limit, brick_size=geo.brick_size, res_bricks=tuple(geo.res_bricks), filter_textures=bool(f & 1),
+                processed=bool(f & 2), refine=bool(f & 4), use_bricks=bool(f & 8), min_voxels=cfg.min_voxels_per_brick,
+                compress_rgb=c.get("dxt", 0))
+
+
+def run_mode_case(name, keep=False):
+    scene, cfg, geo, inv, inv_res = shader_cases.build_mode(synth, capi, name)
+    c = shader_cases.MODE_CASES[name]
+    # setVoxelSize / setBrickSize / divideBox restated by the harness itself (gl_ref.host_grid) must agree with the library's
+    grid = gl_ref.host_grid(c["bbox"][0], c["bbox"][1], c["voxel"], c["brick"])
+    assert grid["res"] == tuple(geo.res_volume) and grid["res_bricks"] == tuple(geo.res_bricks) and grid["brick_size"] == geo.brick_size
+    out = gl_ref.run_frame(scene, c["bbox"][0], c["bbox"][1], tuple(geo.res_volume), inv, keep=keep, **mode_kwargs(name, cfg, geo))
+    return scene, cfg, geo, inv, out
+
+
+def main_modes(names):
+    info = gl_ref.info()
+    for name in names:
+        scene, cfg, geo, inv, out = run_mode_case(name)
+        arrays = {k: np.stack(out[k]) for k in shader_cases.IMAGES}
+        arrays["counters"], arrays["tsdf"] = out["counters"], out["tsdf"]
+        if "occupied" in out:
+            arrays["occupied"] = out["occupied"]
+        arrays["inputs_sha256"] = np.frombuffer(shader_cases.digest_mode(scene, inv).encode(), dtype=np.uint8)
+        arrays["gl_renderer"] = np.frombuffer((info["renderer"] + " / " + info["version"]).encode(), dtype=np.uint8)
+        path = os.path.join(HERE, "gl_passes_%s.npz" % name)
+        np.savez_compressed(path, **arrays)
+        t = out["tsdf"]
+        print("%-40s %7.1f KiB  grid %s  surface voxels %d  +limit voxels %d  occupied bricks %d of %d  counted %d" % (
+            name, os.path.getsize(path) / 1024, "x".join(str(v) for v in geo.res_volume), int(np.sum(np.abs(t) < cfg.tsdf_limit)),
+            int(np.sum(t >= cfg.tsdf_limit)), len(out.get("occupied", [])), out["counters"].size, int(out["counters"].sum())))
+
+
 # ---- BASELINE's sensor size: four 512 x 424 sensors into 128^3, frozen as a SAMPLE (the full frame would be 60 MB) ----
 SAMPLE_NAME = "four_sensors_512x424_into_128"
 SAMPLE_G = 128
@@ -121,9 +158,15 @@ def make_sample():
 
 
 if __name__ == "__main__":
-    if sys.argv[1:] == ["sample"]:
+    args = sys.argv[1:]
+    if args == ["sample"]:
         make_sample()
+    elif args and all(a in shader_cases.MODE_CASES for a in args):
+        main_modes(args)
+    elif args == ["modes"]:
+        main_modes(list(shader_cases.MODE_CASES))
     else:
-        main(sys.argv[1:])
-        if not sys.argv[1:]:
+        main(args)
+        if not args:
+            main_modes(list(shader_cases.MODE_CASES))
             make_sample()

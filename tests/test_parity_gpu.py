@@ -782,6 +782,61 @@ def test_mapped_frame_buffers_equal_plain_upload(pkg):
     ctx.close()
 
 
+def test_host_frames_queued_back_to_back_without_synchronisation(pkg):
+    """Host uploads ride on their own copy stream into two device staging sets (NetKinectArray::update's PBO pair,
+    NetKinectArray.cpp:226-238) while earlier frames are still being processed: a run of different frames enqueued
+    with no host synchronisation in between -- pageable uploads, the page-locked double buffer, both schedules, the
+    brick sweep and the full sweep, u8 depth + DXT1 colour as well -- must leave exactly what the same frames give
+    one at a time (every frame's volume is checked: the staging set of frame k is refilled by frame k + 2)."""
+    capi, synth = pkg.capi, pkg.synth
+    for cfgkw in ({}, {"compress_depth": 1, "compress_rgb": 1}):
+        scene, ctx, _ = build(pkg, **cfgkw)
+        frames = []
+        for seed, r in ((1234, 0.9), (77, 0.7), (5, 0.8), (901, 0.6), (33, 0.75)):
+            sc = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=seed, sphere_r=r)
+            depth = synth.compress_depth_u8(sc.depth) if cfgkw else sc.depth
+            color = np.stack([synth.encode_dxt(sc.color[i], 1) for i in range(2)]) if cfgkw else sc.color
+            frames.append((np.ascontiguousarray(depth), np.ascontiguousarray(color)))
+        want = []
+        for d, c in frames:                                   # one at a time, drained after each
+            ctx.step(d, c)
+            ctx.sync()
+            want.append(ctx.readback_tsdf())
+        assert not same_bits(want[0], want[1])
+        for pipelined in (False, True):
+            for bricks in (True, False):
+                ctx.set_pipelined(pipelined)
+                ctx.set_use_bricks(bricks)
+                ref = []
+                for d, c in frames:
+                    ctx.step(d, c)
+                    ref.append(ctx.readback_tsdf())
+                for mapped in (False, True):
+                    views = []
+                    for k, (d, c) in enumerate(frames * 3):       # 15 frames in flight behind each other
+                        if mapped:
+                            md, mc = ctx.map_frame_buffer()
+                            md[:] = d.view(np.uint8).reshape(-1)
+                            mc[:] = c.view(np.uint8).reshape(-1)
+                            ctx.upload_mapped_frame()
+                        else:
+                            ctx.update(d, c)
+                        ctx.clear_occupied_bricks()
+                        ctx.process_textures()
+                        ctx.update_occupied_bricks()
+                        ctx.integrate()
+                        if k >= 10:                                # the last five: read back (stream-ordered) and compare
+                            views.append(ctx.readback_tsdf())
+                    for k, v in enumerate(views):
+                        assert same_bits(v, ref[k]), "pipelined %s bricks %s mapped %s frame %d: %d voxels differ" % (
+                            pipelined, bricks, mapped, k, count_diff(v, ref[k]))
+                if bricks and not pipelined:
+                    for a, b in zip(ref, want):
+                        assert same_bits(a, b)
+        ctx.set_pipelined(False)
+        ctx.close()
+
+
 def test_settle_leaves_a_usable_context(pkg, orc):
     """rgbdr_settle scribbles over the volume by design; the next sweeps (brick-skipping
     included, whose clear-skipping must not trust the scribbled tiles) are correct again"""
