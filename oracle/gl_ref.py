@@ -232,7 +232,7 @@ class Calib:
         # the fourth component, which no shader reads (tsdf_integration.vs:31 and tsdf_raymarch.fs take .xyz):
         # llvmpipe refuses a 512^3 RGBA32F texture (2 GiB), and takes the 1.5 GiB RGB32F one
         if inv_rgb_only:
-            self.inv = [volume_texture(m.RGB32F, m.RGB, np.ascontiguousarray(v[..., :3])) for v in (inv_luts or [])]
+            self.inv = [volume_texture(m.RGB32F, m.RGB, v if v.shape[-1] == 3 else np.ascontiguousarray(v[..., :3])) for v in (inv_luts or [])]
         else:
             self.inv = [volume_texture(m.RGBA32F, m.RGBA, v) for v in (inv_luts or [])]
         for i in range(self.n):                                                                  # :162-175

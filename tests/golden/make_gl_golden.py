@@ -156,6 +156,109 @@ def make_sample():
     print("%-40s %7.1f KiB  %d texels, %d voxels (%d in the band of %d), counted %d" % (
         SAMPLE_NAME, os.path.getsize(path) / 1024, tex.size, vox.size, int((np.abs(t[vox]) < cfg.tsdf_limit).sum()), band.size, int(out["counters"].sum())))
 
+# ---- larger samples (round 4): BASELINE's grids and the reference's default mode at BASELINE's sensor size ---------------
+# name -> G (grid), full sweep / z bands / bricks, colour format.  Stored like the 128^3 sample: every brick counter, seeded
+# texel and voxel samples (half of the voxels from the surface band).
+BIG_SAMPLES = {
+    # BASELINE configs[1]'s grid, swept whole by tsdf_integration.vs (16.7 M voxel centres)
+    "four_sensors_512x424_into_256": dict(G=256),
+    # BASELINE configs[2]'s grid = the headline.  llvmpipe refuses the 2 GiB RGBA32F inverse-LUT texture of a 512^3 grid, so
+    # this one sample stores the LUT texels as RGB32F (the fourth component is never read: tsdf_integration.vs:31 takes
+    # .xyz; make_big_sample checks on the 128^3 scene that both formats give the same volume bit for bit) and runs the
+    # shader for the voxel centres of four z bands (rows outside the bands hold zeros in the LUT and are not drawn)
+    "four_sensors_512x424_into_512_bands": dict(G=512, bands=((0, 8), (200, 208), (252, 260), (504, 512)), rgb_only=True),
+    # the reference's default mode at BASELINE's sensor size: DXT1 colour 1280 x 1080 decoded by the GL, bricks on
+    "default_mode_dxt1_bricks_512x424_into_128": dict(G=128, dxt=1, color_wh=(1280, 1080), bricks=True),
+}
+
+
+def big_scene(name, decode_dxt=None, lut_rows_only=True):
+    """-> scene, cfg, geo, inv (a list of [Z,Y,X,4] -- or [Z,Y,X,3] with zeros outside the bands for the banded sample)"""
+    c = BIG_SAMPLES[name]
+    G = c["G"]
+    scene = synth.Scene(4, 512, 424, lut_res=(32, 27, 32), seed=1234, color_wh=c.get("color_wh"))
+    cfg = capi.make_config(4, (512, 424), color_wh=c.get("color_wh"), voxel_size=2.0 / G, brick_size=8 * 2.0 / G,
+                           compress_rgb=c.get("dxt", 0), flags=15 if c.get("bricks") else 7)
+    geo = capi.compute_geometry(cfg)
+    if c.get("dxt"):
+        scene.color_blocks = np.stack([synth.encode_dxt(scene.color[i], c["dxt"]) for i in range(4)])
+        if decode_dxt is not None:
+            scene.color = np.stack([decode_dxt(scene.color_blocks[i], c["color_wh"][0], c["color_wh"][1], c["dxt"]) for i in range(4)])
+    if "bands" in c:
+        inv = []
+        for s in scene.sensors:
+            a = np.zeros((G, G, G, 3 if c.get("rgb_only") else 4), np.float32)
+            for z0, z1 in c["bands"]:
+                a[z0:z1] = synth.inverse_lut(s, (G, G, G), z_range=(z0, z1))[..., :a.shape[-1]]
+            inv.append(a)
+    else:
+        inv = scene.inverse((G, G, G))
+    return scene, cfg, geo, inv
+
+
+def band_voxels(name):
+    c = BIG_SAMPLES[name]
+    G = c["G"]
+    return np.concatenate([np.arange(z0 * G * G, z1 * G * G, dtype=np.int64) for z0, z1 in c["bands"]])
+
+
+def big_digest(scene, inv, name):
+    import hashlib
+    h = hashlib.sha256()
+    for a in (scene.depth, getattr(scene, "color_blocks", scene.color), *scene.xyz, *scene.uv):
+        h.update(np.ascontiguousarray(a).tobytes())
+    c = BIG_SAMPLES[name]
+    for a in inv:                                    # the LUT rows the sample can see (hashing 8 GB would take a minute)
+        for z0, z1 in c.get("bands", ((0, 4), (c["G"] // 2, c["G"] // 2 + 4))):
+            h.update(np.ascontiguousarray(a[z0:z1]).tobytes())
+    return h.hexdigest()
+
+
+def make_big_sample(name):
+    c = BIG_SAMPLES[name]
+    G = c["G"]
+    if c.get("rgb_only"):          # RGB32F against RGBA32F inverse-LUT textures on a grid both fit: the same volume, bit for bit
+        sc, cf, ge, iv = sample_scene()
+        kw = dict(limit=cf.tsdf_limit, brick_size=ge.brick_size, res_bricks=tuple(ge.res_bricks))
+        a = gl_ref.run_frame(sc, synth.BBOX_MIN, synth.BBOX_MAX, (SAMPLE_G,) * 3, iv, **kw)["tsdf"]
+        b = gl_ref.run_frame(sc, synth.BBOX_MIN, synth.BBOX_MAX, (SAMPLE_G,) * 3, iv, inv_rgb_only=True, **kw)["tsdf"]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "RGB32F and RGBA32F inverse LUTs disagree on Mesa"
+        print("RGB32F and RGBA32F inverse-LUT textures give the same 128^3 volume bit for bit")
+    scene, cfg, geo, inv = big_scene(name)
+    vox_ids = band_voxels(name) if "bands" in c else None
+    out = gl_ref.run_frame(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, limit=cfg.tsdf_limit, brick_size=geo.brick_size,
+                           res_bricks=tuple(geo.res_bricks), filter_textures=True, processed=True, refine=True,
+                           compress_rgb=c.get("dxt", 0), use_bricks=bool(c.get("bricks")), min_voxels=cfg.min_voxels_per_brick,
+                           inv_rgb_only=bool(c.get("rgb_only")), integrate_voxels=vox_ids)
+    rng = np.random.default_rng(4242)
+    n, H, W = 4, 424, 512
+    arrays = {"counters": out["counters"], "inputs_sha256": np.frombuffer(big_digest(scene, inv, name).encode(), dtype=np.uint8)}
+    if "occupied" in out:
+        arrays["occupied"] = out["occupied"]
+    db = np.stack(out["depth_b"])[..., 0]
+    seen = np.flatnonzero((db > 0) & (db < 1))
+    edge = np.flatnonzero(np.stack(out["depth_b"])[..., 1] > 0)          # pre_boundary's edge classes (q = 0.1 / 1.0): all of them
+    tex = np.unique(np.concatenate([rng.integers(0, n * H * W, SAMPLE_TEXELS // 2), rng.choice(seen, SAMPLE_TEXELS // 2, replace=False),
+                                    edge[:SAMPLE_TEXELS]]))
+    arrays["texels"] = tex.astype(np.uint32)
+    for k in shader_cases.IMAGES:
+        arrays[k] = np.stack(out[k]).reshape(n * H * W, -1)[tex]
+    t = out["tsdf"].reshape(-1)
+    pool = vox_ids if vox_ids is not None else None
+    tt = t if pool is None else t[pool]
+    band = np.flatnonzero(np.abs(tt) < cfg.tsdf_limit)
+    pick = np.unique(np.concatenate([rng.integers(0, tt.size, SAMPLE_VOXELS // 2), rng.choice(band, min(SAMPLE_VOXELS // 2, band.size), replace=False)]))
+    vox = pick if pool is None else pool[pick]
+    arrays["voxels"] = vox.astype(np.uint32)
+    arrays["tsdf"] = t[vox]
+    info = gl_ref.info()
+    arrays["gl_renderer"] = np.frombuffer((info["renderer"] + " / " + info["version"]).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, "gl_sample_%s.npz" % name)
+    np.savez_compressed(path, **arrays)
+    print("%-46s %7.1f KiB  %d texels (%d edge classes), %d voxels (%d in the band of %d), counted %d, occupied bricks %s" % (
+        name, os.path.getsize(path) / 1024, tex.size, edge.size, vox.size, int((np.abs(t[vox]) < cfg.tsdf_limit).sum()), band.size,
+        int(out["counters"].sum()), len(out["occupied"]) if "occupied" in out else "-"))
+
 
 if __name__ == "__main__":
     args = sys.argv[1:]
@@ -163,6 +266,12 @@ if __name__ == "__main__":
         make_sample()
     elif args and all(a in shader_cases.MODE_CASES for a in args):
         main_modes(args)
+    elif args and all(a in BIG_SAMPLES for a in args):
+        for a in args:
+            make_big_sample(a)
+    elif args == ["big"]:
+        for a in BIG_SAMPLES:
+            make_big_sample(a)
     elif args == ["modes"]:
         main_modes(list(shader_cases.MODE_CASES))
     else:
@@ -170,3 +279,5 @@ if __name__ == "__main__":
         if not args:
             main_modes(list(shader_cases.MODE_CASES))
             make_sample()
+            for a in BIG_SAMPLES:
+                make_big_sample(a)

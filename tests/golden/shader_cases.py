@@ -75,9 +75,10 @@ MODE_CASES = {
     # bricks most of which also list the first row of the next brick), inverse LUT at the calib_inverter ratio 0.7
     "bricks_reference_box_5_voxel_bricks": dict(n=3, wh=(128, 106), lut=(32, 27, 32), bbox=((-1.0, 0.0, -1.0), (1.0, 2.2, 1.0)),
                                                 voxel=0.02, brick=0.1, inv=(143, 158, 143), flags=15, seed=77),
-    # last brick of x and of y lists an index past the axis end: the linear index aliases a voxel of the next row / slice
-    "bricks_last_brick_overflows_the_axis": dict(n=2, wh=(128, 106), lut=(32, 27, 32), bbox=((-1.0, 0.0, -1.0), (1.4, 2.4, 1.0)),
-                                                 voxel=0.04, brick=0.2, inv=(40, 40, 33), flags=15, seed=5),
+    # the last brick of x and of y lists an index past the axis end (61 of 61 voxels): the linear index z*X*Y + y*X + x
+    # aliases a voxel of the next row / slice; the box cuts the scene's sphere, so those bricks are occupied
+    "bricks_last_brick_overflows_the_axis": dict(n=2, wh=(128, 106), lut=(32, 27, 32), bbox=((-1.0, 0.0, -1.0), (0.82, 1.81, 1.0)),
+                                                 voxel=0.03, brick=0.15, inv=(43, 43, 47), flags=15, seed=5),
     # the default mode in full: DXT1 colour (at a colour resolution != depth resolution) + bricks on
     "dxt1_colour_bricks_on": dict(n=2, wh=(64, 53), lut=(16, 14, 16), bbox=BOX, voxel=2.0 / 32, brick=8 * 2.0 / 32, inv=None,
                                   flags=15, seed=1234, dxt=1, color_wh=(96, 80)),
