@@ -3,6 +3,10 @@ import os, sys
 sys.path.insert(0, os.getcwd())
 from __graft_entry__ import load_package
 load_package()
+# these probes drive the kernels' developer knobs (RGBDR_TILE_CHUNK, RGBDR_NT), which the shipped library does not read:
+# build it with `make -C rgbd-recon_amd/csrc clean all EXTRA=-DRGBDR_DEV_KNOBS` first
+if b"RGBDR_TILE_CHUNK" not in open(os.path.join(os.getcwd(), "rgbd-recon_amd", "librgbdr_hip.so"), "rb").read():
+    raise SystemExit("librgbdr_hip.so was built without -DRGBDR_DEV_KNOBS: the knobs this probe sets would be ignored")
 from rgbd_recon_amd import capi, synth
 N, W, H, G = 4, 512, 424, 512
 scene = synth.Scene(N, W, H, lut_res=(128, 106, 128))

@@ -59,7 +59,7 @@ static void free_volume(rgbdr_ctx* c)
       c->d_stage[b][f] = nullptr;
     }
   c->stage_target = -1;
-  c->halo_begun = false;  // a resize between begin_step and exchange_async: the exchange has nothing to send
+  c->halo_begun = c->halo_staged = false;  // a resize between begin_step and exchange_async: the exchange has nothing to send
   c->halo_done_rec[0] = c->halo_done_rec[1] = false;
   c->halo_last = -1;
   (void)hipFree(c->d_tile_list);
@@ -845,6 +845,7 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
                             face_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
   ctx->integrated = true;
+  if (sb >= 0 && ctx->halo > 0) ctx->halo_staged = true;  // the staging set of this step holds this sweep's faces
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
     ctx->ev_int_rec[ctx->rbuf] = true;

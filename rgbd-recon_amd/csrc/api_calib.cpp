@@ -94,14 +94,22 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   // Where the driver places this arena shifts the sweep time of integrate by up to 12 % (stable per allocation;
   // DESIGN.md 4.1): a zone of 13-19 GB of the device memory -- usually the one the first large allocation of a
   // process lands in -- streams at 5.9 TB/s, the rest at 6.6.  So the kernel's memory streams are timed on up to
-  // RGBDR_ARENA_TRIALS candidate placements (1..16; default 3 for arenas of 1 GiB and more, else 1 = no probing)
+  // RGBDR_ARENA_TRIALS candidate placements (1..16; default 8 for arenas of 1 GiB and more, else 1 = no probing)
   // and the fastest is kept.  Candidates are held while probing (otherwise the next allocation returns the same
   // place), so this transiently needs up to n x the arena; it stops at the first candidate at the fast level,
   // when less than arena + 4 GiB is free, or after ~1 s.
-  int trials = bytes >= ((size_t)1 << 30) ? 3 : 1;
+  int trials = bytes >= ((size_t)1 << 30) ? 8 : 1;  // (3 until round 4: on one box in four none of the first three was fast)
   if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
   if (trials > 16) trials = 16;
   if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain
+  // four planes: window origins, the tiles' smallest and largest projected depths, footprint size class
+  // (launch_tile_windows).  Allocated BEFORE any candidate is probed: a failure here must not leave a volume the
+  // probe has scribbled over with tile states that still look valid.
+  if (hipMalloc((void**)&ctx->d_win, 4 * ntiles * nsens(ctx) * sizeof(int32_t)) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->d_win = nullptr;
+    return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the per-tile window words failed: out of device memory");
+  }
   float* cand[16] = {nullptr};
   float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too: the volume is invalidated below
   float best_ms = 0.0f;
@@ -118,7 +126,11 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     if (hipMalloc((void**)&cand[t], bytes) != hipSuccess) {
       (void)hipGetLastError();
       cand[t] = nullptr;
-      if (t == 0) return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed: out of device memory");
+      if (t == 0) {
+        (void)hipFree(ctx->d_win);
+        ctx->d_win = nullptr;
+        return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the inverse-LUT arena failed: out of device memory");
+      }
       break;
     }
     got = t + 1;
@@ -158,15 +170,6 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
       struct timespec ts = {0, 50000000};
       nanosleep(&ts, nullptr);
     }
-  }
-  // four planes: window origins, the tiles' smallest and largest projected depths, footprint size class
-  // (launch_tile_windows).  The arena is published only once they exist too: a failure here leaves no half-made state.
-  if (hipMalloc((void**)&ctx->d_win, 4 * ntiles * nsens(ctx) * sizeof(int32_t)) != hipSuccess) {
-    (void)hipGetLastError();
-    ctx->d_win = nullptr;
-    (void)hipFree(cand[best]);
-    ctx->arena_trials = ctx->arena_chosen = 0;
-    return ctx->fail(RGBDR_ERR_HIP, "hipMalloc of the per-tile window words failed: out of device memory");
   }
   ctx->d_lut_tiled_base = cand[best];
   ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;

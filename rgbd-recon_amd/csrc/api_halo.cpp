@@ -170,6 +170,7 @@ int rgbdr_halo_begin_step(rgbdr_ctx* ctx)
   if (ctx->halo_done_rec[b]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done[b], 0));
   ctx->stage_target = b;
   ctx->halo_begun = true;
+  ctx->halo_staged = false;  // set by the rgbdr_integrate that fills set b
   return RGBDR_OK;
 }
 
@@ -181,7 +182,7 @@ int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int 
   HIPCHK(hipSetDevice(ctx->device));
   const int b = ctx->halo_step & 1;
   { int rc_ = check_slab(ctx, b); if (rc_ != RGBDR_OK) return rc_; }
-  if (ctx->stage_target != b || !ctx->integrated)
+  if (ctx->stage_target != b || !ctx->halo_staged)
     return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_exchange_async: no rgbdr_integrate has filled the staging set since rgbdr_halo_begin_step");
   ctx->halo_begun = false;
   ++ctx->halo_step;

@@ -140,6 +140,7 @@ struct rgbdr_ctx {
   hipEvent_t ev_halo_staged[2] = {nullptr, nullptr}, ev_halo_done[2] = {nullptr, nullptr};
   bool halo_done_rec[2] = {false, false};
   bool halo_begun = false;
+  bool halo_staged = false;         // an rgbdr_integrate has filled the staging set since rgbdr_halo_begin_step
   unsigned halo_step = 0;
   int halo_last = -1;
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else

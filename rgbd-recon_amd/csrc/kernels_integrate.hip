@@ -255,7 +255,7 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
     launch_brick_sweep(p, ntiles, s);  // kernels_bricks.hip
     return;
   }
-#ifdef RGBDR_DEV_KNOBS  // developer A/B builds only (make FLAGS+=-DRGBDR_DEV_KNOBS): the shipped launch path reads no environment
+#ifdef RGBDR_DEV_KNOBS  // developer A/B builds only (make EXTRA=-DRGBDR_DEV_KNOBS): the shipped launch path reads no environment
   // RGBDR_INTEGRATE_GROUP=2 folds 3 or 4 sensors in two groups
   static const int maxg = getenv("RGBDR_INTEGRATE_GROUP") ? atoi(getenv("RGBDR_INTEGRATE_GROUP")) : 4;
   if (maxg == 2 && (N == 3 || N == 4)) {

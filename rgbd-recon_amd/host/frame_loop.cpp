@@ -18,9 +18,48 @@
 #include <exception>
 #include <string>
 
+#include <hip/hip_runtime_api.h>
+
 #include "rgbdr_host.hpp"
 
 using namespace rgbdr::host;
+
+// A second drawing mode next to ReconIntegration, with the constructor triple of the reference's other modes --
+// ReconTrigrid(CalibrationFiles const&, CalibVolumes const*, gloost::BoundingBox const&), recon_trigrid.hpp:16 -- that
+// consumes what ReconTrigrid consumes: the frame's colour, depth_b, quality and normal images of every sensor
+// (recon_trigrid.cpp:30-33: kinect_colors 1, kinect_depths 2, kinect_qualities 3, kinect_normals 4).  Its arithmetic
+// (screen-space triangle meshes through the rasteriser) is outside this backend's scope; what it shows is the input
+// side of such a mode over the C ABI: the images are read where they live on the device (rgbdr_device_image:
+// zero-copy views), stream-ordered behind the passes that write them, with no host copy made by the library.
+// draw() leaves a 64-bit FNV-1a digest of every image it consumed (the test compares them with the library's own
+// readbacks) -- the stand-in for "the mode drew something that depends on every texel".
+class ReconFrameConsumer : public Reconstruction {
+ public:
+  ReconFrameConsumer(CalibrationFiles const& cfs, CalibVolumes const* cv, BoundingBox const& bbox) : Reconstruction(cfs, cv, bbox) {}
+  void draw() override
+  {
+    static const char* units[4] = {"color", "depth", "quality", "normal"};
+    m_digests.assign((size_t)m_num_kinects * 4, 0);
+    for (unsigned i = 0; i < m_num_kinects; ++i)
+      for (int u = 0; u < 4; ++u) {
+        rgbdr_image_device_view v = frameImage(units[u], i);
+        const size_t bytes = (size_t)v.width * v.height * v.channels * v.element_bytes;
+        std::vector<unsigned char> host(bytes);
+        // the consumer's own device work: here a copy straight out of the context's image, ordered on the stream the
+        // passes ran on (a renderer would launch its kernels on that stream, or wait for an event recorded on it)
+        if (hipMemcpyAsync(host.data(), v.ptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)v.stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)v.stream) != hipSuccess)
+          throw std::runtime_error("ReconFrameConsumer: reading the device image failed");
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char b : host) h = (h ^ b) * 1099511628211ull;
+        m_digests[(size_t)i * 4 + u] = h;
+      }
+  }
+  std::vector<uint64_t> const& digests() const { return m_digests; }
+
+ private:
+  std::vector<uint64_t> m_digests;
+};
 
 static int run_ks(const char* ks_path, float voxel, const char* out_path)
 {
@@ -127,6 +166,7 @@ int main(int argc, char** argv)
     std::shared_ptr<ReconIntegration> recon_integration = std::make_shared<ReconIntegration>(cf, &cv, bbox, 0.01f, voxel);
     std::vector<std::shared_ptr<Reconstruction>> recons;
     recons.emplace_back(recon_integration);
+    recons.emplace_back(std::make_shared<ReconFrameConsumer>(cf, &cv, bbox));   // like g_recons' ReconTrigrid, kinect_client.cpp:251-255
     const unsigned recon_mode = 0;
     ReconIntegration& recon = *recon_integration;
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
@@ -150,6 +190,23 @@ int main(int argc, char** argv)
     std::fclose(f);
     std::printf("res %d %d %d bricks %u occupied %.4f\n", g.res_volume[0], g.res_volume[1], g.res_volume[2],
                 recon.numBricks(), recon.occupiedRatio());
+    {  // the other drawing mode, through the base pointer like g_recons.at(g_recon_mode)->drawF() (kinect_client.cpp:617):
+       // it consumes the frame's images zero-copy; NetKinectArray's own accessors must hand out the same memory
+      Reconstruction& other = *recons.at(1);
+      other.drawF();
+      auto const& dg = static_cast<ReconFrameConsumer&>(other).digests();
+      std::printf("frame images");
+      for (uint64_t h : dg) std::printf(" %016llx", (unsigned long long)h);
+      std::printf("\n");
+      rgbdr_image_device_view a = nka.deviceImage("quality", 0), b = nka.deviceImage(RGBDR_IMG_QUALITY, 0);
+      if (a.ptr != b.ptr || !a.ptr || a.width != (int)cf.width || a.height != (int)cf.height || a.channels != 1) return 8;
+      if (nka.readbackImage(RGBDR_IMG_DEPTH_B_RG, 0).size() != (size_t)cf.width * cf.height * 2) return 8;
+      try {
+        nka.deviceImage("bg", 0);          // the reference's map throws std::out_of_range for an unknown unit name
+        return 8;
+      } catch (const std::out_of_range&) {
+      }
+    }
     if (argc == 8) {  // g_recons[mode]->drawF() of kinect_client.cpp: ray-march + hole filling for the given uniforms
       rgbdr_view view;
       FILE* vf = std::fopen(argv[7], "rb");

@@ -316,11 +316,58 @@ inline void readStreamFrame(std::string const& path, size_t colorsize, size_t de
   if (!ok) throw std::runtime_error("short read from " + path);
 }
 
+// What the reference's other programs sample from the texture units NetKinectArray binds (setStartTextureUnit /
+// bindToTextureUnits, NetKinectArray.cpp:430-465; kinect_client.cpp:245 passes start unit 1): the unit's NAME in
+// m_texture_unit_offsets -> the image of the C ABI.  "depth" is m_textures_depth_b after processTextures (:379).
+inline int imageOfTextureUnit(std::string const& name)
+{
+  if (name == "color") return RGBDR_IMG_COLOR;
+  if (name == "depth") return RGBDR_IMG_DEPTH_B_RG;
+  if (name == "quality") return RGBDR_IMG_QUALITY;
+  if (name == "normal") return RGBDR_IMG_NORMAL;
+  if (name == "silhouette") return RGBDR_IMG_SILHOUETTE;
+  if (name == "morph_depth") return RGBDR_IMG_DEPTH_MORPH;
+  if (name == "color_lab") return RGBDR_IMG_LAB;
+  if (name == "raw_depth") return RGBDR_IMG_DEPTH_RAW;
+  throw std::out_of_range("no texture unit named " + name);  // m_texture_unit_offsets.at(), NetKinectArray.cpp:248
+}
+// zero-copy view of one sensor's image layer (rgbdr_device_image): the counterpart of sampling the texture unit
+inline rgbdr_image_device_view deviceImage(Backend const& be, int which, unsigned sensor)
+{
+  rgbdr_image_device_view v{};
+  check(be.ctx(), rgbdr_device_image(be.ctx(), which, (int)sensor, &v));
+  return v;
+}
+inline std::vector<float> readbackImage(Backend const& be, int which, unsigned sensor)
+{
+  rgbdr_image_device_view v = deviceImage(be, which, sensor);
+  if (v.element_bytes != 4) throw std::invalid_argument("readbackImage: not a float image (use readbackColor)");
+  std::vector<float> out((size_t)v.width * v.height * v.channels);
+  check(be.ctx(), rgbdr_readback_image(be.ctx(), which, (int)sensor, out.data()));
+  return out;
+}
+inline std::vector<unsigned char> readbackColor(Backend const& be, unsigned sensor)
+{
+  std::vector<unsigned char> out((size_t)be.config().color_w * be.config().color_h * 3);
+  check(be.ctx(), rgbdr_readback_color(be.ctx(), (int)sensor, out.data()));
+  return out;
+}
+
 // kinect::NetKinectArray (ingest + the five pre_* passes).  The ZeroMQ reader
 // thread is transport and stays outside; frames arrive through update().
 class NetKinectArray {
  public:
   explicit NetKinectArray(Backend& be) : m_be(be) {}
+  // unsigned NetKinectArray::getTextureUnit(std::string const& name) (NetKinectArray.cpp:247-249) handed a consumer a
+  // unit number to point its sampler at; here the same name yields the image itself: a zero-copy device view
+  // (deviceImage) or a host copy (readbackImage / readbackColor).  `which` is an RGBDR_IMG_* value.
+  rgbdr_image_device_view deviceImage(int which, unsigned sensor) const { return host::deviceImage(m_be, which, sensor); }
+  rgbdr_image_device_view deviceImage(std::string const& unit_name, unsigned sensor) const
+  {
+    return host::deviceImage(m_be, imageOfTextureUnit(unit_name), sensor);
+  }
+  std::vector<float> readbackImage(int which, unsigned sensor) const { return host::readbackImage(m_be, which, sensor); }
+  std::vector<unsigned char> readbackColor(unsigned sensor) const { return host::readbackColor(m_be, sensor); }
   // the reference's constructor arguments that concern the hot path (NetKinectArray.cpp:42: serverport and
   // slaveport are transport and stay outside); both objects share the backend of `vols`
   NetKinectArray(CalibrationFiles const* calibs, CalibVolumes const* vols) : m_be(vols->backend())
@@ -442,6 +489,15 @@ class Reconstruction {
       m_bbox.pmin[a] = be.config().bbox_min[a];
       m_bbox.pmax[a] = be.config().bbox_max[a];
     }
+  }
+  // The reference's drawing modes reach the frame through texture units 1-7, which NetKinectArray binds globally
+  // (recon_trigrid.cpp:30-33, recon_points.cpp, tsdf_raymarch: kinect_colors 1, kinect_depths 2, kinect_qualities 3,
+  // kinect_normals 4).  There is no global binding here: a mode constructed from the reference's triple
+  // (cfs, cv, bbox) reaches the same images through the backend its calibration volumes live in.
+  rgbdr_image_device_view frameImage(std::string const& unit_name, unsigned sensor) const
+  {
+    if (!m_cv) throw std::logic_error("this Reconstruction was not constructed from calibration volumes");
+    return host::deviceImage(m_cv->backend(), imageOfTextureUnit(unit_name), sensor);
   }
   CalibVolumes const* m_cv;
   CalibrationFiles const* m_cf;

@@ -161,8 +161,38 @@ void (Reconstruction::*p_resize)(std::size_t, std::size_t) = &Reconstruction::re
 void (Reconstruction::*p_mask)(unsigned) = &Reconstruction::setColorMaskMode;
 void (Reconstruction::*p_off)(float, float) = &Reconstruction::setViewportOffset;
 std::vector<std::shared_ptr<Reconstruction>> g_recons;
-int main() { return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off) ? 0 : 1; }
+// a second drawing mode with the constructor triple of the reference's other modes (recon_trigrid.hpp:16) reaches the
+// frame's images -- texture units 1-7 of NetKinectArray::setStartTextureUnit -- through the base class
+struct OtherMode : Reconstruction {
+  OtherMode(CalibrationFiles const& cfs, CalibVolumes const* cv, BoundingBox const& bbox) : Reconstruction(cfs, cv, bbox) {}
+  void draw() override { rgbdr_image_device_view v = frameImage("quality", 0); (void)v; }
+};
+static_assert(std::is_constructible<OtherMode, CalibrationFiles const&, CalibVolumes const*, BoundingBox const&>::value, "");
+rgbdr_image_device_view (NetKinectArray::*p_dev)(int, unsigned) const = &NetKinectArray::deviceImage;
+rgbdr_image_device_view (NetKinectArray::*p_dev_name)(std::string const&, unsigned) const = &NetKinectArray::deviceImage;
+std::vector<float> (NetKinectArray::*p_rb)(int, unsigned) const = &NetKinectArray::readbackImage;
+std::vector<unsigned char> (NetKinectArray::*p_rbc)(unsigned) const = &NetKinectArray::readbackColor;
+int main()
+{
+  // the unit names of NetKinectArray.cpp:430-439 and the images they stand for
+  if (imageOfTextureUnit("color") != RGBDR_IMG_COLOR || imageOfTextureUnit("depth") != RGBDR_IMG_DEPTH_B_RG ||
+      imageOfTextureUnit("quality") != RGBDR_IMG_QUALITY || imageOfTextureUnit("normal") != RGBDR_IMG_NORMAL ||
+      imageOfTextureUnit("silhouette") != RGBDR_IMG_SILHOUETTE || imageOfTextureUnit("morph_depth") != RGBDR_IMG_DEPTH_MORPH ||
+      imageOfTextureUnit("color_lab") != RGBDR_IMG_LAB)
+    return 2;
+  return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off && p_dev && p_dev_name && p_rb && p_rbc) ? 0 : 1;
+}
 ''')
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "rgbd-recon_amd", "host"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    # the unit-name table against the reference's own (read where it lies; absent on the GPU box)
+    ref = "/root/reference/framework/NetKinectArray.cpp"
+    if os.path.exists(ref):
+        import re
+        text = open(ref).read()
+        names = re.findall(r'^\s*m_texture_unit_offsets\["(\w+)"\] = m_start_texture_unit', text, re.M)   # ("bg" is commented out)
+        assert names == ["color", "depth", "quality", "normal", "silhouette", "morph_depth", "color_lab"], names
+        host = open(os.path.join(ROOT, "rgbd-recon_amd", "host", "rgbdr_host.hpp")).read()
+        for nme in names:
+            assert 'name == "%s"' % nme in host

@@ -50,6 +50,7 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
                        text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("res 32 32 32 bricks 64")
+    r_first_stdout = r.stdout
     # Reconstruction::setColorMaskMode through the base pointer (anaglyph path: red, then green + blue of the same pixels)
     import re
     m = re.search(r"color masks: (\d+) pixels hit, (\d+) channel values wrong", r.stdout)
@@ -87,6 +88,23 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
     ref = orc.run_pipeline(scene, synth.BBOX_MIN, synth.BBOX_MAX, (G, G, G), inv, brick_size=g.brick_size,
                            bv=g.brick_voxels, res_bricks=tuple(g.res_bricks))
     assert same_bits(got, ref["tsdf"]), "%d voxels differ" % count_diff(got, ref["tsdf"])
+    # the second drawing mode of frame_loop.cpp (ReconFrameConsumer: the reference's constructor triple, held in the same
+    # vector, drawn through the Reconstruction base pointer) consumed colour / depth_b / quality / normals of every sensor
+    # zero-copy -- the four images ReconTrigrid samples (recon_trigrid.cpp:30-33): their digests are those of the oracle's images
+    m = re.search(r"frame images((?: [0-9a-f]{16})+)", r_first_stdout)
+    assert m, r_first_stdout
+    digests = [int(h, 16) for h in m.group(1).split()]
+
+    def fnv(a):
+        # FNV-1a 64 over the bytes, vectorised: h = (h ^ b) * p is affine in h, so fold blocks with prefix products
+        h, p, mask = 1469598103934665603, 1099511628211, (1 << 64) - 1
+        for b in np.ascontiguousarray(a).view(np.uint8).reshape(-1).tolist():
+            h = ((h ^ b) * p) & mask
+        return h
+    want = []
+    for i in range(n):
+        want += [fnv(scene.color[i]), fnv(ref["depth_b"][i]), fnv(ref["quality"][i]), fnv(ref["normal"][i])]
+    assert digests == want, "the C++ consumer read other images than the oracle's"
     # the same frame as one server message (K1 colour, K1 depth, K2 colour, ...; NetKinectArray.cpp:511-541)
     msg = os.path.join(d, "message.bin")
     with open(msg, "wb") as f:

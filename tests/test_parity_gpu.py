@@ -690,7 +690,7 @@ def test_dxt_compressed_colour_frames(pkg, orc, mode):
 
 def test_lut_arena_placement_probe(pkg, monkeypatch):
     """placing the LUT arena by timing candidate allocations: RGBDR_ARENA_TRIALS=n for arenas of 256 MiB and more; unset,
-    arenas below 1 GiB (this one) take the first allocation without probing, larger ones try up to three.  The choice
+    arenas below 1 GiB (this one) take the first allocation without probing, larger ones try up to eight (the library's default).  The choice
     never changes a result, and a probe leaves the volume cleared and marked as not integrated."""
     out = []
     for trials in (None, "1", "4"):
@@ -1234,4 +1234,14 @@ def test_halo_exchange_after_a_resize_is_refused(pkg):
     # begin_step again but no integrate: still nothing to send
     assert lib.rgbdr_halo_begin_step(ctx._h) == 0
     assert lib.rgbdr_halo_exchange_async(ctx._h, fake_comm, -1, 1) == -6
+    # ... also when an EARLIER integrate has run (the guard is per step, not "something was integrated once"): a sweep
+    # without a staging set, then begin_step + exchange_async with no integrate in between would send stale layers
+    inv = scene.inverse((32, 32, 32))
+    for i in range(2):
+        ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (32, 32, 32))
+    ctx.step(scene.depth, scene.color)
+    assert lib.rgbdr_halo_begin_step(ctx._h) == 0
+    assert lib.rgbdr_halo_exchange_async(ctx._h, fake_comm, -1, 1) == -6
+    assert b"no rgbdr_integrate has filled the staging set" in lib.rgbdr_last_error(ctx._h)
     ctx.close()
