@@ -96,6 +96,15 @@ def main():
     ap.add_argument("--slab-sweep", type=int, default=0,
                     help="k: --slab r/k for every r in one process, one JSON line with a row per rank (projection of the "
                          "multi-GPU balance from single-GPU runs; DESIGN.md section 6)")
+    ap.add_argument("--no-shard", dest="shard", action="store_false",
+                    help="N > 1: every rank runs the pre_* chain for ALL sensors (rounds 1-3) instead of its n / N share followed by "
+                         "the all-gather of the packed frames and the all-reduce of the brick counters (rgbdr_set_sensor_shard; "
+                         "measured per rank of configs[3]: 0.68 against 0.71-0.73 ms per frame, profiles/r04_notes)")
+    ap.add_argument("--torch-collectives", dest="managed", action="store_false",
+                    help="N > 1 over RCCL: halo exchange and frame gather through torch.distributed's process group (rounds 1-3) "
+                         "instead of the C ABI's managed forms, where the LIBRARY enqueues them on its own streams with a raw RCCL "
+                         "communicator (what a C++ host does, host/slab_loop.cpp); gloo runs always go through torch")
+    ap.set_defaults(shard=True, managed=True)
     ap.add_argument("--launch-timeout", type=float, default=3600.0, help="--gpus N > 1 self-launch: seconds before the ranks are stopped")
     args = ap.parse_args()
 
@@ -264,7 +273,8 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         # boundary layers are staged device-to-device, the transfer of step k overlaps step k+1).
         main = torch.cuda.Stream(dev)
         torch.cuda.set_stream(main)
-        ctx.set_stream(main.cuda_stream)
+        if not (args.managed and args.backend == "nccl"):
+            ctx.set_stream(main.cuda_stream)
         # Probe the device transport once before anything is timed.  If RCCL point-to-point
         # on these buffers fails on this node, say so in the JSON line and stop: a run whose halos
         # go through host memory would measure PCIe, not xGMI.
@@ -290,13 +300,45 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                 ctx.close()
                 dist.destroy_process_group()
                 sys.exit(3)
-        exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
-                                        via_host=transport["kind"] != "rccl", ctx=ctx, loopback=loop)
+        if not (args.managed and args.backend == "nccl"):
+            exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
+                                            via_host=transport["kind"] != "rccl", ctx=ctx, loopback=loop)
+    # The pre_* chain sharded by sensor over the ranks: rank r runs it for N / k sensors, the packed frames are all-gathered
+    # and the brick counters all-reduced on the chain's stream (SURVEY 8e's alternative to the redundant chain; the chain's
+    # time then shrinks with the number of GPUs like the sweep's).  On one GPU standing in for a rank (--slab / --loopback)
+    # the other ranks' sensors come from two unsharded frames of the same static scene and the gather's traffic is
+    # reproduced by RCCL send / recv to this process itself (dist.FrameGather loopback).
+    gather = None
+    want_shard = multi and args.shard and N % slab_count == 0 and N > 1
+    managed = bool(multi and args.managed and transport["kind"] == "rccl")
+    if multi and (want_shard or managed):
+        if loop:
+            for _ in range(2):                      # both frame buffers of the two-stream schedule hold every sensor's frame
+                ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
+                ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+            ctx.sync()
+        if managed:
+            try:
+                ctx.enable_timers(True)
+                exchanger = rdist.ManagedSlabExchange(ctx, dev, slab_rank, slab_count, group=transport["group"], shard=want_shard, loopback=loop)
+                gather = exchanger.gather if exchanger.shard else None
+            except Exception as e:  # noqa: BLE001 -- a raw communicator that does not come up must not cost the run
+                sys.stderr.write("[bench rank %d] library-managed RCCL unavailable (%s: %s); using torch.distributed\n" % (rank, type(e).__name__, str(e)[:200]))
+                managed = False
+                ctx.set_sensor_shard(0, 0)
+                ctx.set_stream(main.cuda_stream)
+                exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
+                                                via_host=False, ctx=ctx, loopback=loop)
+        if not managed and want_shard:
+            gather = rdist.FrameGather(ctx, dev, rank=slab_rank, world=slab_count, group=transport["group"],
+                                       via_host=transport["kind"] != "rccl", loopback=loop)
 
     def step(bricks):
         ctx.update_device(d_depth.data_ptr(), d_color.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
+        if gather is not None:
+            gather()                         # the other ranks' sensors: all-gather of the packed frames, all-reduce of the brick counts
         ctx.update_occupied_bricks()
         if halo is not None:
             exchanger.begin_step()           # the sweep stores its boundary layers into a staging set
@@ -492,7 +534,11 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": ("zslab%d" % world if world > 1 else "single") + (
                        " (loopback: slab %d of %d on one GPU, its own neighbour over RCCL)" % (slab_rank, slab_count) if loop else ""),
-                   "halo_transport": transport["kind"] if multi else None},
+                   "halo_transport": transport["kind"] if multi else None,
+                   "pre_chain": ("sharded by sensor: %d of %d sensors per rank, packed frames all-gathered + brick counters all-reduced on "
+                                 "the chain's stream" % (N // slab_count, N)) if gather is not None else "every sensor on every rank",
+                   "collectives": (("library-managed RCCL (C ABI: rgbdr_halo_exchange_async, rgbdr_shard_allgather)" if managed
+                                    else "torch.distributed") if multi else None)},
         "roofline": {"bound": "hbm", "kernel": "rgbdr::k_integrate_tiled<%d, 4, true, false, %s>" % (N, "true" if multi else "false"),
                      "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK, 4), "traffic": None, "traffic_source": None,
@@ -546,7 +592,11 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                        "staging_overhead_ms": round(int_s * 1e3 - plain_ms[0], 4),
                        "ms_per_step": round(ms_per_step, 4), "ms_per_step_without_halo": round(plain_ms[1], 4),
                        "host_enqueue_ms_per_step": round(host_enqueue_ms, 4),
-                       "roofline_frac": round(achieved / HBM_PEAK, 4), "halo_ms_to_self": halo_ms}
+                       "roofline_frac": round(achieved / HBM_PEAK, 4), "halo_ms_to_self": halo_ms,
+                       "frame_gather_ms_to_self": gather.last_ms() if hasattr(gather, "last_ms") else None,
+                       "schedule": ("pipelined" if args.pipeline else "sequential") + (", sharded chain" if gather is not None else "") +
+                                   (", library-managed RCCL" if managed else "") + (
+                                       ", RGBDR_CU_SPLIT=" + os.environ["RGBDR_CU_SPLIT"] if os.environ.get("RGBDR_CU_SPLIT") else "")}
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:

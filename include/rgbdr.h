@@ -365,6 +365,35 @@ int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_h
 int rgbdr_halo_begin_step(rgbdr_ctx* ctx);
 int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi);
 int rgbdr_halo_wait(rgbdr_ctx* ctx);
+
+/* The pre_* chain sharded by SENSOR over the ranks of a Z-slab job ("sensors are split across GPUs and
+ * results all-gathered (ncclAllGather ...) with brick counters ncclAllReduce"; the reference is single-GPU and has no
+ * counterpart).  After rgbdr_set_sensor_shard(ctx, first, count) rgbdr_process_textures runs the five passes for the
+ * sensor layers [first, first + count) only (first = 0 with count = 0 or num_sensors: all of them again); uploads still take
+ * every sensor's frame.  What the sweep and the slab ray-march read of a sensor is its packed frame texel (8 B per pixel),
+ * and each rank has counted only its own sensors' pixels into the bricks, so before rgbdr_update_occupied_bricks /
+ * rgbdr_integrate the frame is completed by
+ *   rgbdr_shard_allgather(ctx, ncclComm_t)   one grouped ncclAllGather of the packed frames (in place) + ncclAllReduce(sum,
+ *                                            u32) of the brick counters, enqueued on the stream the chain ran on (under
+ *                                            RGBDR_FLAG_PIPELINE: next to the sweep of the frame before); rank r of the
+ *                                            k ranks must hold sensors [r n / k, (r + 1) n / k); RCCL is bound at run time;
+ *   or the host's own collectives on the device memory rgbdr_shard_view hands out (torch.distributed:
+ *   rgbd-recon_amd/dist.py FrameGather), enqueued on view.stream.
+ * Calling rgbdr_update_occupied_bricks / rgbdr_integrate on a shard before either returns RGBDR_ERR_STATE.  The float
+ * images (rgbdr_readback_image / rgbdr_device_image) of the other ranks' sensors are NOT gathered: they keep what an earlier
+ * unsharded frame left there.  Timer "gather" brackets the collectives. */
+typedef struct {
+  void* frames;           /* packed frame texels of the frame process_textures wrote last: [num_sensors][H][W] x 8 B */
+  size_t sensor_bytes;    /* bytes of one sensor's layer */
+  int32_t num_sensors;
+  int32_t first, count;   /* the layers this context filled */
+  void* counters;         /* u32[num_bricks]: this rank's brick counts (sum over ranks = the frame's) */
+  uint32_t num_bricks;
+  void* stream;           /* hipStream_t the chain ran on: enqueue the collectives here */
+} rgbdr_shard_device_view;
+int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count);
+int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out);
+int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);

@@ -134,6 +134,11 @@ class ImageDeviceView(C.Structure):
                 ("element_bytes", C.c_int32), ("stream", C.c_void_p)]
 
 
+class ShardDeviceView(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("sensor_bytes", C.c_size_t), ("num_sensors", C.c_int32), ("first", C.c_int32),
+                ("count", C.c_int32), ("counters", C.c_void_p), ("num_bricks", C.c_uint32), ("stream", C.c_void_p)]
+
+
 # every symbol include/rgbdr.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 _CFG, _GEO, _LUT = C.POINTER(Config), C.POINTER(Geometry), C.POINTER(Lut)
@@ -201,6 +206,9 @@ SYMBOLS = {
     "rgbdr_halo_begin_step": (C.c_int, [_P]),
     "rgbdr_halo_exchange_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "rgbdr_halo_wait": (C.c_int, [_P]),
+    "rgbdr_set_sensor_shard": (C.c_int, [_P, C.c_int, C.c_int]),
+    "rgbdr_shard_view": (C.c_int, [_P, C.POINTER(ShardDeviceView)]),
+    "rgbdr_shard_allgather": (C.c_int, [_P, _P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
@@ -588,6 +596,29 @@ class Context:
         h, w = depth.shape
         assert color.shape == (h, w, 4)
         self._chk(lib().rgbdr_upload_view_frame(self._h, w, h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
+
+    # the managed halo exchange of the C ABI (side stream, staging sets and events owned by the context; RCCL bound at run
+    # time): nccl_comm is a raw ncclComm_t (rgbd_recon_amd.dist.RcclComm.handle)
+    def halo_begin_step(self):
+        self._chk(lib().rgbdr_halo_begin_step(self._h))
+
+    def halo_exchange_async(self, nccl_comm, peer_lo, peer_hi):
+        self._chk(lib().rgbdr_halo_exchange_async(self._h, nccl_comm, peer_lo, peer_hi))
+
+    def halo_wait(self):
+        self._chk(lib().rgbdr_halo_wait(self._h))
+
+    def set_sensor_shard(self, first, count):
+        """process_textures runs the pre_* chain for sensors [first, first + count) only (0, 0: all again)"""
+        self._chk(lib().rgbdr_set_sensor_shard(self._h, first, count))
+
+    def shard_view(self):
+        v = ShardDeviceView()
+        self._chk(lib().rgbdr_shard_view(self._h, C.byref(v)))
+        return v
+
+    def shard_allgather(self, nccl_comm):
+        self._chk(lib().rgbdr_shard_allgather(self._h, nccl_comm))
 
     def device_image(self, which, sensor):
         v = ImageDeviceView()

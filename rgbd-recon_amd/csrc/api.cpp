@@ -268,12 +268,41 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
     rgbdr_destroy(ctx);
     return code;
   };
-  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  // Developer experiment (round 4): RGBDR_CU_SPLIT=n gives the second stream (pre_* chain of the two-stream schedule)
+  // n compute units of its own and keeps the sweep's stream off them (hipExtStreamCreateWithCUMask).  Without it the chain's 256-thread blocks
+  // starve next to a sweep whose 262 144 blocks refill every slot that frees up (the chain runs 8-20x longer there).
+  int cu_split = 0;
+  if (const char* e = std::getenv("RGBDR_CU_SPLIT")) cu_split = std::atoi(e);
+  hipDeviceProp_t prop{};
+  if (cu_split > 0 && (hipGetDeviceProperties(&prop, device_id) != hipSuccess || cu_split >= prop.multiProcessorCount)) cu_split = 0;
+  bool masked = false;
+  if (cu_split > 0) {
+    const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+    std::vector<uint32_t> side((size_t)words, 0u), mainm((size_t)words, 0u);
+    for (int i = 0; i < ncu; ++i) {
+      // KFD hands mask bit i to XCC i mod 8 (and spreads an XCC's bits over its shader engines), so a CONTIGUOUS run of
+      // n bits takes n / 8 CUs from every XCD; bits 0, 32, 64 ... would all come out of XCD 0, whose quarter of the
+      // statically round-robined workgroups then runs 25 % longer (measured: sweep 1.06 -> 1.28 ms with 8 such CUs)
+      const bool reserved = i < cu_split;
+      (reserved ? side : mainm)[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    masked = hipExtStreamCreateWithCUMask(&ctx->own_stream, (uint32_t)words, mainm.data()) == hipSuccess &&
+             hipExtStreamCreateWithCUMask(&ctx->pre_stream, (uint32_t)words, side.data()) == hipSuccess;
+    if (masked) ctx->side_cu_mask = side;
+    if (!masked) {
+      (void)hipGetLastError();
+      if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+      if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
+      ctx->own_stream = ctx->pre_stream = nullptr;
+      std::fprintf(stderr, "rgbdr: RGBDR_CU_SPLIT=%d: hipExtStreamCreateWithCUMask failed, using plain streams\n", cu_split);
+    }
+  }
+  if (!masked && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
     ctx->err = "hipStreamCreate failed";
     return cleanup(RGBDR_ERR_HIP);
   }
   ctx->stream = ctx->own_stream;
-  {
+  if (!masked) {
     // the small pre_* kernels of the next frame must not queue behind the 262 144 workgroups
     // of an integrate sweep: give their stream the highest dispatch priority
     int least = 0, greatest = 0;
@@ -577,6 +606,8 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   HIPCHK(hipSetDevice(ctx->device));
   PreParams p{};
   p.N = nsens(ctx);
+  p.first = ctx->shard_count > 0 ? ctx->shard_first : 0;
+  p.count = ctx->shard_count > 0 ? ctx->shard_count : p.N;
   p.W = ctx->cfg.depth_w;
   p.H = ctx->cfg.depth_h;
   p.Wc = ctx->cfg.color_w;
@@ -670,12 +701,16 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   }
   ctx->textures_processed = true;
   ctx->bgmax_for = -1;
+  ctx->shard_pending = p.count < p.N;  // the other sensors' frames and the other ranks' brick counts are still to come
   return RGBDR_OK;
 }
 
 int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->shard_pending)
+    return ctx->fail(RGBDR_ERR_STATE, "update_occupied_bricks on a sensor shard before rgbdr_shard_allgather: the brick counters hold "
+                                      "this rank's sensors only");
   HIPCHK(hipSetDevice(ctx->device));
   { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   hipStream_t ps = ctx->pstream();
@@ -723,6 +758,9 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "integrate before process_textures");
+  if (ctx->shard_pending)
+    return ctx->fail(RGBDR_ERR_STATE, "integrate on a sensor shard before rgbdr_shard_allgather: the frames of the other ranks' sensors "
+                                      "have not arrived");
   const int N = nsens(ctx);
   bool all_tiled = true, any_tiled = false;
   for (int i = 0; i < N; ++i) {

@@ -22,6 +22,10 @@ struct Rccl {
   int (*group_end)() = nullptr;
   int (*send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
   int (*recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*comm_count)(void*, int*) = nullptr;
+  int (*comm_rank)(void*, int*) = nullptr;
   const char* (*error_string)(int) = nullptr;
   std::string why;
 };
@@ -44,6 +48,10 @@ Rccl& rccl()
   r.group_end = (int (*)())dlsym(r.lib, "ncclGroupEnd");
   r.send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclSend");
   r.recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclRecv");
+  r.all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(r.lib, "ncclAllGather");
+  r.all_reduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(r.lib, "ncclAllReduce");
+  r.comm_count = (int (*)(void*, int*))dlsym(r.lib, "ncclCommCount");
+  r.comm_rank = (int (*)(void*, int*))dlsym(r.lib, "ncclCommUserRank");
   r.error_string = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
   if (!r.group_start || !r.group_end || !r.send || !r.recv) {
     r.why = "the RCCL library lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd";
@@ -159,7 +167,10 @@ int rgbdr_halo_begin_step(rgbdr_ctx* ctx)
   { int rc_ = check_slab(ctx, -1); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->halo_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->halo_stream, hipStreamNonBlocking));
+    if (!ctx->side_cu_mask.empty())  // RGBDR_CU_SPLIT: RCCL's kernels run on the CUs set aside for the second stream
+      HIPCHK(hipExtStreamCreateWithCUMask(&ctx->halo_stream, (uint32_t)ctx->side_cu_mask.size(), ctx->side_cu_mask.data()));
+    else
+      HIPCHK(hipStreamCreateWithFlags(&ctx->halo_stream, hipStreamNonBlocking));
     for (int b = 0; b < 2; ++b) {
       HIPCHK(hipEventCreateWithFlags(&ctx->ev_halo_done[b], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&ctx->ev_halo_staged[b], hipEventDisableTiming));
@@ -193,6 +204,80 @@ int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int 
   HIPCHK(hipEventRecord(ctx->ev_halo_done[b], ctx->halo_stream));
   ctx->halo_done_rec[b] = true;
   ctx->halo_last = b;
+  return RGBDR_OK;
+}
+
+// ---- the pre_* chain sharded by sensor over the ranks of a slab job ---------------------------------------
+// Every rank of a Z-slab job needs the frame images of ALL sensors (a voxel may project anywhere), and with the chain
+// run redundantly its time does not shrink with the number of GPUs while the sweep's does: at BASELINE configs[3]
+// (8 sensors, 512^3 / 4) it is 0.14 of a rank's 0.70 ms.  With a shard, rank r runs the chain for sensors
+// [r * n / k, (r + 1) * n / k) only; what the sweep (and the slab ray-march) read of a sensor is its packed 8-byte frame
+// texel, so one all-gather of those (1.7 MB per 512 x 424 sensor) plus an all-reduce(sum) of the u32 brick counters (each
+// rank counted its own sensors' pixels) completes the frame on every rank -- the alternative SURVEY.md 8(e) names.  Both
+// run on the stream the chain ran on, so under RGBDR_FLAG_PIPELINE they overlap the sweep of the frame before.
+int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  const int N = nsens(ctx);
+  if (count <= 0 || (first == 0 && count == N)) {  // back to every sensor
+    ctx->shard_first = ctx->shard_count = 0;
+    return RGBDR_OK;
+  }
+  if (first < 0 || first + count > N) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor shard outside [0, num_sensors)");
+  ctx->shard_first = first;
+  ctx->shard_count = count;
+  return RGBDR_OK;
+}
+
+int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out)
+{
+  if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_view before process_textures");
+  const int N = nsens(ctx);
+  out->frames = ctx->frame_buf(ctx->rbuf);
+  out->sensor_bytes = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sizeof(uint2);
+  out->num_sensors = N;
+  out->first = ctx->shard_count > 0 ? ctx->shard_first : 0;
+  out->count = ctx->shard_count > 0 ? ctx->shard_count : N;
+  out->counters = ctx->counters_cur();
+  out->num_bricks = (uint32_t)ctx->geo.num_bricks;
+  out->stream = (void*)ctx->pstream();
+  ctx->shard_pending = false;  // the host runs the collectives itself, on out->stream
+  return RGBDR_OK;
+}
+
+int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
+{
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather before process_textures");
+  Rccl& r = rccl();
+  if (!r.lib || !r.all_gather || !r.all_reduce || !r.comm_count || !r.comm_rank)
+    return ctx->fail(RGBDR_ERR_STATE, r.lib ? "the RCCL library lacks ncclAllGather / ncclAllReduce / ncclCommCount" : r.why);
+  HIPCHK(hipSetDevice(ctx->device));
+  const int N = nsens(ctx);
+  const int first = ctx->shard_count > 0 ? ctx->shard_first : 0, count = ctx->shard_count > 0 ? ctx->shard_count : N;
+  auto chk = [&](int rc, const char* what) {
+    if (rc == 0) return 0;
+    return ctx->fail(RGBDR_ERR_HIP, std::string(what) + ": " + (r.error_string ? r.error_string(rc) : "RCCL error"));
+  };
+  int world = 0, rank = -1;
+  if (chk(r.comm_count(nccl_comm, &world), "ncclCommCount") || chk(r.comm_rank(nccl_comm, &rank), "ncclCommUserRank")) return RGBDR_ERR_HIP;
+  // ncclAllGather puts rank r's block at r * count: the shards must be equal and in rank order
+  if (count * world != N || first != rank * count)
+    return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather: rank r of a k-rank communicator must hold sensors [r n / k, (r + 1) n / k)");
+  hipStream_t st = ctx->pstream();
+  uint2* frames = ctx->frame_buf(ctx->rbuf);
+  const size_t words = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * 2 * (size_t)count;  // u32 words of one shard
+  tbegin(ctx, "gather", st);
+  int rc = chk(r.group_start(), "ncclGroupStart");
+  if (rc == 0) rc = chk(r.all_gather((const uint32_t*)frames + words * (size_t)rank, frames, words, /*ncclUint32*/ 3, nccl_comm, st), "ncclAllGather");
+  if (rc == 0) rc = chk(r.all_reduce(ctx->counters_cur(), ctx->counters_cur(), (size_t)ctx->geo.num_bricks, /*ncclUint32*/ 3, /*ncclSum*/ 0, nccl_comm, st),
+                        "ncclAllReduce");
+  const int rc_end = chk(r.group_end(), "ncclGroupEnd");
+  tend(ctx, "gather", st);
+  if (rc != 0 || rc_end != 0) return rc != 0 ? rc : rc_end;
+  ctx->shard_pending = false;
   return RGBDR_OK;
 }
 

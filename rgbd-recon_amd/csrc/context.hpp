@@ -40,6 +40,7 @@ struct rgbdr_ctx {
   // only state both touch -- packed frame, occupied mask, occupied count -- is
   // double buffered; events order producer and consumer of each buffer.
   hipStream_t pre_stream = nullptr;
+  std::vector<uint32_t> side_cu_mask;  // RGBDR_CU_SPLIT: the CUs of the second stream (and of the halo stream); empty: no split
   int wbuf = 0, rbuf = 0;            // buffer the next process_textures writes / the latest one written
   hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
   bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
@@ -58,6 +59,12 @@ struct rgbdr_ctx {
   unsigned char* d_box_flags = nullptr;
   uint8_t *d_color = nullptr, *d_color_dxt = nullptr;
   bool frame_uploaded = false, textures_processed = false;
+  // Sensor shard of the pre_* chain (rgbdr_set_sensor_shard): process_textures works on the layers
+  // [shard_first, shard_first + shard_count) only; the packed frames of the other sensors and the other ranks' brick
+  // counts arrive through rgbdr_shard_allgather (or the host's own collective on rgbdr_shard_view) before anything
+  // consumes them -- shard_pending says that has not happened yet for the frame process_textures wrote last.
+  int shard_first = 0, shard_count = 0;  // 0: all sensors
+  bool shard_pending = false;
 
   // forward calibration
   float4* d_cv_xyz[rgbdr::kMaxSensors] = {};

@@ -36,14 +36,16 @@ constexpr int TPITCH = 48;
 struct BlockPos {
   int l, bx;
 };
-__device__ __forceinline__ BlockPos block_pos(int N)
+__device__ __forceinline__ BlockPos block_pos(int N, int first = 0)
 {
   BlockPos b;
   b.bx = (int)blockIdx.x / N;
-  b.l = (int)blockIdx.x - b.bx * N;
+  b.l = first + (int)blockIdx.x - b.bx * N;
   return b;
 }
-static dim3 pass_grid(const PreParams& p) { return dim3((unsigned)(((p.W + BX - 1) / BX) * p.N), (unsigned)((p.H + BY - 1) / BY), 1); }
+// a launch covers the sensor layers [p.first, p.first + p.count): all of them, or this rank's shard of the pre_* chain
+__device__ __forceinline__ BlockPos block_pos(const PreParams& p) { return block_pos(p.count, p.first); }
+static dim3 pass_grid(const PreParams& p) { return dim3((unsigned)(((p.W + BX - 1) / BX) * p.count), (unsigned)((p.H + BY - 1) / BY), 1); }
 
 // 1 - length(vec2(x,y)) * (1/6) for x,y in [-6,6], filled by the host with the
 // same correctly-rounded sqrtf (pre_depth.fs:37-41,115)
@@ -230,10 +232,10 @@ __device__ __forceinline__ void zero_words(uint32_t* __restrict__ zero, unsigned
 }
 
 __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_all, float* __restrict__ out_all, int W,
-                                                  int H, int N, uint32_t* __restrict__ zero, unsigned nzero)
+                                                  int H, int first, int count, uint32_t* __restrict__ zero, unsigned nzero)
 {
   zero_words(zero, nzero);
-  const BlockPos bp = block_pos(N);
+  const BlockPos bp = block_pos(count, first);
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t lo = (size_t)bp.l * W * H;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(BX* BY) void k_upload_morph(const float* __restrict
 
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_morph, pass_grid(p), dim3(BX, BY), 0, s, in, out, p.W, p.H, p.N, zero, nzero);
+  hipLaunchKernelGGL(k_morph, pass_grid(p), dim3(BX, BY), 0, s, in, out, p.W, p.H, p.first, p.count, zero, nzero);
 }
 bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
                          size_t b_bytes, hipStream_t s)
@@ -270,7 +272,7 @@ bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw,
   PreParams p{};
   p.W = W;
   p.H = H;
-  p.N = N;
+  p.N = p.count = N;  // every sensor's raw depth and morph image (first = 0): the copy is what costs, and consumers of the raw frames want them all
   const size_t b16 = b_bytes / 16;
   hipLaunchKernelGGL(k_upload_morph, pass_grid(p), dim3(BX, BY), 0, s, (const float*)depth_src, raw, morph, W, H, N,
                      (const uint4*)b_src, (uint4*)b_dst, b16, (const uint8_t*)b_src + b16 * 16, (uint8_t*)b_dst + b16 * 16,
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p, uint32_t* __r
   zero_words(zero, nzero);  // (when the morph pass did not run in this chain: it was done with the upload)
   __shared__ float tile[TH][TPITCH];
   __shared__ float unorm[256];  // i / 255.0f: what the sampler returns for a u8 colour channel
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const float* depth = p.depth_in + (size_t)l * W * H;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(BX* BY) void k_boundary(PreParams p)
   constexpr int T = BX + 4;
   __shared__ float2 t_rg[T][T + 1];
   __shared__ float t_lab[T][T + 1][3];
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)bp.l * W * H;
@@ -706,7 +708,7 @@ __device__ __forceinline__ float3 normal_at(const PreParams& p, int l, int px, i
 
 __global__ __launch_bounds__(BX* BY) void k_normal(PreParams p)
 {
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   const int W = p.W, H = p.H, l = bp.l;
   if (px >= W || py >= H) return;
@@ -811,7 +813,7 @@ __device__ __forceinline__ void store_quality(const PreParams& p, size_t i, floa
 __global__ __launch_bounds__(BX* BY) void k_quality(PreParams p)
 {
   __shared__ float tile[TH][TPITCH];
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
@@ -846,7 +848,7 @@ template <int WAVES>
 __global__ __launch_bounds__(BX* BY, WAVES) void k_normal_quality(PreParams p)
 {
   __shared__ float tile[TH][TPITCH];
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PrePa
   __shared__ float tile[TH][TPITCH];
   __shared__ float2 w_rg[BW][BP];
   __shared__ float w_lab[BW][BP][3];
-  const BlockPos bp = block_pos(p.N);
+  const BlockPos bp = block_pos(p);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;

@@ -41,6 +41,9 @@ void lut_z_range(int rz, int Z, int vz0, int vz1, int* lo, int* hi);
 // ---- kernel parameter blocks -------------------------------------------------
 struct PreParams {
   int N, W, H, Wc, Hc;
+  // the sensor layers this launch works on: [first, first + count) -- all N unless the pre_* chain is sharded over the
+  // ranks of a multi-GPU job (rgbdr_set_sensor_shard)
+  int first, count;
   float bbox_min[3], bbox_max[3];
   int filter, compress;
   int refine;

@@ -73,6 +73,236 @@ def exchange_halo(send_lo, send_hi, recv_lo, recv_hi, rank=None, world=None, gro
             r.wait()
 
 
+class _DeviceWords:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_words(ptr, nwords, device):
+    """int32 tensor over library-owned HBM (packed frame texels, u32 brick counters: summing u32 as i32 is the same bits)"""
+    return torch.as_tensor(_DeviceWords(ptr, nwords), device=device)
+
+
+class FrameGather:
+    """The pre_* chain sharded by sensor over the ranks of a slab job (rgbdr_set_sensor_shard): rank r runs the five
+    passes for sensors [r n / k, (r + 1) n / k) and this completes the frame on every rank -- one all-gather of the
+    packed 8-byte frame texels (what the sweep and the slab ray-march read of a sensor) and one all-reduce(sum) of the
+    u32 brick counters (each rank counted its own sensors' pixels), on the stream the chain ran on: with
+    RGBDR_FLAG_PIPELINE that is the library's second stream, i.e. next to the sweep of the frame before.
+
+        ctx.update_device(...); ctx.clear_occupied_bricks(); ctx.process_textures()
+        gather()                      # instead of nothing
+        ctx.update_occupied_bricks(); ctx.integrate()
+
+    nccl: torch.distributed collectives on the library's own buffers (zero copy), enqueued on the chain's stream.
+    gloo (`via_host`, several ranks on one GPU for tests): host-staged with synchronisation.
+    `loopback` (one GPU standing in for rank r of k): the other ranks' sensors are not recomputed; the traffic of the
+    gather is reproduced by sending the foreign layers to this process itself into a scratch buffer (same bytes, same
+    RCCL kernels, same stream ordering), the counters are all-reduced in a one-rank group."""
+
+    def __init__(self, ctx, device, rank=None, world=None, group=None, via_host=False, loopback=False):
+        self.ctx, self.device, self.group, self.via_host, self.loopback = ctx, device, group, via_host, loopback
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        n = ctx.cfg.num_sensors
+        if n % self.world:
+            raise ValueError("%d sensors do not split evenly over %d ranks" % (n, self.world))
+        self.count = n // self.world
+        self.first = self.rank * self.count
+        self.all_counts = None
+        if loopback:
+            # the frame the context processed last (unsharded, every sensor): its brick counts stand for "the sum over
+            # the ranks" in every later frame of the same static scene
+            v = ctx.shard_view()
+            torch.cuda.synchronize()
+            self.all_counts = wrap_device_words(v.counters, v.num_bricks, device).clone()
+        ctx.set_sensor_shard(self.first, self.count)
+        self.scratch = None
+        self.foreign_counts = None
+        self.timing = None           # (start, end) events of the last gather on the chain's stream
+
+    def __call__(self):
+        v = self.ctx.shard_view()
+        words = v.sensor_bytes // 4
+        n = v.num_sensors
+        frames = wrap_device_words(v.frames, words * n, self.device)
+        counters = wrap_device_words(v.counters, v.num_bricks, self.device)
+        mine = frames[self.first * words:(self.first + self.count) * words]
+        if self.via_host:                                   # gloo: through host memory, stream order by synchronisation
+            self.ctx.sync()
+            torch.cuda.synchronize()
+            h = mine.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            dist.all_gather(parts, h, group=self.group)
+            c = counters.cpu()
+            dist.all_reduce(c, group=self.group)
+            frames.copy_(torch.cat(parts).to(self.device))
+            counters.copy_(c.to(self.device))
+            torch.cuda.synchronize()
+            return
+        st = torch.cuda.ExternalStream(int(v.stream), device=self.device)
+        with torch.cuda.stream(st):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record(st)
+            self._collectives(frames, counters, mine, words, n)
+            t1.record(st)
+            self.timing = (t0, t1)
+
+    def last_ms(self):
+        """duration of the last gather on the chain's stream (synchronises on its end)"""
+        if self.timing is None:
+            return None
+        self.timing[1].synchronize()
+        return float(self.timing[0].elapsed_time(self.timing[1]))
+
+    def _collectives(self, frames, counters, mine, words, n):
+        if self.loopback:
+            if True:
+                lo, hi = frames[:self.first * words], frames[(self.first + self.count) * words:]
+                if self.scratch is None:
+                    self.scratch = torch.empty(words * (n - self.count), dtype=torch.int32, device=self.device)
+                me = dist.get_rank(self.group)
+                ops = []
+                if lo.numel():
+                    ops += [dist.P2POp(dist.isend, lo, me, self.group), dist.P2POp(dist.irecv, self.scratch[:lo.numel()], me, self.group)]
+                if hi.numel():
+                    ops += [dist.P2POp(dist.isend, hi, me, self.group), dist.P2POp(dist.irecv, self.scratch[lo.numel():], me, self.group)]
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+                # the other ranks' counts: what the unsharded frame counted beyond this shard (static scene); the one-rank
+                # all-reduce costs what the collective's launch costs
+                if self.foreign_counts is None:
+                    self.foreign_counts = self.all_counts - counters
+                dist.all_reduce(counters, group=self.group)
+                counters.add_(self.foreign_counts)
+        else:
+            dist.all_gather_into_tensor(frames, mine, group=self.group)
+            dist.all_reduce(counters, group=self.group)
+
+
+class RcclComm:
+    """A raw RCCL communicator through ctypes, for hosts that let the LIBRARY enqueue the collectives on its own streams
+    (rgbdr_halo_exchange_async, rgbdr_shard_allgather: the C ABI a C++ host uses, host/slab_loop.cpp) instead of going
+    through torch.distributed's process group, whose collectives run on a stream of its own.  The unique id travels
+    through the torch.distributed group that exists anyway (any backend)."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            import ctypes as C
+            # RTLD_GLOBAL: the library binds the copy of RCCL that is already in the process (dlopen RTLD_NOLOAD)
+            cls._lib = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+        return cls._lib
+
+    def __init__(self, rank, world, group=None):
+        import ctypes as C
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        L = self.lib()
+        uid = UniqueId()
+        if rank == 0:
+            rc = L.ncclGetUniqueId(C.byref(uid))
+            if rc:
+                raise RuntimeError("ncclGetUniqueId: %d" % rc)
+        raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+        if world > 1:
+            dist.broadcast(raw, src=0, group=group)
+        C.memmove(C.byref(uid), bytes(raw.numpy().tobytes()), 128)
+        self.handle = C.c_void_p()
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = L.ncclCommInitRank(C.byref(self.handle), world, uid, rank)
+        if rc:
+            raise RuntimeError("ncclCommInitRank: %d" % rc)
+        self.rank, self.world = rank, world
+        for name, args in (("ncclSend", [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                           ("ncclRecv", [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+                           ("ncclAllReduce", [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p])):
+            getattr(L, name).argtypes = args
+
+    def close(self):
+        if self.handle:
+            self.lib().ncclCommDestroy(self.handle)
+            self.handle = None
+
+
+class ManagedSlabExchange:
+    """Per-step communication of one slab rank with everything enqueued by the LIBRARY on its own streams (the C ABI's
+    managed forms): the halo exchange on the context's side stream behind events (rgbdr_halo_begin_step /
+    rgbdr_halo_exchange_async / rgbdr_halo_wait) and, with `shard`, the sensor-sharded pre_* chain completed by
+    rgbdr_shard_allgather on the chain's stream.  `loopback`: one GPU stands in for rank `rank` of `world` -- the
+    communicator has one rank, the halo faces are exchanged with this process itself, and the gather's traffic is
+    reproduced by RCCL send / recv of the other ranks' frame layers to this process itself on the chain's stream (the
+    layers hold an unsharded frame of the same static scene; their brick counts are added back)."""
+
+    def __init__(self, ctx, device, rank, world, group=None, shard=False, loopback=False):
+        self.ctx, self.device, self.rank, self.world, self.loopback = ctx, device, rank, world, loopback
+        self.comm = RcclComm(0 if loopback else rank, 1 if loopback else world, group)
+        me = 0 if loopback else rank
+        self.peer_lo = (me if loopback else rank - 1) if rank > 0 else -1
+        self.peer_hi = (me if loopback else rank + 1) if rank < world - 1 else -1
+        self.shard = None
+        n = ctx.cfg.num_sensors
+        if shard and n % world == 0 and world > 1:
+            self.count, self.first = n // world, rank * (n // world)
+            self.all_counts = None
+            if loopback:
+                v = ctx.shard_view()
+                torch.cuda.synchronize()
+                self.all_counts = wrap_device_words(v.counters, v.num_bricks, device).clone()
+                self.foreign = None
+                self.scratch = torch.empty((v.sensor_bytes // 4) * (n - self.count), dtype=torch.int32, device=device)
+            ctx.set_sensor_shard(self.first, self.count)
+            self.shard = True
+
+    def begin_step(self):
+        self.ctx.halo_begin_step()
+
+    def exchange_async(self):
+        self.ctx.halo_exchange_async(self.comm.handle, self.peer_lo, self.peer_hi)
+
+    def wait(self):
+        self.ctx.halo_wait()
+
+    def gather(self):
+        if not self.shard:
+            return
+        if not self.loopback:
+            self.ctx.shard_allgather(self.comm.handle)
+            return
+        import ctypes as C
+        L, comm = RcclComm.lib(), self.comm.handle
+        v = self.ctx.shard_view()
+        words = v.sensor_bytes // 4
+        st = C.c_void_p(v.stream)
+        lo_words, hi_words = self.first * words, (v.num_sensors - self.first - self.count) * words
+        base = int(v.frames)
+        L.ncclGroupStart()
+        if lo_words:
+            L.ncclSend(C.c_void_p(base), lo_words, 3, 0, comm, st)
+            L.ncclRecv(C.c_void_p(self.scratch.data_ptr()), lo_words, 3, 0, comm, st)
+        if hi_words:
+            L.ncclSend(C.c_void_p(base + 4 * (self.first + self.count) * words), hi_words, 3, 0, comm, st)
+            L.ncclRecv(C.c_void_p(self.scratch.data_ptr() + 4 * lo_words), hi_words, 3, 0, comm, st)
+        L.ncclAllReduce(C.c_void_p(v.counters), C.c_void_p(v.counters), v.num_bricks, 3, 0, comm, st)
+        L.ncclGroupEnd()
+        with torch.cuda.stream(torch.cuda.ExternalStream(int(v.stream), device=self.device)):
+            counters = wrap_device_words(v.counters, v.num_bricks, self.device)
+            if self.foreign is None:
+                self.foreign = self.all_counts - counters
+            counters.add_(self.foreign)
+
+    def last_transfer_ms(self):
+        try:
+            return self.ctx.timer_ns("halo") * 1e-6
+        except Exception:  # noqa: BLE001 -- timers off
+            return None
+
+    def close(self):
+        self.comm.close()
+
+
 class HaloExchanger:
     """The per-step halo exchange, off the critical path.
 

@@ -686,11 +686,31 @@ class HaloExchanger {
   int m_lo = -1, m_hi = -1;
 };
 
+// The pre_* chain sharded by sensor over the ranks of a slab job (no counterpart in the single-GPU
+// reference): rank r of `world` runs NetKinectArray::processTextures for sensors [r n / world, (r + 1) n / world) and
+// gather() completes the frame on every rank -- ncclAllGather of the packed frame texels + ncclAllReduce of the brick
+// counters, on the stream the chain ran on -- between processTextures() and updateOccupiedBricks().
+class FrameGather {
+ public:
+  FrameGather(Backend& be, void* nccl_comm, int rank, int world) : m_be(be), m_comm(nccl_comm)
+  {
+    const int n = (int)be.num();
+    if (world < 1 || n % world) throw std::invalid_argument("the sensors do not split evenly over the ranks");
+    check(be.ctx(), rgbdr_set_sensor_shard(be.ctx(), rank * (n / world), n / world));
+  }
+  void gather() { check(m_be.ctx(), rgbdr_shard_allgather(m_be.ctx(), m_comm)); }
+
+ private:
+  Backend& m_be;
+  void* m_comm;
+};
+
 // process_textures() of source/kinect_client.cpp:572-580
-inline void process_textures(NetKinectArray& nka, ReconIntegration& recon)
+inline void process_textures(NetKinectArray& nka, ReconIntegration& recon, FrameGather* shard = nullptr)
 {
   recon.clearOccupiedBricks();
   nka.processTextures();
+  if (shard) shard->gather();  // multi-GPU hosts with a sharded chain: the other ranks' sensors arrive here
   recon.updateOccupiedBricks();
 }
 

@@ -94,11 +94,15 @@ int main(int argc, char** argv)
     ReconIntegration recon(cf, &cv, bbox, 0.01f, voxel);
     recon.setUseBricks(false);  // full sweep: the kernel stores its boundary layers into the staging set itself
     HaloExchanger halo(be, comm, slab_rank, slab_count, loopback, 0);
+    // the pre_* chain sharded by sensor over the ranks of the communicator (every rank runs n / world sensors and the
+    // packed frames are all-gathered); with --loopback the communicator has one rank, which holds every sensor: the
+    // collectives still run (all-gather and all-reduce of one rank) and must leave the frame as it is
+    FrameGather shard(be, comm, loopback ? 0 : rank, loopback ? 1 : world);
     check(be.ctx(), rgbdr_enable_timers(be.ctx(), 1));
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
     for (int k = 0; k < frames; ++k) {  // no host synchronisation between frames
       nka.readFromFiles(streams, colorsize, depthsize, (size_t)k);
-      process_textures(nka, recon);
+      process_textures(nka, recon, &shard);
       halo.beginStep();
       recon.integrate();
       halo.exchangeAsync();

@@ -108,7 +108,59 @@ def exchanger_mode(out_dir, G, library_staging=False):
     dist.destroy_process_group()
 
 
+def shard_mode(out_dir, G, backend):
+    """The pre_* chain sharded by sensor over the slab ranks (rdist.FrameGather): every rank runs 4 / world sensors, the
+    packed frames are all-gathered and the brick counters all-reduced before updateOccupiedBricks / integrate.  Three
+    different frames, both sweeps; every rank dumps its slab of the last frame, its occupied bricks and a slab
+    ray-march (which shades from the gathered frames of all sensors)."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 4
+    scenes = [synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=s, sphere_r=r) for s, r in ((1, 0.9), (2, 0.6), (3, 0.75))]
+    inv = scenes[0].inverse((G, G, G))
+    ctx = capi.Context(capi.make_config(n, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=rank,
+                                        slab_count=world), 0)
+    for i in range(n):
+        ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    gather = rdist.FrameGather(ctx, dev, rank=rank, world=world, via_host=backend != "nccl")
+    assert (gather.first, gather.count) == (rank * (n // world), n // world)
+    frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
+    torch.cuda.synchronize()
+    for k, (d, c) in enumerate(frames):
+        ctx.set_pipelined(k == 1)                                     # one frame in the two-stream schedule
+        ctx.set_use_bricks(k != 1)
+        ctx.update_device(d.data_ptr(), c.data_ptr())
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        gather()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+    ctx.sync()
+    if world > 1:
+        rdist.exchange_halo_via_host(rdist.halo_views(ctx.device_tsdf(), dev), rank=rank, world=world)
+    torch.cuda.synchronize()
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=0)
+    view.skip_space = 1
+    col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=backend != "nccl")
+    np.savez(os.path.join(out_dir, "shard_r%d.npz" % rank), tsdf=ctx.readback_tsdf(), occupied=ctx.get_occupied()[0],
+             counters=ctx.readback_brick_counters(), color=col.cpu().numpy(), depth=dep.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] in ("shard", "shard_nccl"):
+        return shard_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "shard_nccl" else "gloo")
     if sys.argv[1] == "loopback":
         return loopback_mode(sys.argv[2], int(sys.argv[3]))
     if sys.argv[1] in ("exchanger", "exchanger_lib"):

@@ -94,3 +94,41 @@ def test_async_halo_exchanger_over_rccl_loopback(tmp_path):
     assert lo_matches[3] and hi_matches[3], (lo_matches, hi_matches)
     assert not same_bits(z["hist_lo"][2], z["hist_lo"][3])                          # the frames differ at the faces
     assert float(z["ms"]) > 0
+
+
+@pytest.mark.parametrize("world,mode", [(2, "shard"), (4, "shard"), (1, "shard_nccl")])
+def test_sensor_sharded_chain_over_ranks(world, mode, tmp_path, pkg):
+    """rgbd_recon_amd.dist.FrameGather: the pre_* chain runs for 4 / world sensors per rank, the packed frames are
+    all-gathered and the brick counters all-reduced; the slabs, the occupied bricks and the composited slab ray-march of
+    the last of three frames equal one unsharded context's.  (nccl: one rank on the one GPU, but the collectives run on the
+    library's own buffers and stream through RCCL.)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    G = 64
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py"), mode, str(tmp_path), str(G)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    z = [np.load(os.path.join(str(tmp_path), "shard_r%d.npz" % k)) for k in range(world)]
+    capi, synth = pkg.capi, pkg.synth
+    n = 4
+    first = synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=1, sphere_r=0.9)
+    last = synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=3, sphere_r=0.75)
+    ctx = capi.Context(capi.make_config(n, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
+    inv = first.inverse((G, G, G))
+    for i in range(n):
+        ctx.set_calibration(i, first.xyz[i], first.lut_res, first.uv[i], first.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.step(last.depth, last.color)
+    assert same_bits(np.concatenate([zz["tsdf"] for zz in z], axis=0), ctx.readback_tsdf())
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0), shade_mode=0)
+    view.skip_space = 1
+    col, dep, _ = ctx.raymarch(view)
+    for zz in z:
+        assert np.array_equal(zz["counters"], ctx.readback_brick_counters())
+        assert np.array_equal(zz["occupied"], ctx.get_occupied()[0])
+        assert same_bits(zz["color"], col) and same_bits(zz["depth"], dep)
+    assert (dep < 1).mean() > 0.02
+    ctx.close()

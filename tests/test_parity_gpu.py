@@ -1245,3 +1245,84 @@ def test_halo_exchange_after_a_resize_is_refused(pkg):
     assert lib.rgbdr_halo_exchange_async(ctx._h, fake_comm, -1, 1) == -6
     assert b"no rgbdr_integrate has filled the staging set" in lib.rgbdr_last_error(ctx._h)
     ctx.close()
+
+
+def test_sensor_shards_complete_each_other(pkg, orc):
+    """rgbdr_set_sensor_shard: k contexts stand for the k ranks of a slab job, each runs the pre_* chain for n / k sensors
+    only; copying the packed frame layers between them and summing the brick counters (what rgbdr_shard_allgather /
+    dist.FrameGather do over RCCL) completes the frame: occupied bricks and volume equal the unsharded context's bit for
+    bit, in both sweeps and both schedules; integrating a shard before the gather is refused."""
+    import torch
+    from rgbd_recon_amd import dist as rdist
+    capi, synth = pkg.capi, pkg.synth
+    dev = torch.device("cuda", 0)
+    n, k = 4, 2
+    scene, whole, inv = build(pkg, n=n)
+    scene2 = synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=77, sphere_r=0.7)
+    ranks = []
+    for r in range(k):
+        c = capi.Context(whole.cfg, 0)
+        for i in range(n):
+            c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+            c.set_inverse_calibration(i, inv[i], tuple(c.geo.res_volume))
+        c.set_sensor_shard(r * (n // k), n // k)
+        ranks.append(c)
+    with pytest.raises(capi.RgbdrError) as e:
+        ranks[0].set_sensor_shard(3, 2)
+    assert e.value.status == capi.ERR_OUT_OF_RANGE
+
+    def gather():
+        views = [c.shard_view() for c in ranks]
+        for c in ranks:
+            c.sync()
+        words = views[0].sensor_bytes // 4
+        fr = [rdist.wrap_device_words(v.frames, words * n, dev) for v in views]
+        cn = [rdist.wrap_device_words(v.counters, v.num_bricks, dev) for v in views]
+        assert [(v.first, v.count) for v in views] == [(r * (n // k), n // k) for r in range(k)]
+        total = sum(c.clone() for c in cn)
+        for r, v in enumerate(views):
+            lo, hi = v.first * words, (v.first + v.count) * words
+            for q in range(k):
+                if q != r:
+                    fr[q][lo:hi] = fr[r][lo:hi]
+        for c in cn:
+            c.copy_(total)
+        torch.cuda.synchronize()
+
+    for pipelined in (False, True):
+        for bricks in (True, False):
+            for c in ranks + [whole]:
+                c.set_pipelined(pipelined)
+                c.set_use_bricks(bricks)
+            for sc in (scene, scene2, scene):
+                whole.step(sc.depth, sc.color)
+                want = whole.readback_tsdf()
+                for c in ranks:
+                    c.update(sc.depth, sc.color)
+                    c.clear_occupied_bricks()
+                    c.process_textures()
+                with pytest.raises(capi.RgbdrError) as e:           # the other sensors' frames have not arrived
+                    ranks[1].integrate()
+                assert e.value.status == capi.ERR_STATE
+                with pytest.raises(capi.RgbdrError):
+                    ranks[0].update_occupied_bricks()
+                gather()
+                for r, c in enumerate(ranks):
+                    c.update_occupied_bricks()
+                    c.integrate()
+                    assert np.array_equal(c.readback_brick_counters(), whole.readback_brick_counters())
+                    assert np.array_equal(c.get_occupied()[0], whole.get_occupied()[0])
+                    got = c.readback_tsdf()
+                    assert same_bits(got, want), "rank %d, pipelined %s, bricks %s: %d voxels differ" % (r, pipelined, bricks, count_diff(got, want))
+                    # its own sensors' images are the whole context's; the chain did not touch the others' since the start
+                    for i in range(r * (n // k), (r + 1) * (n // k)):
+                        assert same_bits(c.readback_image(7, i), whole.readback_image(7, i))
+    # back to every sensor: an ordinary context again
+    ranks[0].set_pipelined(False)
+    ranks[0].set_sensor_shard(0, 0)
+    ranks[0].step(scene2.depth, scene2.color)
+    whole.set_pipelined(False)
+    whole.step(scene2.depth, scene2.color)
+    assert same_bits(ranks[0].readback_tsdf(), whole.readback_tsdf())
+    for c in ranks + [whole]:
+        c.close()
