@@ -67,13 +67,15 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
     __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(out));
   } else
     *out = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
-  if (STAGE) {  // boundary tile layers of a Z slab go to the halo staging buffers as well
+  if (STAGE) {  // boundary tile layers of a Z slab go to the halo staging buffers as well (write-once streams too: non-temporal)
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const unsigned per_layer = (unsigned)(p.TX * p.TY), layer = tile / per_layer;
-    const float4 r4 = make_float4(tsd[0], tsd[1], tsd[2], tsd[3]);
-    if (p.stage_lo && layer < (unsigned)p.stage_layers) reinterpret_cast<float4*>(p.stage_lo + (size_t)tile * kTileVoxels)[q] = r4;
+    const v4f r4 = {tsd[0], tsd[1], tsd[2], tsd[3]};
+    if (p.stage_lo && layer < (unsigned)p.stage_layers)
+      __builtin_nontemporal_store(r4, reinterpret_cast<v4f*>(p.stage_lo + (size_t)tile * kTileVoxels) + q);
     const unsigned first_hi = (unsigned)(p.ntz - p.stage_layers);
     if (p.stage_hi && layer >= first_hi)
-      reinterpret_cast<float4*>(p.stage_hi + (size_t)(tile - first_hi * per_layer) * kTileVoxels)[q] = r4;
+      __builtin_nontemporal_store(r4, reinterpret_cast<v4f*>(p.stage_hi + (size_t)(tile - first_hi * per_layer) * kTileVoxels) + q);
   }
 }
 
