@@ -81,11 +81,11 @@ def main():
                          "itself -- exercises the whole N > 1 code path (probe, staging, side stream); value is per slab")
     ap.add_argument("--arena-trials", type=int, default=0,
                     help="RGBDR_ARENA_TRIALS for the headline context; 0 (default) = leave the library's own default in "
-                         "force (up to 8 candidate placements of the LUT arena for arenas of 1 GiB and more; an RGBDR_ARENA_TRIALS "
+                         "force (up to 16 candidate placements of the LUT arena for arenas of 1 GiB and more; an RGBDR_ARENA_TRIALS "
                          "already in the environment is honoured).  Within one box the sweep time differs by up to 12 %% "
                          "with where hipMalloc placed the arena; the candidates' times are reported in "
-                         "roofline.arena_placement_probe_ms, and what the best of 16 placements would give is measured on a "
-                         "second context afterwards and reported as roofline.frac_best_of_16 -- never as `frac`")
+                         "roofline.arena_placement_probe_ms, next to what the first placement alone (frac_first_placement) and "
+                         "round 3's library default of three (frac_first_3) would have given")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="bound the CPU baseline to this many z rows of the volume (0 = the whole volume, about 10 s)")
     ap.add_argument("--slab", default="",
@@ -241,7 +241,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         os.environ["RGBDR_ARENA_TRIALS"] = "1"
     elif args.arena_trials > 0:
         os.environ["RGBDR_ARENA_TRIALS"] = str(args.arena_trials)     # read by the library when the LUT arena is created
-    trials = os.environ.get("RGBDR_ARENA_TRIALS", "library default (8)")
+    trials = os.environ.get("RGBDR_ARENA_TRIALS", "library default (16)")
     load_package()
     from rgbd_recon_amd import capi, synth
     from rgbd_recon_amd import dist as rdist
@@ -568,12 +568,16 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         out["roofline"]["frac_first_placement"] = round(bytes_launch / (first_ms * 1e-3) / HBM_PEAK, 4)
         # (until round 4 bench.py probed more placements than the library's default and this key scaled the result back;
         # now the headline context runs on the library's default, so it is `frac` itself unless --arena-trials was given)
-        dflt_ms = int_s * 1e3 * min(m for m in probe_ms[:8] if m > 0) / probe_ms[kept]
+        dflt_ms = int_s * 1e3 * min(m for m in probe_ms[:16] if m > 0) / probe_ms[kept]
         out["roofline"]["frac_library_default"] = round(bytes_launch / (dflt_ms * 1e-3) / HBM_PEAK, 4)
+        first3_ms = int_s * 1e3 * min(m for m in probe_ms[:3] if m > 0) / probe_ms[kept]
+        out["roofline"]["frac_first_3"] = round(bytes_launch / (first3_ms * 1e-3) / HBM_PEAK, 4)   # round 3's library default
+        if args.arena_trials == 0 and "RGBDR_ARENA_TRIALS" not in os.environ:
+            out["roofline"]["frac_best_of_16"] = out["roofline"]["frac"]   # the library's default IS up to 16 candidates now
         out["roofline"]["placement_note"] = ("RGBDR_ARENA_TRIALS = %s; %d placements were probed: `frac` is on the one the library "
                                              "kept, frac_first_placement / frac_library_default scale the measured launch time by "
-                                             "replay(candidate 0) / replay(kept) and by replay(best of the first eight) / replay(kept); "
-                                             "frac_best_of_16 is measured on a second context that probed up to 16" % (trials, len(probe_ms)))
+                                             "replay(candidate 0) / replay(kept) and by replay(best of the candidates) / replay(kept), "
+                                             "frac_first_3 by replay(best of the first three) / replay(kept)" % (trials, len(probe_ms)))
     elif world == 1:
         out["roofline"]["frac_first_placement"] = out["roofline"]["frac"]       # a single placement was looked at
         out["roofline"]["frac_library_default"] = out["roofline"]["frac"]
@@ -717,48 +721,6 @@ def run_rank(args, slab=None, quiet=False, shared=None):
             rc.close()
         except (capi.RgbdrError, TypeError, ValueError) as e:
             out["reference_defaults"] = {"error": str(e)}
-
-    # ---- what placement shopping would buy (extra key, never `frac`): the same sweep on a second context whose LUT arena
-    # is the fastest of up to 16 candidate placements.  Last of the GPU legs: releasing its candidates' 100 GB makes the
-    # driver wipe memory in the background for a while, which slowed the host-fed legs when this ran before them ----
-    if world == 1 and not loop and not lean and args.arena_trials == 0:
-        keep_env = os.environ.get("RGBDR_ARENA_TRIALS")
-        try:
-            os.environ["RGBDR_ARENA_TRIALS"] = "16"
-            c16 = capi.Context(cfg, local_rank)
-            for i in range(N):
-                c16.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
-                c16.synth_inverse_calibration(i, scene.pinhole(i))
-            c16.set_use_bricks(False)
-
-            def step16():
-                c16.update_device(d_depth.data_ptr(), d_color.data_ptr())
-                c16.clear_occupied_bricks(); c16.process_textures(); c16.update_occupied_bricks(); c16.integrate()
-            step16()
-            c16.settle(3.0)
-            for _ in range(args.warmup):
-                step16()
-            c16.sync()
-            c16.set_timer_detail(0)
-            c16.enable_timer_accumulation(True)
-            for _ in range(max(args.steps // 2, 10)):
-                step16()
-            c16.sync()
-            ns16, n16 = c16.timer_stats("2integrate")
-            c16.enable_timer_accumulation(False)
-            ms16 = ns16 / max(n16, 1) * 1e-6
-            out["roofline"]["avg_launch_ms_best_of_16"] = round(ms16, 4)
-            out["roofline"]["frac_best_of_16"] = round(bytes_launch / (ms16 * 1e-3) / HBM_PEAK, 4) if ms16 > 0 else None
-            out["roofline"]["arena_placement_probe_ms_best_of_16"] = c16.arena_probe()[0]
-            c16.close()
-        except capi.RgbdrError as e:
-            out["roofline"]["frac_best_of_16"] = None
-            out["roofline"]["best_of_16_error"] = str(e)[:200]
-        finally:
-            if keep_env is None:
-                os.environ.pop("RGBDR_ARENA_TRIALS", None)
-            else:
-                os.environ["RGBDR_ARENA_TRIALS"] = keep_env
 
     # ---- CPU baseline: the oracle, bounded sample, rank 0 at N=1 only ---------
     if world == 1 and not loop and rank == 0 and not args.no_cpu_baseline:

@@ -471,11 +471,10 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * driver placed that allocation (stable per allocation, up to 12 % apart: a zone of 13-19 GB of the device memory,
  * usually where the first large allocation of a process lands, streams slower than the rest), so the
  * library times the LUT stream on up to RGBDR_ARENA_TRIALS candidate allocations when the arena is created
- * (environment; 1..16; default 8 for arenas of 1 GiB and more, 1 = the first allocation is taken and nothing is
+ * (environment; 1..16; default 16 for arenas of 1 GiB and more, 1 = the first allocation is taken and nothing is
  * probed for smaller ones) -- held while probing, i.e. up to n x the arena of HBM transiently and never more than
  * what leaves 4 GiB free, at most about 1 s -- stops at the first that streams at the fast level and otherwise
- * keeps the fastest.  bench.py runs on this default, reports every candidate and measures what 16 would give
- * on a second context (roofline.frac_best_of_16).  Reports
+ * keeps the fastest.  bench.py runs on this default and reports every candidate.  Reports
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);

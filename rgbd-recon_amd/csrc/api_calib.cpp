@@ -94,11 +94,13 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   // Where the driver places this arena shifts the sweep time of integrate by up to 12 % (stable per allocation;
   // DESIGN.md 4.1): a zone of 13-19 GB of the device memory -- usually the one the first large allocation of a
   // process lands in -- streams at 5.9 TB/s, the rest at 6.6.  So the kernel's memory streams are timed on up to
-  // RGBDR_ARENA_TRIALS candidate placements (1..16; default 8 for arenas of 1 GiB and more, else 1 = no probing)
+  // RGBDR_ARENA_TRIALS candidate placements (1..16; default 16 for arenas of 1 GiB and more, else 1 = no probing)
   // and the fastest is kept.  Candidates are held while probing (otherwise the next allocation returns the same
   // place), so this transiently needs up to n x the arena; it stops at the first candidate at the fast level,
   // when less than arena + 4 GiB is free, or after ~1 s.
-  int trials = bytes >= ((size_t)1 << 30) ? 8 : 1;  // (3 until round 4: on one box in four none of the first three was fast)
+  // (3 until round 4: on one box in four none of the first three candidates was fast, on one in six none of the first
+  // eight; the loop stops at the first fast one, when memory runs short, or after 1 s, so the maximum only costs where it pays)
+  int trials = bytes >= ((size_t)1 << 30) ? 16 : 1;
   if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
   if (trials > 16) trials = 16;
   if (trials < 1 || bytes < ((size_t)256 << 20)) trials = 1;  // small arenas: nothing to gain

@@ -690,7 +690,7 @@ def test_dxt_compressed_colour_frames(pkg, orc, mode):
 
 def test_lut_arena_placement_probe(pkg, monkeypatch):
     """placing the LUT arena by timing candidate allocations: RGBDR_ARENA_TRIALS=n for arenas of 256 MiB and more; unset,
-    arenas below 1 GiB (this one) take the first allocation without probing, larger ones try up to eight (the library's default).  The choice
+    arenas below 1 GiB (this one) take the first allocation without probing, larger ones try up to sixteen (the library's default).  The choice
     never changes a result, and a probe leaves the volume cleared and marked as not integrated."""
     out = []
     for trials in (None, "1", "4"):
