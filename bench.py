@@ -760,6 +760,9 @@ def run_rank(args, slab=None, quiet=False, shared=None):
             ctx.enable_timers(False)
         except Exception as e:  # noqa: BLE001 -- extra keys must never cost the headline line
             out["post_pass"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    if multi and hasattr(exchanger, "close"):
+        ctx.sync()
+        exchanger.close()                 # the raw RCCL communicators of the library-managed exchange
     ctx.close()
     if multi:
         torch.cuda.set_stream(torch.cuda.default_stream(dev))

@@ -377,6 +377,9 @@ int rgbdr_halo_wait(rgbdr_ctx* ctx);
  *                                            u32) of the brick counters, enqueued on the stream the chain ran on (under
  *                                            RGBDR_FLAG_PIPELINE: next to the sweep of the frame before); rank r of the
  *                                            k ranks must hold sensors [r n / k, (r + 1) n / k); RCCL is bound at run time;
+ *                                            give it a communicator of its OWN: operations on one communicator execute in
+ *                                            issue order whatever their streams, so on the halo exchange's communicator the
+ *                                            gather of frame k+1 would wait for the face transfer of frame k;
  *   or the host's own collectives on the device memory rgbdr_shard_view hands out (torch.distributed:
  *   rgbd-recon_amd/dist.py FrameGather), enqueued on view.stream.
  * Calling rgbdr_update_occupied_bricks / rgbdr_integrate on a shard before either returns RGBDR_ERR_STATE.  The float
