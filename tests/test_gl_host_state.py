@@ -92,6 +92,23 @@ STATEMENTS = [
     ("framework/rendering/screen_quad.cpp", r"-1\.0f, -1\.0f, 0\.0f, 0\.0f,\s*3\.0f, -1\.0f, 2\.0f, 0\.0f,\s*-1\.0f, 3\.0f, 0\.0f, 2\.0f", "screen triangle"),
     ("framework/rendering/volume_sampler.cpp", r"m_pos_voxels\.emplace_back\(\( x\+ 0\.5f\) \* stepX, \(y \+ 0\.5f\) \* stepY, \(z \+ 0\.5f\) \* stepZ\)", "voxel centres"),
     ("framework/rendering/volume_sampler.cpp", r"drawArrays\(GL_POINTS, 0, m_dimensions\.x \* m_dimensions\.y \* m_dimensions\.z\)", "points"),
+    # ---- the default mode (round 4): DXT colour layers, bricks on, the grid and the bricks' index lists ----
+    (NKA, r"if\(m_calib_files->isCompressedRGB\(\) == 1\)\{[^}]*?new TextureArray\(m_resolution_color\.x, m_resolution_color\.y, m_numLayers, GL_COMPRESSED_RGBA_S3TC_DXT1_EXT, GL_COMPRESSED_RGBA_S3TC_DXT1_EXT, GL_UNSIGNED_BYTE, m_colorsize\)", "DXT1 colour layers"),
+    (NKA, r"isCompressedRGB\(\) == 5\)\{[^}]*?GL_COMPRESSED_RGBA_S3TC_DXT5_EXT, GL_COMPRESSED_RGBA_S3TC_DXT5_EXT, GL_UNSIGNED_BYTE, m_colorsize\)", "DXT5 colour layers"),
+    ("framework/rendering/TextureArray.cpp", r"if\(m_storage > 0\) \{\s*m_texture->compressedImage3D\(0, m_internalFormat, m_width, m_height, m_depth, 0, m_storage \* m_depth,", "compressed array: storage x layers"),
+    ("framework/rendering/TextureArray.cpp", r"m_texture\{globjects::Texture::createDefault\(GL_TEXTURE_2D_ARRAY\)\}", "colour array: createDefault = LINEAR, CLAMP_TO_EDGE"),
+    (RI, r",m_use_bricks\{true\}", "bricks on by default"),
+    (RI, r"if \(m_use_bricks\) \{\s*for\(auto const& index : m_bricks_occupied\) \{[^}]*?m_sampler\.sample\(m_bricks\[index\]\.indices\);", "one indexed draw per occupied brick"),
+    ("framework/rendering/volume_sampler.cpp", r"m_va_samples->drawElements\(GL_POINTS, indices\.size\(\), GL_UNSIGNED_INT, indices\.data\(\)\)", "indexed points, u32 indices"),
+    (RI, r"m_res_volume = glm::ceil\(glm::fvec3\{m_bbox\.getPMax\(\)\[0\] - m_bbox\.getPMin\(\)\[0\],", "res = ceil(extent / voxel)"),
+    (RI, r"m_brick_size = m_voxel_size \* glm::round\(size / m_voxel_size\)", "brick size = voxel * round(size / voxel)"),
+    (RI, r"while\(size\.z - start\.z  \+ min\.z > 0\.0f\) \{\s*while\(size\.y - start\.y  \+ min\.y > 0\.0f\) \{\s*while\(size\.x - start\.x  \+ min\.x > 0\.0f\)", "divideBox loop conditions"),
+    (RI, r"m_bricks\.emplace_back\(start, glm::min\(glm::fvec3\{m_brick_size\}, size - start \+ min\)\)", "brick size clipped at the box"),
+    (RI, r"curr_brick\.indices = m_sampler\.containedVoxels\(\(curr_brick\.pos - min\) / size, curr_brick\.size / size\)", "normalised brick -> containedVoxels"),
+    (RI, r"start\.x \+= m_brick_size;", "start accumulates in float"),
+    ("framework/rendering/volume_sampler.cpp", r"glm::fvec3 step\{1\.0f / glm::fvec3\{m_dimensions\}\};\s*for\(unsigned y = pos\.y / step\.y; y < \(pos\.y \+ size\.y\) / step\.y; \+\+y\) \{\s*for\(unsigned x = pos\.x / step\.x; x < \(pos\.x \+ size\.x\) / step\.x; \+\+x\) \{\s*for\(unsigned z = pos\.z / step\.z; z < \(pos\.z \+ size\.z\) / step\.z; \+\+z\)", "containedVoxels loop bounds and order"),
+    ("framework/rendering/volume_sampler.cpp", r"indices\.push_back\(z \* m_dimensions\.x \* m_dimensions\.y \+ y \* m_dimensions\.x \+ x\)", "linear index"),
+    ("framework/calibration/KinectCalibrationFile.cpp", r"_iscompressedrgb\(1\)", "compress_rgb defaults to 1 (DXT1)"),
     # ---- the application ----
     (KC, r"glEnable\(GL_DEPTH_TEST\);\s*glDepthFunc\(GL_LESS\)", "depth test LESS"),
     (KC, r"g_buffer_shading->bindBase\(GL_UNIFORM_BUFFER, 1\)", "Settings UBO binding 1"),
