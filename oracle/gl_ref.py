@@ -294,9 +294,8 @@ def run_frame(scene, bbox_min, bbox_max, res, inv_luts, limit=0.01, brick_size=N
     for k in ("filter", "normal", "quality", "morph", "boundary"):
         prog[k].use()
         prog[k].fv("texSizeInv", tsi, 2)
-    import pyoracle                                    # camera positions: CalibVolumes.cpp:98-122 / frustum.cpp:21-33 (host code)
-    prog["quality"].use()
-    prog["quality"].fv("camera_positions", np.stack([pyoracle.camera_pos(scene.xyz[i]) for i in range(n)]), 3)
+    prog["quality"].use()                              # CalibVolumes::getCameraPositions (host code, restated below)
+    prog["quality"].fv("camera_positions", np.stack([host_camera_pos(scene.xyz[i]) for i in range(n)]), 3)
     prog["filter"].use()
     prog["filter"].i("kinect_depths", UNITS["raw_depth"])
     prog["morph"].use()
@@ -630,6 +629,33 @@ def brick_indices(grid, brick):
     zs = np.arange(*grid["axes"][2][bz], dtype=np.uint64)
     ids = zs[None, None, :] * np.uint64(X * Y) + ys[:, None, None] * np.uint64(X) + xs[None, :, None]
     return (ids.reshape(-1) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def host_camera_pos(cv_xyz):
+    """CalibVolumes::getCameraPositions = Frustum(getCornerPoints(cv_xyz)).getCameraPos() (CalibVolumes.cpp:98-113,224-230;
+    frustum.cpp:21-33, closestPoint :97-111), in binary32 with glm's association (dot = x*x + y*y + z*z, left to right).
+    The harness's own restatement of this host code: the run on Mesa does not borrow it from the oracle."""
+    v = np.asarray(cv_xyz, np.float32)
+    ez, ey, ex = v.shape[0] - 1, v.shape[1] - 1, v.shape[2] - 1
+    c = [v[0, 0, 0], v[0, ey, 0], v[0, ey, ex], v[0, 0, ex], v[ez, 0, 0], v[ez, ey, 0], v[ez, ey, ex], v[ez, 0, ex]]   # curr_volume(x, y, z)
+    c = [np.asarray(p[:3], np.float32) for p in c]
+    four = _F(4.0)
+
+    def dot(a, b):
+        return _F(_F(_F(a[0] * b[0]) + _F(a[1] * b[1])) + _F(a[2] * b[2]))
+
+    def closest(p, u, q, w):
+        w0 = p - q
+        a, b, cc, d, e = dot(u, u), dot(u, w), dot(w, w), dot(u, w0), dot(w, w0)
+        den = _F(_F(a * cc) - _F(b * b))
+        sc = _F(_F(_F(b * e) - _F(cc * d)) / den)
+        tc = _F(_F(_F(a * e) - _F(b * d)) / den)
+        return ((p + u * sc) + (q + w * tc)) * _F(0.5)
+    near = (((c[0] + c[1]) + c[2]) + c[3]) / four
+    far = (((c[4] + c[5]) + c[6]) + c[7]) / four
+    view_dir = far - near
+    pts = [closest(c[i], c[i] - c[i + 4], near, view_dir) for i in range(4)]
+    return ((((pts[0] + pts[1]) + pts[2]) + pts[3]) / four).astype(np.float32)
 
 
 def occupied_bricks(counters, min_voxels):

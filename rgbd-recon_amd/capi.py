@@ -303,6 +303,16 @@ def compute_geometry(cfg):
     return g
 
 
+def camera_position(cv_xyz, res):
+    """rgbdr_camera_position: Frustum(getCornerPoints(cv_xyz)).getCameraPos() of a forward calibration volume (no context needed)"""
+    out = (C.c_float * 3)()
+    lut = make_lut(cv_xyz, res)
+    rc = lib().rgbdr_camera_position(C.byref(lut), out)
+    if rc != OK:
+        raise RgbdrError(rc, lib().rgbdr_last_error(None).decode())
+    return np.array(out[:], dtype=np.float32)
+
+
 def brick_voxel_range(cfg, axis, brick):
     """(first, last) voxel index of `brick` on `axis` as the reference's containedVoxels builds it"""
     a, b = C.c_int32(), C.c_int32()

@@ -109,6 +109,14 @@ STATEMENTS = [
     ("framework/rendering/volume_sampler.cpp", r"glm::fvec3 step\{1\.0f / glm::fvec3\{m_dimensions\}\};\s*for\(unsigned y = pos\.y / step\.y; y < \(pos\.y \+ size\.y\) / step\.y; \+\+y\) \{\s*for\(unsigned x = pos\.x / step\.x; x < \(pos\.x \+ size\.x\) / step\.x; \+\+x\) \{\s*for\(unsigned z = pos\.z / step\.z; z < \(pos\.z \+ size\.z\) / step\.z; \+\+z\)", "containedVoxels loop bounds and order"),
     ("framework/rendering/volume_sampler.cpp", r"indices\.push_back\(z \* m_dimensions\.x \* m_dimensions\.y \+ y \* m_dimensions\.x \+ x\)", "linear index"),
     ("framework/calibration/KinectCalibrationFile.cpp", r"_iscompressedrgb\(1\)", "compress_rgb defaults to 1 (DXT1)"),
+    # ---- camera positions (gl_ref.host_camera_pos) ----
+    ("framework/calibration/frustum.cpp", r"glm::fvec3 center_near\(\(m_corners\[0\] \+ m_corners\[1\] \+ m_corners\[2\] \+ m_corners\[3\]\) / 4\.0f\)", "near centre"),
+    ("framework/calibration/frustum.cpp", r"closestPoint\(m_corners\[0\], m_corners\[0\] - m_corners\[4\], center_near, view_dir\)", "edge ray against the view axis"),
+    ("framework/calibration/frustum.cpp", r"return \(p3 \+ p4 \+ p5 \+ p6\) / 4\.0f;", "mean of the four closest points"),
+    ("framework/calibration/frustum.cpp", r"float sc = \(b \* e - c \* d\) / \(a \* c - b \* b\);\s*float tc = \(a \* e - b \* d\) / \(a \* c - b \* b\);", "closestPoint parameters"),
+    ("framework/calibration/frustum.cpp", r"return \(pc \+ qc\) \* 0\.5f;", "midpoint of the two closest points"),
+    (CV, r"points_corner\[2\] = \(curr_volume\(end_points\.x, end_points\.y, 0\)\);", "corner order"),
+    (CV, r"points_corner\[7\] = \(curr_volume\(end_points\.x, 0,\s*end_points\.z\)\);", "corner order (far)"),
     # ---- the application ----
     (KC, r"glEnable\(GL_DEPTH_TEST\);\s*glDepthFunc\(GL_LESS\)", "depth test LESS"),
     (KC, r"g_buffer_shading->bindBase\(GL_UNIFORM_BUFFER, 1\)", "Settings UBO binding 1"),

@@ -622,6 +622,20 @@ def test_the_harness_brick_lists_are_the_reference_construction(pkg, orc):
     assert g["axes"][0][-1][1] > g["res"][0], "the overflow case no longer overflows"
 
 
+def test_the_harness_camera_positions_are_the_reference_construction(pkg, orc):
+    """gl_ref.host_camera_pos (CalibVolumes::getCameraPositions = Frustum::getCameraPos of the cv_xyz corner samples, the
+    uniform pre_quality.fs gets on Mesa) is the harness's own binary32 restatement; it agrees with the oracle's C
+    restatement bit for bit, with the library's rgbdr_camera_position, and with the analytic sensor position to 1e-6"""
+    import gl_ref
+    for n, wh, lut, seed in ((4, (128, 106), (32, 27, 32), 1234), (5, (64, 53), (16, 14, 16), 4242), (3, (48, 40), (12, 10, 12), 5)):
+        scene = pkg.synth.Scene(n, wh[0], wh[1], lut_res=lut, seed=seed, make_frames=False)
+        for i in range(n):
+            a = gl_ref.host_camera_pos(scene.xyz[i])
+            assert same_bits(a, orc.camera_pos(scene.xyz[i]))
+            assert same_bits(a, np.asarray(pkg.capi.camera_position(scene.xyz[i], scene.lut_res), np.float32))
+            assert np.abs(a - scene.sensors[i].pos).max() < 1e-6
+
+
 def oracle_mode_frame(orc, pkg, name):
     c = shader_cases.MODE_CASES[name]
     scene, cfg, geo, inv, inv_res = shader_cases.build_mode(pkg.synth, pkg.capi, name, decode_dxt=orc.decode_dxt)
