@@ -473,10 +473,8 @@ static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color)
 {
   const size_t dbytes = depth_frame_bytes_all(ctx), cbytes = color_frame_bytes_all(ctx);
   const int s = ctx->in_set;
-  if (!ctx->d_in_depth[s]) {
-    HIPCHK(hipMalloc(&ctx->d_in_depth[s], dbytes));
-    HIPCHK(hipMalloc(&ctx->d_in_color[s], cbytes));
-  }
+  if (!ctx->d_in_depth[s]) HIPCHK(hipMalloc(&ctx->d_in_depth[s], dbytes));  // (checked one by one: a failure of the
+  if (!ctx->d_in_color[s]) HIPCHK(hipMalloc(&ctx->d_in_color[s], cbytes));  // second must not leave a half-made set)
   hipStream_t cs = ctx->copy_stream;
   if (ctx->ev_in_read_rec[s]) HIPCHK(hipStreamWaitEvent(cs, ctx->ev_in_read[s], 0));  // its last reader: two uploads ago
   HIPCHK(hipMemcpyAsync(ctx->d_in_depth[s], depth, dbytes, hipMemcpyHostToDevice, cs));
