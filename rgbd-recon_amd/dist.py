@@ -156,28 +156,28 @@ class FrameGather:
         return float(self.timing[0].elapsed_time(self.timing[1]))
 
     def _collectives(self, frames, counters, mine, words, n):
-        if self.loopback:
-            if True:
-                lo, hi = frames[:self.first * words], frames[(self.first + self.count) * words:]
-                if self.scratch is None:
-                    self.scratch = torch.empty(words * (n - self.count), dtype=torch.int32, device=self.device)
-                me = dist.get_rank(self.group)
-                ops = []
-                if lo.numel():
-                    ops += [dist.P2POp(dist.isend, lo, me, self.group), dist.P2POp(dist.irecv, self.scratch[:lo.numel()], me, self.group)]
-                if hi.numel():
-                    ops += [dist.P2POp(dist.isend, hi, me, self.group), dist.P2POp(dist.irecv, self.scratch[lo.numel():], me, self.group)]
-                for r in dist.batch_isend_irecv(ops):
-                    r.wait()
-                # the other ranks' counts: what the unsharded frame counted beyond this shard (static scene); the one-rank
-                # all-reduce costs what the collective's launch costs
-                if self.foreign_counts is None:
-                    self.foreign_counts = self.all_counts - counters
-                dist.all_reduce(counters, group=self.group)
-                counters.add_(self.foreign_counts)
-        else:
+        if not self.loopback:
             dist.all_gather_into_tensor(frames, mine, group=self.group)
             dist.all_reduce(counters, group=self.group)
+            return
+        # one GPU standing in for a rank: the other ranks' layers travel to this process itself (same bytes, same RCCL
+        # kernels, same stream ordering); their brick counts -- what the unsharded frame counted beyond this shard of the
+        # same static scene -- are added back after the one-rank all-reduce
+        lo, hi = frames[:self.first * words], frames[(self.first + self.count) * words:]
+        if self.scratch is None:
+            self.scratch = torch.empty(words * (n - self.count), dtype=torch.int32, device=self.device)
+        me = dist.get_rank(self.group)
+        ops = []
+        if lo.numel():
+            ops += [dist.P2POp(dist.isend, lo, me, self.group), dist.P2POp(dist.irecv, self.scratch[:lo.numel()], me, self.group)]
+        if hi.numel():
+            ops += [dist.P2POp(dist.isend, hi, me, self.group), dist.P2POp(dist.irecv, self.scratch[lo.numel():], me, self.group)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if self.foreign_counts is None:
+            self.foreign_counts = self.all_counts - counters
+        dist.all_reduce(counters, group=self.group)
+        counters.add_(self.foreign_counts)
 
 
 class RcclComm:
