@@ -369,8 +369,9 @@ int rgbdr_halo_wait(rgbdr_ctx* ctx);
 /* The pre_* chain sharded by SENSOR over the ranks of a Z-slab job ("sensors are split across GPUs and
  * results all-gathered (ncclAllGather ...) with brick counters ncclAllReduce"; the reference is single-GPU and has no
  * counterpart).  After rgbdr_set_sensor_shard(ctx, first, count) rgbdr_process_textures runs the five passes for the
- * sensor layers [first, first + count) only (first = 0 with count = 0 or num_sensors: all of them again); uploads still take
- * every sensor's frame.  What the sweep and the slab ray-march read of a sensor is its packed frame texel (8 B per pixel),
+ * sensor layers [first, first + count) only (first = 0 with count = 0 or num_sensors: all of them again).  Uploads still take
+ * every sensor's frame but bring the raw depth of the shard's layers only (colour: all); changing the shard invalidates the
+ * uploaded frame (upload again before rgbdr_process_textures).  What the sweep and the slab ray-march read of a sensor is its packed frame texel (8 B per pixel),
  * and each rank has counted only its own sensors' pixels into the bricks, so before rgbdr_update_occupied_bricks /
  * rgbdr_integrate the frame is completed by
  *   rgbdr_shard_allgather(ctx, ncclComm_t)   one grouped ncclAllGather of the packed frames (in place) + ncclAllReduce(sum,

@@ -425,8 +425,10 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
   ctx->morph_current = false;
+  // a sensor shard (rgbdr_set_sensor_shard) copies and morphs the raw depth of its own layers only
+  const int first = ctx->shard_count > 0 ? ctx->shard_first : 0, count = ctx->shard_count > 0 ? ctx->shard_count : nsens(ctx);
   if (!ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
-      launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw, ctx->d_depth_morph, color,
+      launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, first, count, depth, ctx->d_depth_raw, ctx->d_depth_morph, color,
                           ctx->d_color, ncol, ps)) {
     LAUNCHCHK("upload_morph");
     ctx->morph_current = true;
@@ -443,7 +445,7 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   if (ctx->cfg.compress_depth) {
     launch_u8_to_unit((const uint8_t*)depth, ctx->d_depth_raw, n, ps);
     LAUNCHCHK("u8_to_unit");
-  } else if (launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, nsens(ctx), depth, ctx->d_depth_raw, ctx->d_depth_morph,
+  } else if (launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, first, count, depth, ctx->d_depth_raw, ctx->d_depth_morph,
                                  color, cdst, cbytes, ps)) {
     color_done = true;
     ctx->morph_current = true;

@@ -219,13 +219,20 @@ int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   const int N = nsens(ctx);
+  const int old_first = ctx->shard_first, old_count = ctx->shard_count;
   if (count <= 0 || (first == 0 && count == N)) {  // back to every sensor
     ctx->shard_first = ctx->shard_count = 0;
-    return RGBDR_OK;
+  } else {
+    if (first < 0 || first + count > N) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor shard outside [0, num_sensors)");
+    ctx->shard_first = first;
+    ctx->shard_count = count;
   }
-  if (first < 0 || first + count > N) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor shard outside [0, num_sensors)");
-  ctx->shard_first = first;
-  ctx->shard_count = count;
+  if (ctx->shard_first != old_first || ctx->shard_count != old_count) {
+    // an upload brings the raw depth (and its pre_morph image) of the shard's layers only: the frame has to be
+    // uploaded again before the chain runs on other layers
+    ctx->frame_uploaded = false;
+    ctx->morph_current = false;
+  }
   return RGBDR_OK;
 }
 

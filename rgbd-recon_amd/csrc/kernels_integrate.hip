@@ -36,14 +36,26 @@ namespace rgbdr {
 // the tile projects into (origins precomputed per tile at LUT upload) -- is issued
 // before that group's barrier, so one memory latency is paid per group; the 2x2
 // footprints of all 512 voxels are then served from LDS.  More than 4 sensors are
-// folded in two groups (the running tsd / weight stay in registers), which keeps
-// the kernel at <= ~100 VGPRs for every N.
+// folded in two groups, eight in three (the running tsd / weight stay in registers), which keeps
+// the kernel at <= 96 VGPRs = five wavefronts per SIMD for every N.
 // One tile: BRICKS marks the voxels of unoccupied bricks -limit after the fold.
+// Sensors per group: every sensor in one group up to MAXG, two halves above that -- except for eight sensors, which are
+// folded as (3, 3, 2): 36 instead of 48 registers of LUT planes in flight take that kernel from 104 VGPRs (four
+// wavefronts per SIMD) to 94 (five, like the 4-sensor kernel); measured 2.09 -> 2.05 ms at 512^3 (round 4; groups of two
+// the same, seven sensors as (3, 3, 1) no better than (4, 3)).
+template <int N, int MAXG>
+struct Groups {
+  static constexpr bool kThrees = N == 8;
+  static constexpr int G1 = kThrees ? 3 : (N <= MAXG ? N : (N + 1) / 2);
+  static constexpr int G2 = kThrees ? 3 : N - G1;
+  static constexpr int G3 = N - G1 - G2;
+};
+
 template <int N, int MAXG, bool NT, bool ELIDE = false, bool STAGE = false>
 __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigned tile, uint2 (*win)[kWin * kWinPitch])
 {
-  constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;  // first group
-  constexpr int G2 = N - G1;                       // second group (0 for N <= MAXG)
+  typedef Groups<N, MAXG> G;
+  constexpr int G1 = G::G1, G2 = G::G2, G3 = G::G3;
   const int q = threadIdx.x;
   float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
   const float limit = p.limit;
@@ -51,6 +63,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
   float wsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   integrate_group<G1, NT, false>(p, tile, q, 0, N, win, false, limit, tsd, wsum);
   if (G2 > 0) integrate_group<(G2 > 0 ? G2 : 1), NT, false>(p, tile, q, G1, N, win, true, limit, tsd, wsum);
+  if (G3 > 0) integrate_group<(G3 > 0 ? G3 : 1), NT, false>(p, tile, q, G1 + G2, N, win, true, limit, tsd, wsum);
   if (ELIDE) {
     // RGBDR_FLAG_ELIDE_STORES: a tile that comes out all -limit and has held -limit since a sweep
     // of this epoch (tile_state, see k_brick_clear) need not be written again
@@ -83,7 +96,7 @@ __device__ __forceinline__ void integrate_tile(const IntegrateParams& p, unsigne
 template <int N, int MAXG = 4, bool NT = true, bool ELIDE = false, bool STAGE = false>
 __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
 {
-  constexpr int G1 = N <= MAXG ? N : (N + 1) / 2;
+  constexpr int G1 = Groups<N, MAXG>::G1;
   __shared__ uint2 win[G1][kWin * kWinPitch];
   // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch).
   // Each XCD takes chunks of `order_chunk` consecutive tiles (neighbouring tiles

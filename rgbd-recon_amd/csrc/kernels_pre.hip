@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BX* BY) void k_morph(const float* __restrict__ in_a
 // A frame that is already on the device: the copy into the context's buffers and the morph pass in one launch (the
 // 3x3 neighbourhood is read from the caller's buffer); `b_*`: the colour frame / DXT blocks, copied by the same lanes.
 __global__ __launch_bounds__(BX* BY) void k_upload_morph(const float* __restrict__ src, float* __restrict__ raw,
-                                                         float* __restrict__ morph, int W, int H, int N,
+                                                         float* __restrict__ morph, int W, int H, int first, int count,
                                                          const uint4* __restrict__ b_src, uint4* __restrict__ b_dst, size_t b_n16,
                                                          const uint8_t* b_tail_src, uint8_t* b_tail_dst, int b_tail)
 {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BX* BY) void k_upload_morph(const float* __restrict
   const size_t tid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BX * BY) + threadIdx.y * BX + threadIdx.x;
   for (size_t i = tid; i < b_n16; i += nthreads) b_dst[i] = b_src[i];
   if (tid < (size_t)b_tail) b_tail_dst[tid] = b_tail_src[tid];
-  const BlockPos bp = block_pos(N);
+  const BlockPos bp = block_pos(count, first);
   const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
   if (px >= W || py >= H) return;
   const size_t lo = (size_t)bp.l * W * H, o = lo + (size_t)py * W + px;
@@ -265,16 +265,19 @@ void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zer
 {
   hipLaunchKernelGGL(k_morph, pass_grid(p), dim3(BX, BY), 0, s, in, out, p.W, p.H, p.first, p.count, zero, nzero);
 }
-bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
-                         size_t b_bytes, hipStream_t s)
+// [first, first + count): the sensor layers whose raw depth is copied and morphed -- every sensor, or this rank's shard of the
+// pre_* chain (the chain reads no other layer); the colour frame / DXT blocks of ALL sensors are copied either way (the
+// slab ray-march shades from every sensor's colour)
+bool launch_upload_morph(int W, int H, int first, int count, const void* depth_src, float* raw, float* morph, const void* b_src,
+                         void* b_dst, size_t b_bytes, hipStream_t s)
 {
   if ((((uintptr_t)depth_src & 3u) | (((uintptr_t)b_src | (uintptr_t)b_dst) & 15u)) != 0) return false;
   PreParams p{};
   p.W = W;
   p.H = H;
-  p.N = p.count = N;  // every sensor's raw depth and morph image (first = 0): the copy is what costs, and consumers of the raw frames want them all
+  p.N = p.count = count;
   const size_t b16 = b_bytes / 16;
-  hipLaunchKernelGGL(k_upload_morph, pass_grid(p), dim3(BX, BY), 0, s, (const float*)depth_src, raw, morph, W, H, N,
+  hipLaunchKernelGGL(k_upload_morph, pass_grid(p), dim3(BX, BY), 0, s, (const float*)depth_src, raw, morph, W, H, first, count,
                      (const uint4*)b_src, (uint4*)b_dst, b16, (const uint8_t*)b_src + b16 * 16, (uint8_t*)b_dst + b16 * 16,
                      (int)(b_bytes - b16 * 16));
   return true;

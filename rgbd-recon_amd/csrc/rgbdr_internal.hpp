@@ -217,7 +217,7 @@ void launch_repack_xyz(const float* src_xyz3, float4* dst, size_t n, hipStream_t
 void launch_morph(const PreParams& p, const float* in, float* out, uint32_t* zero, unsigned nzero, hipStream_t s);
 void launch_pre_cache(const PreParams& p, int sensor, hipStream_t s);
 void launch_pre_depth(const PreParams& p, uint32_t* zero, unsigned nzero, hipStream_t s);
-bool launch_upload_morph(int W, int H, int N, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
+bool launch_upload_morph(int W, int H, int first, int count, const void* depth_src, float* raw, float* morph, const void* b_src, void* b_dst,
                          size_t b_bytes, hipStream_t s);
 void launch_boundary(const PreParams& p, hipStream_t s);
 void launch_normal(const PreParams& p, hipStream_t s);
