@@ -287,15 +287,18 @@ class ManagedSlabExchange:
         st = C.c_void_p(v.stream)
         lo_words, hi_words = self.first * words, (v.num_sensors - self.first - self.count) * words
         base = int(v.frames)
-        L.ncclGroupStart()
+        def chk(rc, what):
+            if rc:
+                raise RuntimeError("%s failed with RCCL status %d" % (what, rc))
+        chk(L.ncclGroupStart(), "ncclGroupStart")
         if lo_words:
-            L.ncclSend(C.c_void_p(base), lo_words, 3, 0, comm, st)
-            L.ncclRecv(C.c_void_p(self.scratch.data_ptr()), lo_words, 3, 0, comm, st)
+            chk(L.ncclSend(C.c_void_p(base), lo_words, 3, 0, comm, st), "ncclSend")
+            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr()), lo_words, 3, 0, comm, st), "ncclRecv")
         if hi_words:
-            L.ncclSend(C.c_void_p(base + 4 * (self.first + self.count) * words), hi_words, 3, 0, comm, st)
-            L.ncclRecv(C.c_void_p(self.scratch.data_ptr() + 4 * lo_words), hi_words, 3, 0, comm, st)
-        L.ncclAllReduce(C.c_void_p(v.counters), C.c_void_p(v.counters), v.num_bricks, 3, 0, comm, st)
-        L.ncclGroupEnd()
+            chk(L.ncclSend(C.c_void_p(base + 4 * (self.first + self.count) * words), hi_words, 3, 0, comm, st), "ncclSend")
+            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr() + 4 * lo_words), hi_words, 3, 0, comm, st), "ncclRecv")
+        chk(L.ncclAllReduce(C.c_void_p(v.counters), C.c_void_p(v.counters), v.num_bricks, 3, 0, comm, st), "ncclAllReduce")
+        chk(L.ncclGroupEnd(), "ncclGroupEnd")
         with torch.cuda.stream(torch.cuda.ExternalStream(int(v.stream), device=self.device)):
             counters = wrap_device_words(v.counters, v.num_bricks, self.device)
             if self.foreign is None:
