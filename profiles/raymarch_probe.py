@@ -1,7 +1,7 @@
 """Developer probe: ray-march the benchmark scene (4 sensors -> 512^3) at 1280x720,
 time the kernel and write PNGs of the colour / shaded / normal views."""
 import sys, time, os, zlib, struct
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 load_package()
 from rgbd_recon_amd import capi, synth
@@ -25,7 +25,8 @@ for i in range(N):
     ctx.synth_inverse_calibration(i, scene.pinhole(i))
 ctx.step(scene.depth, scene.color)
 ctx.enable_timers(True)
-os.makedirs("gpurun_out", exist_ok=True)
+OUTD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+os.makedirs(OUTD, exist_ok=True)
 for mode, name in ((0, "color"), (1, "shaded"), (2, "normal")):
     view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX, shade_mode=mode)
     color, depth, ns = ctx.raymarch(view)
@@ -34,4 +35,4 @@ for mode, name in ((0, "color"), (1, "shaded"), (2, "normal")):
     img = color[..., :3].copy()
     if mode == 2: img = img * 0.5 + 0.5
     img[depth >= 1] = (0.1, 0.1, 0.12)
-    write_png("gpurun_out/raymarch_%s_%d.png" % (name, G), (np.clip(img[::-1], 0, 1) * 255).astype(np.uint8))
+    write_png(OUTD + "/raymarch_%s_%d.png" % (name, G), (np.clip(img[::-1], 0, 1) * 255).astype(np.uint8))
