@@ -387,6 +387,34 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     # Untimed set-up: memory a previous process released is wiped by the driver in the background
     # for a while (a 6 GB free slows the sweep by 4 % for ~0.2 s).  Wait until the
     # sweep time has settled before the warm-up and the timed steps begin.
+    if managed:
+        # The library-managed exchange has never run between two devices (the pool has one GPU per box): its first step is a
+        # trial.  If it fails on ANY rank, every rank goes back to torch.distributed for the exchange and to the redundant
+        # chain, and the line says so -- a scaling run must not be lost to it.
+        ok = 1
+        try:
+            step(False)
+            exchanger.wait()
+            ctx.sync()
+        except Exception as e:  # noqa: BLE001
+            ok = 0
+            sys.stderr.write("[bench rank %d] library-managed exchange failed in its trial step (%s: %s)\n" % (rank, type(e).__name__, str(e)[:200]))
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=shared["fallback"])
+            ok = int(flag[0])
+        if not ok:
+            managed = False
+            try:
+                exchanger.close()
+            except Exception:  # noqa: BLE001
+                pass
+            gather = None
+            ctx.set_sensor_shard(0, 0)
+            ctx.set_halo_staging(-1)
+            ctx.set_stream(main.cuda_stream)
+            exchanger = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=slab_rank, world=slab_count, group=transport["group"],
+                                            via_host=False, ctx=ctx, loopback=loop)
     step(False)
     ctx.settle(3.0)
     if multi:
