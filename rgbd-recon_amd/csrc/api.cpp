@@ -471,7 +471,7 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
 // the compute stream; the chain's stream only waits for the event behind the copy and then runs the same launch a
 // device-resident frame takes.  Page-locked sources (the double frame buffer) are true asynchronous DMA; a pageable
 // source is staged by the runtime before hipMemcpyAsync returns, so the caller may reuse its buffer at once either way.
-static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color)
+static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color, bool caller_buffers)
 {
   const size_t dbytes = depth_frame_bytes_all(ctx), cbytes = color_frame_bytes_all(ctx);
   const int s = ctx->in_set;
@@ -482,6 +482,11 @@ static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color)
   HIPCHK(hipMemcpyAsync(ctx->d_in_depth[s], depth, dbytes, hipMemcpyHostToDevice, cs));
   HIPCHK(hipMemcpyAsync(ctx->d_in_color[s], color, cbytes, hipMemcpyHostToDevice, cs));
   HIPCHK(hipEventRecord(ctx->ev_h2d[s], cs));
+  // rgbdr_upload_frame's contract: the caller may reuse its buffers when the call returns.  A pageable source has been
+  // staged by then; a source the caller page-locked itself is read by the DMA engine asynchronously, so wait for the
+  // copy (not for anything else: the copy stream runs ahead of the passes).  The library's own double buffer is handed
+  // back through rgbdr_map_frame_buffer, which waits for the same event.
+  if (caller_buffers) HIPCHK(hipEventSynchronize(ctx->ev_h2d[s]));
   hipStream_t ps = ctx->pstream();
   HIPCHK(hipStreamWaitEvent(ps, ctx->ev_h2d[s], 0));
   int rc = upload_device(ctx, ctx->d_in_depth[s], ctx->d_in_color[s]);
@@ -492,12 +497,12 @@ static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color)
   return RGBDR_OK;
 }
 
-static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, hipMemcpyKind kind)
+static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, hipMemcpyKind kind, bool caller_buffers = true)
 {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
   HIPCHK(hipSetDevice(ctx->device));
-  return kind == hipMemcpyDeviceToDevice ? upload_device(ctx, depth, color) : upload_host(ctx, depth, color);
+  return kind == hipMemcpyDeviceToDevice ? upload_device(ctx, depth, color) : upload_host(ctx, depth, color, caller_buffers);
 }
 
 int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color)
@@ -534,7 +539,7 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   const int b = ctx->mapped_back;
   if (!ctx->h_depth[b]) return ctx->fail(RGBDR_ERR_STATE, "upload_mapped_frame before map_frame_buffer");
-  int rc = upload_common(ctx, ctx->h_depth[b], ctx->h_color[b], hipMemcpyHostToDevice);  // page-locked: true async DMA
+  int rc = upload_common(ctx, ctx->h_depth[b], ctx->h_color[b], hipMemcpyHostToDevice, false);  // page-locked: true async DMA
   if (rc != RGBDR_OK) return rc;
   HIPCHK(hipEventRecord(ctx->ev_mapped[b], ctx->copy_stream));  // the DMA out of this buffer has drained
   ctx->ev_mapped_rec[b] = true;

@@ -837,6 +837,31 @@ def test_host_frames_queued_back_to_back_without_synchronisation(pkg):
         ctx.close()
 
 
+def test_upload_frame_has_consumed_a_page_locked_source_when_it_returns(pkg):
+    """rgbdr_upload_frame copies its inputs (NetKinectArray::update memcpys the message into the PBO,
+    NetKinectArray.cpp:533-535): the caller may overwrite its buffers as soon as the call returns -- also when it
+    page-locked them itself, in which case the DMA out of them is asynchronous and the library waits for it"""
+    import torch
+    scene, ctx, _ = build(pkg)
+    scene2 = pkg.synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=77, sphere_r=0.7)
+    ctx.step(scene.depth, scene.color)
+    want = ctx.readback_tsdf()
+    d = torch.empty(scene.depth.shape, dtype=torch.float32).pin_memory()
+    c = torch.empty(scene.color.shape, dtype=torch.uint8).pin_memory()
+    for _ in range(5):
+        d.copy_(torch.from_numpy(scene.depth))
+        c.copy_(torch.from_numpy(scene.color))
+        ctx.update(d.numpy(), c.numpy())
+        d.copy_(torch.from_numpy(scene2.depth))               # scribble over the source at once
+        c.copy_(torch.from_numpy(scene2.color))
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        assert same_bits(ctx.readback_tsdf(), want)
+    ctx.close()
+
+
 def test_settle_leaves_a_usable_context(pkg, orc):
     """rgbdr_settle scribbles over the volume by design; the next sweeps (brick-skipping
     included, whose clear-skipping must not trust the scribbled tiles) are correct again"""
