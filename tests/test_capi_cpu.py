@@ -28,6 +28,24 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.capi.SYMBOLS) == names
 
 
+def test_header_is_plain_c_and_the_python_structs_have_the_c_sizes(pkg, tmp_path):
+    """include/rgbdr.h is the boundary a C / cgo / JNI host binds: it must compile as C99 without extensions, and the
+    ctypes mirrors in capi.py must have the C compiler's struct sizes (a drifted field would shift everything behind it)"""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rgbdr.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rgbdr_config), '
+                   'sizeof(rgbdr_geometry), sizeof(rgbdr_lut), sizeof(rgbdr_view), sizeof(rgbdr_tsdf_device_view), '
+                   'sizeof(rgbdr_image_device_view), sizeof(rgbdr_shard_device_view)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
+    capi = pkg.capi
+    mirrors = [capi.Config, capi.Geometry, capi.Lut, capi.View, capi.TsdfDeviceView, capi.ImageDeviceView, capi.ShardDeviceView]
+    assert sizes == [C.sizeof(m) for m in mirrors], (sizes, [C.sizeof(m) for m in mirrors])
+
+
 def test_config_struct_size_is_checked(pkg):
     capi = pkg.capi
     cfg = capi.make_config(1, (16, 16))
