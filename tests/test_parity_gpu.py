@@ -1000,7 +1000,8 @@ def test_random_call_sequences_on_a_slab(pkg, orc, seed, slab):
 
 def run_random_sequence(pkg, orc, seed, slab):
     """state machine check: random interleavings of the setters, both sweeps, both schedules,
-    store elision, background skip, inverse-LUT re-uploads, settle and two different frames -- after every frame the volume, the images
+    store elision, background skip, inverse-LUT re-uploads, settle, two different frames and the four ways a frame can
+    arrive (rgbdr_step, pageable upload, the page-locked double buffer, device-resident) -- after every frame the volume, the images
     and the brick table equal the oracle run with the settings in force"""
     rng = np.random.default_rng(seed)
     kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
@@ -1014,6 +1015,10 @@ def run_random_sequence(pkg, orc, seed, slab):
     cur = 0
     G = 48 if slab else 32
     inv = list(inv)
+    import torch
+    dev_frames = [(torch.from_numpy(np.ascontiguousarray(s.depth)).cuda(), torch.from_numpy(np.ascontiguousarray(s.color)).cuda())
+                  for s in scenes]
+    torch.cuda.synchronize()
     for step_no in range(28):
         op = rng.integers(0, 16)
         if op == 0:
@@ -1056,7 +1061,24 @@ def run_random_sequence(pkg, orc, seed, slab):
         else:
             cur = int(rng.integers(0, 2))
         sc = scenes[cur]
-        ctx.step(sc.depth, sc.color)
+        how = int(rng.integers(0, 4))                  # the frame arrives by a different road every time
+        if how == 0:
+            ctx.step(sc.depth, sc.color)
+        else:
+            if how == 1:                               # pageable host buffers
+                ctx.update(sc.depth, sc.color)
+            elif how == 2:                             # the library's page-locked double buffer
+                md, mc = ctx.map_frame_buffer()
+                md[:] = sc.depth.view(np.uint8).reshape(-1)
+                mc[:] = sc.color.reshape(-1)
+                ctx.upload_mapped_frame()
+            else:                                      # already in HBM (the buffers may go once the call is enqueued:
+                dd, dc = dev_frames[cur]               # these stay alive for the whole sequence)
+                ctx.update_device(dd.data_ptr(), dc.data_ptr())
+            ctx.clear_occupied_bricks()
+            ctx.process_textures()
+            ctx.update_occupied_bricks()
+            ctx.integrate()
         ref = oracle_run(orc, sc, ctx, inv, limit=state["limit"], use_bricks=state["bricks"], filter_textures=state["filt"],
                          processed=state["proc"], refine=state["refine"], min_voxels=state["min_voxels"])
         assert same_bits(ctx.readback_tsdf(), ref["tsdf"][z0:z1]), (seed, step_no, int(op), state)
