@@ -13,7 +13,11 @@
  * stream except the readbacks / getters, which synchronise it.
  *
  * Every function returns RGBDR_OK (0) or a negative rgbdr_status; nothing throws
- * across the ABI.  rgbdr_last_error() returns the message of the last failure.
+ * across the ABI (every entry point contains C++ exceptions: std::bad_alloc comes
+ * back as RGBDR_ERR_NO_MEMORY).  rgbdr_last_error() returns the message of the
+ * last failure.  Grids are bounded to 32768 voxels per axis and fewer than 2^31
+ * 8x8x8 tiles (rgbdr_compute_geometry refuses others), so no size computed from a
+ * configuration can wrap.
  */
 #ifndef RGBDR_H
 #define RGBDR_H
@@ -41,7 +45,9 @@ typedef enum {
   RGBDR_ERR_NO_DEVICE = -3,        /* no HIP device / HIP runtime failure at create: the product never falls back to a CPU path */
   RGBDR_ERR_HIP = -4,              /* reference: exception thrown from the GL-error callback, source/kinect_client.cpp:1051 */
   RGBDR_ERR_IO = -5,               /* reference: exit(1) on missing stream (NetKinectArray.cpp:735-738), NULL deref on missing LUT */
-  RGBDR_ERR_STATE = -6             /* call order violated (e.g. integrate before calibration was set) */
+  RGBDR_ERR_STATE = -6,            /* call order violated (e.g. integrate before calibration was set) */
+  RGBDR_ERR_NO_MEMORY = -7         /* a host-side table could not be allocated: C++ exceptions never cross this boundary (the
+                                      reference lets std::bad_alloc end the process) */
 } rgbdr_status;
 
 /* flags: NetKinectArray::m_filter_textures / m_use_processed_depth / m_refine_bound
@@ -192,7 +198,10 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* cv_xyz, c
 /* CalibVolumes::loadInverseCalibs (CalibVolumes.cpp:64-80): cv_xyz_inv, 16 B records. */
 int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* cv_xyz_inv);
 /* Same, from files in the reference's on-disk format (calibration_volume.hpp:62-79);
- * any path may be NULL to skip it. */
+ * any path may be NULL to skip it.  The header of a file is checked against the bytes
+ * the file holds before anything is sized by it: a truncated payload, a zero or
+ * absurd resolution is RGBDR_ERR_IO (the reference ignores its fread results) and
+ * the context keeps the calibration it had. */
 int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv_xyz,
                                  const char* path_cv_uv, const char* path_cv_xyz_inv);
 /* CalibrationInverter::calculateInverseVolumes (framework/calibration/

@@ -15,6 +15,7 @@ ERR_NO_DEVICE = -3
 ERR_HIP = -4
 ERR_IO = -5
 ERR_STATE = -6
+ERR_NO_MEMORY = -7
 
 FLAG_FILTER, FLAG_PROCESSED, FLAG_REFINE, FLAG_USE_BRICKS = 1, 2, 4, 8
 FLAGS_DEFAULT = 15

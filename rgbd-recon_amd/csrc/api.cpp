@@ -172,6 +172,33 @@ int sync_all(rgbdr_ctx* ctx)
 
 }  // namespace rgbdr
 
+namespace rgbdr {
+int contain_exception(rgbdr_ctx* ctx) noexcept
+{
+  int code = RGBDR_ERR_STATE;
+  const char* what = "a C++ exception of unknown type was contained at the C boundary";
+  char buf[256];
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    code = RGBDR_ERR_NO_MEMORY;
+    what = "host memory exhausted (std::bad_alloc contained at the C boundary)";
+  } catch (const std::length_error&) {
+    code = RGBDR_ERR_NO_MEMORY;
+    what = "host table larger than a container can hold (std::length_error contained at the C boundary)";
+  } catch (const std::exception& e) {
+    std::snprintf(buf, sizeof buf, "C++ exception contained at the C boundary: %s", e.what());
+    what = buf;
+  } catch (...) {
+  }
+  try {
+    (ctx ? ctx->err : g_create_error) = what;
+  } catch (...) {  // not even the message fits: the status code still says what happened
+  }
+  return code;
+}
+}  // namespace rgbdr
+
 extern "C" {
 
 const char* rgbdr_version(void) { return "rgbdr-hip 0.1 (gfx950)"; }
@@ -186,6 +213,7 @@ const char* rgbdr_status_string(int s)
     case RGBDR_ERR_HIP: return "HIP runtime error";
     case RGBDR_ERR_IO: return "I/O error";
     case RGBDR_ERR_STATE: return "call order violated";
+    case RGBDR_ERR_NO_MEMORY: return "host memory exhausted";
     default: return "unknown status";
   }
 }
@@ -193,13 +221,14 @@ const char* rgbdr_status_string(int s)
 const char* rgbdr_last_error(const rgbdr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int rgbdr_compute_geometry(const rgbdr_config* cfg, rgbdr_geometry* out)
-{
+try {
   if (!cfg || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   return compute_geometry(*cfg, out, &g_create_error);
 }
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_brick_voxel_range(const rgbdr_config* cfg, int axis, int brick, int32_t* first, int32_t* last)
-{
+try {
   if (!cfg || !first || !last || axis < 0 || axis > 2) return RGBDR_ERR_INVALID_ARGUMENT;
   rgbdr_geometry g;
   int rc = compute_geometry(*cfg, &g, &g_create_error);
@@ -212,23 +241,26 @@ int rgbdr_brick_voxel_range(const rgbdr_config* cfg, int axis, int brick, int32_
   *last = bt.last[axis][brick];
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_slab_range(int tiles_z, int count, int rank, int* t0, int* t1)
-{
+try {
   if (!t0 || !t1) return RGBDR_ERR_INVALID_ARGUMENT;
   return slab_range(tiles_z, count, rank, t0, t1);
 }
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_camera_position(const rgbdr_lut* cv_xyz, float out[3])
-{
+try {
   if (!cv_xyz || !cv_xyz->data || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   if (cv_xyz->res[0] < 1 || cv_xyz->res[1] < 1 || cv_xyz->res[2] < 1) return RGBDR_ERR_INVALID_ARGUMENT;
   camera_position((const float*)cv_xyz->data, cv_xyz->res, out);
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
-{
+try {
   auto bad = [&](int code, const std::string& m) {
     g_create_error = m;
     return code;
@@ -257,6 +289,10 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
   if (hipSetDevice(device_id) != hipSuccess) return bad(RGBDR_ERR_NO_DEVICE, "hipSetDevice failed");
 
   rgbdr_ctx* ctx = new rgbdr_ctx();
+  struct Unwind {  // an exception below must not leak the half-made context (the handler runs after the locals are gone)
+    rgbdr_ctx* c;
+    ~Unwind() { if (c) rgbdr_destroy(c); }
+  } unwind{ctx};
   ctx->cfg = *cfg;
   if (ctx->cfg.slab_count <= 0) {
     ctx->cfg.slab_count = 1;
@@ -265,6 +301,7 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
   ctx->device = device_id;
   auto cleanup = [&](int code) {
     g_create_error = ctx->err;
+    unwind.c = nullptr;
     rgbdr_destroy(ctx);
     return code;
   };
@@ -359,9 +396,11 @@ int rgbdr_create(const rgbdr_config* cfg, int device_id, rgbdr_ctx** out)
     ctx->err = "device initialisation failed";
     return cleanup(RGBDR_ERR_HIP);
   }
+  unwind.c = nullptr;
   *out = ctx;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 void rgbdr_destroy(rgbdr_ctx* ctx)
 {
@@ -506,16 +545,18 @@ static int upload_common(rgbdr_ctx* ctx, const void* depth, const void* color, h
 }
 
 int rgbdr_upload_frame(rgbdr_ctx* ctx, const void* depth, const void* color)
-{
+try {
   return upload_common(ctx, depth, color, hipMemcpyHostToDevice);
 }
+RGBDR_CONTAIN(ctx)
 int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth, const void* color)
-{
+try {
   return upload_common(ctx, depth, color, hipMemcpyDeviceToDevice);
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_map_frame_buffer(rgbdr_ctx* ctx, void** depth, void** color, size_t* depth_bytes, size_t* color_bytes)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!depth || !color) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null output pointer");
   HIPCHK(hipSetDevice(ctx->device));
@@ -533,9 +574,10 @@ int rgbdr_map_frame_buffer(rgbdr_ctx* ctx, void** depth, void** color, size_t* d
   if (color_bytes) *color_bytes = color_frame_bytes_all(ctx);
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   const int b = ctx->mapped_back;
   if (!ctx->h_depth[b]) return ctx->fail(RGBDR_ERR_STATE, "upload_mapped_frame before map_frame_buffer");
@@ -546,9 +588,10 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx)
   ctx->mapped_back = 1 - b;  // swapBuffers
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->clear_pending) {
     // the counting moves to the other buffer (zeroed by the first kernel of process_textures, or by whoever reads
@@ -563,6 +606,7 @@ int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx)
   ctx->clear_pending = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
@@ -603,7 +647,7 @@ int rgbdr::flush_clear(rgbdr_ctx* ctx)
 extern "C" {
 
 int rgbdr_process_textures(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->frame_uploaded) return ctx->fail(RGBDR_ERR_STATE, "process_textures before any frame was uploaded");
   for (int i = 0; i < nsens(ctx); ++i)
@@ -709,9 +753,10 @@ int rgbdr_process_textures(rgbdr_ctx* ctx)
   ctx->shard_pending = p.count < p.N;  // the other sensors' frames and the other ranks' brick counts are still to come
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ctx->shard_pending)
     return ctx->fail(RGBDR_ERR_STATE, "update_occupied_bricks on a sensor shard before rgbdr_shard_allgather: the brick counters hold "
@@ -741,9 +786,10 @@ int rgbdr_update_occupied_bricks(rgbdr_ctx* ctx)
   ctx->mask_valid = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ids && count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null id list");
   const size_t nb = (size_t)ctx->geo.num_bricks;
@@ -758,9 +804,10 @@ int rgbdr_set_occupied_bricks(rgbdr_ctx* ctx, const uint32_t* ids, size_t count)
   ctx->mask_valid = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_integrate(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "integrate before process_textures");
   if (ctx->shard_pending)
@@ -896,9 +943,10 @@ int rgbdr_integrate(rgbdr_ctx* ctx)
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_step(rgbdr_ctx* ctx, const void* depth, const void* color)
-{
+try {
   int rc = rgbdr_upload_frame(ctx, depth, color);
   if (rc == RGBDR_OK) rc = rgbdr_clear_occupied_bricks(ctx);
   if (rc == RGBDR_OK) rc = rgbdr_process_textures(ctx);
@@ -906,16 +954,18 @@ int rgbdr_step(rgbdr_ctx* ctx, const void* depth, const void* color)
   if (rc == RGBDR_OK) rc = rgbdr_integrate(ctx);
   return rc;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_sync(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   return sync_all(ctx);
 }
+RGBDR_CONTAIN(ctx)
 
 // ---------------------------------------------------------------------------
 int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "voxel size must be > 0");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
@@ -931,9 +981,10 @@ int rgbdr_set_voxel_size(rgbdr_ctx* ctx, float size)
   }
   return alloc_volume(ctx);
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(size > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "brick size must be > 0");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
@@ -951,14 +1002,16 @@ int rgbdr_set_brick_size(rgbdr_ctx* ctx, float size)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!(limit > 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be > 0");
   ctx->cfg.tsdf_limit = limit;
   return bump_clear_epoch(ctx);  // tiles cleared to the old -limit no longer count as cleared
 }
+RGBDR_CONTAIN(ctx)
 
 static int set_flag(rgbdr_ctx* ctx, uint32_t flag, int on)
 {
@@ -971,7 +1024,7 @@ static int set_flag(rgbdr_ctx* ctx, uint32_t flag, int on)
 }
 int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_USE_BRICKS, on); }
 int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   int rc = materialise_mask(ctx);  // (the lazy filter is a single-stream shortcut)
   if (rc == RGBDR_OK) rc = sync_all(ctx);
@@ -980,6 +1033,7 @@ int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on)
   ctx->ev_pre_rec[0] = ctx->ev_pre_rec[1] = ctx->ev_int_rec[0] = ctx->ev_int_rec[1] = false;
   return set_flag(ctx, RGBDR_FLAG_PIPELINE, on);
 }
+RGBDR_CONTAIN(ctx)
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_ELIDE_STORES, on); }
 int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_SKIP_BACKGROUND, on); }
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
@@ -987,11 +1041,12 @@ int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RG
 int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }
 
 int rgbdr_set_min_voxels_per_brick(rgbdr_ctx* ctx, uint32_t n)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   ctx->cfg.min_voxels_per_brick = n;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 float rgbdr_get_brick_size(const rgbdr_ctx* ctx) { return ctx ? ctx->geo.brick_size : 0.0f; }
 uint32_t rgbdr_num_bricks(const rgbdr_ctx* ctx) { return ctx ? (uint32_t)ctx->geo.num_bricks : 0u; }
@@ -1006,23 +1061,25 @@ float rgbdr_occupied_ratio(rgbdr_ctx* ctx)
 }
 
 int rgbdr_get_geometry(const rgbdr_ctx* ctx, rgbdr_geometry* out)
-{
+try {
   if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   *out = ctx->geo;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_get_camera_position(const rgbdr_ctx* ctx, int sensor, float out[3])
-{
+try {
   if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= ctx->cfg.num_sensors || !ctx->have_calib[sensor]) return RGBDR_ERR_OUT_OF_RANGE;
   std::memcpy(out, ctx->cam_pos[sensor], 12);
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 // ---------------------------------------------------------------------------
 int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
@@ -1043,9 +1100,10 @@ int rgbdr_readback_tsdf(rgbdr_ctx* ctx, float* dst)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
@@ -1069,9 +1127,10 @@ int rgbdr_readback_image(rgbdr_ctx* ctx, int which, int sensor, float* dst)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device_view* out)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!out) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null view");
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
@@ -1107,9 +1166,10 @@ int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device
   *out = v;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
@@ -1120,9 +1180,10 @@ int rgbdr_readback_color(rgbdr_ctx* ctx, int sensor, uint8_t* dst)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
-{
+try {
   if (ctx) { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
@@ -1132,9 +1193,10 @@ int rgbdr_readback_brick_counters(rgbdr_ctx* ctx, uint32_t* dst)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* count, float* ratio)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!count) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null count");
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "get_occupied before update_occupied_bricks");
@@ -1156,9 +1218,10 @@ int rgbdr_get_occupied(rgbdr_ctx* ctx, uint32_t* ids, size_t capacity, size_t* c
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out)
-{
+try {
   if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   out->base = ctx->d_tsdf_base;
   out->owned = ctx->d_tsdf_owned;
@@ -1167,23 +1230,26 @@ int rgbdr_device_tsdf(rgbdr_ctx* ctx, rgbdr_tsdf_device_view* out)
   out->halo_layers = ctx->halo;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr)
-{
+try {
   if (!ctx || !ptr) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   *ptr = ctx->frame_buf(ctx->rbuf) + (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sensor;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 void* rgbdr_stream(rgbdr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"

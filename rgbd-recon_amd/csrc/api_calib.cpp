@@ -13,7 +13,7 @@ using namespace rgbdr;
 extern "C" {
 // ---------------------------------------------------------------------------
 int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, const rgbdr_lut* uv)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!xyz || !uv || !xyz->data || !uv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null calibration volume");
@@ -67,6 +67,7 @@ int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, cons
   ctx->have_calib[sensor] = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"
 LutExtent rgbdr::lut_extent(const rgbdr_ctx* ctx)
@@ -185,7 +186,7 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
 }
 
 int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* inv)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!inv || !inv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null inverse calibration volume");
@@ -272,17 +273,32 @@ int rgbdr_set_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* i
   ctx->inv_set[sensor] = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 static int read_lut_file(rgbdr_ctx* ctx, const char* path, size_t rec_bytes, rgbdr_lut* lut, std::vector<char>* buf)
 {
   FILE* f = std::fopen(path, "rb");
   if (!f) return ctx->fail(RGBDR_ERR_IO, std::string("cannot open ") + path);
   bool ok = std::fread(lut->res, 4, 3, f) == 3 && std::fread(lut->depth_limits, 4, 2, f) == 2;
-  size_t n = 0;
   if (ok) {
-    n = (size_t)lut->res[0] * lut->res[1] * lut->res[2] * rec_bytes;
-    buf->resize(n);
-    ok = std::fread(buf->data(), 1, n, f) == n;
+    // the header is checked against what the file holds BEFORE anything is sized by it: a corrupt or truncated file is
+    // an I/O error, not an attempt to allocate res[0] * res[1] * res[2] records (the reference reads header and payload
+    // with its fread results ignored: calibration_volume.hpp:60-78)
+    long here = std::ftell(f), end = -1;
+    if (here >= 0 && std::fseek(f, 0, SEEK_END) == 0) end = std::ftell(f);
+    ok = here >= 0 && end >= here && std::fseek(f, here, SEEK_SET) == 0;
+    const unsigned __int128 want = (unsigned __int128)lut->res[0] * lut->res[1] * lut->res[2] * rec_bytes;
+    if (ok && (lut->res[0] == 0 || lut->res[1] == 0 || lut->res[2] == 0 || want > (unsigned __int128)(end - here))) {
+      std::fclose(f);
+      return ctx->fail(RGBDR_ERR_IO, std::string(path) + ": header says " + std::to_string(lut->res[0]) + " x " + std::to_string(lut->res[1]) +
+                                         " x " + std::to_string(lut->res[2]) + " records of " + std::to_string(rec_bytes) + " bytes, the file holds " +
+                                         std::to_string(end - here) + " bytes after the header");
+    }
+    if (ok) {
+      const size_t n = (size_t)want;
+      buf->resize(n);
+      ok = std::fread(buf->data(), 1, n, f) == n;
+    }
   }
   std::fclose(f);
   if (!ok) return ctx->fail(RGBDR_ERR_IO, std::string("short read from ") + path);
@@ -291,7 +307,7 @@ static int read_lut_file(rgbdr_ctx* ctx, const char* path, size_t rec_bytes, rgb
 }
 
 int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* pxyz, const char* puv, const char* pinv)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if ((pxyz == nullptr) != (puv == nullptr))
     return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz and cv_uv must be given together");
@@ -315,9 +331,10 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* pxyz, c
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!cam) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null pinhole");
@@ -350,6 +367,7 @@ int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinh
   ctx->inv_set[sensor] = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 // CalibrationInverter::calculateInverseVolumes on the device (kernels_invert.hip)
 static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res[3], int window, InvertParams* p)
@@ -375,7 +393,7 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
 }
 
 int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "compute_inverse_calibration before set_calibration");
@@ -439,9 +457,10 @@ int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
   ctx->inv_set[sensor] = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3], int window, float* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!res || !dst || res[0] < 1 || res[1] < 1 || res[2] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad resolution / destination");
@@ -467,9 +486,10 @@ int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3]
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z1, float* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
@@ -501,9 +521,10 @@ int rgbdr_readback_inverse_calibration(rgbdr_ctx* ctx, int sensor, int z0, int z
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->d_lut_tiled) return ctx->fail(RGBDR_ERR_STATE, "settle before the inverse LUTs were set");
   HIPCHK(hipSetDevice(ctx->device));
@@ -531,14 +552,16 @@ int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
   if (stream_ms) *stream_ms = cur;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ms) std::memcpy(ms, ctx->arena_probe_ms, sizeof(ctx->arena_probe_ms));
   if (trials) *trials = ctx->arena_trials;
   if (chosen) *chosen = ctx->arena_chosen;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(nullptr)
 
 }  // extern "C"

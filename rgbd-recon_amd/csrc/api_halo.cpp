@@ -104,7 +104,7 @@ int check_slab(rgbdr_ctx* ctx, int buffer)
 
 extern "C" {
 int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t* bytes)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (buffer < 0 || buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0 or 1");
   if (ctx->halo <= 0) return ctx->fail(RGBDR_ERR_STATE, "halo staging needs a Z-slab context (slab_count > 1)");
@@ -120,9 +120,10 @@ int rgbdr_halo_staging(rgbdr_ctx* ctx, int buffer, void** lo, void** hi, size_t*
   if (bytes) *bytes = face;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (buffer > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "halo staging buffer must be 0, 1 or -1");
   if (buffer >= 0 && (!ctx->d_stage[buffer][0] || !ctx->d_stage[buffer][1]))
@@ -130,9 +131,10 @@ int rgbdr_set_halo_staging(rgbdr_ctx* ctx, int buffer)
   ctx->stage_target = buffer < 0 ? -1 : buffer;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_readback_tile_layers(rgbdr_ctx* ctx, int first, int count, float* dst)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null destination");
   const int resident = ctx->geo.slab_tile_z1 - ctx->geo.slab_tile_z0 + 2 * ctx->halo;
@@ -142,15 +144,17 @@ int rgbdr_readback_tile_layers(rgbdr_ctx* ctx, int first, int count, float* dst)
                    hipMemcpyDeviceToHost));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi, int buffer, void* hip_stream)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
   { int rc_ = check_slab(ctx, buffer); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
   return exchange_on(ctx, nccl_comm, peer_lo, peer_hi, buffer, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
 }
+RGBDR_CONTAIN(ctx)
 
 // ---- the managed form: staging sets, side stream and events owned by the context ---------------------
 // Per step k (b = k mod 2), like rgbd-recon_amd/dist.py:HaloExchanger:
@@ -162,7 +166,7 @@ int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_h
 // The halo layers are only ever written by the side stream and only read after wait(), so a transfer
 // overlaps the whole next frame.
 int rgbdr_halo_begin_step(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   { int rc_ = check_slab(ctx, -1); if (rc_ != RGBDR_OK) return rc_; }
   HIPCHK(hipSetDevice(ctx->device));
@@ -184,9 +188,10 @@ int rgbdr_halo_begin_step(rgbdr_ctx* ctx)
   ctx->halo_staged = false;  // set by the rgbdr_integrate that fills set b
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
   if (!ctx->halo_begun) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_exchange_async before rgbdr_halo_begin_step + rgbdr_integrate");
@@ -206,6 +211,7 @@ int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int 
   ctx->halo_last = b;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 // ---- the pre_* chain sharded by sensor over the ranks of a slab job ---------------------------------------
 // Every rank of a Z-slab job needs the frame images of ALL sensors (a voxel may project anywhere), and with the chain
@@ -216,7 +222,7 @@ int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int 
 // rank counted its own sensors' pixels) completes the frame on every rank -- the alternative SURVEY.md 8(e) names.  Both
 // run on the stream the chain ran on, so under RGBDR_FLAG_PIPELINE they overlap the sweep of the frame before.
 int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   const int N = nsens(ctx);
   const int old_first = ctx->shard_first, old_count = ctx->shard_count;
@@ -235,9 +241,10 @@ int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count)
   }
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out)
-{
+try {
   if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_view before process_textures");
   const int N = nsens(ctx);
@@ -252,9 +259,10 @@ int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out)
   ctx->shard_pending = false;  // the host runs the collectives itself, on out->stream
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather before process_textures");
@@ -287,14 +295,16 @@ int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
   ctx->shard_pending = false;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_halo_wait(rgbdr_ctx* ctx)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ctx->halo_last < 0) return RGBDR_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done[ctx->halo_last], 0));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"

@@ -102,7 +102,7 @@ int rgbdr::skip_sweep(rgbdr_ctx* ctx, IntegrateParams& p)
 extern "C" {
 
 int rgbdr_readback_skip_tables(rgbdr_ctx* ctx, int which, void* dst, size_t bytes)
-{
+try {
   if (!ctx || !dst) return RGBDR_ERR_INVALID_ARGUMENT;
   uint64_t a = 0, b = 0;
   int rc = rgbdr_skipped_pairs(ctx, &a, &b);  // state checks + tables of the current frame (verdict bytes included)
@@ -126,9 +126,10 @@ int rgbdr_readback_skip_tables(rgbdr_ctx* ctx, int which, void* dst, size_t byte
   HIPCHK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total)
-{
+try {
   if (!ctx || !skipped || !total) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "skipped_pairs before process_textures");
   const int N = nsens(ctx);
@@ -153,5 +154,6 @@ int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total)
   *total = npairs;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"

@@ -74,29 +74,32 @@ void destroy_timers(rgbdr_ctx* ctx)
 extern "C" {
 
 int rgbdr_set_timer_detail(rgbdr_ctx* ctx, int detail)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   ctx->timer_detail = detail < 1 ? 0 : (detail < 2 ? 1 : 2);
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_enable_timers(rgbdr_ctx* ctx, int on)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   ctx->timers = on != 0;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_enable_timer_accumulation(rgbdr_ctx* ctx, int on)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   ctx->accumulate = on != 0;
   if (on) ctx->timers = true;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint32_t* count)
-{
+try {
   if (!ctx || !name || !total_ns || !count) return RGBDR_ERR_INVALID_ARGUMENT;
   *total_ns = 0;
   *count = 0;
@@ -123,9 +126,10 @@ int rgbdr_timer_stats(rgbdr_ctx* ctx, const char* name, uint64_t* total_ns, uint
   *total_ns = (uint64_t)total;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns)
-{
+try {
   if (!ctx || !name || !ns) return RGBDR_ERR_INVALID_ARGUMENT;
   auto it = ctx->tm.find(name);
   if (it == ctx->tm.end() || !it->second.recorded) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, std::string("no timer ") + name);
@@ -136,5 +140,6 @@ int rgbdr_timer_ns(rgbdr_ctx* ctx, const char* name, uint64_t* ns)
   *ns = (uint64_t)((double)ms * 1.0e6);
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"

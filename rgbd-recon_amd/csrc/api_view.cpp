@@ -57,7 +57,7 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
 }
 
 int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
@@ -71,6 +71,7 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 // uniforms + resident data of the ray-marcher for `v`; runs the depth peels when asked
 static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
@@ -163,7 +164,7 @@ static int download_view(rgbdr_ctx* ctx, const RaymarchParams& p, float* color, 
 }
 
 int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ctx->cfg.slab_count > 1)
     return ctx->fail(RGBDR_ERR_STATE, "a Z slab cannot ray-march alone: use rgbdr_raymarch_find / _shade across the slabs");
@@ -176,9 +177,10 @@ int rgbdr_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* dep
   LAUNCHCHK("raymarch");
   return download_view(ctx, p, color, depth, num_samples);
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_raymarch_find(rgbdr_ctx* ctx, const rgbdr_view* v, void** first_hit_device)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   RaymarchParams p;
   int rc = prepare_raymarch(ctx, v, &p);
@@ -191,9 +193,10 @@ int rgbdr_raymarch_find(rgbdr_ctx* ctx, const rgbdr_view* v, void** first_hit_de
   if (first_hit_device) *first_hit_device = p.khit;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, float* depth, float* num_samples)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!v || ctx->view_w != v->width || ctx->view_h != v->height)
     return ctx->fail(RGBDR_ERR_STATE, "raymarch_shade needs rgbdr_raymarch_find of the same view first");
@@ -208,9 +211,10 @@ int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* v, float* color, floa
   LAUNCHCHK("raymarch_shade");
   return download_view(ctx, p, color, depth, num_samples);
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "fill_colors before raymarch");
   HIPCHK(hipSetDevice(ctx->device));
@@ -241,9 +245,10 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* color, const float* depth)
-{
+try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (width < 1 || height < 1 || !color || !depth) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view frame");
   HIPCHK(hipSetDevice(ctx->device));
@@ -258,5 +263,6 @@ int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* 
   ctx->view_h = height;
   return RGBDR_OK;
 }
+RGBDR_CONTAIN(ctx)
 
 }  // extern "C"

@@ -180,6 +180,15 @@ struct rgbdr_ctx {
   }
 };
 
+// "Nothing throws" (include/rgbdr.h:15): every int-returning entry point is a function-try-block that ends in
+// RGBDR_CONTAIN -- a std::bad_alloc / std::length_error from a host-side table (a corrupt LUT header, a grid of
+// billions of voxels) comes back as RGBDR_ERR_NO_MEMORY, anything else as RGBDR_ERR_STATE with what() as the message.
+namespace rgbdr {
+int contain_exception(rgbdr_ctx* ctx) noexcept;  // only inside a catch block
+}
+#define RGBDR_CONTAIN(ctx) \
+  catch (...) { return rgbdr::contain_exception(ctx); }
+
 #define HIPCHK(expr)                                                                                       \
   do {                                                                                                     \
     hipError_t e_ = (expr);                                                                                \

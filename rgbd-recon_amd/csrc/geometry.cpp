@@ -36,12 +36,17 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
     if (!(cfg.bbox_max[a] > cfg.bbox_min[a])) return fail("bbox_max must exceed bbox_min on every axis");
 
   for (int a = 0; a < 3; ++a) {
-    if (cfg.res_override[a] > 0)
-      g->res_volume[a] = cfg.res_override[a];
-    else
-      g->res_volume[a] = (int)std::ceil((cfg.bbox_max[a] - cfg.bbox_min[a]) / cfg.voxel_size);
-    if (g->res_volume[a] <= 0) return fail("empty volume");
+    // (the quotient is compared as a float: converting a value beyond INT_MAX, an infinity or a NaN is undefined)
+    const float cells = cfg.res_override[a] > 0 ? (float)cfg.res_override[a] : std::ceil((cfg.bbox_max[a] - cfg.bbox_min[a]) / cfg.voxel_size);
+    if (!(cells >= 1.0f)) return fail("empty volume");
+    if (!(cells <= (float)kMaxRes)) return fail("more than 32768 voxels along an axis");
+    g->res_volume[a] = (int)cells;
   }
+  // tile indices are 31-bit (bit 31 of a work-list entry is the whole-tile flag, kernels_bricks.hip) and every size below
+  // is computed from these counts: 2^31 tiles = 2^40 voxels = 4 TiB of TSDF, fourteen times an MI355X's HBM
+  if ((long long)((g->res_volume[0] + kTile - 1) / kTile) * ((g->res_volume[1] + kTile - 1) / kTile) * ((g->res_volume[2] + kTile - 1) / kTile) >=
+      (1ll << 31))
+    return fail("volume of 2^31 or more 8x8x8 tiles");
   // setBrickSize: m_brick_size = m_voxel_size * round(size / m_voxel_size)
   float ratio = std::round(cfg.brick_size / cfg.voxel_size);
   if (ratio < 1.0f) ratio = 1.0f;

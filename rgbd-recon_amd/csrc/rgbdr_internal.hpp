@@ -13,6 +13,7 @@ namespace rgbdr {
 constexpr int kTile = RGBDR_TILE;          // 8
 constexpr int kTileVoxels = 512;           // 8*8*8
 constexpr int kMaxSensors = RGBDR_MAX_SENSORS;
+constexpr int kMaxRes = 32768;           // voxels along an axis (compute_geometry)
 
 // ---- host-only geometry (geometry.cpp) -------------------------------------
 int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err);

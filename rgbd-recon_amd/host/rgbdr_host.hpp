@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -181,6 +182,7 @@ inline void check(rgbdr_ctx* ctx, int rc)
   switch (rc) {
     case RGBDR_ERR_INVALID_ARGUMENT: throw std::invalid_argument(msg);
     case RGBDR_ERR_OUT_OF_RANGE: throw std::out_of_range(msg);
+    case RGBDR_ERR_NO_MEMORY: throw std::bad_alloc();  // what the reference's own containers would have thrown
     default: throw std::runtime_error(msg);
   }
 }

@@ -67,6 +67,64 @@ def test_invalid_config_rejected(pkg, field, value):
     assert capi.lib().rgbdr_status_string(rc) == b"invalid argument"
 
 
+@pytest.mark.parametrize("voxel,res,why", [(1e-6, (0, 0, 0), b"32768"), (1e-12, (0, 0, 0), b"32768"), (float("inf"), (0, 0, 0), b"empty"),
+                                           (0.01, (40000, 8, 8), b"32768"), (0.01, (32768, 32768, 1024), b"2^31"),
+                                           (0.01, (32768, 32768, 32768), b"2^31")])
+def test_grid_sizes_beyond_the_index_types_are_refused(pkg, voxel, res, why):
+    """compute_geometry bounds what every later size is computed from: a quotient beyond INT_MAX is never converted, an axis
+    holds at most 32768 voxels and a volume fewer than 2^31 tiles (tile indices are 31-bit) -- nothing wraps into a small
+    allocation"""
+    capi = pkg.capi
+    cfg = capi.make_config(1, (16, 16), voxel_size=voxel, res_override=res)
+    g = capi.Geometry()
+    assert capi.lib().rgbdr_compute_geometry(C.byref(cfg), C.byref(g)) == capi.ERR_INVALID_ARGUMENT
+    assert why in capi.lib().rgbdr_last_error(None)
+    h = C.c_void_p()
+    assert capi.lib().rgbdr_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_INVALID_ARGUMENT and not h.value
+    cfg = capi.make_config(1, (16, 16), res_override=(32768, 8, 8))          # the bound itself is a valid grid
+    assert capi.lib().rgbdr_compute_geometry(C.byref(cfg), C.byref(g)) == capi.OK and list(g.tiles) == [4096, 1, 1]
+
+
+def test_status_codes_of_the_header_the_library_and_the_binding_agree(pkg):
+    capi = pkg.capi
+    text = open(os.path.join(ROOT, "include", "rgbdr.h")).read()
+    codes = {n: int(v) for n, v in re.findall(r"^\s*RGBDR_(OK|ERR_[A-Z_]+) = (-?\d+)", text, flags=re.M)}
+    assert len(codes) == 8 and sorted(codes.values()) == list(range(-7, 1))
+    for name, value in codes.items():
+        assert getattr(capi, name) == value, name
+        assert capi.lib().rgbdr_status_string(value) != b"unknown status", name
+    assert capi.lib().rgbdr_status_string(-8) == b"unknown status"
+    assert capi.lib().rgbdr_status_string(capi.ERR_NO_MEMORY) == b"host memory exhausted"
+
+
+def test_no_exception_can_cross_the_c_boundary():
+    """include/rgbdr.h promises that nothing throws: every int-returning entry point with a body of its own is a
+    function-try-block closed by RGBDR_CONTAIN (context.hpp: std::bad_alloc -> RGBDR_ERR_NO_MEMORY, others -> RGBDR_ERR_STATE
+    with what() as the message); one-line forwarders call such a function or a helper that only assigns a message"""
+    import glob
+    guarded = 0
+    for path in sorted(glob.glob(os.path.join(ROOT, "rgbd-recon_amd", "csrc", "api*.cpp"))):
+        lines = open(path).read().split("\n")
+        for i, line in enumerate(lines):
+            if not re.match(r"^int rgbdr_\w+\(", line):
+                continue
+            if line.rstrip().endswith("}"):                           # a one-liner
+                assert re.search(r"\{ return (set_flag|upload_common)\(", line), line
+                continue
+            j = i
+            while not lines[j].rstrip().endswith(")"):
+                j += 1
+            assert lines[j + 1] == "try {", "%s:%d %s" % (path, i + 1, line)
+            k = j + 1
+            while lines[k] != "}":
+                k += 1
+            assert re.match(r"^RGBDR_CONTAIN\((ctx|nullptr)\)$", lines[k + 1]), "%s:%d %s" % (path, k + 2, lines[k + 1])
+            guarded += 1
+    assert guarded >= 60
+    ctx_hpp = open(os.path.join(ROOT, "rgbd-recon_amd", "csrc", "context.hpp")).read()
+    assert "catch (...) { return rgbdr::contain_exception(ctx); }" in ctx_hpp
+
+
 def test_no_device_fails_loudly(pkg):
     import torch
 

@@ -487,6 +487,55 @@ def test_calibration_files_round_trip(pkg, orc, tmp_path):
     ctx2.close()
 
 
+def test_damaged_calibration_files_are_io_errors(pkg, orc, tmp_path):
+    """a LUT file is sized by its own header: a truncated payload, a header that promises more than the file holds (up to
+    2^96 records: nothing is allocated on its word), a zero resolution and a file shorter than the header all come back as
+    RGBDR_ERR_IO -- the process lives, the context keeps the calibration it had and still produces the same volume"""
+    import struct
+    capi = pkg.capi
+    scene, ctx, inv = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
+    ctx.step(scene.depth, scene.color)
+    want = ctx.readback_tsdf()
+    good = {}
+    for ext, data, comps in (("cv_xyz", scene.xyz[0], 3), ("cv_uv", scene.uv[0], 2), ("cv_xyz_inv", inv[0], 4)):
+        good[ext] = str(tmp_path / ("good." + ext))
+        assert orc.lut_write(good[ext], data, comps) == 0
+    ctx.load_calibration_files(0, good["cv_xyz"], good["cv_uv"], good["cv_xyz_inv"])       # the files themselves are fine
+    def variants(raw):
+        res = struct.unpack("<3I", raw[:12])
+        return {
+            "payload cut in half": raw[:20 + (len(raw) - 20) // 2],
+            "one byte short": raw[:-1],
+            "header only": raw[:20],
+            "shorter than the header": raw[:7],
+            "empty": b"",
+            "resolution 0": struct.pack("<3I", 0, res[1], res[2]) + raw[12:],
+            "resolution 2^32 - 1 on every axis": struct.pack("<3I", 0xffffffff, 0xffffffff, 0xffffffff) + raw[12:],
+            "one row too many": struct.pack("<3I", res[0], res[1] + 1, res[2]) + raw[12:],
+        }
+
+    path = str(tmp_path / "bad.lut")
+    for ext in ("cv_xyz_inv", "cv_xyz", "cv_uv"):
+        damaged = variants(open(good[ext], "rb").read())
+        for what, blob in damaged.items():
+            open(path, "wb").write(blob)
+            with pytest.raises(capi.RgbdrError) as e:
+                if ext == "cv_xyz_inv":
+                    ctx.load_calibration_files(0, inv=path)
+                elif ext == "cv_xyz":
+                    ctx.load_calibration_files(0, path, good["cv_uv"], None)
+                else:
+                    ctx.load_calibration_files(0, good["cv_xyz"], path, None)
+            assert e.value.status == capi.ERR_IO, (ext, what)
+    open(path, "wb").write(damaged["resolution 2^32 - 1 on every axis"])
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx.load_calibration_files(0, good["cv_xyz"], path, None)
+    assert "header says 4294967295 x 4294967295 x 4294967295 records of 8 bytes" in str(e.value)
+    ctx.step(scene.depth, scene.color)
+    assert same_bits(ctx.readback_tsdf(), want)
+    ctx.close()
+
+
 def test_timers_report_each_pass(pkg, orc):
     scene, ctx, inv = build(pkg)
     ctx.enable_timers(True)
