@@ -272,6 +272,8 @@ try {
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "num_sensors must be in [1, 8]");
   if (cfg->depth_w < 1 || cfg->depth_h < 1 || cfg->color_w < 1 || cfg->color_h < 1)
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must be positive");
+  if (cfg->depth_w > 32768 || cfg->depth_h > 32768 || cfg->color_w > 32768 || cfg->color_h > 32768)  // (pixel counts times bytes cannot wrap)
+    return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must not exceed 32768 pixels each way");
   if (!(cfg->tsdf_limit > 0.0f)) return bad(RGBDR_ERR_INVALID_ARGUMENT, "tsdf_limit must be > 0");
   if (cfg->compress_rgb != 0 && cfg->compress_rgb != 1 && cfg->compress_rgb != 5)
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "compress_rgb must be 0 (RGB8), 1 (DXT1) or 5 (DXT5)");

@@ -10,6 +10,18 @@
 
 using namespace rgbdr;
 
+// A calibration volume is a 3-D texture in the reference (GL_MAX_3D_TEXTURE_SIZE: 2048 ... 16384); an inverse LUT may be as
+// fine as the voxel grid (kMaxRes).  Bounding every axis keeps the products below far from 2^64 and the int coordinates of
+// the kernels exact.
+static const char* lut_res_error(const uint32_t res[3])
+{
+  for (int a = 0; a < 3; ++a) {
+    if (res[a] < 1) return "empty calibration volume";
+    if (res[a] > (uint32_t)kMaxRes) return "calibration volume with more than 32768 cells along an axis";
+  }
+  return nullptr;
+}
+
 extern "C" {
 // ---------------------------------------------------------------------------
 int rgbdr_set_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_lut* xyz, const rgbdr_lut* uv)
@@ -17,8 +29,8 @@ try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!xyz || !uv || !xyz->data || !uv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null calibration volume");
-  for (int a = 0; a < 3; ++a)
-    if (xyz->res[a] < 1 || uv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty calibration volume");
+  if (const char* e = lut_res_error(xyz->res)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, e);
+  if (const char* e = lut_res_error(uv->res)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, e);
   if (!(xyz->depth_limits[1] > xyz->depth_limits[0]))
     return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "cv_xyz depth limits must satisfy max > min");
   HIPCHK(hipSetDevice(ctx->device));
@@ -190,8 +202,7 @@ try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
   if (!inv || !inv->data) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null inverse calibration volume");
-  for (int a = 0; a < 3; ++a)
-    if (inv->res[a] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "empty inverse calibration volume");
+  if (const char* e = lut_res_error(inv->res)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, e);
   HIPCHK(hipSetDevice(ctx->device));
   const rgbdr_geometry& g = ctx->geo;
   const int X = inv->res[0], Y = inv->res[1], Z = inv->res[2];
@@ -463,7 +474,8 @@ int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3]
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
-  if (!res || !dst || res[0] < 1 || res[1] < 1 || res[2] < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad resolution / destination");
+  if (!res || !dst) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null resolution / destination");
+  if (const char* e = lut_res_error(res)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, e);
   if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "generate_inverse_lut before set_calibration");
   if (window > 8) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "window radius must be <= 8");
   HIPCHK(hipSetDevice(ctx->device));

@@ -10,6 +10,9 @@
 
 using namespace rgbdr;
 
+// a viewport like the reference's window (glViewport): bounded so that pixel counts times bytes per pixel cannot wrap
+static bool view_size_ok(int w, int h) { return w >= 1 && h >= 1 && w <= 32768 && h <= 32768; }
+
 extern "C" {
 // d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4), first-hit index (1)
 static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
@@ -59,7 +62,7 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
 int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)v->width * v->height;
   int rc = ensure_view_buffers(ctx, npix);
@@ -76,7 +79,7 @@ RGBDR_CONTAIN(ctx)
 // uniforms + resident data of the ray-marcher for `v`; runs the depth peels when asked
 static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
 {
-  if (!v || v->width < 1 || v->height < 1) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view");
+  if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
   if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
   if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
   const int N = nsens(ctx);
@@ -250,7 +253,7 @@ RGBDR_CONTAIN(ctx)
 int rgbdr_upload_view_frame(rgbdr_ctx* ctx, int width, int height, const float* color, const float* depth)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (width < 1 || height < 1 || !color || !depth) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view frame");
+  if (!view_size_ok(width, height) || !color || !depth) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view frame (null, or not 1 ... 32768 pixels each way)");
   HIPCHK(hipSetDevice(ctx->device));
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)width * height;

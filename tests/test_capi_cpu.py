@@ -56,7 +56,7 @@ def test_config_struct_size_is_checked(pkg):
 
 
 @pytest.mark.parametrize("field,value", [("num_sensors", 0), ("num_sensors", 9), ("depth_w", 0), ("tsdf_limit", 0.0),
-                                         ("voxel_size", -1.0), ("compress_rgb", 3)])
+                                         ("voxel_size", -1.0), ("compress_rgb", 3), ("depth_h", 32769), ("color_w", 2 ** 31 - 1)])
 def test_invalid_config_rejected(pkg, field, value):
     capi = pkg.capi
     cfg = capi.make_config(2, (16, 16))

@@ -420,6 +420,17 @@ def test_call_order_errors(pkg):
     with pytest.raises(capi.RgbdrError) as e:
         ctx.set_inverse_calibration(3, scene.inverse((32, 32, 32))[0], (32, 32, 32))
     assert e.value.status == capi.ERR_OUT_OF_RANGE
+    for res in ((0, 32, 32), (32, 32768 + 1, 32), (0xffffffff, 0xffffffff, 0xffffffff)):
+        # a resolution nothing can be: refused before any size is computed from it (the data pointer is never read)
+        with pytest.raises(capi.RgbdrError) as e:
+            ctx.set_inverse_calibration(0, np.zeros(4, np.float32), res)
+        assert e.value.status == capi.ERR_INVALID_ARGUMENT
+        with pytest.raises(capi.RgbdrError) as e:
+            ctx.set_calibration(0, np.zeros(3, np.float32), res, scene.uv[0], (16, 13, 16), (0.5, 4.5))
+        assert e.value.status == capi.ERR_INVALID_ARGUMENT
+        with pytest.raises(capi.RgbdrError) as e:
+            ctx.set_calibration(0, scene.xyz[0], (16, 13, 16), np.zeros(2, np.float32), res, (0.5, 4.5))
+        assert e.value.status == capi.ERR_INVALID_ARGUMENT
     ctx.set_inverse_calibration(0, scene.inverse((32, 32, 32))[0], (32, 32, 32))
     with pytest.raises(capi.RgbdrError) as e:
         ctx.integrate()                             # bricks on, but not updated yet

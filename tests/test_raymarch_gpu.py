@@ -1,6 +1,8 @@
 """The TSDF ray-marcher (glsl/tsdf_raymarch.fs + shading.glsl) on the
 device against its oracle restatement: bit-exact colour, gl_FragDepth and sample
 counts for every shade mode, from outside and inside the volume."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -77,9 +79,15 @@ def test_raymarch_errors(pkg, orc):
     view.shade_mode = 7
     with pytest.raises(capi.RgbdrError):
         ctx.raymarch(view)
+    view.shade_mode = 0
+    for w, h in ((0, 24), (32, -1), (32768 + 1, 24), (2 ** 31 - 1, 2 ** 31 - 1)):     # a viewport nothing can be (sizes would wrap)
+        view.width, view.height = w, h
+        ptr = C.c_void_p()
+        assert capi.lib().rgbdr_raymarch_find(ctx._h, C.byref(view), C.byref(ptr)) == capi.ERR_INVALID_ARGUMENT
+        assert capi.lib().rgbdr_draw_depth_limits(ctx._h, C.byref(view), None) == capi.ERR_INVALID_ARGUMENT
+    view.width, view.height = 32, 24
     ctx.close()
     ctx2 = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
-    view.shade_mode = 0
     with pytest.raises(capi.RgbdrError) as e:
         ctx2.raymarch(view)
     assert e.value.status == capi.ERR_STATE
