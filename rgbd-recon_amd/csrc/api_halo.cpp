@@ -30,10 +30,9 @@ struct Rccl {
   std::string why;
 };
 
-Rccl& rccl()
+Rccl load_rccl()
 {
-  static Rccl r;
-  if (r.tried) return r;
+  Rccl r;
   r.tried = true;
   const char* env = std::getenv("RGBDR_RCCL_LIB");
   const char* names[] = {env, "librccl.so.1", "librccl.so"};
@@ -57,6 +56,13 @@ Rccl& rccl()
     r.why = "the RCCL library lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd";
     r.lib = nullptr;
   }
+  return r;
+}
+
+// bound once per process; a function-local static, so two contexts driven by two threads may ask at the same time
+Rccl& rccl()
+{
+  static Rccl r = load_rccl();
   return r;
 }
 

@@ -498,6 +498,58 @@ def test_calibration_files_round_trip(pkg, orc, tmp_path):
     ctx2.close()
 
 
+def test_contexts_driven_by_concurrent_threads(pkg, orc):
+    """a context is single-caller, but a process may drive several (one per slab, one per client): four threads create their
+    own contexts at the same time and run frames of different scenes, grids, limits, sweeps and schedules next to each other on
+    one GPU (ctypes releases the GIL around every call); each volume, image set and brick table equals the oracle's --
+    nothing is shared between contexts except read-only tables"""
+    import threading
+    jobs = [dict(n=2, G=64, seed=1234, tsdf_limit=0.03, bricks=True, pipelined=False),
+            dict(n=3, G=48, seed=7, tsdf_limit=0.05, bricks=False, pipelined=True),
+            dict(n=1, G=32, seed=99, tsdf_limit=0.02, bricks=True, pipelined=True),
+            dict(n=4, G=40, seed=5, tsdf_limit=0.04, bricks=False, pipelined=False)]
+    results, errors = [None] * len(jobs), []
+    start = threading.Barrier(len(jobs))
+
+    def worker(k, job):
+        try:
+            start.wait()
+            scene, ctx, inv = build(pkg, n=job["n"], G=job["G"], seed=job["seed"], tsdf_limit=job["tsdf_limit"])
+            other = pkg.synth.Scene(job["n"], 128, 106, lut_res=(32, 27, 32), seed=job["seed"] + 1, sphere_r=0.7)
+            ctx.set_use_bricks(job["bricks"])
+            ctx.set_pipelined(job["pipelined"])
+            for rep in range(6):                                  # frames alternate; the last one is `scene`
+                sc = other if rep % 2 == 0 else scene
+                md, mc = ctx.map_frame_buffer()
+                md[:] = sc.depth.view(np.uint8).reshape(-1)
+                mc[:] = sc.color.reshape(-1)
+                ctx.upload_mapped_frame()
+                ctx.clear_occupied_bricks()
+                ctx.process_textures()
+                ctx.update_occupied_bricks()
+                ctx.integrate()
+            results[k] = (scene, ctx, inv, ctx.readback_tsdf(), ctx.readback_brick_counters(),
+                          [[ctx.readback_image(w, i) for i in range(job["n"])] for w in IMG.values()])
+        except BaseException as e:                                # noqa: reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k, j)) for k, j in enumerate(jobs)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    for k, job in enumerate(jobs):
+        scene, ctx, inv, tsdf, counters, images = results[k]
+        ref = oracle_run(orc, scene, ctx, inv, use_bricks=job["bricks"])
+        assert same_bits(tsdf, ref["tsdf"]), (k, count_diff(tsdf, ref["tsdf"]))
+        assert np.array_equal(counters, ref["counters"]), k
+        for name, per_sensor in zip(IMG, images):
+            for i, got in enumerate(per_sensor):
+                assert same_bits(got, ref[name][i]), (k, name, i)
+        ctx.close()
+
+
 def test_damaged_calibration_files_are_io_errors(pkg, orc, tmp_path):
     """a LUT file is sized by its own header: a truncated payload, a header that promises more than the file holds (up to
     2^96 records: nothing is allocated on its word), a zero resolution and a file shorter than the header all come back as
