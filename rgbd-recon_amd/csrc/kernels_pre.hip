@@ -34,18 +34,81 @@ constexpr int TPITCH = 48;
 // machine in N bursts of about one heavy wavefront per SIMD, which then issues at a single wavefront's rate
 // (dependencies and LDS waits exposed).  Interleaved, the heavy wavefronts of all sensors are resident together.
 struct BlockPos {
-  int l, bx;
+  int l, bx, by;
 };
 __device__ __forceinline__ BlockPos block_pos(int N, int first = 0)
 {
   BlockPos b;
   b.bx = (int)blockIdx.x / N;
   b.l = first + (int)blockIdx.x - b.bx * N;
+  b.by = (int)blockIdx.y;
   return b;
 }
 // a launch covers the sensor layers [p.first, p.first + p.count): all of them, or this rank's shard of the pre_* chain
 __device__ __forceinline__ BlockPos block_pos(const PreParams& p) { return block_pos(p.count, p.first); }
 static dim3 pass_grid(const PreParams& p) { return dim3((unsigned)(((p.W + BX - 1) / BX) * p.count), (unsigned)((p.H + BY - 1) / BY), 1); }
+
+#ifdef RGBDR_TRACE_BLOCKS
+// Developer build (make EXTRA=-DRGBDR_TRACE_BLOCKS, profiles/pre_blocks_probe.py): where and when every wavefront of the two 13 x 13
+// kernels ran.  Per wavefront {HW_ID, XCC_ID, s_memrealtime at entry (100 MHz), s_memrealtime at exit, shader clocks spent, flag}.
+struct WaveTrace {
+  uint32_t hw_id, xcc_id, t0, t1, clocks, flag;
+};
+__device__ WaveTrace g_wave_trace[2][4096 * 4];
+struct TraceScope {
+  int which;
+  uint32_t t0, flag = 0;
+  long long c0;
+  __device__ TraceScope(int w) : which(w)
+  {
+    t0 = (uint32_t)wall_clock64();
+    c0 = clock64();
+  }
+  __device__ ~TraceScope()
+  {
+    const int tid = threadIdx.y * BX + threadIdx.x;
+    if (tid & 63) return;
+    WaveTrace& t = g_wave_trace[which][((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (tid >> 6)) % (4096 * 4)];
+    t.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+    t.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+    t.t0 = t0;
+    t.t1 = (uint32_t)wall_clock64();
+    t.clocks = (uint32_t)(clock64() - c0);
+    t.flag = flag;
+  }
+};
+extern "C" int rgbdr_debug_wave_trace(int which, void* dst, size_t bytes)
+{
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wave_trace), bytes, (size_t)which * sizeof(WaveTrace) * 4096 * 4, hipMemcpyDeviceToHost);
+}
+// experiment: launch position -> image block, per kernel (0xffff: natural order)
+__device__ uint16_t g_block_order[2][4096];
+__device__ int g_block_order_on[2];
+extern "C" int rgbdr_debug_block_order(int which, const uint16_t* order, size_t n)
+{
+  int on = order != nullptr;
+  if (order && hipMemcpyToSymbol(HIP_SYMBOL(g_block_order), order, n * 2, (size_t)which * 4096 * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_block_order_on), &on, 4, (size_t)which * 4, hipMemcpyHostToDevice);
+}
+__device__ __forceinline__ BlockPos block_pos_ordered(const PreParams& p, int which)
+{
+  int id = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  if (g_block_order_on[which]) id = g_block_order[which][id];
+  const int x = id % (int)gridDim.x;
+  BlockPos b;
+  b.bx = x / p.count;
+  b.l = p.first + x - b.bx * p.count;
+  b.by = id / (int)gridDim.x;
+  return b;
+}
+#define BLOCK_POS(p, which) block_pos_ordered(p, which)
+#define TRACE_SCOPE(which) TraceScope trace_(which)
+#define TRACE_FLAG(v) trace_.flag = (v)
+#else
+#define BLOCK_POS(p, which) block_pos(p)
+#define TRACE_SCOPE(which)
+#define TRACE_FLAG(v)
+#endif
 
 // 1 - length(vec2(x,y)) * (1/6) for x,y in [-6,6], filled by the host with the
 // same correctly-rounded sqrtf (pre_depth.fs:37-41,115)
@@ -403,17 +466,18 @@ void launch_pre_cache(const PreParams& p, int sensor, hipStream_t s)
 
 __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p, uint32_t* __restrict__ zero, unsigned nzero)
 {
+  TRACE_SCOPE(0);
   zero_words(zero, nzero);  // (when the morph pass did not run in this chain: it was done with the upload)
   __shared__ float tile[TH][TPITCH];
   __shared__ float unorm[256];  // i / 255.0f: what the sampler returns for a u8 colour channel
-  const BlockPos bp = block_pos(p);
+  const BlockPos bp = BLOCK_POS(p, 0);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const float* depth = p.depth_in + (size_t)l * W * H;
   const bool compress = p.compress != 0;
   const float scale = p.far_[l] - p.near_[l];
   const float scaled_near = scale / 255.0f;
-  const int bx0 = bp.bx * BX - R13, by0 = blockIdx.y * BY - R13;
+  const int bx0 = bp.bx * BX - R13, by0 = bp.by * BY - R13;
   // stage the (clamped) depth window once per block.  Taps outside [min_ds, max_ds] are skipped by
   // the filter (pre_depth.fs:100-103); they are staged as the finite sentinel 3e38 so that, for a centre
   // depth of ordinary magnitude, the range test |ds - depth| > dist_range_max alone rejects them (NaN taps
@@ -421,7 +485,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p, uint32_t* __r
   // three-test loop.
   const float min_ds = p.cv_min_ds[l], max_ds = p.cv_max_ds[l];
   unorm[threadIdx.y * BX + threadIdx.x] = (float)(threadIdx.y * BX + threadIdx.x) / 255.0f;  // 256 threads, 256 entries
-  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int px = bp.bx * BX + threadIdx.x, py = bp.by * BY + threadIdx.y;
   const bool inside = px < W && py < H;
   const size_t o = (size_t)l * W * H + (inside ? (size_t)py * W + px : 0);
   const float u = ((float)px + 0.5f) / (float)W, v = ((float)py + 0.5f) / (float)H;
@@ -460,6 +524,7 @@ __global__ __launch_bounds__(BX* BY) void k_pre_depth(PreParams p, uint32_t* __r
     in_box = pw.x >= p.bbox_min[0] && pw.y >= p.bbox_min[1] && pw.z >= p.bbox_min[2] &&
              pw.x <= p.bbox_max[0] && pw.y <= p.bbox_max[1] && pw.z <= p.bbox_max[2];
   }
+  TRACE_FLAG((uint32_t)__popcll(__ballot(in_box && p.filter)));  // lanes that run the tap loop
   float2 cc;
   if (depth_norm <= 0.0f || depth_norm >= 1.0f) {
     cc = p.cc_far[o];
@@ -950,16 +1015,17 @@ __device__ __forceinline__ void boundary_texel(const float2 (*rg)[BP], const flo
 template <int WAVES>
 __global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PreParams p)
 {
+  TRACE_SCOPE(1);
   __shared__ float tile[TH][TPITCH];
   __shared__ float2 w_rg[BW][BP];
   __shared__ float w_lab[BW][BP][3];
-  const BlockPos bp = block_pos(p);
+  const BlockPos bp = BLOCK_POS(p, 1);
   const int l = bp.l;
   const int W = p.W, H = p.H;
   const size_t lo = (size_t)l * W * H;
   const float* drg = p.depth_rg + lo * 2;
   const float* lab = p.lab + lo * 3;
-  const int px = bp.bx * BX + threadIdx.x, py = blockIdx.y * BY + threadIdx.y;
+  const int px = bp.bx * BX + threadIdx.x, py = bp.by * BY + threadIdx.y;
   const bool inside = px < W && py < H;
   const size_t o = inside ? (size_t)py * W + px : 0;
   const float2* drg2 = reinterpret_cast<const float2*>(drg);  // (depth, weight) pairs: 8-byte aligned (hipMalloc + a whole layer)
@@ -980,7 +1046,7 @@ __global__ __launch_bounds__(BX* BY, WAVES) void k_boundary_normal_quality(PrePa
     store_quality_sil(p, lo + o, dx0, 0.0f, sil);
     return;
   }
-  const int bx0 = bp.bx * BX - BR, by0 = blockIdx.y * BY - BR;
+  const int bx0 = bp.bx * BX - BR, by0 = bp.by * BY - BR;
   const int tid = threadIdx.y * BX + threadIdx.x;
   bool cand = false;
   for (int i = tid; i < BW * BW; i += BX * BY) {
