@@ -342,6 +342,24 @@ typedef struct {
   void* stream;
 } rgbdr_image_device_view;
 int rgbdr_device_image(rgbdr_ctx* ctx, int which, int sensor, rgbdr_image_device_view* out);
+/* Zero-copy view of a sensor's calibration volumes for the drawing modes that sample them: what the reference hands
+ * out as texture units -- CalibVolumes::getXYZVolumeUnits / getUVVolumeUnits, getVolumeRes, getDepthLimits
+ * (framework/calibration/CalibVolumes.cpp:90-96, 146-159; consumers: recon_calibs.cpp:25-37, recon_trigrid.cpp,
+ * recon_points.cpp).  cv_xyz: xyz_res[2] * xyz_res[1] * xyz_res[0] cells, x fastest, FOUR floats per cell (x, y, z and
+ * an unused lane: the RGB32F records of the file repacked for 16-byte loads); cv_uv: two floats per cell.  Written by
+ * rgbdr_set_calibration / rgbdr_load_calibration_files (which synchronise), constant between those calls, valid until
+ * the next one for this sensor or rgbdr_destroy.  RGBDR_ERR_STATE before the sensor's calibration was set. */
+typedef struct {
+  const void* cv_xyz;
+  const void* cv_uv;
+  uint32_t xyz_res[3], uv_res[3];
+  uint32_t inv_res[3];   /* resolution of the sensor's cv_xyz_inv as it was set -- sensor 0's is CalibVolumes::getVolumeRes() --,
+                            0 0 0 before that; the volume itself is resident in the grid layout and is read
+                            back with rgbdr_readback_inverse_calibration */
+  float depth_limits[2]; /* cv_min_ds, cv_max_ds (NetKinectArray.cpp:339-340) */
+  void* stream;          /* hipStream_t of the context, like the other views */
+} rgbdr_calibration_device_view;
+int rgbdr_device_calibration(rgbdr_ctx* ctx, int sensor, rgbdr_calibration_device_view* out);
 /* Halo staging for Z slabs.  The boundary tile layers a slab sends to its neighbours are the
  * ones the next integrate overwrites, and at 1024^3 / 8 GPUs a face is 64 MiB -- a transfer as
  * long as a frame.  rgbdr_halo_staging returns two device buffers (lower face, upper face:

@@ -135,6 +135,11 @@ class ImageDeviceView(C.Structure):
                 ("element_bytes", C.c_int32), ("stream", C.c_void_p)]
 
 
+class CalibrationDeviceView(C.Structure):
+    _fields_ = [("cv_xyz", C.c_void_p), ("cv_uv", C.c_void_p), ("xyz_res", C.c_uint32 * 3), ("uv_res", C.c_uint32 * 3),
+                ("inv_res", C.c_uint32 * 3), ("depth_limits", C.c_float * 2), ("stream", C.c_void_p)]
+
+
 class ShardDeviceView(C.Structure):
     _fields_ = [("frames", C.c_void_p), ("sensor_bytes", C.c_size_t), ("num_sensors", C.c_int32), ("first", C.c_int32),
                 ("count", C.c_int32), ("counters", C.c_void_p), ("num_bricks", C.c_uint32), ("stream", C.c_void_p)]
@@ -196,6 +201,7 @@ SYMBOLS = {
     "rgbdr_device_tsdf": (C.c_int, [_P, C.POINTER(TsdfDeviceView)]),
     "rgbdr_device_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "rgbdr_device_image": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(ImageDeviceView)]),
+    "rgbdr_device_calibration": (C.c_int, [_P, C.c_int, C.POINTER(CalibrationDeviceView)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
@@ -634,6 +640,12 @@ class Context:
     def device_image(self, which, sensor):
         v = ImageDeviceView()
         self._chk(lib().rgbdr_device_image(self._h, which, sensor, C.byref(v)))
+        return v
+
+    def device_calibration(self, sensor):
+        """CalibVolumes::getXYZVolumeUnits / getUVVolumeUnits / getVolumeRes / getDepthLimits of one sensor, zero-copy"""
+        v = CalibrationDeviceView()
+        self._chk(lib().rgbdr_device_calibration(self._h, sensor, C.byref(v)))
         return v
 
     def device_tsdf(self):

@@ -286,6 +286,26 @@ try {
 }
 RGBDR_CONTAIN(ctx)
 
+int rgbdr_device_calibration(rgbdr_ctx* ctx, int sensor, rgbdr_calibration_device_view* out)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!out) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null view");
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (!ctx->have_calib[sensor]) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_device_calibration before set_calibration of this sensor");
+  out->cv_xyz = ctx->d_cv_xyz[sensor];
+  out->cv_uv = ctx->d_cv_uv[sensor];
+  for (int a = 0; a < 3; ++a) {
+    out->xyz_res[a] = ctx->xyz_res[sensor][a];
+    out->uv_res[a] = ctx->uv_res[sensor][a];
+    out->inv_res[a] = ctx->inv_set[sensor] ? ctx->inv_res[sensor][a] : 0u;
+  }
+  out->depth_limits[0] = ctx->min_ds[sensor];
+  out->depth_limits[1] = ctx->max_ds[sensor];
+  out->stream = (void*)ctx->stream;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
 static int read_lut_file(rgbdr_ctx* ctx, const char* path, size_t rec_bytes, rgbdr_lut* lut, std::vector<char>* buf)
 {
   FILE* f = std::fopen(path, "rb");

@@ -56,6 +56,33 @@ class ReconFrameConsumer : public Reconstruction {
       }
   }
   std::vector<uint64_t> const& digests() const { return m_digests; }
+  // The calibration volumes the reference's other modes sample on CalibVolumes' texture units (recon_calibs.cpp:35-36,
+  // trigrid.vs), read where they live on the device: digests of the cv_xyz records (x, y, z: the 12-byte records of the
+  // file, without the padding lane of the device layout) and of the cv_uv records of every sensor.
+  std::vector<uint64_t> calibrationDigests() const
+  {
+    std::vector<uint64_t> out;
+    for (unsigned i = 0; i < m_num_kinects; ++i) {
+      const rgbdr_calibration_device_view v = m_cv->deviceVolumes(i);
+      const size_t nx = (size_t)v.xyz_res[0] * v.xyz_res[1] * v.xyz_res[2], nu = (size_t)v.uv_res[0] * v.uv_res[1] * v.uv_res[2];
+      std::vector<float> xyz(nx * 4), uv(nu * 2);
+      if (hipMemcpyAsync(xyz.data(), v.cv_xyz, xyz.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)v.stream) != hipSuccess ||
+          hipMemcpyAsync(uv.data(), v.cv_uv, uv.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)v.stream) != hipSuccess ||
+          hipStreamSynchronize((hipStream_t)v.stream) != hipSuccess)
+        throw std::runtime_error("ReconFrameConsumer: reading the calibration volumes failed");
+      uint64_t h = 1469598103934665603ull;
+      for (size_t c = 0; c < nx; ++c) {
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(&xyz[c * 4]);
+        for (int k = 0; k < 12; ++k) h = (h ^ b[k]) * 1099511628211ull;
+      }
+      out.push_back(h);
+      h = 1469598103934665603ull;
+      const unsigned char* b = reinterpret_cast<const unsigned char*>(uv.data());
+      for (size_t k = 0; k < uv.size() * 4; ++k) h = (h ^ b[k]) * 1099511628211ull;
+      out.push_back(h);
+    }
+    return out;
+  }
 
  private:
   std::vector<uint64_t> m_digests;
@@ -198,6 +225,11 @@ int main(int argc, char** argv)
       std::printf("frame images");
       for (uint64_t h : dg) std::printf(" %016llx", (unsigned long long)h);
       std::printf("\n");
+      std::printf("calibration volumes");
+      for (uint64_t h : static_cast<ReconFrameConsumer&>(other).calibrationDigests()) std::printf(" %016llx", (unsigned long long)h);
+      const std::array<uint32_t, 3> vr = cv.getVolumeRes();        // the inverse volume's, like the reference's
+      const std::array<float, 2> dl = cv.getDepthLimits(0);
+      std::printf(" inv_res %u %u %u limits %.9g %.9g\n", vr[0], vr[1], vr[2], dl[0], dl[1]);
       rgbdr_image_device_view a = nka.deviceImage("quality", 0), b = nka.deviceImage(RGBDR_IMG_QUALITY, 0);
       if (a.ptr != b.ptr || !a.ptr || a.width != (int)cf.width || a.height != (int)cf.height || a.channels != 1) return 8;
       if (nka.readbackImage(RGBDR_IMG_DEPTH_B_RG, 0).size() != (size_t)cf.width * cf.height * 2) return 8;

@@ -291,6 +291,25 @@ class CalibVolumes {
     }
   }
   Backend& backend() const { return m_be; }
+  // What the reference hands the other drawing modes as texture units and uniforms (CalibVolumes.cpp:90-96, 146-159;
+  // recon_calibs.cpp:25-37): here the volumes where they live on the device, their resolutions and depth limits.
+  rgbdr_calibration_device_view deviceVolumes(unsigned sensor) const  // getXYZVolumeUnits()[i] / getUVVolumeUnits()[i]
+  {
+    rgbdr_calibration_device_view v{};
+    check(m_be.ctx(), rgbdr_device_calibration(m_be.ctx(), (int)sensor, &v));
+    return v;
+  }
+  std::array<uint32_t, 3> getVolumeRes() const  // m_data_volumes_xyz_inv[0].res() (CalibVolumes.cpp:90-92): (0, 0, 0) before loadInverseCalibs
+  {
+    const rgbdr_calibration_device_view v = deviceVolumes(0);
+    return {{v.inv_res[0], v.inv_res[1], v.inv_res[2]}};
+  }
+  std::array<float, 2> getDepthLimits(unsigned sensor) const
+  {
+    const rgbdr_calibration_device_view v = deviceVolumes(sensor);
+    return {{v.depth_limits[0], v.depth_limits[1]}};
+  }
+  size_t numSensors() const { return m_cv_xyz_filenames.size(); }
   std::vector<std::array<float, 3>> getCameraPositions() const
   {
     std::vector<std::array<float, 3>> out(m_cv_xyz_filenames.size());

@@ -33,16 +33,16 @@ def test_header_is_plain_c_and_the_python_structs_have_the_c_sizes(pkg, tmp_path
     ctypes mirrors in capi.py must have the C compiler's struct sizes (a drifted field would shift everything behind it)"""
     import subprocess
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "rgbdr.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rgbdr_config), '
+    src.write_text('#include <stdio.h>\n#include "rgbdr.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rgbdr_config), '
                    'sizeof(rgbdr_geometry), sizeof(rgbdr_lut), sizeof(rgbdr_view), sizeof(rgbdr_tsdf_device_view), '
-                   'sizeof(rgbdr_image_device_view), sizeof(rgbdr_shard_device_view)); return 0; }\n')
+                   'sizeof(rgbdr_image_device_view), sizeof(rgbdr_shard_device_view), sizeof(rgbdr_calibration_device_view)); return 0; }\n')
     exe = tmp_path / "sizes"
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True).stdout.split()]
     capi = pkg.capi
-    mirrors = [capi.Config, capi.Geometry, capi.Lut, capi.View, capi.TsdfDeviceView, capi.ImageDeviceView, capi.ShardDeviceView]
+    mirrors = [capi.Config, capi.Geometry, capi.Lut, capi.View, capi.TsdfDeviceView, capi.ImageDeviceView, capi.ShardDeviceView, capi.CalibrationDeviceView]
     assert sizes == [C.sizeof(m) for m in mirrors], (sizes, [C.sizeof(m) for m in mirrors])
 
 
@@ -248,6 +248,10 @@ rgbdr_image_device_view (NetKinectArray::*p_dev)(int, unsigned) const = &NetKine
 rgbdr_image_device_view (NetKinectArray::*p_dev_name)(std::string const&, unsigned) const = &NetKinectArray::deviceImage;
 std::vector<float> (NetKinectArray::*p_rb)(int, unsigned) const = &NetKinectArray::readbackImage;
 std::vector<unsigned char> (NetKinectArray::*p_rbc)(unsigned) const = &NetKinectArray::readbackColor;
+// CalibVolumes' accessors for the other modes (CalibVolumes.hpp:38-39; getXYZVolumeUnits / getUVVolumeUnits -> the volumes themselves)
+std::array<uint32_t, 3> (CalibVolumes::*p_vres)() const = &CalibVolumes::getVolumeRes;
+std::array<float, 2> (CalibVolumes::*p_dl)(unsigned) const = &CalibVolumes::getDepthLimits;
+rgbdr_calibration_device_view (CalibVolumes::*p_vol)(unsigned) const = &CalibVolumes::deviceVolumes;
 int main()
 {
   // the unit names of NetKinectArray.cpp:430-439 and the images they stand for
@@ -256,7 +260,7 @@ int main()
       imageOfTextureUnit("silhouette") != RGBDR_IMG_SILHOUETTE || imageOfTextureUnit("morph_depth") != RGBDR_IMG_DEPTH_MORPH ||
       imageOfTextureUnit("color_lab") != RGBDR_IMG_LAB)
     return 2;
-  return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off && p_dev && p_dev_name && p_rb && p_rbc) ? 0 : 1;
+  return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off && p_dev && p_dev_name && p_rb && p_rbc && p_vres && p_dl && p_vol) ? 0 : 1;
 }
 ''')
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "rgbd-recon_amd", "host"), str(src)],

@@ -105,6 +105,16 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
     for i in range(n):
         want += [fnv(scene.color[i]), fnv(ref["depth_b"][i]), fnv(ref["quality"][i]), fnv(ref["normal"][i])]
     assert digests == want, "the C++ consumer read other images than the oracle's"
+    # ... and the calibration volumes the other modes sample on CalibVolumes' units (recon_calibs.cpp:35-36), where they live
+    # on the device: the records of the files, cv_xyz without the padding lane of the device layout; getVolumeRes() is the
+    # inverse volume's resolution as in the reference (CalibVolumes.cpp:90-92), getDepthLimits the file header's
+    m = re.search(r"calibration volumes((?: [0-9a-f]{16})+) inv_res (\d+) (\d+) (\d+) limits (\S+) (\S+)", r_first_stdout)
+    assert m, r_first_stdout
+    want = []
+    for i in range(n):
+        want += [fnv(np.ascontiguousarray(scene.xyz[i], dtype=np.float32)), fnv(np.ascontiguousarray(scene.uv[i], dtype=np.float32))]
+    assert [int(h, 16) for h in m.group(1).split()] == want, "the C++ consumer read other calibration volumes than the files'"
+    assert [int(m.group(k)) for k in (2, 3, 4)] == [G, G, G] and (float(m.group(5)), float(m.group(6))) == (0.5, 4.5)
     # the same frame as one server message (K1 colour, K1 depth, K2 colour, ...; NetKinectArray.cpp:511-541)
     msg = os.path.join(d, "message.bin")
     with open(msg, "wb") as f:

@@ -498,6 +498,38 @@ def test_calibration_files_round_trip(pkg, orc, tmp_path):
     ctx2.close()
 
 
+def test_calibration_volumes_are_visible_on_the_device(pkg):
+    """rgbdr_device_calibration: what CalibVolumes hands the other drawing modes as texture units (getXYZVolumeUnits /
+    getUVVolumeUnits), getVolumeRes and getDepthLimits -- the records that were uploaded, in place, per sensor"""
+    import torch
+    from rgbd_recon_amd import dist as rdist
+    capi, synth = pkg.capi, pkg.synth
+    dev = torch.device("cuda", 0)
+    scene = synth.Scene(2, 64, 53, lut_res=(16, 13, 16))
+    ctx = capi.Context(capi.make_config(2, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx.device_calibration(0)
+    assert e.value.status == capi.ERR_STATE
+    ctx.set_calibration(0, scene.xyz[0], (16, 13, 16), scene.uv[0], (16, 13, 16), (0.5, 4.5))
+    ctx.set_calibration(1, scene.xyz[1], (16, 13, 16), scene.uv[1], (16, 13, 16), (0.25, 5.5))
+    with pytest.raises(capi.RgbdrError) as e:
+        ctx.device_calibration(2)
+    assert e.value.status == capi.ERR_OUT_OF_RANGE
+    inv = scene.inverse((32, 32, 32))
+    ctx.set_inverse_calibration(1, inv[1], (32, 32, 32))
+    for i in range(2):
+        v = ctx.device_calibration(i)
+        assert list(v.xyz_res) == [16, 13, 16] and list(v.uv_res) == [16, 13, 16]
+        assert list(v.inv_res) == ([32, 32, 32] if i == 1 else [0, 0, 0])
+        assert tuple(v.depth_limits) == ((0.5, 4.5), (0.25, 5.5))[i]
+        n = 16 * 13 * 16
+        xyz = rdist.wrap_device_floats(v.cv_xyz, n * 4, dev).cpu().numpy().reshape(16, 13, 16, 4)
+        uv = rdist.wrap_device_floats(v.cv_uv, n * 2, dev).cpu().numpy().reshape(16, 13, 16, 2)
+        assert same_bits(xyz[..., :3], scene.xyz[i]) and same_bits(uv, scene.uv[i])
+        assert v.stream == ctx.stream()
+    ctx.close()
+
+
 def test_contexts_driven_by_concurrent_threads(pkg, orc):
     """a context is single-caller, but a process may drive several (one per slab, one per client): four threads create their
     own contexts at the same time and run frames of different scenes, grids, limits, sweeps and schedules next to each other on
