@@ -435,6 +435,8 @@ class NetKinectArray {
   // copies them as pixels all the same).  Scatters into the mapped back buffer and uploads.
   bool updateFromMessage(const void* message, size_t bytes, unsigned num_sensors)
   {
+    if (num_sensors == 0 || num_sensors != (unsigned)m_be.config().num_sensors)
+      throw std::invalid_argument{"message for another number of sensors than the context's"};
     MappedFrame m = mapBackBuffer();
     const size_t colorsize = m.color_bytes / num_sensors, depthsize = m.depth_bytes / num_sensors;
     if (bytes != (colorsize + depthsize) * num_sensors) throw std::invalid_argument{"message size does not match the sensor set"};
@@ -458,6 +460,16 @@ class NetKinectArray {
   // of every file into contiguous per-sensor buffers and uploads them.
   bool readFromFiles(std::vector<std::string> const& stream_files, size_t colorsize, size_t depthsize, size_t index = 0)
   {
+    // update() reads num_sensors frames of the context's own sizes: anything else would read past these buffers
+    if (stream_files.size() != (size_t)m_be.config().num_sensors) throw std::invalid_argument{"one stream file per sensor expected"};
+    {
+      const rgbdr_config& c = m_be.config();
+      const size_t blocks = (size_t)((c.color_w + 3) / 4) * ((c.color_h + 3) / 4);
+      const size_t want_c = c.compress_rgb == 1 ? blocks * 8 : (c.compress_rgb == 5 ? blocks * 16 : (size_t)c.color_w * c.color_h * 3);
+      const size_t want_d = (size_t)c.depth_w * c.depth_h * (c.compress_depth ? 1 : 4);
+      if (colorsize != want_c || depthsize != want_d)
+        throw std::invalid_argument{"frame sizes do not match the calibration files' image sizes and compression"};
+    }
     std::vector<unsigned char> color(colorsize * stream_files.size()), depth(depthsize * stream_files.size());
     for (size_t i = 0; i < stream_files.size(); ++i)
       readStreamFrame(stream_files[i], colorsize, depthsize, index, color.data() + i * colorsize, depth.data() + i * depthsize);
