@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where and when the wavefronts of the two 13 x 13 kernels of the pre_* chain run (4 x 512 x 424 benchmark frames).
 Needs the developer build of the library:
-    make -C rgbd-recon_amd/csrc EXTRA=-DRGBDR_TRACE_BLOCKS   (kept as profiles/probes_src/librgbdr_hip_trace.so)
+    make -C rgbd-recon_amd/csrc trace      (-> profiles/probes_src/librgbdr_hip_trace.so; the product library is not touched)
     python3 profiles/pre_blocks_probe.py [out.json]
 Per kernel: heavy wavefronts per SIMD / CU / XCD (heavy = ran the tap loops), when the last wavefront of each CU
 finished, and the span of the launch by the wavefronts' own clocks."""
