@@ -318,12 +318,29 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                 ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
             ctx.sync()
         if managed:
+            made = None
             try:
                 ctx.enable_timers(True)
-                exchanger = rdist.ManagedSlabExchange(ctx, dev, slab_rank, slab_count, group=transport["group"], shard=want_shard, loopback=loop)
-                gather = exchanger.gather if exchanger.shard else None
+                if os.environ.get("RGBDR_BENCH_FAIL_MANAGED") == "construct":   # test hook: tests/test_bench_gpu.py walks the fallback roads
+                    raise RuntimeError("RGBDR_BENCH_FAIL_MANAGED=construct")
+                made = rdist.ManagedSlabExchange(ctx, dev, slab_rank, slab_count, group=transport["group"], shard=want_shard, loopback=loop)
             except Exception as e:  # noqa: BLE001 -- a raw communicator that does not come up must not cost the run
-                sys.stderr.write("[bench rank %d] library-managed RCCL unavailable (%s: %s); using torch.distributed\n" % (rank, type(e).__name__, str(e)[:200]))
+                sys.stderr.write("[bench rank %d] library-managed RCCL unavailable (%s: %s)\n" % (rank, type(e).__name__, str(e)[:200]))
+            ok = 1 if made is not None else 0
+            if world > 1:   # every rank takes the same road: one rank without its communicator sends all of them to torch.distributed
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=shared["fallback"])
+                ok = int(flag[0])
+            if ok:
+                exchanger = made
+                gather = exchanger.gather if exchanger.shard else None
+            else:
+                sys.stderr.write("[bench rank %d] using torch.distributed for the exchange\n" % rank)
+                if made is not None:
+                    try:
+                        made.close()
+                    except Exception:  # noqa: BLE001
+                        pass
                 managed = False
                 ctx.set_sensor_shard(0, 0)
                 ctx.set_stream(main.cuda_stream)
@@ -396,6 +413,8 @@ def run_rank(args, slab=None, quiet=False, shared=None):
             step(False)
             exchanger.wait()
             ctx.sync()
+            if os.environ.get("RGBDR_BENCH_FAIL_MANAGED") == "trial":
+                raise RuntimeError("RGBDR_BENCH_FAIL_MANAGED=trial")
         except Exception as e:  # noqa: BLE001
             ok = 0
             sys.stderr.write("[bench rank %d] library-managed exchange failed in its trial step (%s: %s)\n" % (rank, type(e).__name__, str(e)[:200]))

@@ -108,6 +108,20 @@ def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     assert "voxel_sensor_updates_per_s" in j["scaling_note"]
 
 
+@pytest.mark.parametrize("where", ["construct", "trial"])
+def test_a_rank_whose_managed_exchange_fails_goes_back_to_torch_distributed(where, monkeypatch):
+    """bench.py's N > 1 default lets the LIBRARY enqueue RCCL (raw communicators, never run between two devices on this pool): if
+    a communicator does not come up, or the first step fails, the run continues with torch.distributed's collectives and the
+    redundant or torch-gathered chain -- and the line says which it was"""
+    monkeypatch.setenv("RGBDR_BENCH_FAIL_MANAGED", where)
+    j = run_bench("--slab", "1/4", "--steps", "4", "--warmup", "2")
+    assert j["config"]["collectives"] == "torch.distributed" and j["config"]["halo_transport"] == "rccl"
+    assert j["slab"]["integrate_ms"] > 0 and j["ms_per_step"] > 0
+    monkeypatch.delenv("RGBDR_BENCH_FAIL_MANAGED")
+    j = run_bench("--slab", "1/4", "--steps", "4", "--warmup", "2")
+    assert j["config"]["collectives"].startswith("library-managed RCCL")
+
+
 def test_one_slab_of_config_3_as_its_rank_would_run_it():
     j = run_bench("--slab", "0/4", "--steps", "6", "--warmup", "2")
     s = j["slab"]
