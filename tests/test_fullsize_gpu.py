@@ -136,7 +136,7 @@ def test_eight_sensors_1024_slabs_with_post_pass(pkg, orc):
 
     orc.set_threads(16)
     dev = torch.device("cuda:0")
-    free, total = torch.cuda.mem_get_info()
+    free, _ = torch.cuda.mem_get_info()
     if free < 232e9:
         pytest.skip("needs 232 GB of free HBM for the 1024^3 volume next to its eight slabs")
     scene = scene_for(pkg, 8)

@@ -616,7 +616,7 @@ def test_the_harness_brick_lists_are_the_reference_construction(pkg, orc):
         for b in np.flatnonzero(occ):
             ids = gl_ref.brick_indices(grid, int(b))
             mine[ids[ids < X * Y * Z]] = 1
-        lit, rb, outside = orc.brick_voxel_mask(c["bbox"][0], c["bbox"][1], geo.brick_size, grid["res"], occ)
+        lit, _, _ = orc.brick_voxel_mask(c["bbox"][0], c["bbox"][1], geo.brick_size, grid["res"], occ)
         assert np.array_equal(mine.reshape(Z, Y, X), lit), "%s: %d voxels differ" % (name, int((mine.reshape(Z, Y, X) != lit).sum()))
     g = gl_ref.host_grid(*shader_cases.MODE_CASES["bricks_last_brick_overflows_the_axis"]["bbox"], 0.03, 0.15)
     assert g["axes"][0][-1][1] > g["res"][0], "the overflow case no longer overflows"

@@ -4,7 +4,6 @@ derived from the shader source."""
 import math
 
 import numpy as np
-import pytest
 
 LIMIT = 0.01
 

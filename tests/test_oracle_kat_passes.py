@@ -11,7 +11,6 @@ the reference's quirks in a scratch copy of the oracle and shows that at least o
 import math
 
 import numpy as np
-import pytest
 
 F = np.float32
 BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)

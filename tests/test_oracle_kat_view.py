@@ -11,7 +11,6 @@ surface), on a grid fine enough in z that LINEAR sampling is exact inside the ba
 import math
 
 import numpy as np
-import pytest
 
 LIMIT = 0.01
 SD = LIMIT * 0.5             # sampleDistance = limit * 0.5f  (tsdf_raymarch.fs:33)
