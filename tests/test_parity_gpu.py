@@ -90,6 +90,22 @@ def test_sensor_counts(pkg, orc, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("wh,G", [((5, 3), 16), ((17, 1), 16), ((1, 1), 8), ((13, 13), 24), ((33, 17), 32), ((70, 53), 32), ((16, 16), 9)])
+def test_images_smaller_than_a_block_or_the_filter_window(pkg, orc, wh, G):
+    """sensors of a few pixels (narrower than the 16 x 16 block, than the 13 x 13 window, a single row, a single pixel) and grids
+    that are no multiple of the 8-voxel tile: every clamp at an image border and every partial block / tile is exercised; both
+    sweeps, images and brick table equal the oracle's"""
+    scene, ctx, inv = build(pkg, n=2, wh=wh, G=G, lut_res=(8, 7, 8), tsdf_limit=0.15, min_voxels=1)   # (a wide band: a few pixels reach voxels)
+    for bricks in (True, False):
+        ctx.set_use_bricks(bricks)
+        ctx.step(scene.depth, scene.color)
+        ref = oracle_run(orc, scene, ctx, inv, use_bricks=bricks)
+        check_images(ctx, ref, 2)
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (wh, G, bricks, count_diff(ctx.readback_tsdf(), ref["tsdf"]))
+    ctx.close()
+
+
 @pytest.mark.parametrize("resample", [True, False])
 @pytest.mark.parametrize("G,inv_res", [(64, (45, 45, 45)), (64, (90, 70, 80)), (50, None), (40, (64, 64, 64))])
 def test_generic_inverse_lut_resolution(pkg, orc, G, inv_res, resample):
