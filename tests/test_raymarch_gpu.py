@@ -50,6 +50,34 @@ def test_raymarch_matches_oracle(pkg, orc, shade_mode, eye):
     ctx.close()
 
 
+@pytest.mark.parametrize("wh", [(1, 1), (7, 3), (17, 9), (63, 65), (129, 1)])
+def test_viewports_off_the_block_size(pkg, orc, wh):
+    """viewports of one pixel, narrower than the 8 x 8 square a wavefront covers, one row high, one past a block edge: the
+    ray-march (with and without the brick depth peels) and the hole filling with its degenerate LOD pyramids equal the oracle"""
+    scene, ctx, inv = setup(pkg, orc)
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, wh[0], wh[1], BMIN, BMAX)
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images(orc, ctx, scene, inv, view)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc)
+    fc, fd = ctx.fill_colors(wh[0], wh[1])
+    oc, od = orc.fill_colors(rc, rd)
+    assert same_bits(fc, oc) and same_bits(fd, od)
+    ctx.set_use_bricks(True)                                 # the occupied bricks of the frame, for the peels
+    ctx.step(scene.depth, scene.color)
+    g = ctx.geo
+    peels = ctx.draw_depth_limits(view)
+    ids, _ = ctx.get_occupied()
+    mask = np.zeros(g.num_bricks, np.uint8)
+    mask[ids] = 1
+    ref = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+    assert same_bits(peels, ref)
+    view.skip_space = 1
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images_skip(orc, ctx, scene, inv, view, ref)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc)
+    ctx.close()
+
+
 def test_raymarch_with_file_layout_lut(pkg, orc):
     """RGBDR_FLAG_NO_RESAMPLE: colours are looked up through the file-resolution LUT"""
     scene, ctx, inv = setup(pkg, orc, flags=15 | pkg.capi.FLAG_NO_RESAMPLE, inv_res=(45, 50, 45))
