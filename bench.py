@@ -44,7 +44,8 @@ def choose_workload(world, loopback=False, weak=False, sensors=0, cubic_grid=0):
         n = sensors or 4
         grid = GRID_FOR_GPUS.get(world, (512, 512, 512))
         cfg = "configs[2]: 4 sensors, 512^3 TSDF, full pre_* depth-filter chain on 1 MI355X" if world == 1 and not loopback \
-            else "weak-scaling grid (not a BASELINE config)"
+            else ("configs[2] at fixed work per GPU (weak scaling): %d sensors, 512^3 voxels per MI355X as Z slabs of a %dx%dx%d TSDF, "
+                  "staged RCCL halo exchange per step" % ((n,) + tuple(grid)))
         scaling = "weak"
     elif world == 8:
         n = sensors or 8
@@ -70,7 +71,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (gloo: debugging several "
                                                       "ranks on one GPU)")
     ap.add_argument("--sensors", type=int, default=0, help="0 = what the BASELINE config of --gpus names (4 at 1 GPU, 8 above)")
-    ap.add_argument("--weak", action="store_true", help="N > 1: weak-scaling grids with 4 sensors instead of BASELINE configs[3]/[4]")
+    ap.add_argument("--weak", action="store_true", help="N > 1: only the weak-scaling grids (4 sensors, 512^3 voxels per GPU), without the "
+                                                        "BASELINE configs[3]/[4] run that the default adds under baseline_configs_run")
+    ap.add_argument("--baseline-configs", action="store_true",
+                    help="N > 1: make BASELINE configs[3] (N = 2, 4) / configs[4] (N = 8) -- 8 sensors -- the headline and report the "
+                         "weak-scaling twin under weak_scaling_4_sensors (the default is the other way round: the headline of an N > 1 "
+                         "run is the N = 1 workload at fixed work per GPU, so that value(N) is comparable with N x value(1))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", action="store_true",
                     help="RGBDR_FLAG_PIPELINE for the headline: the pre_* chain of step k+1 overlaps integrate of step k on a "
@@ -120,6 +126,19 @@ def main():
     os.dup2(2, 1)
     if args.slab_sweep:
         sys.exit(slab_sweep(args))
+    # What an N > 1 run times.  Default: the N = 1 workload at fixed work per GPU -- 4 sensors, 512^3 voxels per
+    # rank as Z slabs of one larger volume, halo exchange and all ("scaling": "weak") -- as the headline, so that value(N)
+    # compares with N x value(1); BASELINE.json's own multi-GPU configs (8 sensors: configs[3] at N = 2 / 4, configs[4] at
+    # N = 8) are timed in the same run and reported under baseline_configs_run.  --baseline-configs swaps the roles,
+    # --weak drops the second run.
+    args.twin = None
+    if args.gpus > 1 and not args.sensors and not args.grid:
+        if args.baseline_configs:
+            args.weak, args.twin = False, "weak"
+        elif args.weak:
+            args.twin = None
+        else:
+            args.weak, args.twin = True, "baseline"
     run_rank(args)
 
 
@@ -633,9 +652,12 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         out["per_rank"] = per_rank
         # BASELINE.json's multi-GPU configs name 8 sensors, its single-GPU config 4: a voxel of the N > 1 runs costs
         # twice the LUT bytes of a voxel of the N = 1 run, so `value` (Mvoxels/s) is not comparable across that step
-        out["scaling_note"] = ("N = 1 runs configs[2] (4 sensors), N = 2 / 4 configs[3] (8 sensors, 512^3), N = 8 configs[4] (8 sensors, "
-                               "1024^3): compare voxel_sensor_updates_per_s across N, not value; --weak runs the fixed-sensor weak-"
-                               "scaling grids (4 sensors, 134 M voxels per GPU) instead")
+        out["scaling_note"] = (
+            "weak scaling of the N = 1 workload: every GPU owns 512^3 voxels of a %dx%dx%d volume and sweeps them from 4 sensors, "
+            "value(N) compares with N x value(1); BASELINE.json's multi-GPU configs (8 sensors) are under baseline_configs_run" % tuple(grid)
+            if args.weak else
+            "N = 1 runs configs[2] (4 sensors), N = 2 / 4 configs[3] (8 sensors, 512^3), N = 8 configs[4] (8 sensors, 1024^3): compare "
+            "voxel_sensor_updates_per_s across N, not value; the fixed-work-per-GPU twin is under weak_scaling_4_sensors")
     if loop:
         out["slab"] = {"rank": slab_rank, "of": slab_count, "owned_z_rows": int(g.slab_voxel_z1 - g.slab_voxel_z0),
                        "faces_staged": int(slab_rank > 0) + int(slab_rank < slab_count - 1),
@@ -817,22 +839,27 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     # multi-GPU configs 8 sensors -- so next to configs[3] / configs[4] the run also times the weak-scaling grid with the
     # N = 1 sensor count (134 M voxels and 4 sensors per GPU: 512x512x1024 / 512x1024x1024 / 1024^3), whose value is
     # directly comparable with N times the N = 1 value.
-    if world > 1 and not loop and not args.weak and not lean and not args.sensors and not args.grid:
+    twin = getattr(args, "twin", None)
+    if world > 1 and not loop and twin and not lean:
+        key = "weak_scaling_4_sensors" if twin == "weak" else "baseline_configs_run"
         try:
             a2 = argparse.Namespace(**vars(args))
-            a2.weak = True
+            a2.weak, a2.twin = twin == "weak", None
             sub = dict(shared)
             sub.update(lean=True, keep_pg=True)
             w = run_rank(a2, quiet=True, shared=sub)
             for k in ("scene", "scene_n", "d_depth", "d_color"):
                 shared.pop(k, None)
-            out["weak_scaling_4_sensors"] = {"grid": w["config"]["grid"], "sensors": w["config"]["sensors"], "value": w["value"],
-                                             "ms_per_step": w["ms_per_step"], "frames_per_s": w["frames_per_s"],
-                                             "voxel_sensor_updates_per_s": w["voxel_sensor_updates_per_s"],
-                                             "per_rank": w.get("per_rank"), "roofline_frac_slowest_rank": w["roofline"]["frac"],
-                                             "comparable_with": "N x the value of the N = 1 run (same sensors, same voxels per GPU)"}
+            out[key] = {"baseline_config": w["config"]["baseline_config"], "grid": w["config"]["grid"], "sensors": w["config"]["sensors"],
+                        "scaling": w["scaling"], "value": w["value"], "ms_per_step": w["ms_per_step"], "frames_per_s": w["frames_per_s"],
+                        "voxel_sensor_updates_per_s": w["voxel_sensor_updates_per_s"],
+                        "per_rank": w.get("per_rank"), "roofline_frac_slowest_rank": w["roofline"]["frac"],
+                        "pre_chain": w["config"]["pre_chain"], "collectives": w["config"]["collectives"],
+                        "comparable_with": ("N x the value of the N = 1 run (same sensors, same voxels per GPU)" if twin == "weak" else
+                                            "the 1-GPU time of the same config (8 sensors: DESIGN.md 6 has the denominators); across "
+                                            "N by voxel_sensor_updates_per_s, not by value")}
         except Exception as e:  # noqa: BLE001 -- an extra key must never cost the line
-            out["weak_scaling_4_sensors"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0 and not quiet:
         emit(out)
     if multi and not shared.get("keep_pg"):

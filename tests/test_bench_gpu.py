@@ -85,10 +85,13 @@ def test_bench_loopback_runs_the_multi_gpu_path():
 
 def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     """`python3 bench.py --gpus 2` exactly as the driver starts it (no torch.distributed.run around it); gloo because
-    the box has one GPU: both ranks share it and the halos travel through the host"""
+    the box has one GPU: both ranks share it and the halos travel through the host.  The headline of an N > 1 run is the
+    N = 1 workload at fixed work per GPU (4 sensors, 512^3 voxels per rank: value(N) compares with N x value(1)); BASELINE's
+    own multi-GPU config is timed in the same run and reported under baseline_configs_run."""
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1")
-    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "strong"
-    assert j["config"]["baseline_config"].startswith("configs[3]") and "8 sensors" in j["metric"]
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["config"]["baseline_config"].startswith("configs[2] at fixed work per GPU") and "4 sensors" in j["metric"]
+    assert j["config"]["grid"] == [512, 512, 1024] and j["config"]["sensors"] == 4
     pr = j["per_rank"]
     for key in ("integrate_ms", "halo_ms", "ms_per_step", "roofline_frac"):
         assert len(pr[key]) == 2 and all(v is not None and v > 0 for v in pr[key]), (key, pr[key])
@@ -96,11 +99,26 @@ def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     assert pr["integrate_ms"][slow] == max(pr["integrate_ms"])
     r = j["roofline"]
     assert r["rank"] == slow and abs(r["avg_launch_ms"] - pr["integrate_ms"][slow]) < 1e-3
-    assert r["bytes_per_launch"] == 512 * 512 * 256 * (4 + 12 * 8) + 8 * 512 * 424 * 8
-    assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
+    assert r["bytes_per_launch"] == 512 ** 3 * (4 + 12 * 4) + 4 * 512 * 424 * 8            # a rank's slab: the N = 1 launch
+    assert abs(j["value"] - 512 * 512 * 1024 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
     assert j["ms_per_step"] >= max(pr["ms_per_step"]) * 0.999
     assert "host-staged" in j["config"]["halo_transport"] and j["halo"]["transfer_ms_max"] > 0
-    # the fixed-work-per-GPU twin of the run: 4 sensors, 134 M voxels per rank -- comparable with N x the N = 1 value
+    assert "N x value(1)" in j["scaling_note"]
+    b = j["baseline_configs_run"]
+    assert "error" not in b, b
+    assert b["baseline_config"].startswith("configs[3]") and b["grid"] == [512, 512, 512] and b["sensors"] == 8 and b["scaling"] == "strong"
+    assert b["value"] > 0 and len(b["per_rank"]["integrate_ms"]) == 2
+    assert abs(b["value"] - 512 ** 3 / (b["ms_per_step"] * 1e-3) / 1e6) < 0.01 * b["value"]
+    assert abs(b["voxel_sensor_updates_per_s"] - 8 * b["value"] * 1e6) < 0.01 * b["voxel_sensor_updates_per_s"]
+
+
+def test_baseline_configs_as_the_headline_of_a_two_gpu_run():
+    """--baseline-configs: configs[3] (8 sensors, 512^3 over the ranks) is the headline, the fixed-work twin the extra key"""
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--baseline-configs")
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+    assert j["config"]["baseline_config"].startswith("configs[3]") and "8 sensors" in j["metric"]
+    assert j["roofline"]["bytes_per_launch"] == 512 * 512 * 256 * (4 + 12 * 8) + 8 * 512 * 424 * 8
+    assert abs(j["value"] - 512 ** 3 / (j["ms_per_step"] * 1e-3) / 1e6) < 0.01 * j["value"]
     w = j["weak_scaling_4_sensors"]
     assert "error" not in w, w
     assert w["grid"] == [512, 512, 1024] and w["sensors"] == 4 and w["value"] > 0 and len(w["per_rank"]["integrate_ms"]) == 2
@@ -134,14 +152,16 @@ def test_one_slab_of_config_3_as_its_rank_would_run_it():
 
 def test_eight_ranks_run_config_4_end_to_end_on_one_gpu():
     """`python3 bench.py --gpus 8`, the driver's command for BASELINE configs[4] (8 sensors, 1024^3, eight Z slabs with two
-    halo tile layers per face, slab ray-march + hole filling, the weak-scaling twin), with every rank on the one GPU of
+    halo tile layers per face, slab ray-march + hole filling; the headline is its fixed-work twin with 4 sensors), with every rank on the one GPU of
     the box and the halos through the host (gloo): the numbers mean nothing, the whole multi-rank code path runs"""
     j = run_bench("--gpus", "8", "--backend", "gloo", "--steps", "2", "--warmup", "1")
-    assert j["n_gpus"] == 8 and j["config"]["baseline_config"].startswith("configs[4]") and j["config"]["grid"] == [1024, 1024, 1024]
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["grid"] == [1024, 1024, 1024] and j["config"]["sensors"] == 4
+    assert j["config"]["baseline_config"].startswith("configs[2] at fixed work per GPU")
     pr = j["per_rank"]
     assert len(pr["integrate_ms"]) == 8 and all(v > 0 for v in pr["integrate_ms"]) and all(v is not None for v in pr["halo_ms"])
     assert j["halo"]["layers_per_face"] == 2 and j["halo"]["bytes_per_face"] == 2 * 128 * 128 * 2048
-    assert j["roofline"]["bytes_per_launch"] == 1024 * 1024 * 128 * (4 + 12 * 8) + 8 * 512 * 424 * 8
+    assert j["roofline"]["bytes_per_launch"] == 1024 * 1024 * 128 * (4 + 12 * 4) + 4 * 512 * 424 * 8
     assert "error" not in j["post_pass"] and j["post_pass"]["slab_raymarch_composited_ms"] > 0 and j["post_pass"]["surface_pixels"] > 0.05
-    w = j["weak_scaling_4_sensors"]
-    assert "error" not in w and w["grid"] == [1024, 1024, 1024] and w["sensors"] == 4 and len(w["per_rank"]["integrate_ms"]) == 8
+    b = j["baseline_configs_run"]
+    assert "error" not in b and b["baseline_config"].startswith("configs[4]") and b["grid"] == [1024, 1024, 1024] and b["sensors"] == 8
+    assert len(b["per_rank"]["integrate_ms"]) == 8
