@@ -13,6 +13,9 @@ load_package()
 import torch  # noqa: E402,F401
 from rgbd_recon_amd import capi, synth  # noqa: E402
 
+if os.environ.get("RGBDR_PROBE_LIB"):       # A/B against a developer build (e.g. profiles/probes_src/librgbdr_hip_nolab.so)
+    capi.LIB_PATH = os.path.join(ROOT, os.environ["RGBDR_PROBE_LIB"])
+
 N, W, H, G = 4, 512, 424, 128
 scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
 ctx = capi.Context(capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
