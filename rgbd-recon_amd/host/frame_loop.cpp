@@ -294,6 +294,43 @@ int main(int argc, char** argv)
       return 4;
     } catch (const std::invalid_argument&) {
     }
+    if (const char* csv = std::getenv("RGBDR_TIMER_CSV")) {
+      // The timing side of the application: TimerDatabase::instance().duration(name) every frame for the GUI
+      // (kinect_client.cpp:431-481), writeMean / writeMin / writeMax when it quits (:835-851).  Four more frames of the same
+      // loop with the timers on; with a view also the draw of every frame (depth limits, ray-march, hole filling).
+      TimerDatabase timers(be);
+      recon_integration->setColorFilling(true);
+      recon_integration->setSpaceSkip(true);
+      rgbdr_view view{};
+      bool have_view = false;
+      if (argc == 8) {
+        FILE* vf = std::fopen(argv[7], "rb");
+        have_view = vf && std::fread(&view, sizeof(view), 1, vf) == 1;
+        if (vf) std::fclose(vf);
+      }
+      for (int frame_no = 0; frame_no < 4; ++frame_no) {
+        nka.readFromFiles(streams, colorsize, depthsize, 0);
+        process_textures(nka, recon);
+        recon.integrate();
+        if (have_view) {
+          recons.at(recon_mode)->setView(view);
+          recons.at(recon_mode)->drawF();
+        }
+        timers.sample();
+      }
+      std::printf("timers");
+      for (const char* n : {"1preprocess", "2integrate", "3recon", "bilateral", "boundary", "brickdraw", "draw", "holefill", "morph", "normal", "quality"})
+        std::printf(" %s %.0f %.0f %.0f", n, timers.duration(n), timers.mean(n), timers.getNum(n));
+      std::printf("\n");
+      timers.writeMean(csv);
+      timers.writeMin(csv);
+      timers.writeMax(csv);
+      try {
+        timers.duration("no such timer");
+        return 9;
+      } catch (const std::out_of_range&) {
+      }
+    }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "frame_loop: %s\n", e.what());
     return 1;

@@ -21,6 +21,8 @@
 #include <cstring>
 #include <cstdlib>
 #include <fstream>
+#include <limits>
+#include <map>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -232,6 +234,97 @@ class Backend {
   std::shared_ptr<rgbdr_ctx> m_ctx;
   unsigned m_num = 0;
   rgbdr_config m_cfg{};
+};
+
+// TimerDatabase (framework/rendering/timer_database.{hpp,cpp}): the application reads duration(name) every frame for its GUI
+// (source/kinect_client.cpp:431-481) and writes the means, minima and maxima as three CSV files when it quits (:835-851).
+// The library times its own launches under the reference's names (rgbdr_timer_ns); this class keeps the reference's
+// statistics -- the fold of TimerDatabase::begin, timer_database.cpp:26-41, `else if` and all -- and its file format on
+// top of them.  The reference folds a timer's previous interval when the timer is started again; there is no begin() on this
+// side (the library brackets its launches itself), so the host calls sample() once per frame after the frame's calls.
+// "3recon" (ReconIntegration::drawF as a whole, recon_integration.cpp:151-175) is the sum of the intervals it spans:
+// "brickdraw" + "draw" + "holefill".  Durations are nanoseconds, like TimerGPU's GL_TIMESTAMP differences.
+class TimerDatabase {
+ public:
+  explicit TimerDatabase(Backend& be) : m_be(be)
+  {
+    // the timers the reference registers (NetKinectArray.cpp:211-216, recon_integration.cpp:146-148, reconstruction.cpp:25-26)
+    for (const char* n : {"morph", "bilateral", "boundary", "normal", "quality", "1preprocess", "holefill", "2integrate", "brickdraw",
+                          "3recon", "draw"})
+      addTimer(n);
+    check(m_be.ctx(), rgbdr_enable_timers(m_be.ctx(), 1));
+  }
+  void addTimer(std::string const& name)
+  {
+    m_means.emplace(name, 0.0);
+    m_nums.emplace(name, 0);
+    m_extrema.emplace(name, std::make_pair(std::numeric_limits<double>::infinity(), 0.0));
+  }
+  // last completed interval in ns; 0 for a pass that has not run yet (the reference's query returns 0 - 0 there)
+  double duration(std::string const& name) const
+  {
+    if (m_means.find(name) == m_means.end()) throw std::out_of_range("TimerDatabase: no timer " + name);   // std::map::at
+    if (name == "3recon") return last("brickdraw") + last("draw") + last("holefill");
+    return last(name);
+  }
+  void sample()
+  {
+    for (auto& kv : m_means) {
+      const double d = duration(kv.first);
+      if (!(d > 0.0)) continue;                     // never ran: nothing to fold
+      std::size_t& num = m_nums.at(kv.first);
+      kv.second = (kv.second * (double)num + d) / (double)(num + 1);
+      auto& extremum = m_extrema.at(kv.first);
+      if (extremum.first > d) {
+        extremum.first = d;
+      } else if (extremum.second < d) {
+        extremum.second = d;
+      }
+      num += 1;
+    }
+  }
+  double mean(std::string const& name) const { return m_means.at(name); }
+  double getNum(std::string const& name) const { return (double)m_nums.at(name); }
+  // "<path>mean_<file>", "<path>min_<file>", "<path>max_<file>": a header line `timer,"name",...` in map order and one
+  // data line that starts with the part of <file> before its first comma (the configuration's name in the reference's
+  // file names), values in ms (timer_database.cpp:59-121)
+  void writeMean(std::string const& file_name) const
+  {
+    write(file_name, "mean_", [&](std::string const& n) { return m_means.at(n); });
+  }
+  void writeMin(std::string const& file_name) const
+  {
+    write(file_name, "min_", [&](std::string const& n) { return m_extrema.at(n).first; });
+  }
+  void writeMax(std::string const& file_name) const
+  {
+    write(file_name, "max_", [&](std::string const& n) { return m_extrema.at(n).second; });
+  }
+
+ private:
+  double last(std::string const& name) const
+  {
+    uint64_t ns = 0;
+    return rgbdr_timer_ns(m_be.ctx(), name.c_str(), &ns) == RGBDR_OK ? (double)ns : 0.0;
+  }
+  template <typename F>
+  void write(std::string const& file_name, const char* prefix, F value) const
+  {
+    const std::size_t pos = file_name.find_last_of('/');
+    const std::string filename = file_name.substr(pos + 1), path = file_name.substr(0, pos + 1);
+    const std::string name = filename.substr(0, filename.find_first_of(','));
+    std::ofstream file(path + prefix + filename);
+    if (!file) throw std::runtime_error("cannot write " + path + prefix + filename);
+    file << "timer";
+    for (auto const& kv : m_means) file << ",\"" << kv.first << "\"";
+    file << std::endl << name;
+    for (auto const& kv : m_means) file << "," << value(kv.first) / 1000000.0f;
+    file << std::endl;
+  }
+  Backend& m_be;
+  std::map<std::string, std::size_t> m_nums;
+  std::map<std::string, double> m_means;
+  std::map<std::string, std::pair<double, double>> m_extrema;
 };
 
 // kinect::CalibVolumes

@@ -252,6 +252,13 @@ std::vector<unsigned char> (NetKinectArray::*p_rbc)(unsigned) const = &NetKinect
 std::array<uint32_t, 3> (CalibVolumes::*p_vres)() const = &CalibVolumes::getVolumeRes;
 std::array<float, 2> (CalibVolumes::*p_dl)(unsigned) const = &CalibVolumes::getDepthLimits;
 rgbdr_calibration_device_view (CalibVolumes::*p_vol)(unsigned) const = &CalibVolumes::deviceVolumes;
+// TimerDatabase's public surface (timer_database.hpp:12-22; begin / end live inside the library, sample() folds a frame)
+double (TimerDatabase::*p_dur)(std::string const&) const = &TimerDatabase::duration;
+double (TimerDatabase::*p_mean)(std::string const&) const = &TimerDatabase::mean;
+void (TimerDatabase::*p_add)(std::string const&) = &TimerDatabase::addTimer;
+void (TimerDatabase::*p_wmean)(std::string const&) const = &TimerDatabase::writeMean;
+void (TimerDatabase::*p_wmin)(std::string const&) const = &TimerDatabase::writeMin;
+void (TimerDatabase::*p_wmax)(std::string const&) const = &TimerDatabase::writeMax;
 int main()
 {
   // the unit names of NetKinectArray.cpp:430-439 and the images they stand for
@@ -260,7 +267,7 @@ int main()
       imageOfTextureUnit("silhouette") != RGBDR_IMG_SILHOUETTE || imageOfTextureUnit("morph_depth") != RGBDR_IMG_DEPTH_MORPH ||
       imageOfTextureUnit("color_lab") != RGBDR_IMG_LAB)
     return 2;
-  return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off && p_dev && p_dev_name && p_rb && p_rbc && p_vres && p_dl && p_vol) ? 0 : 1;
+  return (p_draw && p_drawF && p_reload && p_resize && p_mask && p_off && p_dev && p_dev_name && p_rb && p_rbc && p_vres && p_dl && p_vol && p_dur && p_mean && p_add && p_wmean && p_wmin && p_wmax) ? 0 : 1;
 }
 ''')
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "rgbd-recon_amd", "host"), str(src)],

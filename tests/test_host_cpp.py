@@ -131,6 +131,57 @@ def test_frame_loop_matches_oracle(pkg, orc, tmp_path):
 
 
 @pytest.mark.gpu
+def test_timer_database_keeps_the_reference_statistics_and_csv_files(pkg, orc, tmp_path):
+    """host::TimerDatabase over the library's timers: duration(name) per frame like the application's GUI reads it
+    (kinect_client.cpp:431-481), the fold of timer_database.cpp:26-41 in sample(), and the three CSV files the application
+    writes when it quits (:835-851) -- names in map order, the configuration's name in front of the data line, values in ms"""
+    import re
+    synth = pkg.synth
+    n, W, H, G = 2, 64, 53, 32
+    scene = synth.Scene(n, W, H, lut_res=(16, 13, 16), seed=77)
+    inv = scene.inverse((G, G, G))
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, "recordings"))
+    for i in range(n):
+        assert orc.lut_write(os.path.join(d, "s%d.cv_xyz" % i), scene.xyz[i], 3) == 0
+        assert orc.lut_write(os.path.join(d, "s%d.cv_uv" % i), scene.uv[i], 2) == 0
+        assert orc.lut_write(os.path.join(d, "s%d.cv_xyz_inv" % i), inv[i], 4) == 0
+        with open(os.path.join(d, "recordings", "s%d.stream" % i), "wb") as f:
+            f.write(scene.color[i].tobytes())
+            f.write(scene.depth[i].tobytes())
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 48, 36, synth.BBOX_MIN, synth.BBOX_MAX)
+    with open(os.path.join(d, "view.bin"), "wb") as f:
+        f.write(bytes(view))
+    csv = os.path.join(d, "scene,2026-10-4,3-5.csv")            # <conf>,<date>,<time>.csv like kinect_client.cpp:840-847
+    r = subprocess.run([EXE, d, str(n), str(W), str(H), str(G), os.path.join(d, "out.tsdf"), os.path.join(d, "view.bin")],
+                       capture_output=True, text=True, env=dict(os.environ, RGBDR_TIMER_CSV=csv))
+    assert r.returncode == 0, r.stderr
+    names = ["1preprocess", "2integrate", "3recon", "bilateral", "boundary", "brickdraw", "draw", "holefill", "morph", "normal", "quality"]
+    m = re.search(r"^timers (.*)$", r.stdout, flags=re.M)
+    assert m, r.stdout
+    tok = m.group(1).split()
+    last = {tok[4 * k]: (float(tok[4 * k + 1]), float(tok[4 * k + 2]), float(tok[4 * k + 3])) for k in range(len(names))}
+    assert sorted(last) == names
+    for name, (dur, mean, num) in last.items():
+        assert dur > 0 and mean > 0 and num == 4, (name, dur, mean, num)             # every pass ran in each of the four frames
+    assert abs(last["3recon"][0] - (last["brickdraw"][0] + last["draw"][0] + last["holefill"][0])) < 1.0
+    assert last["1preprocess"][0] >= last["bilateral"][0]
+    rows = {}
+    for kind in ("mean", "min", "max"):
+        text = open(os.path.join(d, kind + "_scene,2026-10-4,3-5.csv")).read().splitlines()
+        assert text[0] == "timer," + ",".join('"%s"' % n for n in names), text[0]
+        cells = text[1].split(",")
+        assert cells[0] == "scene" and len(cells) == 1 + len(names) and len(text) == 2
+        rows[kind] = [float(c) for c in cells[1:]]
+    for k, name in enumerate(names):
+        assert rows["min"][k] <= rows["mean"][k] * 1.000001, name
+        assert abs(rows["mean"][k] - last[name][1] / 1e6) <= 1e-4 * rows["mean"][k] + 1e-9, name       # ms (six digits in the file, whole ns on stdout)
+        # the reference's `else if`: the first sample only lowers the minimum, so a timer whose first sample was its largest
+        # keeps max 0 -- min <= max holds only when a later sample exceeded an earlier one
+        assert rows["max"][k] == 0.0 or rows["max"][k] >= rows["min"][k], name
+
+
+@pytest.mark.gpu
 def test_frame_loop_from_ks_scene_with_reference_defaults(pkg, orc, tmp_path):
     """`.ks` + sensor `.yml` + LUT files + `.stream` recordings exactly as the
     reference lays them out, at its default operating point (voxel 0.01, brick 0.1,
