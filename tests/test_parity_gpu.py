@@ -1153,7 +1153,9 @@ def test_random_call_sequences(pkg, orc, seed):
     run_random_sequence(pkg, orc, seed, None)
 
 
-@pytest.mark.parametrize("seed,slab", [(11, (0, 2)), (12, (1, 2)), (13, (1, 3)), (14, (2, 3))])
+_SLABS = [(0, 2), (1, 2), (1, 3), (2, 3), (0, 3), (1, 4), (3, 4)]      # (for G = 48: six tile layers, so up to six slabs)
+@pytest.mark.parametrize("seed,slab", [(11, (0, 2)), (12, (1, 2)), (13, (1, 3)), (14, (2, 3))] +
+                         [(2000 + k, _SLABS[k % len(_SLABS)]) for k in range(int(__import__("os").environ.get("RGBDR_EXTRA_SEEDS", "0")) // 4)])
 def test_random_call_sequences_on_a_slab(pkg, orc, seed, slab):
     run_random_sequence(pkg, orc, seed, slab)
 
