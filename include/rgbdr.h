@@ -484,7 +484,9 @@ int rgbdr_raymarch_shade(rgbdr_ctx* ctx, const rgbdr_view* view, float* color, f
 /* ReconIntegration::drawDepthLimits (recon_integration.cpp:409-429, glsl/bricks.*): the
  * occupied bricks' depth peels for `view`: height*width RGBA32F texels (nearest face z,
  * -farthest face z, nearest back-face z, 0), cleared value (1,0,1,0).  rgbdr_raymarch runs
- * it by itself when view->skip_space is set; this entry point exposes the image. */
+ * it by itself when view->skip_space is set; this entry point exposes the image.  The peels
+ * live in a buffer of their own (the reference's m_view_depth): drawing them, for any
+ * viewport, leaves the last ray-marched frame -- what rgbdr_fill_colors fills -- untouched. */
 int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels);
 
 /* ReconIntegration::fillColors (recon_integration.cpp:280-339): screen-space hole

@@ -48,6 +48,9 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_tsdf_base);
   (void)hipFree(c->d_linear);
   (void)hipFree(c->d_view);
+  (void)hipFree(c->d_peels);
+  c->d_peels = nullptr;
+  c->peel_pixels = 0;
   (void)hipFree(c->d_fill);
   c->d_view = c->d_fill = nullptr;
   c->view_pixels = c->fill_floats = 0;

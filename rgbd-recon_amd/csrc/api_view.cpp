@@ -14,15 +14,28 @@ using namespace rgbdr;
 static bool view_size_ok(int w, int h) { return w >= 1 && h >= 1 && w <= 32768 && h <= 32768; }
 
 extern "C" {
-// d_view holds, per pixel: rgba (4), depth (1), samples (1), depth peels (4), first-hit index (1)
+// d_view holds, per pixel: rgba (4), depth (1), samples (1), first-hit index (1).  Only calls that write a whole new frame
+// (ray-march, rgbdr_upload_view_frame) size it: growing it drops the frame it held.
 static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
 {
   if (ctx->view_pixels >= npix) return RGBDR_OK;
   (void)hipFree(ctx->d_view);
   ctx->d_view = nullptr;
   ctx->view_pixels = 0;
-  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 11 * sizeof(float)));
+  ctx->view_w = ctx->view_h = 0;   // (the callers set the new frame's size once it is written)
+  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 7 * sizeof(float)));
   ctx->view_pixels = npix;
+  return RGBDR_OK;
+}
+// the depth peels of a viewport: RGBA32F per pixel, their own allocation (context.hpp)
+static int ensure_peel_buffer(rgbdr_ctx* ctx, size_t npix)
+{
+  if (ctx->peel_pixels >= npix) return RGBDR_OK;
+  (void)hipFree(ctx->d_peels);
+  ctx->d_peels = nullptr;
+  ctx->peel_pixels = 0;
+  HIPCHK(hipMalloc((void**)&ctx->d_peels, npix * 4 * sizeof(float)));
+  ctx->peel_pixels = npix;
   return RGBDR_OK;
 }
 
@@ -65,9 +78,9 @@ try {
   if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)v->width * v->height;
-  int rc = ensure_view_buffers(ctx, npix);
+  int rc = ensure_peel_buffer(ctx, npix);
   if (rc != RGBDR_OK) return rc;
-  float4* out = (float4*)(ctx->d_view + npix * 6);
+  float4* out = (float4*)ctx->d_peels;
   rc = draw_depth_limits(ctx, v, out);
   if (rc != RGBDR_OK) return rc;
   if (peels) HIPCHK(hipMemcpyAsync(peels, out, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -99,11 +112,13 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   RaymarchParams& p = *pp;
   p = RaymarchParams{};
   p.skip_space = v->skip_space ? 1 : 0;
-  p.peels = (const float4*)(ctx->d_view + npix * 6);
   if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
-    int rc_ = draw_depth_limits(ctx, v, (float4*)(ctx->d_view + npix * 6));
+    int rc_ = ensure_peel_buffer(ctx, npix);
+    if (rc_ != RGBDR_OK) return rc_;
+    rc_ = draw_depth_limits(ctx, v, (float4*)ctx->d_peels);
     if (rc_ != RGBDR_OK) return rc_;
   }
+  p.peels = (const float4*)ctx->d_peels;   // read with skip_space only
   std::memcpy(p.projection, v->projection, 64);
   std::memcpy(p.normal_matrix, v->normal_matrix, 64);
   std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);
@@ -150,7 +165,7 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   p.out_color = (float4*)ctx->d_view;
   p.out_depth = ctx->d_view + npix * 4;
   p.out_samples = ctx->d_view + npix * 5;
-  p.khit = (int*)(ctx->d_view + npix * 10);
+  p.khit = (int*)(ctx->d_view + npix * 6);
   ctx->view_w = v->width;
   ctx->view_h = v->height;
   return RGBDR_OK;

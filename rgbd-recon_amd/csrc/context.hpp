@@ -122,8 +122,12 @@ struct rgbdr_ctx {
   int halo = 0;
   float* d_linear = nullptr;  // readback scratch
   size_t linear_floats = 0;
-  float* d_view = nullptr;    // ray-march outputs: rgba, depth, samples
+  float* d_view = nullptr;    // the last ray-marched frame: rgba, depth, samples (+ the first-hit indices of the slab protocol)
   size_t view_pixels = 0;
+  // the depth peels have a buffer of their own (the reference draws them into m_view_depth, not into the window): a
+  // stand-alone rgbdr_draw_depth_limits of any viewport leaves the frame rgbdr_fill_colors reads alone
+  float* d_peels = nullptr;
+  size_t peel_pixels = 0;
   int view_w = 0, view_h = 0; // size of the last ray-marched frame
   float* d_fill = nullptr;    // hole-fill atlases (2 x colour + depth) and the filled frame
   size_t fill_floats = 0;

@@ -78,6 +78,95 @@ def test_viewports_off_the_block_size(pkg, orc, wh):
     ctx.close()
 
 
+def test_depth_limits_of_another_viewport_leave_the_last_frame_alone(pkg, orc):
+    """the reference draws its depth limits into their own FBO (m_view_depth), not into the window: a stand-alone
+    rgbdr_draw_depth_limits -- of a smaller viewport, whose peels once landed inside the stored frame, or of a larger one,
+    which once re-allocated it away -- must not change what rgbdr_fill_colors fills afterwards (found by
+    test_random_view_sequences)"""
+    scene, ctx, inv = setup(pkg, orc)
+    ctx.set_use_bricks(True)
+    ctx.step(scene.depth, scene.color)
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 48, 36, BMIN, BMAX)
+    color, depth, _ = ctx.raymarch(view)
+    want = orc.fill_colors(color, depth)
+    for wh in ((33, 17), (64, 64), (200, 150), (48, 36)):
+        other = pkg.capi.make_view((0.85, 1.7, 0.8), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, wh[0], wh[1], BMIN, BMAX)
+        ctx.draw_depth_limits(other)
+        fc, fd = ctx.fill_colors(48, 36)
+        assert same_bits(fc, want[0]) and same_bits(fd, want[1]), wh
+    ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 5 + int(__import__("os").environ.get("RGBDR_EXTRA_SEEDS", "0")) // 8)))
+def test_random_view_sequences(pkg, orc, seed):
+    """state machine of the consumer side: random interleavings of new frames (two scenes, both sweeps, another truncation
+    limit), views of changing size / eye / shade mode, with and without space skipping, depth-limit draws, hole filling and
+    externally uploaded view frames -- after every call the result equals the oracle's for the state in force (the view
+    buffers are re-used and re-sized between calls, the peels and the brick table belong to the current frame)"""
+    rng = np.random.default_rng(seed)
+    capi, synth = pkg.capi, pkg.synth
+    scene, ctx, inv = setup(pkg, orc, G=48)
+    # 48 is no power of two: (x + 0.5) / 48 * 48 - 0.5 is not exactly x for every x, so the library keeps the LUT resampled at the
+    # voxel centres (what tsdf_integration.vs looks up, ulps from the file's texels) and the ray-marcher samples THAT
+    # (test_raymarch_with_resampled_lut; RGBDR_FLAG_NO_RESAMPLE keeps the file layout): the oracle gets the resident LUT
+    inv = [ctx.readback_inverse_calibration(i, 0, 48) for i in range(2)]
+    other = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7)
+    scenes = [scene, other]
+    cur, limit, bricks = 0, np.float32(0.01), False
+    eyes = [(2.2, 1.6, 1.9), (0.85, 1.7, 0.8), (-2.0, 1.2, 2.1), (0.05, 1.95, 0.02)]
+    sizes = [(48, 36), (33, 17), (64, 64), (9, 70), (96, 40)]
+    last = None                                            # (colour, depth) of the last ray-marched / uploaded frame
+    for step_no in range(14):
+        op = int(rng.integers(0, 6))
+        if op == 0 or step_no == 0:                        # a new frame
+            cur = int(rng.integers(0, 2))
+            bricks = bool(rng.integers(0, 2))
+            limit = np.float32(rng.choice([0.01, 0.03]))
+            ctx.set_use_bricks(bricks)
+            ctx.set_tsdf_limit(float(limit))
+            ctx.step(scenes[cur].depth, scenes[cur].color)
+            last = None
+            continue
+        sc = scenes[cur]
+        w, h = sizes[int(rng.integers(0, len(sizes)))]
+        view = capi.make_view(eyes[int(rng.integers(0, len(eyes)))], (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, w, h, BMIN, BMAX,
+                              shade_mode=int(rng.integers(0, 4)))
+        g = ctx.geo
+        if op in (1, 2):                                   # ray-march, with the peels when the frame has an occupied list
+            peels = None
+            if op == 2 and bricks:
+                ids, _ = ctx.get_occupied()
+                mask = np.zeros(g.num_bricks, np.uint8)
+                mask[ids] = 1
+                peels = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+                view.skip_space = 1
+            color, depth, ns = ctx.raymarch(view)
+            tsdf = ctx.readback_tsdf()
+            db = [ctx.readback_image(4, i) for i in range(2)]
+            q = [ctx.readback_image(7, i) for i in range(2)]
+            # (the calibration is `scene`'s whichever scene the frame's images came from)
+            rc, rd, rn = orc.raymarch(bytes(view), tsdf, inv, scene.uv, [sc.color[i] for i in range(2)], db, q, limit=float(limit), peels=peels)
+            assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc), (seed, step_no, op, (w, h))
+            last = (rc, rd)
+        elif op == 3 and bricks:                           # the depth limits alone
+            ids, _ = ctx.get_occupied()
+            mask = np.zeros(g.num_bricks, np.uint8)
+            mask[ids] = 1
+            ref = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+            assert same_bits(ctx.draw_depth_limits(view), ref), (seed, step_no, op, (w, h))
+        elif op == 4 and last is not None:                 # hole filling of the last frame (whatever was drawn or peeled since)
+            fc, fd = ctx.fill_colors(last[1].shape[1], last[1].shape[0])
+            oc, od = orc.fill_colors(*last)
+            assert same_bits(fc, oc) and same_bits(fd, od), (seed, step_no, op, last[1].shape)
+        elif op == 5:                                      # a frame composited elsewhere becomes the last frame
+            col = rng.random((h, w, 4), dtype=np.float32)
+            dep = np.where(rng.random((h, w)) < 0.4, np.float32(1.0), rng.random((h, w), dtype=np.float32)).astype(np.float32)
+            col[dep >= 1] = np.float32([0, 1, 0, 0])
+            ctx.upload_view_frame(col, dep)
+            last = (col, dep)
+    ctx.close()
+
+
 def test_raymarch_with_file_layout_lut(pkg, orc):
     """RGBDR_FLAG_NO_RESAMPLE: colours are looked up through the file-resolution LUT"""
     scene, ctx, inv = setup(pkg, orc, flags=15 | pkg.capi.FLAG_NO_RESAMPLE, inv_res=(45, 50, 45))
