@@ -320,7 +320,7 @@ int main(int argc, char** argv)
       }
       std::printf("timers");
       for (const char* n : {"1preprocess", "2integrate", "3recon", "bilateral", "boundary", "brickdraw", "draw", "holefill", "morph", "normal", "quality"})
-        std::printf(" %s %.0f %.0f %.0f", n, timers.duration(n), timers.mean(n), timers.getNum(n));
+        std::printf(" %s %.0f %.4f %.0f", n, timers.duration(n), timers.mean(n), timers.getNum(n));
       std::printf("\n");
       timers.writeMean(csv);
       timers.writeMin(csv);
