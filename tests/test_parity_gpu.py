@@ -1177,12 +1177,13 @@ def run_random_sequence(pkg, orc, seed, slab):
     cur = 0
     G = 48 if slab else 32
     inv = list(inv)
+    inv_res = tuple(ctx.geo.res_volume)
     import torch
     dev_frames = [(torch.from_numpy(np.ascontiguousarray(s.depth)).cuda(), torch.from_numpy(np.ascontiguousarray(s.color)).cuda())
                   for s in scenes]
     torch.cuda.synchronize()
     for step_no in range(28):
-        op = rng.integers(0, 16)
+        op = rng.integers(0, 18)
         if op == 0:
             state["bricks"] = not state["bricks"]
             ctx.set_use_bricks(state["bricks"])
@@ -1219,7 +1220,26 @@ def run_random_sequence(pkg, orc, seed, slab):
             # the two sensors trade inverse LUTs (each voxel is then projected into the other sensor's frame)
             inv[0], inv[1] = inv[1], inv[0]
             for i in range(2):
-                ctx.set_inverse_calibration(i, inv[i], tuple(ctx.geo.res_volume))
+                ctx.set_inverse_calibration(i, inv[i], inv_res)
+        elif op == 13 and not slab:
+            # setVoxelSize: the volume, the brick table and the LUT arena are re-allocated; the inverse LUTs have to be set
+            # again -- at the new grid's resolution or at one of their own (resampled into the grid layout once)
+            G = int(rng.choice([32, 40, 48]))
+            ctx.set_voxel_size(2.0 / G)
+            ctx.set_brick_size(8 * 2.0 / G)
+            res = (G, G, G) if rng.integers(0, 2) else (int(rng.integers(20, 44)), int(rng.integers(20, 44)), int(rng.integers(20, 44)))
+            inv, inv_res = list(scene.inverse(res)), res
+            for i in range(2):
+                ctx.set_inverse_calibration(i, inv[i], res)
+            z0, z1 = ctx.geo.slab_voxel_z0, ctx.geo.slab_voxel_z1
+        elif op == 14 and not slab and G == 32:            # (a power of two: voxel centres hit the texels of a 1:1 LUT exactly)
+            # the device computes the inverse LUT itself (CalibrationInverter on the device, at the grid's resolution); what
+            # is resident then is read back for the oracle
+            for i in range(2):
+                ctx.compute_inverse_calibration(i, 2)
+            g_ = ctx.geo
+            inv = [ctx.readback_inverse_calibration(i, 0, int(g_.res_volume[2])) for i in range(2)]
+            inv_res = tuple(g_.res_volume)
         else:
             cur = int(rng.integers(0, 2))
         sc = scenes[cur]
