@@ -1160,27 +1160,46 @@ def test_random_call_sequences_on_a_slab(pkg, orc, seed, slab):
     run_random_sequence(pkg, orc, seed, slab)
 
 
-def run_random_sequence(pkg, orc, seed, slab):
+@pytest.mark.parametrize("seed", [21, 22, 23] + [3000 + k for k in range(int(__import__("os").environ.get("RGBDR_EXTRA_SEEDS", "0")) // 8)])
+def test_random_call_sequences_with_dxt1_colour_frames(pkg, orc, seed):
+    """the same machine fed with DXT1 colour blocks (compress_rgb 1, the reference's yml default): the chain reads the
+    blocks themselves, whichever road brought them"""
+    run_random_sequence(pkg, orc, seed, None, dxt=True)
+
+
+def run_random_sequence(pkg, orc, seed, slab, dxt=False):
     """state machine check: random interleavings of the setters, both sweeps, both schedules,
     store elision, background skip, inverse-LUT re-uploads, settle, two different frames and the four ways a frame can
     arrive (rgbdr_step, pageable upload, the page-locked double buffer, device-resident) -- after every frame the volume, the images
     and the brick table equal the oracle run with the settings in force"""
     rng = np.random.default_rng(seed)
     kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
+    if dxt:
+        kw["compress_rgb"] = 1
     scene, ctx, inv = build(pkg, wh=(64, 53), G=48 if slab else 32, lut_res=(16, 13, 16), **kw)
     z0, z1 = ctx.geo.slab_voxel_z0, ctx.geo.slab_voxel_z1
     if slab:
         for b in range(2):
             ctx.halo_staging(b)
     scenes = [scene, pkg.synth.Scene(2, 64, 53, lut_res=(16, 13, 16), seed=99, sphere_r=0.7)]
+    up_color = [s_.color for s_ in scenes]             # what is uploaded: RGB8 pixels, or DXT1 blocks
+    if dxt:
+        class Decoded:                                 # what the oracle sees: the colours the blocks decode to
+            pass
+        for k, s_ in enumerate(scenes):
+            blocks = np.stack([pkg.synth.encode_dxt(s_.color[i], 1) for i in range(2)])
+            d_ = Decoded()
+            d_.__dict__.update(s_.__dict__)
+            d_.color = np.stack([orc.decode_dxt(blocks[i], 64, 53, 1) for i in range(2)])
+            scenes[k], up_color[k] = d_, blocks
     state = dict(limit=np.float32(0.01), bricks=True, filt=True, proc=True, refine=True, min_voxels=10)
     cur = 0
     G = 48 if slab else 32
     inv = list(inv)
     inv_res = tuple(ctx.geo.res_volume)
     import torch
-    dev_frames = [(torch.from_numpy(np.ascontiguousarray(s.depth)).cuda(), torch.from_numpy(np.ascontiguousarray(s.color)).cuda())
-                  for s in scenes]
+    dev_frames = [(torch.from_numpy(np.ascontiguousarray(s.depth)).cuda(), torch.from_numpy(np.ascontiguousarray(c)).cuda())
+                  for s, c in zip(scenes, up_color)]
     torch.cuda.synchronize()
     for step_no in range(28):
         op = rng.integers(0, 18)
@@ -1245,14 +1264,14 @@ def run_random_sequence(pkg, orc, seed, slab):
         sc = scenes[cur]
         how = int(rng.integers(0, 4))                  # the frame arrives by a different road every time
         if how == 0:
-            ctx.step(sc.depth, sc.color)
+            ctx.step(sc.depth, up_color[cur])
         else:
             if how == 1:                               # pageable host buffers
-                ctx.update(sc.depth, sc.color)
+                ctx.update(sc.depth, up_color[cur])
             elif how == 2:                             # the library's page-locked double buffer
                 md, mc = ctx.map_frame_buffer()
                 md[:] = sc.depth.view(np.uint8).reshape(-1)
-                mc[:] = sc.color.reshape(-1)
+                mc[:] = up_color[cur].reshape(-1)
                 ctx.upload_mapped_frame()
             else:                                      # already in HBM (the buffers may go once the call is enqueued:
                 dd, dc = dev_frames[cur]               # these stay alive for the whole sequence)
