@@ -106,7 +106,8 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   }
   const rgbdr_geometry& g = ctx->geo;
   if (ctx->cfg.slab_count > 1) {
-    const int rows = (int)std::ceil(ctx->cfg.tsdf_limit * (float)g.res_volume[2]) + 2;
+    const float frows = std::ceil(ctx->cfg.tsdf_limit * (float)g.res_volume[2]);   // (compared as a float: the limit may have grown without bound)
+    const int rows = frows <= (float)kMaxRes ? (int)frows + 2 : kMaxRes + 2;
     if (rows > ctx->halo * kTile) return ctx->fail(RGBDR_ERR_STATE, "tsdf_limit grew beyond what the slab halo covers; recreate the context");
   }
   RaymarchParams& p = *pp;

@@ -30,10 +30,15 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
     if (err) *err = m;
     return (int)RGBDR_ERR_INVALID_ARGUMENT;
   };
-  if (!(cfg.voxel_size > 0.0f)) return fail("voxel_size must be > 0");
-  if (!(cfg.brick_size > 0.0f)) return fail("brick_size must be > 0");
-  for (int a = 0; a < 3; ++a)
+  // finite everywhere first: every conversion and loop below assumes it (an infinite box side makes divideBox's loop
+  // condition NaN, an infinite brick a float -> int conversion of infinity; found by tests/native/geometry_fuzz.cpp)
+  if (!(cfg.voxel_size > 0.0f) || !std::isfinite(cfg.voxel_size)) return fail("voxel_size must be a finite number > 0");
+  if (!(cfg.brick_size > 0.0f) || !std::isfinite(cfg.brick_size)) return fail("brick_size must be a finite number > 0");
+  for (int a = 0; a < 3; ++a) {
+    if (!std::isfinite(cfg.bbox_min[a]) || !std::isfinite(cfg.bbox_max[a]) || !std::isfinite(cfg.bbox_max[a] - cfg.bbox_min[a]))
+      return fail("the bounding box must be finite");
     if (!(cfg.bbox_max[a] > cfg.bbox_min[a])) return fail("bbox_max must exceed bbox_min on every axis");
+  }
 
   for (int a = 0; a < 3; ++a) {
     // (the quotient is compared as a float: converting a value beyond INT_MAX, an infinity or a NaN is undefined)
@@ -50,6 +55,7 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
   // setBrickSize: m_brick_size = m_voxel_size * round(size / m_voxel_size)
   float ratio = std::round(cfg.brick_size / cfg.voxel_size);
   if (ratio < 1.0f) ratio = 1.0f;
+  if (!(ratio <= 1.0e6f)) return fail("brick_size of more than a million voxels");   // (and no float -> int conversion of a huge ratio)
   g->brick_size = cfg.voxel_size * ratio;
   g->brick_voxels = (int)ratio;
   for (int a = 0; a < 3; ++a) {
@@ -57,6 +63,7 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
     if (cfg.res_override[a] > 0) {  // voxel edge on this axis = extent / res
       const float edge = (cfg.bbox_max[a] - cfg.bbox_min[a]) / (float)cfg.res_override[a];
       float r = std::round(g->brick_size / edge);
+      if (!(r <= 1.0e6f)) return fail("brick_size of more than a million voxels");       // (also NaN)
       g->brick_voxels_axis[a] = r < 1.0f ? 1 : (int)r;
     }
   }
@@ -75,6 +82,7 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
       ++n;
       if (n > 65535) return fail("brick grid too fine");
     }
+    if (n < 1) return fail("the brick grid is empty along an axis");
     g->res_bricks[a] = n;
   }
   const long long nb = (long long)g->res_bricks[0] * g->res_bricks[1] * g->res_bricks[2];
@@ -92,7 +100,11 @@ int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* er
   if (count > 1) {
     // a ray-marcher stepping limit/2 samples, refines and takes +-limit/2 gradients up to
     // limit * res_z + 2 voxel rows beyond the rows a slab owns (DESIGN.md "Multi-GPU")
-    const int rows = (int)std::ceil(cfg.tsdf_limit * (float)g->res_volume[2]) + 2;
+    // (tsdf_limit is a fraction of the volume's unit cube: a limit at which the halo would span the whole grid -- or a
+    // NaN -- cannot be served by any slab)
+    const float frows = std::ceil(cfg.tsdf_limit * (float)g->res_volume[2]);
+    if (!(frows >= 0.0f && frows <= (float)kMaxRes)) return fail("tsdf_limit must be a finite number in (0, 1]: the slab halo would exceed the grid");
+    const int rows = (int)frows + 2;
     g->halo_tile_layers = rows <= kTile ? 1 : (rows + kTile - 1) / kTile;
     if (g->slab_tile_z1 - g->slab_tile_z0 < g->halo_tile_layers) return fail("slab thinner than its halo");
   }

@@ -67,7 +67,7 @@ def test_invalid_config_rejected(pkg, field, value):
     assert capi.lib().rgbdr_status_string(rc) == b"invalid argument"
 
 
-@pytest.mark.parametrize("voxel,res,why", [(1e-6, (0, 0, 0), b"32768"), (1e-12, (0, 0, 0), b"32768"), (float("inf"), (0, 0, 0), b"empty"),
+@pytest.mark.parametrize("voxel,res,why", [(1e-6, (0, 0, 0), b"32768"), (1e-12, (0, 0, 0), b"32768"), (float("inf"), (0, 0, 0), b"finite"),
                                            (0.01, (40000, 8, 8), b"32768"), (0.01, (32768, 32768, 1024), b"2^31"),
                                            (0.01, (32768, 32768, 32768), b"2^31")])
 def test_grid_sizes_beyond_the_index_types_are_refused(pkg, voxel, res, why):
@@ -83,6 +83,43 @@ def test_grid_sizes_beyond_the_index_types_are_refused(pkg, voxel, res, why):
     assert capi.lib().rgbdr_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_INVALID_ARGUMENT and not h.value
     cfg = capi.make_config(1, (16, 16), res_override=(32768, 8, 8))          # the bound itself is a valid grid
     assert capi.lib().rgbdr_compute_geometry(C.byref(cfg), C.byref(g)) == capi.OK and list(g.tiles) == [4096, 1, 1]
+
+
+@pytest.mark.parametrize("field,value", [("bbox_min", (float("-inf"), 0.0, -1.0)), ("bbox_max", (1.0, float("inf"), 1.0)),
+                                         ("bbox_min", (-3e38, 0.0, -1.0)), ("bbox_max", (1.0, float("nan"), 1.0)),
+                                         ("voxel_size", float("inf")), ("brick_size", float("inf")), ("brick_size", 3e38),
+                                         ("tsdf_limit", float("inf")), ("tsdf_limit", float("nan"))])
+def test_non_finite_configurations_are_refused(pkg, field, value):
+    """an infinite box side made divideBox's loop condition NaN (a brick grid of zero bricks was accepted), an infinite brick or
+    truncation limit reached a float -> int conversion: everything has to be finite before anything is derived from it
+    (tests/native/geometry_fuzz.cpp found these under UBSan)"""
+    capi = pkg.capi
+    cfg = capi.make_config(2, (16, 16), res_override=(64, 64, 64), slab_count=2, slab_rank=1)
+    if isinstance(value, tuple):
+        getattr(cfg, field)[:] = value
+    else:
+        setattr(cfg, field, value)
+    h = C.c_void_p()
+    assert capi.lib().rgbdr_create(C.byref(cfg), 0, C.byref(h)) == capi.ERR_INVALID_ARGUMENT and not h.value
+    g = capi.Geometry()
+    if field != "tsdf_limit" or value != value or value == float("inf"):
+        assert capi.lib().rgbdr_compute_geometry(C.byref(cfg), C.byref(g)) == capi.ERR_INVALID_ARGUMENT
+
+
+def test_host_geometry_is_clean_under_asan_and_ubsan(tmp_path):
+    """csrc/geometry.cpp (grid, bricks, slabs, LOD atlas, camera position, frustum planes: the part of the product that runs
+    on the host) with 3000 random and hostile configurations under AddressSanitizer + UBSan + float-cast-overflow"""
+    import subprocess
+    exe = str(tmp_path / "geometry_fuzz")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                        os.path.join(ROOT, "tests", "native", "geometry_fuzz.cpp"), os.path.join(ROOT, "rgbd-recon_amd", "csrc", "geometry.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "3000"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    m = re.search(r"geometry fuzz: (\d+) configurations accepted, (\d+) refused, (\d+) brick tables built", r.stdout)
+    assert m and int(m.group(1)) > 300 and int(m.group(2)) > 300 and int(m.group(3)) > 300, r.stdout
 
 
 def test_status_codes_of_the_header_the_library_and_the_binding_agree(pkg):
