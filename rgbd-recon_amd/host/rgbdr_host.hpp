@@ -99,6 +99,11 @@ inline KsFile parseKs(std::string const& file_name)
 // stand-alone "[" token, then values of which all but the last carry a trailing
 // comma.  Only the keys the hot path needs are read; defaults as in the
 // reference (:88-95): near 0.3, far 7.0, compress_rgb 1 (DXT1), compress_depth 0.
+// The reference converts the tokens with static_cast<unsigned>(float) (KinectCalibrationFile.cpp:612-628 feeding
+// :190-240), which is undefined for negative, huge and non-numeric values; a damaged or hostile yml gets 0 here --
+// a size the backend then refuses -- instead (tests/native/parser_fuzz.cpp).
+inline unsigned toUnsigned(float v) { return (v >= 0.0f && v < 4294967296.0f) ? (unsigned)v : 0u; }
+
 inline CalibrationFiles parseCalibrationFiles(std::vector<std::string> const& calib_filenames)
 {
   if (calib_filenames.empty()) throw std::invalid_argument{"no calibration files"};
@@ -130,23 +135,23 @@ inline CalibrationFiles parseCalibrationFiles(std::vector<std::string> const& ca
     while (f >> token) {
       if (token == "rgb_size:") {
         advance(f, "[");
-        wc = (unsigned)komma(f);
-        hc = (unsigned)plain(f);
+        wc = toUnsigned(komma(f));
+        hc = toUnsigned(plain(f));
       } else if (token == "depth_size:") {
         advance(f, "[");
-        w = (unsigned)komma(f);
-        h = (unsigned)plain(f);
+        w = toUnsigned(komma(f));
+        h = toUnsigned(plain(f));
       } else if (token == "near_far:") {
         advance(f, "[");
         near_ = komma(f);
         far_ = plain(f);
       } else if (token == "compress_rgb:") {
         advance(f, "[");
-        crgb = (int)(unsigned)komma(f);
+        crgb = (int)toUnsigned(komma(f));
         plain(f);
       } else if (token == "compress_depth:") {
         advance(f, "[");
-        cdepth = (bool)((unsigned)komma(f));
+        cdepth = (bool)(toUnsigned(komma(f)));
         plain(f);
       }
     }
