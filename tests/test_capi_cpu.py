@@ -28,6 +28,42 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.capi.SYMBOLS) == names
 
 
+def test_the_binding_table_has_the_header_s_signatures(pkg):
+    """every prototype of include/rgbdr.h against capi.SYMBOLS: argument count, and per argument and for the result whether it is
+    a pointer, a 32-bit integer (signed / unsigned), a float or a 64-bit size -- a drifted ctypes signature passes garbage
+    without any error"""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgbdr.h")).read(), flags=re.S)
+    protos = re.findall(r"([A-Za-z_][\w\s\*]*?)\b(rgbdr_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text)
+    scalars = {"int": "i32", "int32_t": "i32", "unsigned": "u32", "unsigned int": "u32", "uint32_t": "u32", "float": "f32",
+               "size_t": "64", "uint64_t": "64", "double": "f64"}
+
+    def kind_c(decl, named=True):
+        decl = re.sub(r"\s+", " ", decl.strip())
+        if decl in ("void", ""):
+            return None
+        if "*" in decl or "[" in decl:
+            return "ptr"
+        toks = decl.replace("const ", "").split(" ")
+        return scalars[" ".join(toks[:-1]) if named and len(toks) > 1 else " ".join(toks)]
+
+    def kind_py(t):
+        if t is None:
+            return None
+        for types, k in (((C.c_int, C.c_int32), "i32"), ((C.c_uint32, C.c_uint), "u32"), ((C.c_float,), "f32"),
+                         ((C.c_size_t, C.c_uint64), "64"), ((C.c_double,), "f64")):
+            if t in types:
+                return k
+        assert t in (C.c_void_p, C.c_char_p) or issubclass(t, C._Pointer), t
+        return "ptr"
+
+    assert len(protos) == len(pkg.capi.SYMBOLS) >= 79
+    for ret, name, args in protos:
+        res, argtypes = pkg.capi.SYMBOLS[name]
+        want = [kind_c(a) for a in (x.strip() for x in args.split(",")) if a and a != "void"]
+        assert want == [kind_py(t) for t in argtypes], (name, want, argtypes)
+        assert kind_c(ret, named=False) == kind_py(res), (name, ret, res)
+
+
 def test_header_is_plain_c_and_the_python_structs_have_the_c_sizes(pkg, tmp_path):
     """include/rgbdr.h is the boundary a C / cgo / JNI host binds: it must compile as C99 without extensions, and the
     ctypes mirrors in capi.py must have the C compiler's struct sizes (a drifted field would shift everything behind it)"""
@@ -44,6 +80,24 @@ def test_header_is_plain_c_and_the_python_structs_have_the_c_sizes(pkg, tmp_path
     capi = pkg.capi
     mirrors = [capi.Config, capi.Geometry, capi.Lut, capi.View, capi.TsdfDeviceView, capi.ImageDeviceView, capi.ShardDeviceView, capi.CalibrationDeviceView]
     assert sizes == [C.sizeof(m) for m in mirrors], (sizes, [C.sizeof(m) for m in mirrors])
+    # ... and every field sits where the C compiler puts it, under the same name (offsetof / sizeof of each member)
+    cnames = ["rgbdr_config", "rgbdr_geometry", "rgbdr_lut", "rgbdr_view", "rgbdr_tsdf_device_view", "rgbdr_image_device_view",
+              "rgbdr_shard_device_view", "rgbdr_calibration_device_view"]
+    body, want = "", []
+    for cls, cname in zip(mirrors, cnames):
+        for field in cls._fields_:
+            body += 'printf("%%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s*)0)->%s));\n' % (cname, field[0], cname, field[0])
+            d = getattr(cls, field[0])
+            want.append((cname, field[0], d.offset, d.size))
+    src2 = tmp_path / "offsets.c"
+    src2.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rgbdr.h"\nint main(void) {\n' + body + "return 0; }\n")
+    exe2 = tmp_path / "offsets"
+    r = subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src2), "-o", str(exe2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = [tuple(int(v) for v in line.split()) for line in subprocess.run([str(exe2)], capture_output=True, text=True).stdout.splitlines()]
+    assert len(got) == len(want) >= 70
+    for (cname, fname, off, size), g in zip(want, got):
+        assert (off, size) == g, (cname, fname, (off, size), g)
 
 
 def test_config_struct_size_is_checked(pkg):
