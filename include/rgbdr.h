@@ -515,7 +515,8 @@ int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* 
  * driver in the background and slows every stream for a moment.  rgbdr_settle replays the
  * integrate kernel's LUT-read + TSDF-store stream (the volume's contents are undefined
  * afterwards, until the next integrate) until it runs at the fastest level of the hardware
- * (>= 6.55 TB/s) or max_seconds have passed, and returns the last replay's time in ms.  For benchmarks and
+ * (>= 6.55 TB/s) or max_seconds have passed (at most 60; a negative or non-numeric budget is
+ * RGBDR_ERR_INVALID_ARGUMENT), and returns the last replay's time in ms.  For benchmarks and
  * latency-critical start-up; never needed for correctness. */
 int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms);
 

@@ -277,7 +277,8 @@ try {
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must be positive");
   if (cfg->depth_w > 32768 || cfg->depth_h > 32768 || cfg->color_w > 32768 || cfg->color_h > 32768)  // (pixel counts times bytes cannot wrap)
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "image sizes must not exceed 32768 pixels each way");
-  if (!(cfg->tsdf_limit > 0.0f) || !std::isfinite(cfg->tsdf_limit)) return bad(RGBDR_ERR_INVALID_ARGUMENT, "tsdf_limit must be a finite number > 0");
+  if (!(cfg->tsdf_limit >= kMinTsdfLimit) || !std::isfinite(cfg->tsdf_limit))
+    return bad(RGBDR_ERR_INVALID_ARGUMENT, "tsdf_limit must be a finite number >= 1e-6 (the ray-marcher steps limit / 2 through the unit cube)");
   if (cfg->compress_rgb != 0 && cfg->compress_rgb != 1 && cfg->compress_rgb != 5)
     return bad(RGBDR_ERR_INVALID_ARGUMENT, "compress_rgb must be 0 (RGB8), 1 (DXT1) or 5 (DXT5)");
   rgbdr_geometry g;
@@ -1012,7 +1013,8 @@ RGBDR_CONTAIN(ctx)
 int rgbdr_set_tsdf_limit(rgbdr_ctx* ctx, float limit)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (!(limit > 0.0f) || !std::isfinite(limit)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be a finite number > 0");
+  if (!(limit >= kMinTsdfLimit) || !std::isfinite(limit))
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "tsdf limit must be a finite number >= 1e-6 (the ray-marcher steps limit / 2 through the unit cube)");
   ctx->cfg.tsdf_limit = limit;
   return bump_clear_epoch(ctx);  // tiles cleared to the old -limit no longer count as cleared
 }

@@ -559,6 +559,10 @@ int rgbdr_settle(rgbdr_ctx* ctx, float max_seconds, float* stream_ms)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->d_lut_tiled) return ctx->fail(RGBDR_ERR_STATE, "settle before the inverse LUTs were set");
+  // the budget bounds the loop below: a NaN would never compare as exceeded (a hang found by tests/test_chaos_gpu.py on a
+  // volume too small to ever stream at the "steady" rate), and no caller means to wait longer than a minute
+  if (!(max_seconds >= 0.0f)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "settle: the budget must be a number of seconds >= 0");
+  const double budget = max_seconds < 60.0f ? (double)max_seconds : 60.0;
   HIPCHK(hipSetDevice(ctx->device));
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const rgbdr_geometry& g = ctx->geo;
@@ -577,7 +581,7 @@ try {
     if (cur < 0.0f) return ctx->fail(RGBDR_ERR_HIP, "settle: the stream replay failed");
     if (stream_bytes / (cur * 1e-3) >= 6.55e12) break;
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > (double)max_seconds) break;
+    if (!((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) <= budget)) break;
     struct timespec ts = {0, 50000000};
     nanosleep(&ts, nullptr);
   }

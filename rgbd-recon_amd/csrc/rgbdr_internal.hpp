@@ -14,6 +14,9 @@ constexpr int kTile = RGBDR_TILE;          // 8
 constexpr int kTileVoxels = 512;           // 8*8*8
 constexpr int kMaxSensors = RGBDR_MAX_SENSORS;
 constexpr int kMaxRes = 32768;           // voxels along an axis (compute_geometry)
+// tsdf_raymarch.fs:34,73 marches in steps of limit / 2 for up to ceil(length / step) samples: below this a single ray takes
+// millions of samples and a frame's kernel does not come back in any useful time (the reference hangs its GPU the same way)
+constexpr float kMinTsdfLimit = 1.0e-6f;
 
 // ---- host-only geometry (geometry.cpp) -------------------------------------
 int compute_geometry(const rgbdr_config& cfg, rgbdr_geometry* g, std::string* err);
