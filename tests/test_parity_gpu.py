@@ -598,6 +598,56 @@ def test_contexts_driven_by_concurrent_threads(pkg, orc):
         ctx.close()
 
 
+def test_create_destroy_cycles_return_every_byte(pkg):
+    """contexts come and go (a host that re-creates its backend when the scene changes): 25 cycles that touch every optional
+    allocation -- LUT arena, view / peel / fill buffers, page-locked double buffer, halo staging sets and stream, timers, skip
+    tables, DXT staging -- destroyed with work still queued, leave the device's free memory where it was"""
+    import torch
+    capi, synth = pkg.capi, pkg.synth
+    scene = synth.Scene(2, 64, 53, lut_res=(16, 13, 16))
+    inv = scene.inverse((48, 48, 48))
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 64, 48, BMIN, BMAX)
+
+    def cycle(k):
+        slab = dict(slab_rank=k % 2, slab_count=2) if k % 3 == 0 else {}
+        ctx = capi.Context(capi.make_config(2, (64, 53), voxel_size=2.0 / 48, brick_size=8 * 2.0 / 48, **slab), 0)
+        for i in range(2):
+            ctx.set_calibration(i, scene.xyz[i], (16, 13, 16), scene.uv[i], (16, 13, 16), (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (48, 48, 48))
+        ctx.enable_timers(True)
+        ctx.set_skip_background(k % 2 == 0)
+        ctx.set_pipelined(k % 4 == 1)
+        if slab:
+            for b in range(2):
+                ctx.halo_staging(b)
+            ctx.halo_begin_step()
+        md, mc = ctx.map_frame_buffer()
+        md[:] = scene.depth.view(np.uint8).reshape(-1)
+        mc[:] = scene.color.reshape(-1)
+        ctx.upload_mapped_frame()
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        if not slab:
+            view.skip_space = k % 2
+            ctx.raymarch(view)
+            ctx.fill_colors(64, 48)
+            ctx.draw_depth_limits(view)
+        ctx.step(scene.depth, scene.color)                   # left queued: destroy has to drain it
+        ctx.close()
+
+    cycle(0)
+    cycle(1)                                                 # (first uses may keep runtime-internal pools)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(25):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, "device memory shrank by %.1f MiB over 25 create / destroy cycles" % ((free0 - free1) / 2 ** 20)
+
+
 def test_damaged_calibration_files_are_io_errors(pkg, orc, tmp_path):
     """a LUT file is sized by its own header: a truncated payload, a header that promises more than the file holds (up to
     2^96 records: nothing is allocated on its word), a zero resolution and a file shorter than the header all come back as
