@@ -21,11 +21,32 @@ static bool timer_muted(const rgbdr_ctx* c, const char* n)
   return c->timer_detail < 2 && timer_is_pass(n);
 }
 
+// Accumulating mode keeps an event pair per interval until rgbdr_timer_stats reads them.  Past kMaxPending the oldest half
+// is read here (those intervals ended long ago: the wait is for the first one at most) and kept as a sum.
+constexpr size_t kMaxPending = 2048;
+static void fold_oldest(Timer& t)
+{
+  const size_t n = t.pending.size() / 2;
+  for (size_t i = 0; i < n; ++i) {
+    const auto ev = t.pending[i];
+    float ms = 0.0f;
+    if (ev.second && hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      t.folded_ns += (double)ms * 1.0e6;
+      ++t.folded_count;
+    } else {
+      (void)hipGetLastError();  // begin without end: dropped, as rgbdr_timer_stats does
+    }
+    t.pool.push_back(ev);
+  }
+  t.pending.erase(t.pending.begin(), t.pending.begin() + (std::ptrdiff_t)n);
+}
+
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st)
 {
   if (timer_muted(c, name)) return;
   Timer& t = c->tm[name];
   if (c->accumulate) {
+    if (t.pending.size() >= kMaxPending) fold_oldest(t);
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (!t.pool.empty()) {
       ev = t.pool.back();
@@ -108,7 +129,10 @@ try {
   // the intervals may have been recorded on either stream (pipelined mode: the pre_* timers
   // and "bricks" live on the second one)
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
-  double total = 0.0;
+  double total = it->second.folded_ns;
+  *count = it->second.folded_count;
+  it->second.folded_ns = 0.0;
+  it->second.folded_count = 0;
   auto& pend = it->second.pending;
   while (!pend.empty()) {
     const auto ev = pend.back();

@@ -26,6 +26,10 @@ struct Timer {
   hipEvent_t a = nullptr, b = nullptr;
   bool recorded = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending, pool;
+  // intervals folded out of `pending` before rgbdr_timer_stats asked for them (a host that accumulates for hours without
+  // asking must not grow an event pair per interval without bound: api_timers.cpp)
+  double folded_ns = 0.0;
+  uint32_t folded_count = 0;
 };
 }  // namespace rgbdr
 

@@ -720,6 +720,30 @@ def test_timers_report_each_pass(pkg, orc):
     ctx.close()
 
 
+def test_accumulating_timers_count_every_interval_however_long_nobody_asks(pkg):
+    """rgbdr_enable_timer_accumulation keeps an event pair per interval until rgbdr_timer_stats reads them; a host that
+    lets it run keeps at most a few thousand pairs (older intervals are folded into a sum): 5000 frames without a
+    question, then every interval is accounted for exactly once"""
+    scene, ctx, _ = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
+    ctx.enable_timer_accumulation(True)
+    ctx.set_timer_detail(1)
+    frames = 5000
+    for _ in range(frames):
+        ctx.update(scene.depth, scene.color) if _ == 0 else None
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+    total, count = ctx.timer_stats("2integrate")
+    assert count == frames and total > frames * 1000, (count, total)          # (a sweep of 32^3 takes a few microseconds)
+    total_p, count_p = ctx.timer_stats("1preprocess")
+    assert count_p == frames and total_p > total_p // frames > 0
+    assert ctx.timer_stats("2integrate") == (0, 0)                            # read once
+    ctx.integrate()
+    assert ctx.timer_stats("2integrate")[1] == 1
+    ctx.close()
+
+
 def test_device_resident_frames(pkg):
     import torch
 
