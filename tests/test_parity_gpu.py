@@ -90,7 +90,8 @@ def test_sensor_counts(pkg, orc, n):
     ctx.close()
 
 
-@pytest.mark.parametrize("wh,G", [((5, 3), 16), ((17, 1), 16), ((1, 1), 8), ((13, 13), 24), ((33, 17), 32), ((70, 53), 32), ((16, 16), 9)])
+@pytest.mark.parametrize("wh,G", [((5, 3), 16), ((17, 1), 16), ((1, 1), 8), ((13, 13), 24), ((33, 17), 32), ((70, 53), 32), ((16, 16), 9),
+                                  ((70, 53), 1), ((70, 53), 2), ((70, 53), 3), ((70, 53), 5), ((70, 53), 7)])      # grids smaller than one tile
 def test_images_smaller_than_a_block_or_the_filter_window(pkg, orc, wh, G):
     """sensors of a few pixels (narrower than the 16 x 16 block, than the 13 x 13 window, a single row, a single pixel) and grids
     that are no multiple of the 8-voxel tile: every clamp at an image border and every partial block / tile is exercised; both
