@@ -107,6 +107,23 @@ def test_images_smaller_than_a_block_or_the_filter_window(pkg, orc, wh, G):
     ctx.close()
 
 
+@pytest.mark.parametrize("lut_res", [(1, 1, 1), (2, 2, 2), (3, 1, 2), (1, 5, 1)])
+def test_calibration_volumes_of_one_or_two_cells(pkg, orc, lut_res):
+    """cv_xyz / cv_uv volumes with a single cell along some or all axes: every LINEAR lookup clamps both taps to the same
+    texel, camera position and frustum planes come from coincident corner samples (NaN and all) -- images, counters and
+    volume still equal the oracle's"""
+    scene, ctx, inv = build(pkg, wh=(64, 53), G=16, lut_res=lut_res, seed=5)
+    assert np.array_equal(ctx.camera_position(0), orc.camera_pos(scene.xyz[0]), equal_nan=True)
+    for bricks in (True, False):
+        ctx.set_use_bricks(bricks)
+        ctx.step(scene.depth, scene.color)
+        ref = oracle_run(orc, scene, ctx, inv, use_bricks=bricks)
+        check_images(ctx, ref, 2)
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"])
+    ctx.close()
+
+
 @pytest.mark.parametrize("resample", [True, False])
 @pytest.mark.parametrize("G,inv_res", [(64, (45, 45, 45)), (64, (90, 70, 80)), (50, None), (40, (64, 64, 64))])
 def test_generic_inverse_lut_resolution(pkg, orc, G, inv_res, resample):
