@@ -39,6 +39,26 @@ def test_generate_inverse_lut_matches_exact_search(pkg, orc, res, lut_res):
     ctx.close()
 
 
+@pytest.mark.parametrize("lut_res", [(1, 1, 1), (2, 2, 2), (3, 1, 2), (1, 5, 1), (8, 8, 8)])
+@pytest.mark.parametrize("window", [0, 1, 8])
+def test_inverter_on_calibration_volumes_with_fewer_than_eight_samples_per_axis(pkg, orc, lut_res, window):
+    """cv_xyz volumes of one, two, a few cells: fewer samples than the eight neighbours the reference asks its k-d tree for,
+    search windows larger than the volume.  With a window that spans the whole volume the local search IS the exhaustive
+    one: frustum column identical to the exact restatement, and wherever that holds at least eight samples the same eight;
+    smaller windows must stay inside the volume (values finite or the rejected voxel's -1)"""
+    scene, ctx = make(pkg, lut_res=lut_res)
+    res = (12, 10, 14)
+    got = ctx.generate_inverse_lut(0, res, window=window)
+    ref = orc.inverse_volume(scene.xyz[0], BMIN, BMAX, res)
+    assert got.shape == ref.shape and np.array_equal(got[..., 3], ref[..., 3])
+    assert not np.isinf(got).any()
+    if window == 8 and lut_res[0] * lut_res[1] * lut_res[2] >= 8:
+        inside = ref[..., 3] > 0
+        assert np.all(got == ref, axis=-1)[inside].mean() > 0.99
+    ctx.compute_inverse_calibration(0, window if window else 2)       # the same search at the grid's own resolution
+    ctx.close()
+
+
 def test_window_two_is_close_and_reprojects(pkg, orc):
     """default window (R = 2): nearly always the same neighbours; the generated
     inverse composed with the forward LUT returns the voxel's world position to
