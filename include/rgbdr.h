@@ -441,7 +441,9 @@ int rgbdr_set_stream(rgbdr_ctx* ctx, void* hip_stream);
 /* The uniforms ReconIntegration::draw uploads for glsl/tsdf_raymarch.{vs,fs}
  * (framework/reconstruction/recon_integration.cpp:177-241), computed by the host
  * exactly as there (glm / gloost); all matrices column-major as glGetFloatv returns
- * them. */
+ * them.  Every matrix entry and the camera position must be finite: a NaN or an infinity
+ * is RGBDR_ERR_INVALID_ARGUMENT (tsdf_raymarch.fs:86 would turn it into four billion
+ * samples per ray). */
 typedef struct {
   float modelview[16];           /* GL_MODELVIEW_MATRIX */
   float projection[16];          /* GL_PROJECTION_MATRIX */

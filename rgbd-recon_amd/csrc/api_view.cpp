@@ -1,6 +1,7 @@
 // api_view.cpp -- consumers of the volume: ReconIntegration::drawDepthLimits,
 // ::draw (ray-march, whole volume and Z slabs) and ::fillColors.
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +13,18 @@ using namespace rgbdr;
 
 // a viewport like the reference's window (glViewport): bounded so that pixel counts times bytes per pixel cannot wrap
 static bool view_size_ok(int w, int h) { return w >= 1 && h >= 1 && w <= 32768 && h <= 32768; }
+// The march is bounded by the unit cube only for finite uniforms: tsdf_raymarch.fs:86 converts ceil(|t_far - t_near|) to a
+// sample count, and a NaN / infinite camera makes that the largest unsigned -- four billion samples per ray, a kernel that
+// does not come back.  8 matrices + the camera position = 131 floats at the head of rgbdr_view.
+static bool view_is_finite(const rgbdr_view* v)
+{
+  const float* f = v->modelview;
+  for (int i = 0; i < 8 * 16 + 3; ++i)
+    if (!std::isfinite(f[i])) return false;
+  return true;
+}
+static_assert(offsetof(rgbdr_view, camera_pos) == 8 * 16 * sizeof(float) && offsetof(rgbdr_view, width) == (8 * 16 + 3) * sizeof(float),
+              "rgbdr_view starts with eight 4x4 matrices and the camera position");
 
 extern "C" {
 // d_view holds, per pixel: rgba (4), depth (1), samples (1), first-hit index (1).  Only calls that write a whole new frame
@@ -76,6 +89,7 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float* peels)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
+  if (!view_is_finite(v)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view: a matrix or the camera position holds a NaN or an infinity");
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)v->width * v->height;
   int rc = ensure_peel_buffer(ctx, npix);
@@ -93,6 +107,7 @@ RGBDR_CONTAIN(ctx)
 static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
 {
   if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
+  if (!view_is_finite(v)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view: a matrix or the camera position holds a NaN or an infinity");
   if (v->shade_mode < 0 || v->shade_mode > 3) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "shade_mode must be 0..3");
   if (!ctx->integrated) return ctx->fail(RGBDR_ERR_STATE, "raymarch before integrate");
   const int N = nsens(ctx);

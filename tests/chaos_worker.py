@@ -43,6 +43,9 @@ def run(pkg, orc, seed, slab, trace):
         v.skip_space = int(rng.integers(0, 2))
         if rng.integers(0, 6) == 0:
             v.shade_mode = 7
+        if rng.integers(0, 5) == 0:                       # a poisoned uniform: refused, never marched
+            member = str(rng.choice(["camera_pos", "modelview", "projection", "img_to_eye", "modelview_inv"]))
+            getattr(v, member)[int(rng.integers(0, 3))] = float(rng.choice([float("nan"), float("inf"), -float("inf")]))
         return v
 
     ids = np.array([0, 1, 5, 2 ** 31], np.uint32)

@@ -203,6 +203,14 @@ def test_raymarch_errors(pkg, orc):
         assert capi.lib().rgbdr_raymarch_find(ctx._h, C.byref(view), C.byref(ptr)) == capi.ERR_INVALID_ARGUMENT
         assert capi.lib().rgbdr_draw_depth_limits(ctx._h, C.byref(view), None) == capi.ERR_INVALID_ARGUMENT
     view.width, view.height = 32, 24
+    # a NaN / infinite uniform would turn the sample count of tsdf_raymarch.fs:86 into the largest unsigned: refused, not marched
+    for poison in (float("nan"), float("inf"), float("-inf")):
+        for member, k in (("camera_pos", 0), ("modelview", 5), ("img_to_eye", 15), ("projection", 10), ("vol_to_world_inv", 0)):
+            bad = capi.View.from_buffer_copy(bytes(view))
+            getattr(bad, member)[k] = poison
+            ptr = C.c_void_p()
+            assert capi.lib().rgbdr_raymarch_find(ctx._h, C.byref(bad), C.byref(ptr)) == capi.ERR_INVALID_ARGUMENT, (member, poison)
+            assert capi.lib().rgbdr_draw_depth_limits(ctx._h, C.byref(bad), None) == capi.ERR_INVALID_ARGUMENT
     ctx.close()
     ctx2 = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
     with pytest.raises(capi.RgbdrError) as e:
