@@ -314,6 +314,69 @@ def test_edge_cases(pkg, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("where", ["inverse", "forward"])
+def test_calibration_volumes_with_non_finite_entries(pkg, orc, where):
+    """NaN, infinities and huge values sprinkled into the inverse LUT (texture coordinates and depths the sweep addresses the
+    frame windows with) or into cv_xyz / cv_uv (world positions, colour coordinates, camera position, frustum planes): a
+    damaged calibration must not crash or hang anything, and both sweeps still equal the oracle, which follows GL's rules
+    for such coordinates (NaN -> texel 0, clamp to edge) -- except right next to a damaged texel of a 1:1 inverse LUT, see below"""
+    scene, ctx, inv = build(pkg, wh=(64, 53), G=32, lut_res=(16, 13, 16))
+    rng = np.random.default_rng(17)
+    specials = np.float32([np.nan, np.inf, -np.inf, 3e38, -3e38, 1e20, -7.5, 0.0, 1.0])
+
+    def poison(a, count):
+        a = np.array(a, dtype=np.float32, copy=True)
+        flat = a.reshape(-1)
+        flat[rng.integers(0, flat.size, count)] = rng.choice(specials, count)
+        return a
+
+    if where == "inverse":
+        inv = [poison(a, 400) for a in inv]
+        inv[1][10:12, 8:16, 4:20] = np.nan                 # a whole region, so that entire tiles see nothing but NaN
+        inv[0][20:22, 0:8, 0:8, 2] = np.inf
+        for i in range(2):
+            ctx.set_inverse_calibration(i, inv[i], (32, 32, 32))
+    else:
+        class Damaged:
+            pass
+        d = Damaged()
+        d.__dict__.update(scene.__dict__)
+        d.xyz = [poison(a, 60) for a in scene.xyz]
+        d.uv = [poison(a, 60) for a in scene.uv]
+        scene = d
+        for i in range(2):
+            ctx.set_calibration(i, scene.xyz[i], (16, 13, 16), scene.uv[i], (16, 13, 16), (0.5, 4.5))
+            assert np.array_equal(ctx.camera_position(i), orc.camera_pos(scene.xyz[i]), equal_nan=True)
+    for bricks in (True, False):
+        ctx.set_use_bricks(bricks)
+        ctx.set_skip_background(not bricks)                 # the classifier reads the same planes
+        ctx.step(scene.depth, scene.color)
+        ref = oracle_run(orc, scene, ctx, inv, use_bricks=bricks)
+        check_images(ctx, ref, 2)
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        got = ctx.readback_tsdf()
+        if where == "forward":
+            assert same_bits(got, ref["tsdf"]), (where, bricks, count_diff(got, ref["tsdf"]))
+        else:
+            # A voxel centre of a 1:1 LUT hits its texel with interpolation weights of exactly 0, and the library reads
+            # that texel alone (the grid layout).  GL -- and the oracle -- still evaluate a + 0 * (b - a) with the next
+            # texel b along every axis: for finite b that IS a; for a NaN or an infinite b it is NaN.  So the two agree
+            # wherever the 2 x 2 x 2 texels a lookup touches are finite (and everywhere on an undamaged LUT); next to a
+            # damaged texel the library's voxel keeps its own, clean entry.
+            fin = np.ones((32, 32, 32), bool)
+            for a in inv:
+                f = np.isfinite(a).all(axis=-1)
+                n = f.copy()
+                for ax in range(3):
+                    n &= np.concatenate([np.take(n, range(1, 32), axis=ax), np.take(n, [31], axis=ax)], axis=ax)
+                fin &= n
+            assert 0.5 < fin.mean() < 0.99
+            same = (got == ref["tsdf"]) | (np.isnan(got) & np.isnan(ref["tsdf"]))
+            assert same[fin].all(), (where, bricks, int((~same[fin]).sum()))
+            assert (~same).sum() > 0            # (the convention above is visible on this LUT)
+    ctx.close()
+
+
 def test_normal_and_quality_in_one_launch_or_two(pkg, orc):
     """process_textures runs pre_normal + pre_quality as one kernel; a host that asks for the per-pass timers
     ("normal" / "quality", NetKinectArray.cpp:381-414) gets the two separate ones.  Same images, same brick
