@@ -8,6 +8,8 @@ bricks and -limit outside, Z slabs concatenate to the whole volume, and the slab
 ray-march composites to the single-volume frame."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -215,6 +217,35 @@ def run_1024_body(pkg, orc, torch, rdist, dev, scene, grid, view, live):
         assert same_bits(color, want[skip][0]) and same_bits(depth, want[skip][1])
         ctxs[0].upload_view_frame(color, depth)
         assert frames_equal(ctxs[0].fill_colors(view.width, view.height), want[skip, "fill"])
+
+
+def test_a_volume_of_two_to_the_32_voxels(pkg, orc, monkeypatch):
+    """2048 x 2048 x 1024 voxels from one sensor: 17 GB of TSDF and a 52 GB LUT arena, sizes a 288 GB device is built for and
+    where every voxel, byte and tile index computed in 32 bits would wrap (2^32 voxels, 8.4 M tiles).  Tile layers at the
+    start, either side of voxel 2^31, and at the very end equal the oracle's z rows bit for bit."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 << 30:
+        pytest.skip("needs 100 GB of free HBM")
+    monkeypatch.setenv("RGBDR_ARENA_TRIALS", "1")          # one 52 GB arena, no placement shopping
+    orc.set_threads(16)
+    scene = scene_for(pkg, 1)
+    grid = (2048, 2048, 1024)
+    ctx = make_ctx(pkg, scene, grid)
+    g = ctx.geo
+    assert tuple(g.tiles) == (256, 256, 128) and g.tiles[0] * g.tiles[1] * g.tiles[2] * 512 == 1 << 32
+    ctx.set_use_bricks(False)
+    ctx.step(scene.depth, scene.color)
+    ctx.sync()
+    layer = np.empty(2048 * 2048 * 8, np.float32)
+    seen_band = 0
+    for tz in (0, 63, 64, 127):
+        ctx._chk(pkg.capi.lib().rgbdr_readback_tile_layers(ctx._h, tz, 1, layer.ctypes.data_as(C.POINTER(C.c_float))))
+        rows = layer.reshape(256, 256, 8, 8, 8).transpose(2, 0, 3, 1, 4).reshape(8, 2048, 2048)     # [ty, tx, z, y, x] -> [z, Y, X]
+        ref = check_rows(orc, ctx, rows, tz * 8, 8)
+        seen_band += int((np.abs(ref) < np.float32(0.01)).sum())
+    assert seen_band > 1000                                  # the surface crosses the layers looked at
+    ctx.close()
 
 
 def test_one_recorded_stream_128(pkg, orc, tmp_path):
