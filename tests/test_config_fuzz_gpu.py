@@ -1,0 +1,70 @@
+"""Differential fuzz over configurations: every seed draws its own sensor count, image and colour sizes, calibration-volume
+resolutions, grid (cubic, anisotropic, off the tile size), brick size, truncation limit, inverse-LUT resolution, pass
+flags, sweep and schedule -- and the frame's images, brick table and volume have to equal the oracle's.  The fixed
+parametrisations elsewhere pin the sizes the reference and BASELINE.json name; this one looks for the sizes nobody thought of."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import count_diff, same_bits
+
+pytestmark = pytest.mark.gpu
+BMIN, BMAX = (-1.0, 0.0, -1.0), (1.0, 2.0, 1.0)
+IMG = {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}
+
+
+@pytest.mark.parametrize("seed", list(range(1, 9 + int(os.environ.get("RGBDR_EXTRA_SEEDS", "0")) // 4)))
+def test_random_configuration(pkg, orc, seed):
+    capi, synth = pkg.capi, pkg.synth
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 2, 3, 4, 5, 8]))
+    W, H = int(rng.integers(6, 150)), int(rng.integers(6, 120))
+    color_wh = (int(rng.integers(8, 160)), int(rng.integers(8, 130))) if rng.integers(0, 3) == 0 else None
+    lut_res = tuple(int(v) for v in rng.integers(2, 22, 3))
+    G = int(rng.integers(9, 60))
+    res = (G, G, G)
+    override = (0, 0, 0)
+    if rng.integers(0, 4) == 0:                            # an anisotropic grid through res_override
+        res = tuple(int(v) for v in rng.integers(9, 70, 3))
+        override = res
+    voxel = 2.0 / res[0]
+    brick = float(rng.integers(3, 13)) * voxel
+    limit = float(rng.choice([0.01, 0.02, 0.05, 0.1]))
+    flags = 8 | int(rng.integers(0, 8))                     # bricks bit + any of filter / processed depths / refine
+    if rng.integers(0, 3):
+        flags |= 7
+    min_voxels = int(rng.choice([1, 5, 10, 30]))
+    cfg = capi.make_config(n, (W, H), color_wh=color_wh, voxel_size=voxel, brick_size=brick, tsdf_limit=limit, min_voxels=min_voxels,
+                           flags=flags, res_override=override)
+    ctx = capi.Context(cfg, 0)
+    g = ctx.geo
+    assert tuple(g.res_volume) == res
+    scene = synth.Scene(n, W, H, lut_res=lut_res, seed=seed, color_wh=color_wh, sphere_r=float(rng.choice([0.5, 0.7, 0.9])))
+    inv_res = res if rng.integers(0, 3) else tuple(int(v) for v in rng.integers(8, 50, 3))
+    inv = scene.inverse(inv_res)
+    for i in range(n):
+        ctx.set_calibration(i, scene.xyz[i], lut_res, scene.uv[i], lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], inv_res)
+    desc = dict(seed=seed, n=n, wh=(W, H), color_wh=color_wh, lut_res=lut_res, res=res, inv_res=inv_res, brick_voxels=g.brick_voxels,
+                limit=limit, flags=flags, min_voxels=min_voxels)
+    for bricks in (bool(rng.integers(0, 2)), None):
+        bricks = (not last) if bricks is None else bricks     # both sweeps, in a random order
+        last = bricks
+        ctx.set_use_bricks(bricks)
+        ctx.set_pipelined(bool(rng.integers(0, 2)))
+        ctx.set_skip_background(bool(rng.integers(0, 2)))
+        ctx.set_elide_stores(bool(rng.integers(0, 2)))
+        ctx.step(scene.depth, scene.color)
+        ref = orc.run_pipeline(scene, BMIN, BMAX, res, inv, limit=limit, brick_size=g.brick_size, bv=g.brick_voxels,
+                               res_bricks=tuple(g.res_bricks), min_voxels=min_voxels, filter_textures=bool(flags & 1),
+                               processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=bricks)
+        for name, which in IMG.items():
+            for i in range(n):
+                got = ctx.readback_image(which, i)
+                assert same_bits(got, ref[name][i]), (desc, name, i, count_diff(got, ref[name][i]))
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"]), desc
+        assert np.array_equal(ctx.get_occupied()[0], ref["occupied"]), desc
+        got = ctx.readback_tsdf()
+        assert same_bits(got, ref["tsdf"]), (desc, bricks, count_diff(got, ref["tsdf"]))
+    ctx.close()
