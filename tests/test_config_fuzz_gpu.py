@@ -67,4 +67,26 @@ def test_random_configuration(pkg, orc, seed):
         assert np.array_equal(ctx.get_occupied()[0], ref["occupied"]), desc
         got = ctx.readback_tsdf()
         assert same_bits(got, ref["tsdf"]), (desc, bricks, count_diff(got, ref["tsdf"]))
+    # the consumer side on the same configuration: one view of a random size, eye and shade mode through the ray-marcher
+    # (with the depth peels when the last sweep left an occupied list) and the hole filling.  The ray-marcher samples the
+    # LUT as it is resident -- the grid layout at the grid's resolution, which is what is read back for the oracle
+    resident = [ctx.readback_inverse_calibration(i, 0, res[2]) for i in range(n)]
+    vw, vh = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+    eye = [(2.2, 1.6, 1.9), (0.85, 1.7, 0.8), (-2.0, 1.2, 2.1), (0.05, 1.95, 0.02)][int(rng.integers(0, 4))]
+    view = capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, vw, vh, BMIN, BMAX, shade_mode=int(rng.integers(0, 4)))
+    peels = None
+    if last and rng.integers(0, 2):
+        mask = np.zeros(g.num_bricks, np.uint8)
+        mask[ctx.get_occupied()[0]] = 1
+        peels = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+        view.skip_space = 1
+        assert same_bits(ctx.draw_depth_limits(view), peels), desc
+    color, depth, ns = ctx.raymarch(view)
+    db = [ctx.readback_image(IMG["depth_b"], i) for i in range(n)]
+    q = [ctx.readback_image(IMG["quality"], i) for i in range(n)]
+    rc, rd, rn = orc.raymarch(bytes(view), ctx.readback_tsdf(), resident, scene.uv, [scene.color[i] for i in range(n)], db, q, limit=limit, peels=peels)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc), (desc, (vw, vh), view.shade_mode, view.skip_space)
+    fc, fd = ctx.fill_colors(vw, vh)
+    oc, od = orc.fill_colors(rc, rd)
+    assert same_bits(fc, oc) and same_bits(fd, od), (desc, (vw, vh))
     ctx.close()
