@@ -39,7 +39,7 @@ def test_random_configuration(pkg, orc, seed):
                            flags=flags, res_override=override)
     ctx = capi.Context(cfg, 0)
     g = ctx.geo
-    assert tuple(g.res_volume) == res
+    res = tuple(g.res_volume)                              # (ceil(extent / voxel_size) in float: may be one more than G)
     scene = synth.Scene(n, W, H, lut_res=lut_res, seed=seed, color_wh=color_wh, sphere_r=float(rng.choice([0.5, 0.7, 0.9])))
     inv_res = res if rng.integers(0, 3) else tuple(int(v) for v in rng.integers(8, 50, 3))
     inv = scene.inverse(inv_res)
@@ -90,3 +90,60 @@ def test_random_configuration(pkg, orc, seed):
     oc, od = orc.fill_colors(rc, rd)
     assert same_bits(fc, oc) and same_bits(fd, od), (desc, (vw, vh))
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(1, 5 + int(os.environ.get("RGBDR_EXTRA_SEEDS", "0")) // 8)))
+def test_random_slab_configuration(pkg, orc, seed):
+    """the same draw cut into Z slabs: k contexts (as the k ranks of a job would hold them) sweep their slabs of a random
+    grid -- whole tile layers each, a halo sized by the truncation limit -- and the slabs concatenate to the oracle's volume;
+    every rank counts the whole brick table"""
+    capi, synth = pkg.capi, pkg.synth
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([1, 2, 3, 4]))
+    W, H = int(rng.integers(20, 130)), int(rng.integers(20, 110))
+    lut_res = tuple(int(v) for v in rng.integers(3, 20, 3))
+    res = tuple(int(v) for v in rng.integers(17, 70, 3)) if rng.integers(0, 3) == 0 else (int(rng.integers(17, 64)),) * 3
+    voxel = 2.0 / res[0]
+    brick = float(rng.integers(3, 12)) * voxel
+    limit = float(rng.choice([0.01, 0.03, 0.08]))
+    override = res if res[0] != res[1] or res[1] != res[2] else (0, 0, 0)
+    # (a cubic grid is ceil(extent / voxel_size) in float, setVoxelSize's rule: 2 / float32(2 / 61) is a hair above 61 -> 62 rows)
+    res = tuple(capi.compute_geometry(capi.make_config(n, (W, H), voxel_size=voxel, brick_size=brick, res_override=override)).res_volume)
+    tiles_z = (res[2] + 7) // 8
+    halo = 1 if int(np.ceil(np.float32(limit) * np.float32(res[2]))) + 2 <= 8 else (int(np.ceil(np.float32(limit) * np.float32(res[2]))) + 2 + 7) // 8
+    max_count = tiles_z // halo
+    if max_count < 2:
+        pytest.skip("grid too thin for two slabs with this limit")
+    count = int(rng.integers(2, min(6, max_count) + 1))
+    scene = synth.Scene(n, W, H, lut_res=lut_res, seed=seed, sphere_r=0.8)
+    inv_res = res if rng.integers(0, 2) else tuple(int(v) for v in rng.integers(10, 48, 3))
+    inv = scene.inverse(inv_res)
+    bricks = bool(rng.integers(0, 2))
+    parts, ref = [], None
+    desc = dict(seed=seed, n=n, wh=(W, H), res=res, inv_res=inv_res, count=count, limit=limit, bricks=bricks)
+    for rank in range(count):
+        cfg = capi.make_config(n, (W, H), voxel_size=voxel, brick_size=brick, tsdf_limit=limit, res_override=override,
+                               slab_rank=rank, slab_count=count)
+        try:
+            ctx = capi.Context(cfg, 0)
+        except capi.RgbdrError as e:
+            assert "slab" in str(e), (desc, str(e))          # (a split this grid cannot serve: refused at create, by every rank alike)
+            assert rank == 0 or not parts
+            pytest.skip("split refused: %s" % e)
+        g = ctx.geo
+        for i in range(n):
+            ctx.set_calibration(i, scene.xyz[i], lut_res, scene.uv[i], lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], inv_res)
+        ctx.set_use_bricks(bricks)
+        ctx.set_skip_background(bool(rng.integers(0, 2)))
+        ctx.step(scene.depth, scene.color)
+        if ref is None:
+            ref = orc.run_pipeline(scene, BMIN, BMAX, res, inv, limit=limit, brick_size=g.brick_size, bv=g.brick_voxels,
+                                   res_bricks=tuple(g.res_bricks), use_bricks=bricks)
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"]), (desc, rank)
+        part = ctx.readback_tsdf()
+        assert part.shape[0] == g.slab_voxel_z1 - g.slab_voxel_z0
+        parts.append(part)
+        ctx.close()
+    whole = np.concatenate(parts, axis=0)
+    assert same_bits(whole, ref["tsdf"]), (desc, count_diff(whole, ref["tsdf"]))
