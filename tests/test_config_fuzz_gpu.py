@@ -35,6 +35,9 @@ def test_random_configuration(pkg, orc, seed):
     if rng.integers(0, 3):
         flags |= 7
     min_voxels = int(rng.choice([1, 5, 10, 30]))
+    keep_file_layout = bool(rng.integers(0, 4) == 0)        # RGBDR_FLAG_NO_RESAMPLE: the LUT stays at its own resolution, 8-tap lookups per voxel
+    if keep_file_layout:
+        flags |= capi.FLAG_NO_RESAMPLE
     cfg = capi.make_config(n, (W, H), color_wh=color_wh, voxel_size=voxel, brick_size=brick, tsdf_limit=limit, min_voxels=min_voxels,
                            flags=flags, res_override=override)
     ctx = capi.Context(cfg, 0)
@@ -47,7 +50,7 @@ def test_random_configuration(pkg, orc, seed):
         ctx.set_calibration(i, scene.xyz[i], lut_res, scene.uv[i], lut_res, (0.5, 4.5))
         ctx.set_inverse_calibration(i, inv[i], inv_res)
     desc = dict(seed=seed, n=n, wh=(W, H), color_wh=color_wh, lut_res=lut_res, res=res, inv_res=inv_res, brick_voxels=g.brick_voxels,
-                limit=limit, flags=flags, min_voxels=min_voxels)
+                limit=limit, flags=flags, min_voxels=min_voxels, keep_file_layout=keep_file_layout)
     for bricks in (bool(rng.integers(0, 2)), None):
         bricks = (not last) if bricks is None else bricks     # both sweeps, in a random order
         last = bricks
@@ -70,7 +73,7 @@ def test_random_configuration(pkg, orc, seed):
     # the consumer side on the same configuration: one view of a random size, eye and shade mode through the ray-marcher
     # (with the depth peels when the last sweep left an occupied list) and the hole filling.  The ray-marcher samples the
     # LUT as it is resident -- the grid layout at the grid's resolution, which is what is read back for the oracle
-    resident = [ctx.readback_inverse_calibration(i, 0, res[2]) for i in range(n)]
+    resident = inv if keep_file_layout else [ctx.readback_inverse_calibration(i, 0, res[2]) for i in range(n)]
     vw, vh = int(rng.integers(1, 90)), int(rng.integers(1, 70))
     eye = [(2.2, 1.6, 1.9), (0.85, 1.7, 0.8), (-2.0, 1.2, 2.1), (0.05, 1.95, 0.02)][int(rng.integers(0, 4))]
     view = capi.make_view(eye, (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, vw, vh, BMIN, BMAX, shade_mode=int(rng.integers(0, 4)))
