@@ -949,13 +949,19 @@ def fill_colors(a, W, H):
     vs = "texture_passthrough.vs"
     transfer, inpaint, colorfill = Prog("transfer", [vs, "framebuffer_transfer.fs"]), Prog("inpaint", [vs, "tsdf_inpaint.fs"]), Prog("colorfill", [vs, "tsdf_colorfill.fs"])
     rinv = np.array([np.float32(1.0) / np.float32(a.FW), np.float32(1.0) / np.float32(H)], np.float32)
+    # uvec2[20] arrays of which the reference uploads numLods elements (:502-510).  tsdf_colorfill.fs reads levels + 1 and + 2
+    # past num_lods: zeros in a freshly linked program -- what the oracle and the library evaluate --, but whatever an earlier,
+    # larger window left there after a resize.  The programs of this harness are cached across calls, so all 20 elements
+    # are written: every call sees the fresh program of the reference's start-up.
+    off20, res20 = np.zeros((20, 2), np.uint32), np.zeros((20, 2), np.uint32)
+    off20[:nl], res20[:nl] = a.off, a.res
     for p in (inpaint, colorfill):                                                             # ctor :103-128, resize :502-510
         p.use()
         p.i("texture_color", 15)
         p.i("texture_depth", 16)
         p.fv("viewport_offset", [0.0, 0.0], 2)
-        p.uv("texture_offsets", a.off, 2)
-        p.uv("texture_resolutions", a.res, 2)
+        p.uv("texture_offsets", off20, 2)
+        p.uv("texture_resolutions", res20, 2)
         p.fv("resolution_inv", rinv, 2)
     colorfill.i("num_lods", nl)
     transfer.use()

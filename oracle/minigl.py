@@ -67,6 +67,7 @@ _SIGS = {
     "glTexParameteri": (None, [C.c_uint, C.c_uint, C.c_int]),
     "glTexImage2D": (None, [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p]),
     "glTexImage3D": (None, [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p]),
+    "glTexSubImage2D": (None, [C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p]),
     "glCompressedTexImage3D": (None, [C.c_uint, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "glGetTexImage": (None, [C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_void_p]),
     "glClearTexImage": (None, [C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_void_p]),
