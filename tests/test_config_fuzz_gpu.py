@@ -150,3 +150,82 @@ def test_random_slab_configuration(pkg, orc, seed):
         ctx.close()
     whole = np.concatenate(parts, axis=0)
     assert same_bits(whole, ref["tsdf"]), (desc, count_diff(whole, ref["tsdf"]))
+
+
+@pytest.mark.parametrize("seed", list(range(1, 4 + int(os.environ.get("RGBDR_EXTRA_SEEDS", "0")) // 16)))
+def test_random_sensor_shard_configuration(pkg, orc, seed):
+    """the pre_* chain sharded by sensor over k contexts (as the k ranks of a slab job hold them: rgbdr_set_sensor_shard), the
+    packed frame layers copied between them and the brick counters summed the way rgbdr_shard_allgather / dist.FrameGather
+    do it over RCCL -- random sensor counts and shard sizes, image sizes, grids, sweeps, schedules and upload roads; every
+    rank's brick table, occupied list and volume equal the oracle's for three frames in a row"""
+    import torch
+    from rgbd_recon_amd import dist as rdist
+    capi, synth = pkg.capi, pkg.synth
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11000 + seed)
+    n, k = [(2, 2), (4, 2), (4, 4), (6, 2), (6, 3), (8, 2), (8, 4), (3, 3)][int(rng.integers(0, 8))]
+    W, H = int(rng.integers(20, 120)), int(rng.integers(20, 100))
+    lut_res = tuple(int(v) for v in rng.integers(3, 18, 3))
+    G = int(rng.integers(12, 56))
+    limit = float(rng.choice([0.01, 0.03]))
+    cfg = capi.make_config(n, (W, H), voxel_size=2.0 / G, brick_size=float(rng.integers(4, 11)) * 2.0 / G, tsdf_limit=limit, min_voxels=int(rng.choice([1, 10])))
+    res = tuple(capi.compute_geometry(cfg).res_volume)
+    scenes = [synth.Scene(n, W, H, lut_res=lut_res, seed=seed, sphere_r=0.8), synth.Scene(n, W, H, lut_res=lut_res, seed=seed + 500, sphere_r=0.6)]
+    inv_res = res if rng.integers(0, 2) else tuple(int(v) for v in rng.integers(10, 40, 3))
+    inv = scenes[0].inverse(inv_res)
+    ranks = []
+    for r in range(k):
+        c = capi.Context(cfg, 0)
+        for i in range(n):
+            c.set_calibration(i, scenes[0].xyz[i], lut_res, scenes[0].uv[i], lut_res, (0.5, 4.5))
+            c.set_inverse_calibration(i, inv[i], inv_res)
+        c.set_sensor_shard(r * (n // k), n // k)
+        ranks.append(c)
+    g = ranks[0].geo
+    desc = dict(seed=seed, n=n, k=k, wh=(W, H), res=res, inv_res=inv_res, limit=limit)
+    for frame_no in range(3):
+        sc = scenes[int(rng.integers(0, 2))]
+        bricks, pipelined, skip = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        for c in ranks:
+            c.set_use_bricks(bricks)
+            c.set_pipelined(pipelined)
+            c.set_skip_background(skip)
+            if rng.integers(0, 2):
+                c.update(sc.depth, sc.color)
+            else:
+                md, mc = c.map_frame_buffer()
+                md[:] = sc.depth.view(np.uint8).reshape(-1)
+                mc[:] = sc.color.reshape(-1)
+                c.upload_mapped_frame()
+            c.clear_occupied_bricks()
+            c.process_textures()
+        with pytest.raises(capi.RgbdrError):
+            ranks[int(rng.integers(0, k))].integrate()              # the other ranks' sensors have not arrived
+        views = [c.shard_view() for c in ranks]
+        for c in ranks:
+            c.sync()
+        words = views[0].sensor_bytes // 4
+        fr = [rdist.wrap_device_words(v.frames, words * n, dev) for v in views]
+        cn = [rdist.wrap_device_words(v.counters, v.num_bricks, dev) for v in views]
+        total = sum(t.clone() for t in cn)
+        for r, v in enumerate(views):
+            lo, hi = v.first * words, (v.first + v.count) * words
+            for q in range(k):
+                if q != r:
+                    fr[q][lo:hi] = fr[r][lo:hi]
+        for t in cn:
+            t.copy_(total)
+        torch.cuda.synchronize()
+        ref = orc.run_pipeline(sc, BMIN, BMAX, res, inv, limit=limit, brick_size=g.brick_size, bv=g.brick_voxels, res_bricks=tuple(g.res_bricks),
+                               min_voxels=cfg.min_voxels_per_brick, use_bricks=bricks)
+        for r, c in enumerate(ranks):
+            c.update_occupied_bricks()
+            c.integrate()
+            assert np.array_equal(c.readback_brick_counters(), ref["counters"]), (desc, frame_no, r)
+            assert np.array_equal(c.get_occupied()[0], ref["occupied"]), (desc, frame_no, r)
+            got = c.readback_tsdf()
+            assert same_bits(got, ref["tsdf"]), (desc, frame_no, r, bricks, pipelined, skip, count_diff(got, ref["tsdf"]))
+            for i in range(r * (n // k), (r + 1) * (n // k)):     # the images of its own sensors
+                assert same_bits(c.readback_image(IMG["quality"], i), ref["quality"][i]), (desc, frame_no, r, i)
+    for c in ranks:
+        c.close()
