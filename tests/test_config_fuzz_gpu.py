@@ -38,8 +38,14 @@ def test_random_configuration(pkg, orc, seed):
     keep_file_layout = bool(rng.integers(0, 4) == 0)        # RGBDR_FLAG_NO_RESAMPLE: the LUT stays at its own resolution, 8-tap lookups per voxel
     if keep_file_layout:
         flags |= capi.FLAG_NO_RESAMPLE
+    # input formats (f-1): DXT1 / DXT5 colour blocks (compress_rgb; 1 is the reference's yml default), 8-bit depth (compress_depth;
+    # coherent only without the morph-processed depths, SURVEY A.5: the processed-depths bit is cleared)
+    dxt = int(rng.choice([0, 0, 1, 5]))
+    u8 = bool(rng.integers(0, 6) == 0)
+    if u8:
+        flags &= ~2
     cfg = capi.make_config(n, (W, H), color_wh=color_wh, voxel_size=voxel, brick_size=brick, tsdf_limit=limit, min_voxels=min_voxels,
-                           flags=flags, res_override=override)
+                           flags=flags, res_override=override, compress_rgb=dxt, compress_depth=int(u8))
     ctx = capi.Context(cfg, 0)
     g = ctx.geo
     res = tuple(g.res_volume)                              # (ceil(extent / voxel_size) in float: may be one more than G)
@@ -49,8 +55,22 @@ def test_random_configuration(pkg, orc, seed):
     for i in range(n):
         ctx.set_calibration(i, scene.xyz[i], lut_res, scene.uv[i], lut_res, (0.5, 4.5))
         ctx.set_inverse_calibration(i, inv[i], inv_res)
+    up_depth, up_color, oracle_kw = scene.depth, scene.color, {}
+    if dxt:
+        Hc, Wc = scene.color.shape[1:3]
+        up_color = np.stack([synth.encode_dxt(scene.color[i], dxt) for i in range(n)])
+
+        class Decoded:                                      # the oracle sees the colours the blocks decode to
+            pass
+        d_ = Decoded()
+        d_.__dict__.update(scene.__dict__)
+        d_.color = np.stack([orc.decode_dxt(up_color[i], Wc, Hc, dxt) for i in range(n)])
+        scene = d_
+    if u8:
+        up_depth = synth.compress_depth_u8(scene.depth)
+        oracle_kw = dict(compress=True, depth_override=(up_depth.astype(np.float32) / np.float32(255.0)).astype(np.float32))
     desc = dict(seed=seed, n=n, wh=(W, H), color_wh=color_wh, lut_res=lut_res, res=res, inv_res=inv_res, brick_voxels=g.brick_voxels,
-                limit=limit, flags=flags, min_voxels=min_voxels, keep_file_layout=keep_file_layout)
+                limit=limit, flags=flags, min_voxels=min_voxels, keep_file_layout=keep_file_layout, dxt=dxt, u8=u8)
     for bricks in (bool(rng.integers(0, 2)), None):
         bricks = (not last) if bricks is None else bricks     # both sweeps, in a random order
         last = bricks
@@ -58,10 +78,10 @@ def test_random_configuration(pkg, orc, seed):
         ctx.set_pipelined(bool(rng.integers(0, 2)))
         ctx.set_skip_background(bool(rng.integers(0, 2)))
         ctx.set_elide_stores(bool(rng.integers(0, 2)))
-        ctx.step(scene.depth, scene.color)
+        ctx.step(up_depth, up_color)
         ref = orc.run_pipeline(scene, BMIN, BMAX, res, inv, limit=limit, brick_size=g.brick_size, bv=g.brick_voxels,
                                res_bricks=tuple(g.res_bricks), min_voxels=min_voxels, filter_textures=bool(flags & 1),
-                               processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=bricks)
+                               processed=bool(flags & 2), refine=bool(flags & 4), use_bricks=bricks, **oracle_kw)
         for name, which in IMG.items():
             for i in range(n):
                 got = ctx.readback_image(which, i)
