@@ -315,7 +315,7 @@ try {
   // n compute units of its own and keeps the sweep's stream off them (hipExtStreamCreateWithCUMask).  Without it the chain's 256-thread blocks
   // starve next to a sweep whose 262 144 blocks refill every slot that frees up (the chain runs 8-20x longer there).
   int cu_split = 0;
-  if (const char* e = std::getenv("RGBDR_CU_SPLIT")) cu_split = std::atoi(e);
+  if (const char* env = std::getenv("RGBDR_CU_SPLIT")) cu_split = std::atoi(env);
   hipDeviceProp_t prop{};
   if (cu_split > 0 && (hipGetDeviceProperties(&prop, device_id) != hipSuccess || cu_split >= prop.multiProcessorCount)) cu_split = 0;
   bool masked = false;
