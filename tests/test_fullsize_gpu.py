@@ -238,13 +238,32 @@ def test_a_volume_of_two_to_the_32_voxels(pkg, orc, monkeypatch):
     ctx.step(scene.depth, scene.color)
     ctx.sync()
     layer = np.empty(2048 * 2048 * 8, np.float32)
-    seen_band = 0
+    seen_band, full = 0, {}
     for tz in (0, 63, 64, 127):
         ctx._chk(pkg.capi.lib().rgbdr_readback_tile_layers(ctx._h, tz, 1, layer.ctypes.data_as(C.POINTER(C.c_float))))
         rows = layer.reshape(256, 256, 8, 8, 8).transpose(2, 0, 3, 1, 4).reshape(8, 2048, 2048)     # [ty, tx, z, y, x] -> [z, Y, X]
         ref = check_rows(orc, ctx, rows, tz * 8, 8)
         seen_band += int((np.abs(ref) < np.float32(0.01)).sum())
+        full[tz] = layer.copy()
     assert seen_band > 1000                                  # the surface crosses the layers looked at
+    # the brick-skipping sweep over the same 8.4 M tiles (work list, tile states, clears): the full sweep's values inside
+    # occupied bricks, -limit everywhere else.  The z voxels are twice as long as the others on this grid, so a brick is
+    # 8 x 8 x 4 voxels: 16.8 M bricks, two to a tile; one pixel marks a brick (a brick is smaller than a pixel's footprint)
+    ctx.set_min_voxels_per_brick(1)
+    ctx.set_use_bricks(True)
+    ctx.step(scene.depth, scene.color)
+    ctx.sync()
+    occupied = np.zeros(g.num_bricks, bool)
+    occupied[ctx.get_occupied()[0]] = True
+    assert 0 < occupied.sum() < occupied.size and tuple(g.res_bricks) == (256, 256, 256) and tuple(g.brick_voxels_axis) == (8, 8, 4)
+    drawn = 0
+    for tz in (0, 63, 64, 127):
+        ctx._chk(pkg.capi.lib().rgbdr_readback_tile_layers(ctx._h, tz, 1, layer.ctypes.data_as(C.POINTER(C.c_float))))
+        pair = occupied.reshape(256, 256 * 256)[2 * tz:2 * tz + 2]                                    # the two brick layers of this tile layer
+        occ = np.repeat(pair.T[:, :, None], 256, axis=2).reshape(-1)                                  # [tile][z half][256 voxels]
+        assert same_bits(layer[occ], full[tz][occ]) and np.all(layer[~occ] == np.float32(-0.01)), tz
+        drawn += int(occ.sum())
+    assert drawn > 0
     ctx.close()
 
 
