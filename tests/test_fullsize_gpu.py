@@ -267,6 +267,44 @@ def test_a_volume_of_two_to_the_32_voxels(pkg, orc, monkeypatch):
     ctx.close()
 
 
+def test_a_volume_that_does_not_fit_is_refused_and_leaves_the_device_usable(pkg, orc, monkeypatch):
+    """a voxel size too fine for the device (4096 x 4096 x 2048 voxels: 137 GB of TSDF, 412 GB of LUT planes per sensor): whichever
+    allocation fails, the call returns a HIP error status -- no crash, nothing left behind -- and the next context of an
+    ordinary size reproduces the oracle"""
+    import torch
+    monkeypatch.setenv("RGBDR_ARENA_TRIALS", "1")
+    capi = pkg.capi
+    scene = scene_for(pkg, 1)
+    warm = make_ctx(pkg, scene, (64, 64, 64))                # (the runtime's first-use allocations: code objects, pools)
+    warm.step(scene.depth, scene.color)
+    warm.close()
+    torch.cuda.synchronize()
+    free0, total = torch.cuda.mem_get_info()
+    cfg = capi.make_config(1, (W, H), voxel_size=2.0 / 4096, brick_size=8 * 2.0 / 4096, res_override=(4096, 4096, 2048))
+    refused = False
+    try:
+        ctx = capi.Context(cfg, 0)                           # the TSDF alone may or may not fit
+    except capi.RgbdrError as e:
+        refused = True
+        assert e.status == capi.ERR_HIP, e
+    else:
+        ctx.set_calibration(0, scene.xyz[0], scene.lut_res, scene.uv[0], scene.lut_res, (0.5, 4.5))
+        with pytest.raises(capi.RgbdrError) as e:            # 412 GB of LUT planes never do
+            ctx.synth_inverse_calibration(0, scene.pinhole(0))
+        assert e.value.status in (capi.ERR_HIP, capi.ERR_STATE), e.value
+        refused = True
+        ctx.close()
+    assert refused
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "%.1f MiB not returned" % ((free0 - free1) / 2 ** 20)
+    small = make_ctx(pkg, scene, (64, 64, 64))
+    small.set_use_bricks(False)
+    small.step(scene.depth, scene.color)
+    check_rows(orc, small, small.readback_tsdf(), 0, 64)
+    small.close()
+
+
 def test_one_recorded_stream_128(pkg, orc, tmp_path):
     """configs[0]: one sensor's `.stream` recording (512x424 f32 depth + RGB8 colour in the
     reference's frame layout) and LUT files through the C++ host mirror into a 128^3 TSDF,
