@@ -12,6 +12,8 @@ load_package()
 import torch  # noqa: E402,F401
 from rgbd_recon_amd import capi, synth  # noqa: E402
 
+if os.environ.get("RGBDR_PROBE_LIB"):       # A/B against a developer build under profiles/probes_src/
+    capi.LIB_PATH = os.path.join(ROOT, os.environ["RGBDR_PROBE_LIB"])
 N, W, H = 4, 512, 424
 scene = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234)
 c = capi.Context(capi.make_config(N, (W, H), voxel_size=2.0 / 512, brick_size=8 * 2.0 / 512), 0)

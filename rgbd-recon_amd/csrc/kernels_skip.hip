@@ -14,68 +14,76 @@ namespace rgbdr {
 //   bound 0: all background (silhouette 0, depth not NaN) -> their largest depth, else +inf
 //   bound 1, 2: all surface (silhouette 1, depth not NaN) -> their smallest / largest depth, else -inf / +inf
 // Squares of 8 and 16 are folded from two of the next smaller size, along x and then along y.
-__global__ __launch_bounds__(256) void k_window_background(const uint2* __restrict__ frames, int W, int H,
-                                                           float* __restrict__ bgmax)
+// One block serves O x O origins from (O + 15)^2 texels: with O = 32 a texel is staged 2.2 times (O = 16: 3.75).
+// Every stage walks its array with a linear index whose row width IS the LDS pitch P, so the 32 lanes of a
+// ds_read_b32 group touch 32 consecutive words: no bank conflicts and no division by an odd row width (round 3:
+// index rows of 28 / 24 over a pitch of 32 -- 49 % of the kernel's LDS cycles were conflicts).  Entries whose window
+// runs off the row or the array are folded from whatever lies there and never read by an origin of the block.
+// Round 4: 21.9 -> 15.9 us at 4 x 512 x 424 (O = 16 with the linear index: 19.8; four entries per lane with 16-byte
+// LDS accesses: 16.3 -- LDS is no longer what the kernel waits for; the three bounds of an origin in one 16-byte entry
+// instead of three planes: the same here and +1.8 us in the classifier; profiles/r04_notes/experiments.md).
+template <int O>
+__global__ __launch_bounds__(O * O) void k_window_background(const uint2* __restrict__ frames, int W, int H,
+                                                             float* __restrict__ bgmax)
 {
-  constexpr int T = 16 + kWin - 1;  // 31 texels per axis feed 16 origins
-  __shared__ float tex[3][T][T + 1];  // rows, then reduced along x in place
+  constexpr int T = O + kWin - 1;  // texels per axis feeding O origins (47)
+  constexpr int P = T + 1;         // pitch = index row width (48)
+  constexpr int NT = O * O;
+  __shared__ float bufa[3][T * P + 4], bufb[3][T * P + 4];  // + 4: the tail of the last row reads past it
   const int l = blockIdx.z;
   const uint2* frame = frames + (size_t)l * W * H;
-  const int ox0 = (int)blockIdx.x * 16 - 1, oy0 = (int)blockIdx.y * 16 - 1;
-  const int t = threadIdx.y * 16 + threadIdx.x;
+  const int ox0 = (int)blockIdx.x * O - 1, oy0 = (int)blockIdx.y * O - 1;
+  const int t = threadIdx.y * O + threadIdx.x;
   const float inf = __builtin_inff();
-  for (int i = t; i < T * T; i += 256) {
-    const int ty = i / T, tx = i - ty * T;
+  for (int i = t; i < T * P; i += NT) {
+    const int ty = i / P, tx = i - ty * P;
     const uint2 v = frame[(size_t)clampi(oy0 + ty, 0, H - 1) * W + clampi(ox0 + tx, 0, W - 1)];
     const float d = texel_depth(v);
     const bool num = d == d, bg = (v.y >> 31) != 0;
-    tex[0][ty][tx] = (bg && num) ? d : inf;    // max-reduced
-    tex[1][ty][tx] = (!bg && num) ? d : -inf;  // min-reduced
-    tex[2][ty][tx] = (!bg && num) ? d : inf;   // max-reduced
+    bufa[0][i] = (bg && num) ? d : inf;    // max-reduced
+    bufa[1][i] = (!bg && num) ? d : -inf;  // min-reduced
+    bufa[2][i] = (!bg && num) ? d : inf;   // max-reduced
+  }
+  if (t < 12) bufa[t >> 2][T * P + (t & 3)] = 0.0f;
+  __syncthreads();
+  auto red = [](int b, float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
+  // squares by doubling, each level staged in LDS: rows of 4 (bufb) -> squares of 4 (c4, bufa) -> squares of 8 (c8, bufb)
+  // -> squares of 16 from four c8
+  for (int i = t; i < T * P; i += NT) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      bufb[b][i] = red(b, red(b, bufa[b][i], bufa[b][i + 1]), red(b, bufa[b][i + 2], bufa[b][i + 3]));
+  }
+  __syncthreads();
+  for (int i = t; i < (T - 3) * P; i += NT) {  // c4[y][x], x, y in [0, T - 4]
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      bufa[b][i] = red(b, red(b, bufb[b][i], bufb[b][i + P]), red(b, bufb[b][i + 2 * P], bufb[b][i + 3 * P]));
+  }
+  __syncthreads();
+  for (int i = t; i < (T - 7) * P; i += NT) {  // c8[y][x], x, y in [0, T - 8]
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+      bufb[b][i] = red(b, red(b, bufa[b][i], bufa[b][i + 4]), red(b, bufa[b][i + 4 * P], bufa[b][i + 4 * P + 4]));
   }
   __syncthreads();
   const int ox = ox0 + (int)threadIdx.x, oy = oy0 + (int)threadIdx.y;
-  const bool live = ox <= W - 1 && oy <= H - 1;
+  if (ox > W - 1 || oy > H - 1) return;
   const size_t plane = (size_t)(W + 1) * (H + 1), o = (size_t)(oy + 1) * (W + 1) + (ox + 1);
-  // squares by doubling, each level staged in LDS: rows of 4 -> squares of 4 (c4, in place of tex) -> squares of 8
-  // (c8, in place of r4) -> squares of 16 from four c8
-  __shared__ float r4[3][T][T + 1];
-  auto red = [](int b, float x, float y) { return (b == 1) ? fminf(x, y) : fmaxf(x, y); };
-  for (int i = t; i < T * (T - 3); i += 256) {
-    const int ty = i / (T - 3), tx = i - ty * (T - 3);
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 1]), red(b, tex[b][ty][tx + 2], tex[b][ty][tx + 3]));
-  }
-  __syncthreads();
-  for (int i = t; i < (T - 3) * (T - 3); i += 256) {  // c4[y][x], x, y in [0, 27]
-    const int ty = i / (T - 3), tx = i - ty * (T - 3);
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      tex[b][ty][tx] = red(b, red(b, r4[b][ty][tx], r4[b][ty + 1][tx]), red(b, r4[b][ty + 2][tx], r4[b][ty + 3][tx]));
-  }
-  __syncthreads();
-  for (int i = t; i < (T - 7) * (T - 7); i += 256) {  // c8[y][x], x, y in [0, 23]
-    const int ty = i / (T - 7), tx = i - ty * (T - 7);
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      r4[b][ty][tx] = red(b, red(b, tex[b][ty][tx], tex[b][ty][tx + 4]), red(b, tex[b][ty + 4][tx], tex[b][ty + 4][tx + 4]));
-  }
-  __syncthreads();
-  if (!live) return;
-  const int x = threadIdx.x, y = threadIdx.y;
+  const int c = (int)threadIdx.y * P + (int)threadIdx.x;
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
-    const float q16 = red(b, red(b, r4[b][y][x], r4[b][y][x + 8]), red(b, r4[b][y + 8][x], r4[b][y + 8][x + 8]));
-    bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = tex[b][y][x];
-    bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = r4[b][y][x];
+    const float q16 = red(b, red(b, bufb[b][c], bufb[b][c + 8]), red(b, bufb[b][c + 8 * P], bufb[b][c + 8 * P + 8]));
+    bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = bufa[b][c];
+    bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = bufb[b][c];
     bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
   }
 }
 void launch_window_background(const uint2* frames, int W, int H, int N, float* bgmax, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_window_background, dim3((unsigned)((W + 1 + 15) / 16), (unsigned)((H + 1 + 15) / 16), (unsigned)N),
-                     dim3(16, 16), 0, s, frames, W, H, bgmax);
+  constexpr int O = 32;
+  hipLaunchKernelGGL((k_window_background<O>), dim3((unsigned)((W + 1 + O - 1) / O), (unsigned)((H + 1 + O - 1) / O), (unsigned)N),
+                     dim3(O, O), 0, s, frames, W, H, bgmax);
 }
 
 // The verdict of one (tile, sensor) pair for the current frame (kSkip*)

@@ -1254,6 +1254,34 @@ def test_background_skip_verdicts_follow_lut_and_limit_changes(pkg, orc):
     ctx.close()
 
 
+def test_background_skip_window_bounds_table(pkg):
+    """rgbdr_readback_skip_tables(2): what the squares of 4 / 8 / 16 edge-clamped texels at every window origin
+    in [-1, W-1] x [-1, H-1] have in common, against a sliding-window restatement over the frame's own images
+    (widths that are not a multiple of the kernel's 32 origins per block, holes and non-finite depths included)"""
+    from numpy.lib.stride_tricks import sliding_window_view
+    for wh, holes in (((128, 106), False), ((75, 41), True), ((33, 97), True)):
+        scene, ctx, inv = build(pkg, n=2, wh=wh, G=32)
+        if holes:
+            rng = np.random.default_rng(wh[0])
+            scene.depth[:, rng.integers(0, wh[1], 40), rng.integers(0, wh[0], 40)] = 0.0
+        ctx.set_use_bricks(False)
+        ctx.set_skip_background(True)
+        ctx.step(scene.depth, scene.color)
+        got = ctx.readback_skip_tables(2)
+        assert got.shape == (2, 3, 3, wh[1] + 1, wh[0] + 1)
+        for s in range(2):
+            d = ctx.readback_image(pkg.capi.IMG_DEPTH_B_RG, s)[..., 0]
+            sil = ctx.readback_image(pkg.capi.IMG_SILHOUETTE, s)
+            num, bg = ~np.isnan(d), sil < 1.0
+            planes = (np.where(bg & num, d, np.inf), np.where(~bg & num, d, -np.inf), np.where(~bg & num, d, np.inf))
+            for k, size in enumerate((4, 8, 16)):
+                for b, a in enumerate(planes):
+                    w = sliding_window_view(np.pad(a, ((1, 16), (1, 16)), mode="edge"), (size, size))[:wh[1] + 1, :wh[0] + 1]
+                    want = w.min(axis=(2, 3)) if b == 1 else w.max(axis=(2, 3))
+                    assert same_bits(got[s, k, b], want.astype(np.float32)), (wh, s, size, b)
+        ctx.close()
+
+
 def test_background_skip_on_slabs_and_resampled_luts(pkg, orc):
     scene, ctx, inv = build(pkg, n=3, wh=(128, 106), G=64, inv_res=(40, 44, 48), slab_rank=1, slab_count=3)
     ctx.set_use_bricks(False)
