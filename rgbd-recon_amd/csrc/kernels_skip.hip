@@ -114,36 +114,42 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
 // every sensor: +limit -- and the tile is filled here, unless tile_state says it has held -limit since a sweep of
 // this epoch (the bookkeeping of the brick sweep and of RGBDR_FLAG_ELIDE_STORES; this sweep always keeps it).
 // Otherwise {tile, verdicts, window origins} goes on the list of k_integrate_tiled_listed.
-// One lane per (tile, sensor) pair takes that pair's verdict -- the four words of the pair are read coalesced, the three
-// bounds behind the window origin are one dependent round trip, every pair of the block in flight at once -- then one
-// lane per tile combines them from LDS, and the block appends its listed tiles with ONE atomic on the list counter
-// (round 2: one lane per tile walked its sensors in turn and every wavefront took its own atomic on that one word:
-// 4096 same-address atomics were most of the kernel's 50 us).
+// One lane per tile, 1024 tiles per block.  The block's 1024 N pairs are taken N per lane -- the four words of a pair
+// are read coalesced, the three bounds behind the window origin are one dependent round trip, all N of a lane in
+// flight at once -- then every lane combines its tile's verdicts from LDS, and the block appends its listed tiles
+// with ONE atomic on the list counter.  That counter is what the kernel's time follows -- a returning atomic on one
+// address costs about 10 ns (round 2: one per wavefront, 65 536 of them, most of 50 us; round 3: one per 256 tiles,
+// 20.3 us, and with 128 / 64 tiles per block 28.4 / 48.7 us) -- until the block's own chain of dependent round trips
+// is what is left: one per 1024 tiles (256 blocks at 512^3, one per CU) 18.5 us, one per 512 tiles in this form
+// 20.7 us (profiles/r04_notes/experiments.md).
 constexpr int kClassifyThreads = 1024;
-__global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegrateParams p, unsigned ntiles, unsigned tiles_per_block)
+template <int N>
+__global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegrateParams p, unsigned ntiles)
 {
-  __shared__ unsigned char verdict[kClassifyThreads];  // [tile in block][sensor]
-  __shared__ int origin[kClassifyThreads];             // the pair's window origin word (goes into the list entry)
-  __shared__ unsigned todo[kClassifyThreads];          // tile | (value is +limit) << 31
+  __shared__ unsigned char verdict[N * kClassifyThreads];  // [tile in block][sensor]
+  __shared__ int origin[N * kClassifyThreads];             // the pair's window origin word (goes into the list entry)
+  __shared__ unsigned todo[kClassifyThreads];              // tile | (value is +limit) << 31
   __shared__ unsigned ntodo, wave_listed[kClassifyThreads / 64], list_base;
   if (threadIdx.x == 0) ntodo = 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.skip_count_next = 0u;  // the counter the next sweep appends to
-  const unsigned N = (unsigned)p.N;
-  const unsigned tile0 = blockIdx.x * tiles_per_block;
-  {
-    const size_t pair = (size_t)tile0 * N + threadIdx.x;
-    if (threadIdx.x < tiles_per_block * N && pair < (size_t)ntiles * N) {
-      origin[threadIdx.x] = p.win[pair];
-      verdict[threadIdx.x] = (unsigned char)skip_verdict(p, pair, (int)(threadIdx.x % N));
+  const unsigned tile0 = blockIdx.x * (unsigned)kClassifyThreads;
+  const size_t pair0 = (size_t)tile0 * N, pair_end = (size_t)ntiles * N;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const unsigned j = (unsigned)k * kClassifyThreads + threadIdx.x;  // pair of the block; pair0 is a multiple of N
+    if (pair0 + j < pair_end) {
+      origin[j] = p.win[pair0 + j];
+      verdict[j] = (unsigned char)skip_verdict(p, pair0 + j, (int)(j % (unsigned)N));
     }
   }
   __syncthreads();
   const unsigned tile = tile0 + threadIdx.x;
   bool listed = false, fill = false, positive = false;
   unsigned actions = 0u;
-  if (threadIdx.x < tiles_per_block && tile < ntiles) {
+  if (tile < ntiles) {
     bool all = true, negative = false;
-    for (unsigned s = 0; s < N; ++s) {
+#pragma unroll
+    for (unsigned s = 0; s < (unsigned)N; ++s) {
       const unsigned a = verdict[threadIdx.x * N + s];
       actions |= a << (2 * s);
       all = all && a != kSkipNone;
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(kClassifyThreads) void k_skip_classify(IntegratePar
     unsigned* e = p.skip_list + (size_t)(list_base + wave_listed[wave] + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) * (2 + N);
     e[0] = tile;
     e[1] = actions;
-    for (unsigned s = 0; s < N; ++s) e[2 + s] = (unsigned)origin[threadIdx.x * N + s];
+#pragma unroll
+    for (unsigned s = 0; s < (unsigned)N; ++s) e[2 + s] = (unsigned)origin[threadIdx.x * N + s];
   }
   const unsigned n = ntodo;
   if (n == 0) return;
@@ -228,25 +235,24 @@ void launch_skip_mask(const IntegrateParams& p, unsigned npairs, uint8_t* mask, 
   hipLaunchKernelGGL(k_skip_mask, dim3((npairs + 255) / 256), dim3(256), 0, s, p, npairs, mask);
 }
 template <int N>
-static void launch_listed_n(const IntegrateParams& p, unsigned blocks, hipStream_t s)
+static void launch_skip_sweep_n(const IntegrateParams& p, unsigned ntiles, unsigned blocks, hipStream_t s)
 {
+  hipLaunchKernelGGL((k_skip_classify<N>), dim3((ntiles + kClassifyThreads - 1) / kClassifyThreads), dim3(kClassifyThreads), 0, s, p, ntiles);
   hipLaunchKernelGGL((k_integrate_tiled_listed<N>), dim3(blocks), dim3(128), 0, s, p);
 }
 // the background-skip sweep: classifier + one block per listed tile (`blocks`: the host's estimate of the list length)
 void launch_skip_sweep(const IntegrateParams& p, unsigned blocks, hipStream_t s)
 {
   const unsigned ntiles = (unsigned)p.TX * p.TY * p.ntz;
-  const unsigned tpb = (unsigned)kClassifyThreads / (unsigned)p.N;  // 64 tiles per block at 4 sensors
-  hipLaunchKernelGGL(k_skip_classify, dim3((ntiles + tpb - 1) / tpb), dim3(kClassifyThreads), 0, s, p, ntiles, tpb);
   switch (p.N) {
-    case 1: launch_listed_n<1>(p, blocks, s); break;
-    case 2: launch_listed_n<2>(p, blocks, s); break;
-    case 3: launch_listed_n<3>(p, blocks, s); break;
-    case 4: launch_listed_n<4>(p, blocks, s); break;
-    case 5: launch_listed_n<5>(p, blocks, s); break;
-    case 6: launch_listed_n<6>(p, blocks, s); break;
-    case 7: launch_listed_n<7>(p, blocks, s); break;
-    default: launch_listed_n<8>(p, blocks, s); break;
+    case 1: launch_skip_sweep_n<1>(p, ntiles, blocks, s); break;
+    case 2: launch_skip_sweep_n<2>(p, ntiles, blocks, s); break;
+    case 3: launch_skip_sweep_n<3>(p, ntiles, blocks, s); break;
+    case 4: launch_skip_sweep_n<4>(p, ntiles, blocks, s); break;
+    case 5: launch_skip_sweep_n<5>(p, ntiles, blocks, s); break;
+    case 6: launch_skip_sweep_n<6>(p, ntiles, blocks, s); break;
+    case 7: launch_skip_sweep_n<7>(p, ntiles, blocks, s); break;
+    default: launch_skip_sweep_n<8>(p, ntiles, blocks, s); break;
   }
 }
 // number of non-zero mask bytes (diagnostic, on demand: thousands of atomics on one word cost more than the mask itself)
