@@ -1282,6 +1282,22 @@ def test_background_skip_window_bounds_table(pkg):
         ctx.close()
 
 
+@pytest.mark.parametrize("n", [1, 5, 6, 7, 8])
+def test_background_skip_every_sensor_count(pkg, orc, n):
+    """the classifier and the listed-tile kernel are instantiated per sensor count: 1 .. 8 sensors (2, 3, 4 above), on a
+    grid whose tile count is not a multiple of the classifier's 1024 tiles per block"""
+    scene, ctx, inv = build(pkg, n=n, wh=(96, 80), G=40)
+    ctx.set_use_bricks(False)
+    ref = oracle_run(orc, scene, ctx, inv, use_bricks=False)
+    for skip in (True, False, True):
+        ctx.set_skip_background(skip)
+        ctx.step(scene.depth, scene.color)
+        assert same_bits(ctx.readback_tsdf(), ref["tsdf"]), (n, skip)
+    skipped, total = ctx.skipped_pairs()
+    assert total == np.prod(ctx.geo.tiles) * n and skipped > 0
+    ctx.close()
+
+
 def test_background_skip_on_slabs_and_resampled_luts(pkg, orc):
     scene, ctx, inv = build(pkg, n=3, wh=(128, 106), G=64, inv_res=(40, 44, 48), slab_rank=1, slab_count=3)
     ctx.set_use_bricks(False)
