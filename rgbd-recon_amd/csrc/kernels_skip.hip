@@ -118,8 +118,8 @@ __global__ void k_skip_mask(IntegrateParams p, unsigned npairs, uint8_t* __restr
 // are read coalesced, the three bounds behind the window origin are one dependent round trip, all N of a lane in
 // flight at once -- then every lane combines its tile's verdicts from LDS, and the block appends its listed tiles
 // with ONE atomic on the list counter.  That counter is what the kernel's time follows -- a returning atomic on one
-// address costs about 10 ns (round 2: one per wavefront, 65 536 of them, most of 50 us; round 3: one per 256 tiles,
-// 20.3 us, and with 128 / 64 tiles per block 28.4 / 48.7 us) -- until the block's own chain of dependent round trips
+// address costs about 10 ns (round 2: one per wavefront of 64 tiles, 4096 of them at 512^3, 48 us; round 3: one per 256
+// tiles, 20.3 us, and that kernel with 128 / 64 tiles per block 28.4 / 48.7 us) -- until the block's own chain of dependent round trips
 // is what is left: one per 1024 tiles (256 blocks at 512^3, one per CU) 18.5 us, one per 512 tiles in this form
 // 20.7 us (profiles/r04_notes/experiments.md).
 constexpr int kClassifyThreads = 1024;
