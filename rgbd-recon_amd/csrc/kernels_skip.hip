@@ -74,6 +74,9 @@ __global__ __launch_bounds__(O * O) void k_window_background(const uint2* __rest
 #pragma unroll
   for (int b = 0; b < 3; ++b) {
     const float q16 = red(b, red(b, bufb[b][c], bufb[b][c + 8]), red(b, bufb[b][c + 8 * P], bufb[b][c + 8 * P + 8]));
+#ifdef RGBDR_WB_NO_STORE
+    if (q16 + bufa[b][c] + bufb[b][c] != 12345.678f) continue;  // diagnostic build: everything but the stores
+#endif
     bgmax[(((size_t)l * 3 + 0) * 3 + b) * plane + o] = bufa[b][c];
     bgmax[(((size_t)l * 3 + 1) * 3 + b) * plane + o] = bufb[b][c];
     bgmax[(((size_t)l * 3 + 2) * 3 + b) * plane + o] = q16;
