@@ -209,8 +209,14 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv
  * on the device, from the cv_xyz volume set_calibration uploaded: frustum reject ->
  * (-1,-1,-1,-1), else the inverse-distance-weighted index of the 8 nearest cv_xyz
  * samples, (index + 0.5) / dims, 1.  The k-d tree search is replaced by a local
- * search on the warped sample grid with a (2*window+1)^3 candidate window
- * (window <= 0 selects the default 2).
+ * search on the warped sample grid: a (2*window+1)^3 candidate window (window <= 0
+ * selects the default 2) that is accepted only with a certificate that no sample
+ * outside it can be among the 8 nearest, widened (up to radius 8) until it has one, and
+ * replaced by a scan of the whole volume for a voxel that never gets one -- the result
+ * equals the exact search for every voxel (kernels_invert.hip states the argument and
+ * its assumption: a convex sampled region whose lattice does not fold).
+ * rgbdr_inverse_search_stats: how many voxels of the sensor's last search needed a wider
+ * window / the exhaustive scan.
  *   compute_inverse_calibration: directly at this context's grid resolution into the
  *     resident grid layout (what `calib_inverter` + loadInverseCalibs would produce
  *     for a LUT at 1:1); with RGBDR_FLAG_NO_RESAMPLE -- every sensor of a context is resident in
@@ -219,6 +225,7 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv
  *     host memory, ready to be written as a `.cv_xyz_inv` file. */
 int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window);
 int rgbdr_generate_inverse_lut(rgbdr_ctx* ctx, int sensor, const uint32_t res[3], int window, float* dst);
+int rgbdr_inverse_search_stats(rgbdr_ctx* ctx, int sensor, uint64_t* widened, uint64_t* exhaustive);
 /* benchmark support: fill sensor's inverse LUT on the device at 1:1 TSDF resolution */
 int rgbdr_synth_inverse_calibration(rgbdr_ctx* ctx, int sensor, const rgbdr_pinhole* cam);
 
@@ -409,7 +416,9 @@ int rgbdr_halo_wait(rgbdr_ctx* ctx);
  *                                            issue order whatever their streams, so on the halo exchange's communicator the
  *                                            gather of frame k+1 would wait for the face transfer of frame k;
  *   or the host's own collectives on the device memory rgbdr_shard_view hands out (torch.distributed:
- *   rgbd-recon_amd/dist.py FrameGather), enqueued on view.stream.
+ *   rgbd-recon_amd/dist.py FrameGather), enqueued on view.stream, followed by rgbdr_shard_gather_done(ctx) -- the host's
+ *   word that the frame is complete in stream order.  rgbdr_shard_view itself changes nothing: it may be called at any
+ *   time to inspect the buffers.
  * Calling rgbdr_update_occupied_bricks / rgbdr_integrate on a shard before either returns RGBDR_ERR_STATE.  The float
  * images (rgbdr_readback_image / rgbdr_device_image) of the other ranks' sensors are NOT gathered: they keep what an earlier
  * unsharded frame left there.  Timer "gather" brackets the collectives. */
@@ -425,6 +434,7 @@ typedef struct {
 int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count);
 int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out);
 int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm);
+int rgbdr_shard_gather_done(rgbdr_ctx* ctx);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);

@@ -165,6 +165,7 @@ SYMBOLS = {
     "rgbdr_synth_inverse_calibration": (C.c_int, [_P, C.c_int, C.POINTER(Pinhole)]),
     "rgbdr_compute_inverse_calibration": (C.c_int, [_P, C.c_int, C.c_int]),
     "rgbdr_generate_inverse_lut": (C.c_int, [_P, C.c_int, _U32, C.c_int, _F]),
+    "rgbdr_inverse_search_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rgbdr_upload_frame": (C.c_int, [_P, _P, _P]),
     "rgbdr_upload_frame_device": (C.c_int, [_P, _P, _P]),
     "rgbdr_clear_occupied_bricks": (C.c_int, [_P]),
@@ -216,6 +217,7 @@ SYMBOLS = {
     "rgbdr_set_sensor_shard": (C.c_int, [_P, C.c_int, C.c_int]),
     "rgbdr_shard_view": (C.c_int, [_P, C.POINTER(ShardDeviceView)]),
     "rgbdr_shard_allgather": (C.c_int, [_P, _P]),
+    "rgbdr_shard_gather_done": (C.c_int, [_P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
@@ -382,6 +384,12 @@ class Context:
         r = (C.c_uint32 * 3)(*res)
         self._chk(lib().rgbdr_generate_inverse_lut(self._h, sensor, r, window, out.ctypes.data_as(_F)))
         return out
+
+    def inverse_search_stats(self, sensor):
+        """(voxels whose window was widened, voxels searched exhaustively) in the sensor's last inverse-LUT search"""
+        w, e = C.c_uint64(0), C.c_uint64(0)
+        self._chk(lib().rgbdr_inverse_search_stats(self._h, sensor, C.byref(w), C.byref(e)))
+        return int(w.value), int(e.value)
 
     def synth_inverse_calibration(self, sensor, pinhole):
         self._chk(lib().rgbdr_synth_inverse_calibration(self._h, sensor, C.byref(pinhole)))
@@ -633,6 +641,10 @@ class Context:
         v = ShardDeviceView()
         self._chk(lib().rgbdr_shard_view(self._h, C.byref(v)))
         return v
+
+    def shard_gather_done(self):
+        """the host has enqueued its own collectives on shard_view().stream: the frame is complete in stream order"""
+        self._chk(lib().rgbdr_shard_gather_done(self._h))
 
     def shard_allgather(self, nccl_comm):
         self._chk(lib().rgbdr_shard_allgather(self._h, nccl_comm))

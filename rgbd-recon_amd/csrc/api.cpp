@@ -470,6 +470,7 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
   ctx->morph_current = false;
+  ctx->frame_uploaded = false;  // until every launch below is enqueued: an upload that fails part-way leaves no frame
   // a sensor shard (rgbdr_set_sensor_shard) copies and morphs the raw depth of its own layers only
   const int first = ctx->shard_count > 0 ? ctx->shard_first : 0, count = ctx->shard_count > 0 ? ctx->shard_count : nsens(ctx);
   if (!ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
@@ -534,10 +535,14 @@ static int upload_host(rgbdr_ctx* ctx, const void* depth, const void* color, boo
   if (caller_buffers) HIPCHK(hipEventSynchronize(ctx->ev_h2d[s]));
   hipStream_t ps = ctx->pstream();
   HIPCHK(hipStreamWaitEvent(ps, ctx->ev_h2d[s], 0));
-  int rc = upload_device(ctx, ctx->d_in_depth[s], ctx->d_in_color[s]);
+  const int rc = upload_device(ctx, ctx->d_in_depth[s], ctx->d_in_color[s]);
+  // Whatever upload_device enqueued on `ps` before it failed may still read staging set s: the event is recorded on
+  // the failure path too, so the next host upload (which DMAs into a staging set on the copy stream) waits for it.
+  const hipError_t ev = hipEventRecord(ctx->ev_in_read[s], ps);
+  if (ev == hipSuccess) ctx->ev_in_read_rec[s] = true;
+  else (void)hipStreamSynchronize(ps);  // no event to order against: drain the readers now
   if (rc != RGBDR_OK) return rc;
-  HIPCHK(hipEventRecord(ctx->ev_in_read[s], ps));
-  ctx->ev_in_read_rec[s] = true;
+  HIPCHK(ev);
   ctx->in_set = 1 - s;
   return RGBDR_OK;
 }

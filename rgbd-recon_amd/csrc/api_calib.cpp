@@ -423,6 +423,61 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
   p->N = ctx->cfg.num_sensors;
 }
 
+// One certified search over the z rows [p.z0, p.z0 + p.nz): the per-slice edge bound of the forward LUT, the local search,
+// the exhaustive scan of whatever it could not certify (kernels_invert.hip).  Rows are taken in pieces of at most 64 so that
+// the list of uncertified voxels (one word per voxel of a piece: it can never overflow) stays small.
+static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
+{
+  const int z_begin = p.z0, z_end = p.z0 + p.nz;
+  const int piece = 64;
+  const size_t row = (size_t)p.X * p.Y;
+  const size_t words = (size_t)p.rz + 2 + 4 + row * (size_t)std::min(piece, p.nz);
+  DevScratch aux;
+  HIPCHK(hipMalloc(&aux.p, words * sizeof(unsigned)));
+  unsigned* base = aux.as<unsigned>();
+  unsigned* emax2 = base;                                            // [rz]
+  unsigned* count = base + p.rz;                                     // [1] (+1 pad: the counters below are 8-byte aligned)
+  unsigned long long* stats = (unsigned long long*)(base + ((p.rz + 2 + 1) & ~1));   // [2]
+  unsigned* todo = base + p.rz + 2 + 4;
+  HIPCHK(hipMemsetAsync(base, 0, ((size_t)p.rz + 2 + 4) * sizeof(unsigned), ctx->stream));
+  launch_lut_edge_max(p.xyz, p.rx, p.ry, p.rz, emax2, ctx->stream);
+  LAUNCHCHK("lut_edge_max");
+  p.emax2 = emax2;
+  p.todo = todo;
+  p.todo_count = count;
+  p.stats = stats;
+  float* tiled = p.out_tiled;
+  float4* linear = p.out_linear;
+  for (int z = z_begin; z < z_end; z += piece) {
+    p.z0 = z;
+    p.nz = std::min(piece, z_end - z);
+    const size_t done_tiles = (size_t)((z - z_begin) / kTile) * p.TX * p.TY;
+    p.out_tiled = tiled ? tiled + done_tiles * (size_t)p.N * 3 * kTileVoxels : nullptr;
+    p.out_linear = linear ? linear + row * (size_t)(z - z_begin) : nullptr;
+    HIPCHK(hipMemsetAsync(count, 0, sizeof(unsigned), ctx->stream));
+    launch_invert_lut(p, ctx->stream);
+    LAUNCHCHK("invert_lut");
+    launch_invert_exhaustive(p, ctx->stream);
+    LAUNCHCHK("invert_exhaustive");
+  }
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->inv_search_widened[sensor] = h[0];
+  ctx->inv_search_exhaustive[sensor] = h[1];
+  return RGBDR_OK;
+}
+
+int rgbdr_inverse_search_stats(rgbdr_ctx* ctx, int sensor, uint64_t* widened, uint64_t* exhaustive)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (sensor < 0 || sensor >= nsens(ctx)) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor index out of range");
+  if (widened) *widened = ctx->inv_search_widened[sensor];
+  if (exhaustive) *exhaustive = ctx->inv_search_exhaustive[sensor];
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
 int rgbdr_compute_inverse_calibration(rgbdr_ctx* ctx, int sensor, int window)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
@@ -456,9 +511,7 @@ try {
     p.nz = hi - lo + 1;
     p.out_linear = ctx->d_lut_generic[sensor];
     p.out_tiled = nullptr;
-    launch_invert_lut(p, ctx->stream);
-    LAUNCHCHK("invert_lut");
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
     for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = (uint32_t)g.res_volume[a];
     ctx->zoff[sensor] = lo;
     ctx->inv_tiled[sensor] = false;
@@ -472,8 +525,7 @@ try {
   p.z0 = ext.vz0;
   p.nz = ext.vz1 - ext.vz0;
   p.out_tiled = ext.dst;
-  launch_invert_lut(p, ctx->stream);
-  LAUNCHCHK("invert_lut");
+  { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
   launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
                       g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
                       ctx->stream);
@@ -510,8 +562,7 @@ try {
     p.z0 = z;
     p.nz = z + chunk <= (int)res[2] ? chunk : (int)res[2] - z;
     p.out_linear = tmp.as<float4>();
-    launch_invert_lut(p, ctx->stream);
-    LAUNCHCHK("invert_lut");
+    { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
     HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp.p, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

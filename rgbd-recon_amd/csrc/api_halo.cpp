@@ -244,6 +244,7 @@ try {
     // uploaded again before the chain runs on other layers
     ctx->frame_uploaded = false;
     ctx->morph_current = false;
+    ctx->shard_pending = false;  // belongs to a frame of the old shard; the next process_textures sets it for the new one
   }
   return RGBDR_OK;
 }
@@ -262,7 +263,15 @@ try {
   out->counters = ctx->counters_cur();
   out->num_bricks = (uint32_t)ctx->geo.num_bricks;
   out->stream = (void*)ctx->pstream();
-  ctx->shard_pending = false;  // the host runs the collectives itself, on out->stream
+  return RGBDR_OK;  // (a pure getter: the host that runs the collectives itself says so with rgbdr_shard_gather_done)
+}
+RGBDR_CONTAIN(ctx)
+
+int rgbdr_shard_gather_done(rgbdr_ctx* ctx)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_gather_done before process_textures");
+  ctx->shard_pending = false;
   return RGBDR_OK;
 }
 RGBDR_CONTAIN(ctx)

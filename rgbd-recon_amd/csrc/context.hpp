@@ -72,6 +72,8 @@ struct rgbdr_ctx {
 
   // forward calibration
   float4* d_cv_xyz[rgbdr::kMaxSensors] = {};
+  uint64_t inv_search_widened[rgbdr::kMaxSensors] = {};     // last inverse-LUT search of the sensor: voxels that needed a wider
+  uint64_t inv_search_exhaustive[rgbdr::kMaxSensors] = {};  // window / a scan of the whole volume (rgbdr_inverse_search_stats)
   float2* d_cv_uv[rgbdr::kMaxSensors] = {};
   uint32_t xyz_res[rgbdr::kMaxSensors][3] = {}, uv_res[rgbdr::kMaxSensors][3] = {};
   float min_ds[rgbdr::kMaxSensors] = {}, max_ds[rgbdr::kMaxSensors] = {};

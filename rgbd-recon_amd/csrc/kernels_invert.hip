@@ -12,9 +12,26 @@
 // scan per 8x8x8 tile finds the sample nearest to the tile centre, every voxel
 // walks downhill from there (strides 4, 2, 1) to its own nearest sample, and the 8
 // nearest are selected from the (2R+1)^3 index window around it.  Neighbours are
-// ordered by (squared distance, sample index) like the oracle's exact search, so
-// wherever the window holds the true 8 nearest the result is bit-identical;
-// DESIGN.md states how often that is and the reprojection error otherwise.
+// ordered by (squared distance, sample index) like the oracle's exact search.
+//
+// EXACTNESS.  A window's result is accepted only with a certificate that no sample
+// outside the window can be among the 8 nearest.  The faces of the index window that
+// have samples beyond them (its SHELL; faces on the border of the LUT have none) are
+// a closed surface of samples between the query q and everything outside, as long as
+// the sampled region is convex and the lattice does not fold (a sensor's calibration
+// volume is a warped frustum).  A segment from q to an outside sample crosses that
+// surface in a facet whose corners are shell samples, and a point of a facet is no
+// farther from its nearest corner than the facet's longest edge e, so every outside
+// sample is at least  min_shell |q - s| - e  away.  With e bounded by the longest
+// lattice edge of the depth slices the window spans (k_lut_edge_max), the window is
+// certified when
+//        sqrt(d8) < sqrt(min_shell d) - e        (or the window has no shell at all).
+// The same inequality fails when the window does not contain q (the walk got stuck):
+// then the point of the window nearest to q lies on the shell.  Without a certificate
+// the window is re-centred on its nearest sample and widened (R -> R + max(1, R/2), up
+// to 8); a voxel still uncertified at R = 8 is appended to a list and k_invert_exhaustive
+// scans the WHOLE volume for it, one workgroup per voxel.  So the result equals the exact
+// search for every voxel (tests/test_inverter_gpu.py asserts 100 %, not a fraction).
 #include <hip/hip_runtime.h>
 
 #include "rgbdr_internal.hpp"
@@ -43,6 +60,65 @@ __device__ __forceinline__ bool inside_frustum(const InvertParams& p, float px, 
     if (d < 0.0f) return false;
   }
   return true;
+}
+
+// longest lattice edge touching each depth slice, as the bits of its squared length (positive floats order like their bits)
+__global__ __launch_bounds__(256) void k_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2)
+{
+  const size_t n = (size_t)rx * ry * rz;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int sx = (int)(i % rx), sy = (int)((i / rx) % ry), sz = (int)(i / ((size_t)rx * ry));
+  const float4 a = xyz[i];
+  auto len2 = [&](size_t j) {
+    const float4 b = xyz[j];
+    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return dx * dx + dy * dy + dz * dz;
+  };
+  float m = 0.0f;
+  if (sx + 1 < rx) m = fmaxf(m, len2(i + 1));
+  if (sy + 1 < ry) m = fmaxf(m, len2(i + rx));
+  if (m > 0.0f) atomicMax(&emax2[sz], __float_as_uint(m));
+  if (sz + 1 < rz) {
+    const float e = len2(i + (size_t)rx * ry);
+    atomicMax(&emax2[sz], __float_as_uint(e));
+    atomicMax(&emax2[sz + 1], __float_as_uint(e));
+  }
+}
+
+// the eight nearest samples -> the record calibration_inverter.cpp:55-69 stores
+__device__ __forceinline__ void weigh(const InvertParams& p, const Best8& b, float& u, float& v, float& d)
+{
+  const int ryz = p.ry * p.rz;
+  float tw = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (b.i[k] == 0x7fffffff) continue;  // fewer than 8 samples in the LUT
+    const float w = 1.0f / sqrtf(b.d[k]);
+    wx += w * (float)(b.i[k] / ryz);
+    wy += w * (float)((b.i[k] / p.rz) % p.ry);
+    wz += w * (float)(b.i[k] % p.rz);
+    tw += w;
+  }
+  u = (wx / tw + 0.5f) / (float)p.rx;
+  v = (wy / tw + 0.5f) / (float)p.ry;
+  d = (wz / tw + 0.5f) / (float)p.rz;
+}
+
+__device__ __forceinline__ void insert8(Best8& b, float d2, int lin)
+{
+  if (!nn_less(d2, lin, b.d[7], b.i[7])) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // insertion: carry the larger element forward
+    if (nn_less(d2, lin, b.d[k], b.i[k])) {
+      const float td = b.d[k];
+      const int ti = b.i[k];
+      b.d[k] = d2;
+      b.i[k] = lin;
+      d2 = td;
+      lin = ti;
+    }
+  }
 }
 
 __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
@@ -124,48 +200,62 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
         cd = bd;
       }
     }
-    // ---- 8 nearest of the index window, kept sorted by (d2, sample index)
+    // ---- 8 nearest of the index window, kept sorted by (d2, sample index); widened until certified
     Best8 b;
+    int R = p.window;
+    bool certified = false, recentred = false;
+#pragma unroll 1
+    for (;;) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      b.d[k] = __builtin_inff();
-      b.i[k] = 0x7fffffff;
-    }
-    const int R = p.window;
-    const int x0 = max(cx - R, 0), x1 = min(cx + R, p.rx - 1);
-    const int y0 = max(cy - R, 0), y1 = min(cy + R, p.ry - 1);
-    const int z0 = max(cz - R, 0), z1 = min(cz + R, p.rz - 1);
-    for (int sz = z0; sz <= z1; ++sz)
-      for (int sy = y0; sy <= y1; ++sy)
-        for (int sx = x0; sx <= x1; ++sx) {
-          float d2 = sample_d2(p, sx, sy, sz, px, py, pz);
-          int lin = (sx * p.ry + sy) * p.rz + sz;
-          if (!nn_less(d2, lin, b.d[7], b.i[7])) continue;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {  // insertion: carry the larger element forward
-            if (nn_less(d2, lin, b.d[k], b.i[k])) {
-              const float td = b.d[k];
-              const int ti = b.i[k];
-              b.d[k] = d2;
-              b.i[k] = lin;
-              d2 = td;
-              lin = ti;
-            }
+      for (int k = 0; k < 8; ++k) {
+        b.d[k] = __builtin_inff();
+        b.i[k] = 0x7fffffff;
+      }
+      const int x0 = max(cx - R, 0), x1 = min(cx + R, p.rx - 1);
+      const int y0 = max(cy - R, 0), y1 = min(cy + R, p.ry - 1);
+      const int z0 = max(cz - R, 0), z1 = min(cz + R, p.rz - 1);
+      // faces with samples beyond them
+      const bool fx0 = x0 > 0, fx1 = x1 < p.rx - 1, fy0 = y0 > 0, fy1 = y1 < p.ry - 1, fz0 = z0 > 0, fz1 = z1 < p.rz - 1;
+      float shell = __builtin_inff();
+      for (int sz = z0; sz <= z1; ++sz)
+        for (int sy = y0; sy <= y1; ++sy)
+          for (int sx = x0; sx <= x1; ++sx) {
+            const float d2 = sample_d2(p, sx, sy, sz, px, py, pz);
+            const bool on_shell = (fx0 && sx == x0) || (fx1 && sx == x1) || (fy0 && sy == y0) || (fy1 && sy == y1) ||
+                                  (fz0 && sz == z0) || (fz1 && sz == z1);
+            if (on_shell) shell = fminf(shell, d2);
+            insert8(b, d2, (sx * p.ry + sy) * p.rz + sz);
           }
-        }
-    float tw = 0.0f, wx = 0.0f, wy = 0.0f, wz = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (b.i[k] == 0x7fffffff) continue;  // fewer than 8 samples in the LUT
-      const float w = 1.0f / sqrtf(b.d[k]);
-      wx += w * (float)(b.i[k] / ryz);
-      wy += w * (float)((b.i[k] / p.rz) % p.ry);
-      wz += w * (float)(b.i[k] % p.rz);
-      tw += w;
+      if (!(fx0 || fx1 || fy0 || fy1 || fz0 || fz1)) {
+        certified = true;  // the window is the whole volume
+        break;
+      }
+      unsigned e2 = 0;
+      for (int sz = z0; sz <= z1; ++sz) e2 = max(e2, p.emax2[sz]);
+      // (rounded against acceptance: the left side up, the right side down by an ulp-scale margin)
+      const float lhs = sqrtf(b.d[7]) * 1.000001f, rhs = sqrtf(shell) * 0.999999f - sqrtf(__uint_as_float(e2)) * 1.000001f;
+      if (lhs < rhs) {
+        certified = true;
+        break;
+      }
+      const int ncx = b.i[0] / ryz, ncy = (b.i[0] / p.rz) % p.ry, ncz = b.i[0] % p.rz;
+      if (!recentred && b.i[0] != 0x7fffffff && (ncx != cx || ncy != cy || ncz != cz)) {
+        recentred = true;  // the walk stopped short of the nearest sample: same radius around the better centre
+        cx = ncx;
+        cy = ncy;
+        cz = ncz;
+        continue;
+      }
+      if (R >= 8) break;
+      R = min(8, R + max(1, R / 2));
+      recentred = false;
     }
-    ou[j] = (wx / tw + 0.5f) / (float)p.rx;
-    ov[j] = (wy / tw + 0.5f) / (float)p.ry;
-    od[j] = (wz / tw + 0.5f) / (float)p.rz;
+    if (R != p.window) atomicAdd(&p.stats[0], 1ull);
+    if (!certified) {  // exhaustive scan of the whole volume, later (k_invert_exhaustive overwrites this record)
+      const unsigned slot = atomicAdd(p.todo_count, 1u);
+      p.todo[slot] = (unsigned)(((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx);
+    }
+    weigh(p, b, ou[j], ov[j], od[j]);
     ow[j] = 1.0f;
   }
   if (p.out_tiled) {
@@ -181,6 +271,77 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
       p.out_linear[((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx] = make_float4(ou[j], ov[j], od[j], ow[j]);
     }
   }
+}
+
+// One workgroup per uncertified voxel: every sample of the volume, the 256 partial lists merged pairwise in LDS.
+__global__ __launch_bounds__(256) void k_invert_exhaustive(InvertParams p)
+{
+  __shared__ float s_d[256][8];
+  __shared__ int s_i[256][8];
+  const unsigned count = *p.todo_count;
+  const int q = threadIdx.x;
+  const size_t n = (size_t)p.rx * p.ry * p.rz;
+  for (unsigned e = blockIdx.x; e < count; e += gridDim.x) {
+    const unsigned v = p.todo[e];
+    const int vx = (int)(v % (unsigned)p.X), vy = (int)((v / (unsigned)p.X) % (unsigned)p.Y), lz = (int)(v / ((unsigned)p.X * p.Y));
+    const float px = p.start[0] + (float)vx * p.step[0];
+    const float py = p.start[1] + (float)vy * p.step[1];
+    const float pz = p.start[2] + (float)(p.z0 + lz) * p.step[2];
+    Best8 b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      b.d[k] = __builtin_inff();
+      b.i[k] = 0x7fffffff;
+    }
+    for (size_t i = q; i < n; i += 256) {
+      const int sx = (int)(i % p.rx), sy = (int)((i / p.rx) % p.ry), sz = (int)(i / ((size_t)p.rx * p.ry));
+      insert8(b, sample_d2(p, sx, sy, sz, px, py, pz), (sx * p.ry + sy) * p.rz + sz);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s_d[q][k] = b.d[k];
+      s_i[q][k] = b.i[k];
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (q < o) {
+        for (int k = 0; k < 8; ++k) insert8(b, s_d[q + o][k], s_i[q + o][k]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          s_d[q][k] = b.d[k];
+          s_i[q][k] = b.i[k];
+        }
+      }
+      __syncthreads();
+    }
+    if (q == 0) {
+      float u, w, d;
+      weigh(p, b, u, w, d);
+      if (p.out_tiled) {
+        const int tile = ((lz / kTile) * p.TY + vy / kTile) * p.TX + vx / kTile;
+        const int local = ((lz % kTile) * kTile + vy % kTile) * kTile + vx % kTile;
+        float* o = p.out_tiled + ((size_t)tile * p.N + p.sensor) * 3 * kTileVoxels + local;
+        o[0] = u;
+        o[kTileVoxels] = w;
+        o[2 * kTileVoxels] = d;
+      } else {
+        p.out_linear[v] = make_float4(u, w, d, 1.0f);
+      }
+      atomicAdd(&p.stats[1], 1ull);
+    }
+    __syncthreads();
+  }
+}
+
+void launch_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2, hipStream_t s)
+{
+  const size_t n = (size_t)rx * ry * rz;
+  hipLaunchKernelGGL(k_lut_edge_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz, rx, ry, rz, emax2);
+}
+
+void launch_invert_exhaustive(const InvertParams& p, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_invert_exhaustive, dim3(2048), dim3(256), 0, s, p);
 }
 
 void launch_invert_lut(const InvertParams& p, hipStream_t s)

@@ -153,7 +153,11 @@ struct InvertParams {
   int X, Y;                // inverse volume resolution in x, y
   int z0, nz;              // z rows [z0, z0 + nz) handled by this launch
   int TX, TY;              // tiles in x, y
-  int window;              // index radius R of the candidate window
+  int window;              // index radius R of the first candidate window (widened until certified, kernels_invert.hip)
+  const unsigned* emax2;   // [rz] longest lattice edge touching each depth slice: bits of its squared length
+  unsigned* todo;          // voxels (launch-relative linear index) left to k_invert_exhaustive, and their number
+  unsigned* todo_count;
+  unsigned long long* stats;  // [0] voxels whose window was widened, [1] voxels searched exhaustively
   float4* out_linear;      // [nz][Y][X] RGBA records, or
   float* out_tiled;        // grid layout planes of `sensor` ([tile][N][3][512], z0 must be tile aligned)
   int sensor, N;
@@ -213,6 +217,8 @@ void launch_fill_colors(const FillLayout& L, const float4* frame_col, const floa
 
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
+void launch_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2, hipStream_t s);
+void launch_invert_exhaustive(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
 void launch_decode_dxt(const uint8_t* blocks, int W, int H, int mode, int N, size_t layer_bytes, uint8_t* rgb,

@@ -139,6 +139,7 @@ class FrameGather:
             frames.copy_(torch.cat(parts).to(self.device))
             counters.copy_(c.to(self.device))
             torch.cuda.synchronize()
+            self.ctx.shard_gather_done()
             return
         st = torch.cuda.ExternalStream(int(v.stream), device=self.device)
         with torch.cuda.stream(st):
@@ -147,6 +148,7 @@ class FrameGather:
             self._collectives(frames, counters, mine, words, n)
             t1.record(st)
             self.timing = (t0, t1)
+        self.ctx.shard_gather_done()
 
     def last_ms(self):
         """duration of the last gather on the chain's stream (synchronises on its end)"""
@@ -186,14 +188,72 @@ class RcclComm:
     through torch.distributed's process group, whose collectives run on a stream of its own.  The unique id travels
     through the torch.distributed group that exists anyway (any backend)."""
     _lib = None
+    _how = None
 
     @classmethod
     def lib(cls):
+        """ONE RCCL per process: the copy that is mapped already (torch links its own librccl.so, soname librccl.so.1) is
+        bound with RTLD_NOLOAD; only a process without any loads the system's.  A second copy next to torch's would have
+        its own bootstrap state, and a rendezvous between two different RCCL builds blocks instead of failing.  The C
+        library binds the same way (csrc/api_halo.cpp load_rccl)."""
         if cls._lib is None:
             import ctypes as C
-            # RTLD_GLOBAL: the library binds the copy of RCCL that is already in the process (dlopen RTLD_NOLOAD)
-            cls._lib = C.CDLL("librccl.so.1", mode=C.RTLD_GLOBAL)
+            import os
+            RTLD_NOLOAD = 4
+            names = [n for n in (os.environ.get("RGBDR_RCCL_LIB"), "librccl.so.1", "librccl.so") if n]
+            for name in names:
+                try:
+                    cls._lib, cls._how = C.CDLL(name, mode=C.RTLD_GLOBAL | RTLD_NOLOAD), "already mapped (RTLD_NOLOAD %s)" % name
+                    break
+                except OSError:
+                    pass
+            if cls._lib is None:
+                for name in names:
+                    try:
+                        # RTLD_GLOBAL: the C library then finds this copy with its own RTLD_NOLOAD
+                        cls._lib, cls._how = C.CDLL(name, mode=C.RTLD_GLOBAL), "loaded here (%s)" % name
+                        break
+                    except OSError:
+                        pass
+            if cls._lib is None:
+                raise OSError("no librccl.so.1 in this process or on the library path (set RGBDR_RCCL_LIB)")
         return cls._lib
+
+    @classmethod
+    def library_info(cls):
+        """{"path": file of the bound RCCL, "version": ncclGetVersion, "bound": how, "copies_mapped": RCCL files in this process}"""
+        import ctypes as C
+        L = cls.lib()
+        v = C.c_int(0)
+        version = int(v.value) if L.ncclGetVersion(C.byref(v)) else int(v.value)
+
+        class DlInfo(C.Structure):
+            _fields_ = [("dli_fname", C.c_char_p), ("dli_fbase", C.c_void_p), ("dli_sname", C.c_char_p), ("dli_saddr", C.c_void_p)]
+        info, path = DlInfo(), None
+        libc = C.CDLL(None)
+        libc.dladdr.argtypes = [C.c_void_p, C.POINTER(DlInfo)]
+        if libc.dladdr(C.cast(L.ncclGetVersion, C.c_void_p), C.byref(info)) and info.dli_fname:
+            path = info.dli_fname.decode()
+        copies = set()
+        try:
+            for ln in open("/proc/self/maps"):
+                f = ln.split()[-1]
+                if "librccl" in f or "libnccl" in f:
+                    copies.add(f)
+        except OSError:
+            pass
+        return {"path": path, "version": version, "bound": cls._how, "copies_mapped": sorted(copies)}
+
+    def describe(self):
+        """library_info() + the number of ranks and this rank's index as the COMMUNICATOR reports them"""
+        import ctypes as C
+        L = self.lib()
+        n, r = C.c_int(-1), C.c_int(-1)
+        L.ncclCommCount(self.handle, C.byref(n))
+        L.ncclCommUserRank(self.handle, C.byref(r))
+        d = self.library_info()
+        d.update(ranks=int(n.value), rank=int(r.value), communicator="raw ncclComm_t created by rgbd_recon_amd.dist.RcclComm")
+        return d
 
     def __init__(self, rank, world, group=None, device=None):
         import ctypes as C
@@ -304,6 +364,7 @@ class ManagedSlabExchange:
             if self.foreign is None:
                 self.foreign = self.all_counts - counters
             counters.add_(self.foreign)
+        self.ctx.shard_gather_done()
 
     def last_transfer_ms(self):
         try:
@@ -424,6 +485,25 @@ class HaloExchanger:
         """make `stream` (default: the compute stream) wait for the newest halos"""
         if self.k:
             (stream or self.compute).wait_event(self.last)
+
+
+def torch_rccl_info():
+    """what carried the exchange when torch.distributed did: RCCL as torch reports it, the ranks of its process group"""
+    try:
+        version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        version = None
+    copies = set()
+    try:
+        for ln in open("/proc/self/maps"):
+            f = ln.split()[-1]
+            if "librccl" in f or "libnccl" in f:
+                copies.add(f)
+    except OSError:
+        pass
+    return {"path": sorted(copies)[0] if len(copies) == 1 else None, "version": version, "bound": "torch.distributed (ProcessGroupNCCL)",
+            "copies_mapped": sorted(copies), "ranks": dist.get_world_size(), "rank": dist.get_rank(),
+            "communicator": "torch.distributed default process group"}
 
 
 NO_HIT = 0x7FFFFFFF

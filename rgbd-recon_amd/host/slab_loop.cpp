@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
+#include <memory>
 #include <string>
 #include <thread>
 
@@ -53,13 +54,16 @@ int main(int argc, char** argv)
     }
     const int device = loopback ? 0 : rank;
     if (hipSetDevice(device) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
-    // communicator over the slab ranks
-    ncclUniqueId id;
+    // Two communicators over the slab ranks: one for the halo exchange, one for the frame gather.  Operations on ONE
+    // communicator execute in issue order whatever their streams (include/rgbdr.h, rgbdr_shard_allgather), so on a shared one
+    // the gather of frame k+1 would queue behind the face transfer of frame k and the overlap would be lost.
+    ncclUniqueId ids[2];
     if (loopback || rank == 0) {
-      NCCLCHK(ncclGetUniqueId(&id));
+      NCCLCHK(ncclGetUniqueId(&ids[0]));
+      NCCLCHK(ncclGetUniqueId(&ids[1]));
       if (!loopback) {
         FILE* f = std::fopen((id_file + ".tmp").c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + id_file);
+        if (!f || std::fwrite(ids, sizeof(ids[0]), 2, f) != 2) throw std::runtime_error("cannot write " + id_file);
         std::fclose(f);
         std::rename((id_file + ".tmp").c_str(), id_file.c_str());
       }
@@ -67,11 +71,16 @@ int main(int argc, char** argv)
       FILE* f = nullptr;
       for (int tries = 0; tries < 600 && !(f = std::fopen(id_file.c_str(), "rb")); ++tries)
         std::this_thread::sleep_for(std::chrono::milliseconds(100));
-      if (!f || std::fread(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot read " + id_file);
+      if (!f || std::fread(ids, sizeof(ids[0]), 2, f) != 2) throw std::runtime_error("cannot read " + id_file);
       std::fclose(f);
     }
-    ncclComm_t comm;
-    NCCLCHK(ncclCommInitRank(&comm, loopback ? 1 : world, id, loopback ? 0 : rank));
+    ncclComm_t comm, comm_gather = nullptr;
+    NCCLCHK(ncclCommInitRank(&comm, loopback ? 1 : world, ids[0], loopback ? 0 : rank));
+    // The pre_* chain is sharded by sensor only when the sensors split evenly over the ranks; otherwise (one sensor, two
+    // sensors on four ranks ...) every rank runs the whole chain, as a single-GPU host does.
+    const int gather_world = loopback ? 1 : world;
+    const bool sharded = n > 1 && n % gather_world == 0;
+    if (sharded) NCCLCHK(ncclCommInitRank(&comm_gather, gather_world, ids[1], loopback ? 0 : rank));
 
     CalibrationFiles cf;
     cf.width = cf.widthC = (unsigned)std::atoi(argv[3]);
@@ -97,12 +106,13 @@ int main(int argc, char** argv)
     // the pre_* chain sharded by sensor over the ranks of the communicator (every rank runs n / world sensors and the
     // packed frames are all-gathered); with --loopback the communicator has one rank, which holds every sensor: the
     // collectives still run (all-gather and all-reduce of one rank) and must leave the frame as it is
-    FrameGather shard(be, comm, loopback ? 0 : rank, loopback ? 1 : world);
+    std::unique_ptr<FrameGather> shard;
+    if (sharded) shard.reset(new FrameGather(be, comm_gather, loopback ? 0 : rank, gather_world));
     check(be.ctx(), rgbdr_enable_timers(be.ctx(), 1));
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
     for (int k = 0; k < frames; ++k) {  // no host synchronisation between frames
       nka.readFromFiles(streams, colorsize, depthsize, (size_t)k);
-      process_textures(nka, recon, &shard);
+      process_textures(nka, recon, shard.get());
       halo.beginStep();
       recon.integrate();
       halo.exchangeAsync();
@@ -129,6 +139,7 @@ int main(int argc, char** argv)
     std::fclose(f);
     std::printf("slab %d of %d: tile layers [%d, %d), halo %d layers, last transfer %.4f ms\n", slab_rank, slab_count,
                 g.slab_tile_z0, g.slab_tile_z1, h, ms);
+    if (comm_gather) NCCLCHK(ncclCommDestroy(comm_gather));
     NCCLCHK(ncclCommDestroy(comm));
   } catch (const std::exception& e) {
     std::fprintf(stderr, "slab_loop: %s\n", e.what());

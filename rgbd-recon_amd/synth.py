@@ -73,6 +73,26 @@ def render_depth(s, seed, noise_sigma=0.002, hole_fraction=0.02, sphere_c=(0.0, 
     return depth.astype(np.float32)
 
 
+def render_shell_depth(s, seed, noise_sigma=0.002, shell_c=(0.0, 1.0, 0.0), shell_r=0.95):
+    """The DENSE scene: the inside of a spherical shell inscribed in the box, seen through its (one-sided) near half.
+    A sensor 1.4 m from the centre sees the shell over its whole field of view (asin(0.95 / 1.4) = 42.7 deg > the 42.3 deg
+    half-diagonal of a 512 x 424 image at fx = 365), so EVERY pixel carries a measurement whose point lies inside the
+    box: no holes, no background -- the worst case for the per-pixel work of the pre_* chain (169 taps everywhere,
+    glsl/pre_depth.fs:85-127) and for anything that skips undecided or empty regions."""
+    py, px = np.meshgrid(np.arange(s.H) + 0.5, np.arange(s.W) + 0.5, indexing="ij")
+    d = s.rays(px, py)
+    oc = s.pos - np.asarray(shell_c)
+    a = np.sum(d * d, axis=-1)
+    b = 2.0 * np.sum(d * oc, axis=-1)
+    c = oc @ oc - shell_r ** 2
+    disc = b * b - 4 * a * c
+    t = np.where(disc > 0, (-b + np.sqrt(np.maximum(disc, 0))) / (2 * a), 0.0)     # the FAR intersection: the inner wall
+    rng = np.random.default_rng(seed)
+    depth = t + rng.normal(0.0, noise_sigma, t.shape) * (t > 0)
+    depth[(depth < DEPTH_MIN) | (depth > DEPTH_MAX)] = 0.0
+    return depth.astype(np.float32)
+
+
 def render_color(s, seed, wh=None):
     """procedural RGB8 checker (optionally at a colour resolution != the depth resolution;
     cv_uv is normalised, so it addresses either)"""
@@ -130,8 +150,12 @@ class Scene:
     """All inputs of one configuration."""
 
     def __init__(self, num_sensors, width, height, lut_res=(32, 27, 32), seed=1234, make_frames=True, sphere_r=None,
-                 color_wh=None):
+                 color_wh=None, layout="ring"):
+        """layout "ring": SURVEY 8(d)'s scene (sensors 2.5 m out, a sphere over a floor; two thirds of the pixels see
+        nothing).  layout "dense": sensors 1.4 m from the centre at its height, looking into a spherical shell that fills
+        every field of view (render_shell_depth): every pixel valid and inside the box."""
         self.N, self.W, self.H = num_sensors, width, height
+        self.layout, self.seed, self.color_wh = layout, seed, color_wh
         # SURVEY 8(d) scene: sphere r = 0.5 m.  At small test resolutions a 13x13
         # window spans most of such a sphere and the bilateral pass rejects every
         # pixel, so low-resolution scenes use a larger sphere to stay non-trivial.
@@ -139,15 +163,41 @@ class Scene:
             sphere_r = 0.5 if width >= 256 else 0.9
         self.sphere_r = sphere_r
         self.lut_res = tuple(lut_res)
-        self.sensors = [Sensor(i, num_sensors, width, height) for i in range(num_sensors)]
+        if layout == "dense":
+            self.sensors = [Sensor(i, num_sensors, width, height, radius=1.4, cam_height=1.0) for i in range(num_sensors)]
+        elif layout == "ring":
+            self.sensors = [Sensor(i, num_sensors, width, height) for i in range(num_sensors)]
+        else:
+            raise ValueError("layout is 'ring' or 'dense'")
         self.xyz, self.uv = [], []
         for s in self.sensors:
             a, b = forward_luts(s, lut_res)
             self.xyz.append(a)
             self.uv.append(b)
         if make_frames:
-            self.depth = np.stack([render_depth(s, seed + i, sphere_r=sphere_r) for i, s in enumerate(self.sensors)])
-            self.color = np.stack([render_color(s, seed + i, color_wh) for i, s in enumerate(self.sensors)])
+            self.depth, self.color = self.frame(0)
+
+    def frame(self, k):
+        """(depth [N,H,W] f32, colour [N,h,w,3] u8) of frame k of a MOVING sequence: frame 0 is the static scene; in frame
+        k > 0 every sensor draws new noise and new holes, the ring scene's sphere has moved by k * (6, 0, 4) cm and the
+        dense scene's shell by k * (2, 0, 1.5) cm (it stays inside the box) -- so occupied bricks, tile states, list
+        sizes and store elision see change from one step to the next."""
+        seed = self.seed + 1000 * k
+        if self.layout == "dense":
+            c = (0.02 * k, 1.0, 0.015 * k)
+            depth = [render_shell_depth(s, seed + i, shell_c=c) for i, s in enumerate(self.sensors)]
+        else:
+            c = (0.06 * k, 1.0, 0.04 * k)
+            depth = [render_depth(s, seed + i, sphere_c=c, sphere_r=self.sphere_r) for i, s in enumerate(self.sensors)]
+        color = [render_color(s, seed + i, self.color_wh) for i, s in enumerate(self.sensors)]
+        return np.stack(depth), np.stack(color)
+
+    def at_frame(self, k):
+        """a shallow copy of the scene holding frame k (for the oracle, which reads scene.depth / scene.color)"""
+        import copy
+        other = copy.copy(self)
+        other.depth, other.color = self.frame(k)
+        return other
 
     def inverse(self, res, bbox_min=BBOX_MIN, bbox_max=BBOX_MAX):
         return [inverse_lut(s, res, bbox_min, bbox_max) for s in self.sensors]

@@ -78,8 +78,8 @@ def test_launcher_stops_the_other_ranks_when_one_fails():
 
 
 def test_plain_multi_gpu_command_fails_loudly_without_a_gpu_and_never_touches_torch_in_the_parent():
-    """the driver's command line; in this container there is no HIP device, so the ranks refuse and the parent
-    reports it with a non-zero status instead of hanging or printing a line"""
+    """the driver's command line; in this container there is no HIP device, so the ranks of every rung refuse and rank 0's
+    supervisor reports it: ONE line with "error" and the attempts, a non-zero status -- no hang, no silent end"""
     import subprocess
     import sys
     import torch
@@ -89,10 +89,95 @@ def test_plain_multi_gpu_command_fails_loudly_without_a_gpu_and_never_touches_to
     r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "needs a HIP device" in r.stderr and "[bench launcher] rank" in r.stderr
-    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
-    # -X importtime lists what the PARENT imported (the ranks are started without it): no torch, so no GPU runtime
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "every rung" in lines[0]["error"] and "value" not in lines[0]
+    assert [a["rung"] for a in lines[0]["attempts"]] == [0, 1, 2] and lines[0]["attempts"][2]["flags"] == b_rung_flags(2)
+    # -X importtime lists what the PARENT imported (supervisors and ranks are started without it): no torch, so no GPU runtime
     imported = [l.split("|")[-1].strip() for l in r.stderr.splitlines() if l.startswith("import time:")]
     assert "json" in imported and "torch" not in imported
+
+
+def b_rung_flags(k):
+    return load_bench().RUNGS[k][1]
+
+
+# ---- the launch ladder (VERDICT r4 task 1): an N > 1 run cannot end without a JSON line ---------------------------------
+STUB = [__import__("sys").executable, os.path.join(ROOT, "tests", "ladder_stub.py")]
+
+
+def run_ladder(plan, tmp_path, *extra, via_torchrun=False, budgets="5,5,5", timeout=120, n=2):
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, RGBDR_BENCH_CHILD_CMD=json.dumps(STUB), STUB_PLAN=json.dumps(plan), STUB_LOG=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--rung-budgets", budgets] + list(extra)
+    if via_torchrun:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(load_bench().free_port())] + args
+    else:
+        cmd = [sys.executable] + args
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    took = time.monotonic() - t0
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    return r.returncode, lines[0], took, r.stderr
+
+
+def test_ladder_first_rung_hangs_second_succeeds(tmp_path):
+    """rung 0 (library-managed RCCL) hangs on every rank: its budget ends it, FRESH children run rung 1 with
+    --torch-collectives on a new rendezvous port, and the one line says which rung produced it and what failed before"""
+    rc, line, took, err = run_ladder(["hang", "ok", "ok"], tmp_path)
+    assert rc == 0 and line["value"] == 101.0 and line["legs"] == "done" and "provisional" not in line
+    la = line["launch"]
+    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives"] and la["line"] == "final" and la["launched_by"] == "bench.py"
+    assert len(la["failed_attempts"]) == 1 and la["failed_attempts"][0]["rung"] == 0 and "budget" in la["failed_attempts"][0]["outcome"]
+    assert took < 40
+    seen = {f: json.load(open(os.path.join(str(tmp_path), f))) for f in os.listdir(str(tmp_path))}
+    assert set(seen) == {"rung0.rank0", "rung0.rank1", "rung1.rank0", "rung1.rank1"}
+    assert seen["rung1.rank0"]["argv"][-1:] == ["--torch-collectives"] and "--torch-collectives" not in seen["rung0.rank0"]["argv"]
+    assert seen["rung0.rank0"]["port"] == seen["rung0.rank1"]["port"] != seen["rung1.rank0"]["port"] == seen["rung1.rank1"]["port"]
+
+
+def test_ladder_under_torch_distributed_run(tmp_path):
+    """the same when torch.distributed.run starts the ranks (how the driver starts an N > 1 run): each rank it starts is a
+    supervisor; the children rendezvous on their own port, not through the agent's store"""
+    rc, line, took, err = run_ladder(["fail", "hang", "ok"], tmp_path, via_torchrun=True, timeout=180)
+    assert rc == 0 and line["value"] == 102.0
+    la = line["launch"]
+    assert la["rung"] == 2 and la["rung_flags"] == ["--torch-collectives", "--no-shard", "--weak"] and la["launched_by"] == "torch.distributed.run"
+    assert [a["rung"] for a in la["failed_attempts"]] == [0, 1]
+    assert la["failed_attempts"][0]["child_errors"] == ["stub failure on rung 0"] and la["failed_attempts"][0]["child_status"] == 5
+
+
+def test_ladder_every_rung_fails_ends_with_an_error_line(tmp_path):
+    rc, line, took, err = run_ladder(["fail", "fail", "hang"], tmp_path, budgets="4,4,4")
+    assert rc != 0 and "error" in line and "value" not in line and [a["rung"] for a in line["attempts"]] == [0, 1, 2]
+    assert took < 40
+
+
+def test_ladder_keeps_the_provisional_line_when_the_legs_hang(tmp_path):
+    """the headline exists (rank 0 printed its provisional line) and then a leg hangs: the rung's budget ends the children and
+    the line is the provisional one, marked as such -- not a second attempt, not an error"""
+    rc, line, took, err = run_ladder(["provisional", "ok", "ok"], tmp_path)
+    assert rc == 0 and line["value"] == 100.0 and "legs" not in line and "provisional" not in line
+    assert line["launch"]["rung"] == 0 and line["launch"]["line"].startswith("provisional") and line["launch"]["failed_attempts"] == []
+
+
+def test_ladder_a_dead_rank_ends_the_rung_early(tmp_path):
+    """rank 1's child dies at once while rank 0's would wait for ever: the rung is given up after a short grace, long before its
+    budget, and the next rung runs"""
+    rc, line, took, err = run_ladder(["rank1 dies", "ok", "ok"], tmp_path, budgets="300,20,20")
+    assert rc == 0 and line["launch"]["rung"] == 1 and "rank 1" in line["launch"]["failed_attempts"][0]["outcome"]
+    assert took < 60
+
+
+def test_ladder_never_exceeds_the_launch_timeout(tmp_path):
+    """--launch-timeout bounds the whole ladder: with 26 s and rungs of 20 s the second rung gets what is left or is not started"""
+    rc, line, took, err = run_ladder(["hang", "hang", "hang"], tmp_path, "--launch-timeout", "26", budgets="20,20,20")
+    assert rc != 0 and "error" in line and took < 40
+    assert "not started" in line["attempts"][-1]["outcome"] or line["attempts"][-1]["seconds"] < 10
 
 
 def test_slab_argument():

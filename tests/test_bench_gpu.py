@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900)
+def run_bench(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -36,7 +37,7 @@ def test_bench_line_contract():
     assert r["traffic"] is None or 0.9 * r["bytes_per_launch"] < r["traffic"] < 1.2 * r["bytes_per_launch"]
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mvoxels/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
-    assert c["parity_rows_bit_exact"] is True and c["parity_rows"] == 64
+    assert c["parity_rows_bit_exact"] is True and c["parity_rows"] == 64 and c["repetitions"] >= 5 and "median of 5" in c["sample"]
     # the reference's own shader text, compiled (it travels as oracle/_ref/libref_shaders.so where the build container had
     # /root/reference): timed on a bounded sample and bit-identical to the HIP rows / images at the benchmark size
     rt = c["reference_shader_text"]
@@ -54,7 +55,14 @@ def test_bench_line_contract():
     assert big["brick_counts_differing"] <= 1e-3 * big["brick_counts"]
     # box calibration: a replay of the kernel's memory streams on the same box, and the GPU state beside it
     assert r["box_stream_GBps"] > 3000 and abs(r["frac_of_box_stream"] - r["achieved"] / r["box_stream_GBps"]) < 2e-3
-    assert 0.8 < r["frac_of_box_stream"] < 1.1 and isinstance(r["box"], dict)
+    assert 0.8 < r["frac_of_box_stream"] < 1.1
+    # clocks / power UNDER LOAD: a burst of at least a second of the same step loop, sampled from a side thread
+    box = r["box"]
+    assert "error" not in box, box
+    if "unavailable" not in box:
+        assert box["burst_s"] >= 1.0 and box["samples"] >= 5
+        assert box["sclk_MHz"] is None or box["sclk_MHz"]["max"] >= 500.0          # an idle clock is dropped, never printed
+        assert box["pci"] is not None and box["power_W"]["median"] > 100.0
     # the placement probe is bench.py's opt-in: the line also carries what the first placement (library default) gives
     assert 0.5 < r["frac_first_placement"] <= r["frac"] * 1.02 and r["avg_launch_ms_first_placement"] > 0
     # ... and what the library's own default (the best of three bounded candidates) gives
@@ -71,6 +79,38 @@ def test_bench_line_contract():
     assert sk["ms_per_step"] < 0.8 * j["ms_per_step"] and 0.3 < sk["frac_decided"] <= 1.0
     assert sum(sk["verdicts"].values()) == sk["pairs"] and sk["verdicts"]["none"] == sk["pairs"] - sk["pairs_decided"]
     assert sk["GBps"] < 8000.0   # the bytes it asks for over its time: never above the HBM peak
+    # the data-dependent modes on more than their best case: static / moving / dense / dense + moving
+    sc = j["scenes"]
+    assert "error" not in sc, sc
+    assert sc["static"]["valid_pixels"] < 0.5 and sc["dense"]["valid_pixels"] == 1.0 and sc["dense_moving"]["valid_pixels"] > 0.98
+    assert sc["moving"]["frames_in_rotation"] == 4 and sc["dense_moving"]["frames_in_rotation"] == 4
+    for name in ("static", "moving", "dense", "dense_moving"):
+        m = sc[name]
+        assert m["pre_chain_ms"] > 0 and m["bricked"]["ms_per_step"] > 0 and 0.0 <= m["background_skip"]["frac_decided"] <= 1.0
+        assert abs(m["full_sweep"]["integrate_ms"] - r["avg_launch_ms"]) < 0.25 * r["avg_launch_ms"]      # the headline does not depend on the data
+    assert sc["dense"]["pre_chain_ms"] > sc["static"]["pre_chain_ms"]          # 169 taps for every pixel instead of a third of them
+    assert sc["dense"]["bricked"]["occupied_ratio"] > sc["static"]["bricked"]["occupied_ratio"]
+    assert abs(sc["static"]["bricked"]["ms_per_step"] - j["bricked"]["ms_per_step"]) < 0.3 * j["bricked"]["ms_per_step"]
+    rd = j["reference_defaults"]
+    assert rd["ms_per_frame_moving"] > 0
+    il = j["inverse_lut"]
+    assert "error" not in il and il["inverse_lut_generate_ms"] > 0 and il["Gvoxels_per_s"] > 0
+
+
+def test_a_failing_leg_costs_its_own_key_and_nothing_else():
+    """VERDICT r4 task 2: every leg after the headline is isolated; here the brick-skipping leg throws"""
+    j = run_bench("--steps", "4", "--warmup", "1", "--cpu-rows", "8", env={"RGBDR_BENCH_FAIL_LEG": "bricked"})
+    assert j["bricked"] == {"error": "RuntimeError: RGBDR_BENCH_FAIL_LEG=bricked"}
+    assert j["value"] > 0 and 0.5 < j["roofline"]["frac"] < 1.0 and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["parity_rows_bit_exact"] is True
+    for later in ("other_schedule", "full_sweep_store_elision", "full_sweep_background_skip", "scenes", "post_pass", "host_fed"):
+        assert "error" not in j[later], (later, j[later])
+
+
+def test_a_hanging_leg_is_ended_by_the_watchdog_and_the_line_is_printed():
+    """... and here the host-fed leg never returns: the watchdog prints the line as far as it got, status 0"""
+    j = run_bench("--steps", "4", "--warmup", "1", "--no-cpu-baseline", env={"RGBDR_BENCH_FAIL_LEG": "host_fed:hang", "RGBDR_BENCH_LEG_BUDGET": "25"})
+    assert "watchdog" in j["host_fed"]["error"] and "host_fed" in j["legs_incomplete"]
+    assert j["value"] > 0 and 0.5 < j["roofline"]["frac"] < 1.0 and "error" not in j["bricked"] and "error" not in j["scenes"]
 
 
 def test_bench_loopback_runs_the_multi_gpu_path():
@@ -90,6 +130,7 @@ def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     own multi-GPU config is timed in the same run and reported under baseline_configs_run."""
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1")
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["scaling"] == "weak"
+    assert j["launch"]["rung"] == 0 and j["launch"]["line"] == "final" and j["launch"]["failed_attempts"] == [] and j["launch"]["child_status"] == 0
     assert j["config"]["baseline_config"].startswith("configs[2] at fixed work per GPU") and "4 sensors" in j["metric"]
     assert j["config"]["grid"] == [512, 512, 1024] and j["config"]["sensors"] == 4
     pr = j["per_rank"]
@@ -126,6 +167,37 @@ def test_baseline_configs_as_the_headline_of_a_two_gpu_run():
     assert "voxel_sensor_updates_per_s" in j["scaling_note"]
 
 
+def test_ladder_on_the_gpu_a_hung_first_rung_is_replaced_by_fresh_children():
+    """VERDICT r4 task 1 on the real child: rung 0's ranks hang in their init phase (hook), the supervisors end them when the
+    rung's budget is up and start rung 1 (--torch-collectives) with fresh processes, which produces the line; two ranks share
+    the one GPU, so gloo carries the halos"""
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--weak", "--rung-budgets", "30,500,500",
+                  env={"RGBDR_BENCH_HANG": "0:init"})
+    la = j["launch"]
+    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives"] and la["line"] == "final"
+    assert len(la["failed_attempts"]) == 1 and la["failed_attempts"][0]["rung"] == 0 and "budget" in la["failed_attempts"][0]["outcome"]
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["collectives"] == "torch.distributed"
+    assert j["config"]["pre_chain"].startswith("sharded by sensor")
+
+
+def test_ladder_last_rung_is_the_redundant_chain_and_the_weak_run_only():
+    j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--first-rung", "2")
+    assert j["launch"]["rung"] == 2 and j["launch"]["rung_flags"] == ["--torch-collectives", "--no-shard", "--weak"]
+    assert j["config"]["pre_chain"] == "every sensor on every rank" and j["config"]["collectives"] == "torch.distributed"
+    assert j["scaling"] == "weak" and "baseline_configs_run" not in j and j["value"] > 0 and len(j["per_rank"]["integrate_ms"]) == 2
+    assert "error" not in j["post_pass"] and "error" not in j["bricked"] and "error" not in j["halo"]
+
+
+def test_the_watchdog_of_a_child_ends_a_phase_that_overruns():
+    """a child whose phase exceeds its budget leaves with os._exit (status 75) without waiting for the supervisor: the trial
+    step of the library-managed exchange, hung by the hook, with every budget scaled down"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--slab", "1/4", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, RGBDR_BENCH_HANG="-:trial step", RGBDR_BENCH_RUNG="-", RGBDR_BENCH_BUDGET_SCALE="0.3"))
+    assert r.returncode == 75 and "watchdog: phase 'trial step'" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("where", ["construct", "trial"])
 def test_a_rank_whose_managed_exchange_fails_goes_back_to_torch_distributed(where, monkeypatch):
     """bench.py's N > 1 default lets the LIBRARY enqueue RCCL (raw communicators, never run between two devices on this pool): if
@@ -138,6 +210,10 @@ def test_a_rank_whose_managed_exchange_fails_goes_back_to_torch_distributed(wher
     monkeypatch.delenv("RGBDR_BENCH_FAIL_MANAGED")
     j = run_bench("--slab", "1/4", "--steps", "4", "--warmup", "2")
     assert j["config"]["collectives"].startswith("library-managed RCCL")
+    # ONE RCCL in the process: the copy torch had mapped already, named with its version; the communicator reports its ranks
+    rc = j["config"]["rccl"]
+    assert len(rc["copies_mapped"]) == 1 and rc["path"] == rc["copies_mapped"][0] and rc["version"] > 20000 and "RTLD_NOLOAD" in rc["bound"]
+    assert j["config"]["rccl_ranks"] == rc["ranks"] == 1          # one GPU stands in for its neighbours: a one-rank communicator
 
 
 def test_one_slab_of_config_3_as_its_rank_would_run_it():

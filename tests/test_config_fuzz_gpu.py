@@ -236,6 +236,10 @@ def test_random_sensor_shard_configuration(pkg, orc, seed):
         for t in cn:
             t.copy_(total)
         torch.cuda.synchronize()
+        for c in ranks:
+            with pytest.raises(capi.RgbdrError):
+                c.integrate()                       # looking at the buffers (shard_view) does not disarm the guard ...
+            c.shard_gather_done()                   # ... the host's word that its own gather is enqueued does
         ref = orc.run_pipeline(sc, BMIN, BMAX, res, inv, limit=limit, brick_size=g.brick_size, bv=g.brick_voxels, res_bricks=tuple(g.res_bricks),
                                min_voxels=cfg.min_voxels_per_brick, use_bricks=bricks)
         for r, c in enumerate(ranks):

@@ -1735,6 +1735,10 @@ def test_sensor_shards_complete_each_other(pkg, orc):
         for c in cn:
             c.copy_(total)
         torch.cuda.synchronize()
+        for c in ranks:
+            with pytest.raises(capi.RgbdrError):
+                c.integrate()                       # looking at the buffers (shard_view) does not disarm the guard ...
+            c.shard_gather_done()                   # ... the host's word that its own gather is enqueued does
 
     for pipelined in (False, True):
         for bricks in (True, False):
