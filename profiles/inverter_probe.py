@@ -11,9 +11,11 @@ for G in (256, 512):
     ctx = capi.Context(capi.make_config(N, (W, H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
     ctx.set_calibration(0, scene.xyz[0], scene.lut_res, scene.uv[0], scene.lut_res, (0.5, 4.5))
     for R in (2, 3):
+        ctx.compute_inverse_calibration(0, R)
         ctx.sync(); t0 = time.perf_counter()
         ctx.compute_inverse_calibration(0, R)
         ctx.sync(); dt = time.perf_counter() - t0
+        print("  first window %d: widened %d, exhaustive %d of %d voxels" % ((R,) + ctx.inverse_search_stats(0) + (G ** 3,)))
         inv = ctx.readback_inverse_calibration(0, G // 2, G // 2 + 2)
         ana = synth.inverse_lut(scene.sensors[0], (G, G, G), z_range=(G // 2, G // 2 + 2))
         both = (ana[..., 3] > 0) & (inv[..., 0] >= 0)

@@ -49,8 +49,10 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_linear);
   (void)hipFree(c->d_view);
   (void)hipFree(c->d_peels);
+  (void)hipFree(c->d_peel_near);
   c->d_peels = nullptr;
-  c->peel_pixels = 0;
+  c->d_peel_near = nullptr;
+  c->peel_pixels = c->peel_near_cap = 0;
   (void)hipFree(c->d_fill);
   c->d_view = c->d_fill = nullptr;
   c->view_pixels = c->fill_floats = 0;

@@ -418,31 +418,28 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
   p->Y = vol_res[1];
   p->TX = (vol_res[0] + kTile - 1) / kTile;
   p->TY = (vol_res[1] + kTile - 1) / kTile;
-  p->window = window < 1 ? 2 : window;
+  p->window = window < 1 ? 3 : window;  // R = 3 certifies all but ~1e-5 of the voxels at once (R = 2: 12 % are widened)
   p->sensor = sensor;
   p->N = ctx->cfg.num_sensors;
 }
 
-// One certified search over the z rows [p.z0, p.z0 + p.nz): the per-slice edge bound of the forward LUT, the local search,
-// the exhaustive scan of whatever it could not certify (kernels_invert.hip).  Rows are taken in pieces of at most 64 so that
-// the list of uncertified voxels (one word per voxel of a piece: it can never overflow) stays small.
+// One certified search over the z rows [p.z0, p.z0 + p.nz): the local search and the exhaustive scan of whatever it could
+// not certify (kernels_invert.hip).  Rows are taken in pieces of at most 64 so that the list of uncertified voxels (one
+// word per voxel of a piece: it can never overflow) stays small.
 static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
 {
   const int z_begin = p.z0, z_end = p.z0 + p.nz;
   const int piece = 64;
   const size_t row = (size_t)p.X * p.Y;
-  const size_t words = (size_t)p.rz + 2 + 4 + row * (size_t)std::min(piece, p.nz);
+  const size_t head = 6;  // [2] list length (+pad), [4] two 64-bit counters
+  const size_t words = head + row * (size_t)std::min(piece, p.nz);
   DevScratch aux;
   HIPCHK(hipMalloc(&aux.p, words * sizeof(unsigned)));
   unsigned* base = aux.as<unsigned>();
-  unsigned* emax2 = base;                                            // [rz]
-  unsigned* count = base + p.rz;                                     // [1] (+1 pad: the counters below are 8-byte aligned)
-  unsigned long long* stats = (unsigned long long*)(base + ((p.rz + 2 + 1) & ~1));   // [2]
-  unsigned* todo = base + p.rz + 2 + 4;
-  HIPCHK(hipMemsetAsync(base, 0, ((size_t)p.rz + 2 + 4) * sizeof(unsigned), ctx->stream));
-  launch_lut_edge_max(p.xyz, p.rx, p.ry, p.rz, emax2, ctx->stream);
-  LAUNCHCHK("lut_edge_max");
-  p.emax2 = emax2;
+  unsigned* count = base;
+  unsigned long long* stats = (unsigned long long*)(base + 2);  // 8-byte aligned
+  unsigned* todo = base + head;
+  HIPCHK(hipMemsetAsync(base, 0, head * sizeof(unsigned), ctx->stream));
   p.todo = todo;
   p.todo_count = count;
   p.stats = stats;

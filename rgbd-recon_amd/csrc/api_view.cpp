@@ -77,6 +77,21 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
   p.brick_size = ctx->geo.brick_size;
   p.counters = ctx->counters_cur();
   p.mask = ctx->mask_buf(ctx->rbuf);
+  size_t supers = 1;
+  for (int a = 0; a < 3; ++a) {
+    p.res_super[a] = (p.res_bricks[a] + 3) / 4;
+    supers *= (size_t)p.res_super[a];
+  }
+  (void)supers;
+  const size_t bricks = (size_t)ctx->geo.num_bricks;
+  if (ctx->peel_near_cap < bricks) {
+    (void)hipFree(ctx->d_peel_near);
+    ctx->d_peel_near = nullptr;
+    ctx->peel_near_cap = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_peel_near, bricks));
+    ctx->peel_near_cap = bricks;
+  }
+  p.cells = ctx->d_peel_near;
   p.out = out;
   tbegin(ctx, "brickdraw", ctx->stream);
   launch_depth_peels(p, ctx->stream);

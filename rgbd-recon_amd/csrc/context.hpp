@@ -133,6 +133,8 @@ struct rgbdr_ctx {
   // the depth peels have a buffer of their own (the reference draws them into m_view_depth, not into the window): a
   // stand-alone rgbdr_draw_depth_limits of any viewport leaves the frame rgbdr_fill_colors reads alone
   float* d_peels = nullptr;
+  uint8_t* d_peel_near = nullptr;   // per brick: listed | near << 1, for the brick walk (kernels_raymarch.hip k_peel_near)
+  size_t peel_near_cap = 0;
   size_t peel_pixels = 0;
   int view_w = 0, view_h = 0; // size of the last ray-marched frame
   float* d_fill = nullptr;    // hole-fill atlases (2 x colour + depth) and the filled frame

@@ -17,21 +17,24 @@
 // EXACTNESS.  A window's result is accepted only with a certificate that no sample
 // outside the window can be among the 8 nearest.  The faces of the index window that
 // have samples beyond them (its SHELL; faces on the border of the LUT have none) are
-// a closed surface of samples between the query q and everything outside, as long as
-// the sampled region is convex and the lattice does not fold (a sensor's calibration
-// volume is a warped frustum).  A segment from q to an outside sample crosses that
-// surface in a facet whose corners are shell samples, and a point of a facet is no
-// farther from its nearest corner than the facet's longest edge e, so every outside
-// sample is at least  min_shell |q - s| - e  away.  With e bounded by the longest
-// lattice edge of the depth slices the window spans (k_lut_edge_max), the window is
-// certified when
-//        sqrt(d8) < sqrt(min_shell d) - e        (or the window has no shell at all).
-// The same inequality fails when the window does not contain q (the walk got stuck):
-// then the point of the window nearest to q lies on the shell.  Without a certificate
-// the window is re-centred on its nearest sample and widened (R -> R + max(1, R/2), up
-// to 8); a voxel still uncertified at R = 8 is appended to a list and k_invert_exhaustive
-// scans the WHOLE volume for it, one workgroup per voxel.  So the result equals the exact
-// search for every voxel (tests/test_inverter_gpu.py asserts 100 %, not a fraction).
+// a closed surface between the query q and everything outside, as long as the sampled
+// region is convex and the lattice does not fold (a sensor's calibration volume is a
+// warped frustum): a segment from q to an outside sample crosses that surface in a
+// patch of one face, and a (bi)linear patch lies in the convex hull of its corner
+// samples.  So for ANY unit vector u and any point p of face f
+//        |p - q|  >=  u . (p - q)  >=  min over the samples s of f of  u . (s - q),
+// and with u_f = the outward normal of the lattice at the window's centre (cross product
+// of the two in-face index directions) the right side is the distance of q to the face
+// when the face is flat -- no slack for the size or the elongation of the cells.  The
+// window is certified when
+//        sqrt(d8)  <  min over its shell faces f of  min_s u_f . (s - q)
+// (or it has no shell at all).  The inequality also fails when the window does not
+// contain q (the walk got stuck): the face towards q then has samples behind q.  Without
+// a certificate the window is re-centred on its nearest sample and widened (R -> R +
+// max(1, R/2), up to 8); a voxel still uncertified at R = 8 is appended to a list and
+// k_invert_exhaustive scans the WHOLE volume for it, one workgroup per voxel.  So the
+// result equals the exact search for every voxel (tests/test_inverter_gpu.py asserts
+// equality, not a fraction).
 #include <hip/hip_runtime.h>
 
 #include "rgbdr_internal.hpp"
@@ -60,30 +63,6 @@ __device__ __forceinline__ bool inside_frustum(const InvertParams& p, float px, 
     if (d < 0.0f) return false;
   }
   return true;
-}
-
-// longest lattice edge touching each depth slice, as the bits of its squared length (positive floats order like their bits)
-__global__ __launch_bounds__(256) void k_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2)
-{
-  const size_t n = (size_t)rx * ry * rz;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int sx = (int)(i % rx), sy = (int)((i / rx) % ry), sz = (int)(i / ((size_t)rx * ry));
-  const float4 a = xyz[i];
-  auto len2 = [&](size_t j) {
-    const float4 b = xyz[j];
-    const float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    return dx * dx + dy * dy + dz * dz;
-  };
-  float m = 0.0f;
-  if (sx + 1 < rx) m = fmaxf(m, len2(i + 1));
-  if (sy + 1 < ry) m = fmaxf(m, len2(i + rx));
-  if (m > 0.0f) atomicMax(&emax2[sz], __float_as_uint(m));
-  if (sz + 1 < rz) {
-    const float e = len2(i + (size_t)rx * ry);
-    atomicMax(&emax2[sz], __float_as_uint(e));
-    atomicMax(&emax2[sz + 1], __float_as_uint(e));
-  }
 }
 
 // the eight nearest samples -> the record calibration_inverter.cpp:55-69 stores
@@ -119,6 +98,17 @@ __device__ __forceinline__ void insert8(Best8& b, float d2, int lin)
       lin = ti;
     }
   }
+}
+
+// n = normalize(cross(a, b)), oriented along `towards`
+__device__ __forceinline__ void unit_normal(const float* a, const float* b, const float* towards, float* n)
+{
+  const float cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+  const float len = sqrtf(cx * cx + cy * cy + cz * cz);
+  const float sgn = (cx * towards[0] + cy * towards[1] + cz * towards[2]) < 0.0f ? -1.0f : 1.0f;
+  n[0] = sgn * cx / len;
+  n[1] = sgn * cy / len;
+  n[2] = sgn * cz / len;
 }
 
 __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
@@ -214,27 +204,47 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
       const int x0 = max(cx - R, 0), x1 = min(cx + R, p.rx - 1);
       const int y0 = max(cy - R, 0), y1 = min(cy + R, p.ry - 1);
       const int z0 = max(cz - R, 0), z1 = min(cz + R, p.rz - 1);
-      // faces with samples beyond them
+      // faces with samples beyond them, and the lattice's outward directions at the centre
       const bool fx0 = x0 > 0, fx1 = x1 < p.rx - 1, fy0 = y0 > 0, fy1 = y1 < p.ry - 1, fz0 = z0 > 0, fz1 = z1 < p.rz - 1;
-      float shell = __builtin_inff();
+      const bool any_shell = fx0 || fx1 || fy0 || fy1 || fz0 || fz1;
+      float nx[3], ny[3], nz[3];
+      if (any_shell) {
+        const float4 xa = p.xyz[((size_t)cz * p.ry + cy) * p.rx + max(cx - 1, 0)], xb = p.xyz[((size_t)cz * p.ry + cy) * p.rx + min(cx + 1, p.rx - 1)];
+        const float4 ya = p.xyz[((size_t)cz * p.ry + max(cy - 1, 0)) * p.rx + cx], yb = p.xyz[((size_t)cz * p.ry + min(cy + 1, p.ry - 1)) * p.rx + cx];
+        const float4 za = p.xyz[((size_t)max(cz - 1, 0) * p.ry + cy) * p.rx + cx], zb = p.xyz[((size_t)min(cz + 1, p.rz - 1) * p.ry + cy) * p.rx + cx];
+        const float ex[3] = {xb.x - xa.x, xb.y - xa.y, xb.z - xa.z};
+        const float ey[3] = {yb.x - ya.x, yb.y - ya.y, yb.z - ya.z};
+        const float ez[3] = {zb.x - za.x, zb.y - za.y, zb.z - za.z};
+        unit_normal(ey, ez, ex, nx);  // normal of the faces of constant x, pointing towards +x
+        unit_normal(ez, ex, ey, ny);
+        unit_normal(ex, ey, ez, nz);
+      }
+      float plane = __builtin_inff();  // smallest outward distance of a shell sample along its face's normal
       for (int sz = z0; sz <= z1; ++sz)
         for (int sy = y0; sy <= y1; ++sy)
           for (int sx = x0; sx <= x1; ++sx) {
-            const float d2 = sample_d2(p, sx, sy, sz, px, py, pz);
-            const bool on_shell = (fx0 && sx == x0) || (fx1 && sx == x1) || (fy0 && sy == y0) || (fy1 && sy == y1) ||
-                                  (fz0 && sz == z0) || (fz1 && sz == z1);
-            if (on_shell) shell = fminf(shell, d2);
+            const float4 sp = p.xyz[((size_t)sz * p.ry + sy) * p.rx + sx];
+            const float dx = px - sp.x, dy = py - sp.y, dz = pz - sp.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            if (any_shell) {
+              const float tx = -(nx[0] * dx + nx[1] * dy + nx[2] * dz);  // n . (s - q)
+              const float ty = -(ny[0] * dx + ny[1] * dy + ny[2] * dz);
+              const float tz = -(nz[0] * dx + nz[1] * dy + nz[2] * dz);
+              if (fx0 && sx == x0) plane = fminf(plane, -tx);
+              if (fx1 && sx == x1) plane = fminf(plane, tx);
+              if (fy0 && sy == y0) plane = fminf(plane, -ty);
+              if (fy1 && sy == y1) plane = fminf(plane, ty);
+              if (fz0 && sz == z0) plane = fminf(plane, -tz);
+              if (fz1 && sz == z1) plane = fminf(plane, tz);
+            }
             insert8(b, d2, (sx * p.ry + sy) * p.rz + sz);
           }
-      if (!(fx0 || fx1 || fy0 || fy1 || fz0 || fz1)) {
+      if (!any_shell) {
         certified = true;  // the window is the whole volume
         break;
       }
-      unsigned e2 = 0;
-      for (int sz = z0; sz <= z1; ++sz) e2 = max(e2, p.emax2[sz]);
-      // (rounded against acceptance: the left side up, the right side down by an ulp-scale margin)
-      const float lhs = sqrtf(b.d[7]) * 1.000001f, rhs = sqrtf(shell) * 0.999999f - sqrtf(__uint_as_float(e2)) * 1.000001f;
-      if (lhs < rhs) {
+      // (rounded against acceptance; a NaN normal -- a degenerate lattice -- compares false: not certified)
+      if (plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f) {
         certified = true;
         break;
       }
@@ -331,12 +341,6 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive(InvertParams p)
     }
     __syncthreads();
   }
-}
-
-void launch_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2, hipStream_t s)
-{
-  const size_t n = (size_t)rx * ry * rz;
-  hipLaunchKernelGGL(k_lut_edge_max, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xyz, rx, ry, rz, emax2);
 }
 
 void launch_invert_exhaustive(const InvertParams& p, hipStream_t s)

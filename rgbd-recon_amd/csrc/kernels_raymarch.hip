@@ -12,6 +12,8 @@
 // resident inverse LUT (grid layout, or the file volume with
 // RGBDR_FLAG_NO_RESAMPLE), cv_uv, the RGB8 colour frames and the packed
 // depth/quality frames.  Latency / gather bound; reported as time.
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "rgbdr_internal.hpp"
@@ -415,6 +417,8 @@ __device__ __forceinline__ bool peel_in_grid(const PeelParams& p, const int* c)
 {
   return !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= p.res_bricks[0] || c[1] >= p.res_bricks[1] || c[2] >= p.res_bricks[2]);
 }
+// (the same by linear id: the id is linear in the cell's coordinates, one cell outside the grid included)
+__device__ __forceinline__ bool peel_gt10_id(const PeelParams& p, long long id, long long nb) { return id >= 0 && id < nb && p.counters[id] > 10u; }
 __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
 {
   // c may lie one cell outside the grid along one axis (see above): linear id with the shader's wrap-around
@@ -422,9 +426,32 @@ __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
   const long long id = ((long long)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0];
   return id >= 0 && id < nb && p.counters[id] > 10u;
 }
-__device__ __forceinline__ bool peel_listed(const PeelParams& p, const int* c)
+
+// Empty-space flags of the walk below.  A super-cell of 4 x 4 x 4 bricks is NEAR when a listed brick lies in it or next
+// to it (the super-cell dilated by one brick, clipped to the grid).  While the walk is in a super-cell that is not near,
+// neither the cell it is in, nor the one it came from, nor the one it goes to is listed, so no face can be crossed.
+// One wavefront per super-cell finds the flag and writes a byte per brick of the super-cell: bit 0 = the brick is listed
+// (the library's mask), bit 1 = its super-cell is near -- so the walk gets both from the one byte it loads per cell.
+// Most of a frame is empty space (3 % of the bricks are occupied in SURVEY 8d's scene, 13 % of the super-cells near).
+__global__ __launch_bounds__(64) void k_peel_near(const uint8_t* mask, int rx, int ry, int rz, int sx, int sy, int sz, uint8_t* cells, int force)
 {
-  return peel_in_grid(p, c) && p.mask[((size_t)c[2] * p.res_bricks[1] + c[1]) * p.res_bricks[0] + c[0]] != 0;
+  const int id = blockIdx.x;
+  const int cx = id % sx, cy = (id / sx) % sy, cz = id / (sx * sy);
+  const int x0 = max(4 * cx - 1, 0), x1 = min(4 * cx + 4, rx - 1);
+  const int y0 = max(4 * cy - 1, 0), y1 = min(4 * cy + 4, ry - 1);
+  const int z0 = max(4 * cz - 1, 0), z1 = min(4 * cz + 4, rz - 1);
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, n = nx * ny * (z1 - z0 + 1);
+  unsigned any = 0;
+  for (int k = threadIdx.x; k < n; k += 64) {
+    const int x = x0 + k % nx, y = y0 + (k / nx) % ny, z = z0 + k / (nx * ny);
+    any |= mask[((size_t)z * ry + y) * rx + x];
+  }
+  const unsigned nearbit = (__ballot(any != 0) != 0 || force) ? 2u : 0u;
+  const int bx = 4 * cx + (threadIdx.x & 3), by = 4 * cy + ((threadIdx.x >> 2) & 3), bz = 4 * cz + (threadIdx.x >> 4);
+  if (bx < rx && by < ry && bz < rz) {
+    const size_t at = ((size_t)bz * ry + by) * rx + bx;
+    cells[at] = (uint8_t)((mask[at] != 0 ? 1u : 0u) | nearbit);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
@@ -481,43 +508,112 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
     prev[1] = cell[1] - (entry_axis == 1 ? stepi[1] : 0);
     prev[2] = cell[2] - (entry_axis == 2 ? stepi[2] : 0);
     bool prev_in_grid = false, first = true;
-    // one mask byte per cell, loaded one cell ahead: the walk itself needs no loads, so the next cell is known before
+    // One mask byte per cell, loaded one cell ahead: the walk itself needs no loads, so the next cell is known before
+    // this cell's faces are looked at and its byte is in flight meanwhile.
+    // Empty space (k_peel_near): a lane whose cell lies in a super-cell that neither holds nor touches a listed brick
+    // crosses no face until it leaves that super-cell, so it takes the whole super-cell in ONE step.  The t values of the
+    // three axes are independent sequences (t += delta, one addition per crossing), so the state the cell-by-cell walk
+    // would have on leaving the super-cell follows without walking: per axis the values of its next (up to four) crossings,
+    // the axis whose crossing of the super-cell's boundary comes first in the walk's order (smallest value, lowest axis
+    // on a tie) is the exit, and of the other axes exactly the crossings that precede it in that order have happened.
+    // Same additions in the same order per axis: the state is bit-identical, ~12 instead of ~65 instructions per cell.
+    // The ray's first stretch -- from where it enters the grid to the first super-cell that holds or touches a listed
+    // brick -- is taken a super-cell per step (k_peel_near explains why that is exact); from there on the walk goes cell
+    // by cell.  (Alternating between the two for the rest of the ray -- as one loop, as loops nested in an outer one, or
+    // written out A B A B A B -- executed fewer instructions but measured slower: profiles/r05_notes.md.)
+    unsigned cur = p.cells[((size_t)cell[2] * p.res_bricks[1] + cell[1]) * p.res_bricks[0] + cell[0]];
+    float tcur = t0;
+    int steps = 0;                          // index of the current cell along the ray (cells 0 ... 4095 are looked at)
+    bool ended = false;
+    while ((cur & 2u) == 0) {
+#define RGBDR_PEEL_AXIS(A)                                                                                   \
+  const int n##A = stepi[A] > 0 ? 4 - (cell[A] & 3) : (cell[A] & 3) + 1; /* cells to the super-cell's boundary */ \
+  const float v##A##0 = tmax[A], v##A##1 = v##A##0 + tdelta[A], v##A##2 = v##A##1 + tdelta[A], v##A##3 = v##A##2 + tdelta[A]; \
+  const float T##A = n##A == 1 ? v##A##0 : n##A == 2 ? v##A##1 : n##A == 3 ? v##A##2 : v##A##3;
+      RGBDR_PEEL_AXIS(0)
+      RGBDR_PEEL_AXIS(1)
+      RGBDR_PEEL_AXIS(2)
+#undef RGBDR_PEEL_AXIS
+      int ax = 0;
+      float T = T0;
+      if (T1 < T) {
+        ax = 1;
+        T = T1;
+      }
+      if (T2 < T) {
+        ax = 2;
+        T = T2;
+      }
+      if (!(T < t1) || steps >= 4096) {      // the ray ends inside this super-cell: no face
+        ended = true;
+        break;
+      }
+      // crossings of axis A that the walk makes before (T, ax): value below T, or equal to it on a lower axis;
+      // the exit axis makes its n crossings
+#define RGBDR_PEEL_TAKE(A)                                                                                    \
+  {                                                                                                           \
+    const bool tie = A < ax;                                                                                  \
+    const int c = ax == A ? n##A                                                                              \
+                          : (int)(v##A##0 < T || (tie && v##A##0 == T)) + (int)(v##A##1 < T || (tie && v##A##1 == T)) + \
+                                (int)(v##A##2 < T || (tie && v##A##2 == T));                                  \
+    const float after = c == 0 ? v##A##0 : c == 1 ? v##A##1 : c == 2 ? v##A##2 : c == 3 ? v##A##3 : v##A##3 + tdelta[A]; \
+    tmax[A] = after;                                                                                          \
+    cell[A] += c * stepi[A];                                                                                  \
+    prev[A] = ax == A ? cell[A] - stepi[A] : cell[A];                                                         \
+    steps += c;                                                                                               \
+  }
+      RGBDR_PEEL_TAKE(0)
+      RGBDR_PEEL_TAKE(1)
+      RGBDR_PEEL_TAKE(2)
+#undef RGBDR_PEEL_TAKE
+      tcur = T;
+      first = false;
+      prev_in_grid = true;
+      if (!peel_in_grid(p, cell)) {          // out of the grid from an unlisted cell: no face
+        ended = true;
+        break;
+      }
+      cur = p.cells[((size_t)cell[2] * p.res_bricks[1] + cell[1]) * p.res_bricks[0] + cell[0]];
+    }
+    if (ended) break;
+    // one byte per cell, loaded one cell ahead: the walk itself needs no loads, so the next cell is known before
     // this cell's faces are looked at and its byte is in flight meanwhile
     bool last_list = false;                 // was the cell the ray just left on the list?
-    bool cur_list = peel_listed(p, cell);
-    float tcur = t0;
-    for (int iter = 0; iter < 4096; ++iter) {
+    bool cur_list = (cur & 1u) != 0;
+    // linear ids of the cell and of the one before it, advanced by the stride of the axis stepped along
+    const long long rx = p.res_bricks[0], rxy = rx * p.res_bricks[1], nb = rxy * p.res_bricks[2];
+    const long long stride0 = stepi[0], stride1 = stepi[1] * rx, stride2 = stepi[2] * rxy;
+    long long idx = ((long long)cell[2] * p.res_bricks[1] + cell[1]) * rx + cell[0];
+    long long pidx = ((long long)prev[2] * p.res_bricks[1] + prev[1]) * rx + prev[0];
+    for (int iter = steps; iter < 4096; ++iter) {
       int a = 0;
       if (tmax[1] < tmax[a]) a = 1;
       if (tmax[2] < tmax[a]) a = 2;
       const float tnext = tmax[a];
       const bool leaving = !(tnext < t1);
-      int ncell[3] = {cell[0], cell[1], cell[2]};
-      if (a == 0) ncell[0] += stepi[0];
-      else if (a == 1) ncell[1] += stepi[1];
-      else ncell[2] += stepi[2];
-      const bool next_in_grid = !leaving && peel_in_grid(p, ncell);
-      const bool next_list = next_in_grid && p.mask[((size_t)ncell[2] * p.res_bricks[1] + ncell[1]) * p.res_bricks[0] + ncell[0]] != 0;
-      if (!(first && !(t0 > 0.0f))) {
-        const bool prev_list = prev_in_grid && last_list;
-        if (cur_list || prev_list) {
+      const int n0 = cell[0] + (a == 0 ? stepi[0] : 0), n1 = cell[1] + (a == 1 ? stepi[1] : 0), n2 = cell[2] + (a == 2 ? stepi[2] : 0);
+      const long long nidx = idx + (a == 0 ? stride0 : a == 1 ? stride1 : stride2);
+      const bool next_in_grid = !leaving && (unsigned)n0 < (unsigned)p.res_bricks[0] && (unsigned)n1 < (unsigned)p.res_bricks[1] &&
+                                (unsigned)n2 < (unsigned)p.res_bricks[2];
+      const bool next_list = next_in_grid && (p.cells[nidx] & 1u) != 0;
+      const bool prev_list = prev_in_grid && last_list;
+      // most cells of a near super-cell are not listed themselves: one test keeps them out of the face logic
+      if (cur_list || prev_list) {
+        if (!(first && !(t0 > 0.0f))) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
-            if (cur_list && !peel_gt10(p, prev)) {
+            if (cur_list && !peel_gt10_id(p, pidx, nb)) {
               r = fminf(r, z);
               gneg = fminf(gneg, -z);
             }
-            if (prev_list && !peel_gt10(p, cell)) {
+            if (prev_list && !peel_gt10_id(p, idx, nb)) {
               r = fminf(r, z);
               gneg = fminf(gneg, -z);
               b = fminf(b, z);
             }
           }
         }
-      }
-      first = false;
-      if (leaving) {
-        if (cur_list && !peel_gt10(p, ncell)) {
+        if (leaving && cur_list && !peel_gt10_id(p, nidx, nb)) {
           const float z = peel_z(p, o, d, t1);
           if (t1 < 1.0f && z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);
@@ -525,23 +621,22 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
             b = fminf(b, z);
           }
         }
-        break;
       }
-      prev[0] = cell[0];
-      prev[1] = cell[1];
-      prev[2] = cell[2];
+      first = false;
+      if (leaving) break;
       prev_in_grid = true;
       last_list = cur_list;
-      cell[0] = ncell[0];
-      cell[1] = ncell[1];
-      cell[2] = ncell[2];
-      // no runtime-indexed register arrays: step the selected axis explicitly
-      if (a == 0) tmax[0] += tdelta[0];
-      else if (a == 1) tmax[1] += tdelta[1];
-      else tmax[2] += tdelta[2];
+      pidx = idx;
+      idx = nidx;
+      cell[0] = n0;
+      cell[1] = n1;
+      cell[2] = n2;
+      tmax[0] = a == 0 ? tmax[0] + tdelta[0] : tmax[0];
+      tmax[1] = a == 1 ? tmax[1] + tdelta[1] : tmax[1];
+      tmax[2] = a == 2 ? tmax[2] + tdelta[2] : tmax[2];
       tcur = tnext;
       if (!next_in_grid) {
-        if (last_list && !peel_gt10(p, cell)) {
+        if (last_list && !peel_gt10_id(p, idx, nb)) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
             r = fminf(r, z);
@@ -559,6 +654,11 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
 
 void launch_depth_peels(const PeelParams& p, hipStream_t s)
 {
+  // RGBDR_PEEL_ALLNEAR=1 (diagnostic, profiles/pmc_peels.sh): every super-cell counts as near, i.e. the plain walk
+  static const int all_near = std::getenv("RGBDR_PEEL_ALLNEAR") ? 1 : 0;
+  const int ns = p.res_super[0] * p.res_super[1] * p.res_super[2];
+  hipLaunchKernelGGL(k_peel_near, dim3((unsigned)ns), dim3(64), 0, s, p.mask, p.res_bricks[0], p.res_bricks[1],
+                     p.res_bricks[2], p.res_super[0], p.res_super[1], p.res_super[2], p.cells, all_near);
   dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
   hipLaunchKernelGGL(k_depth_peels, grid, dim3(16, 16), 0, s, p);
 }

@@ -154,7 +154,6 @@ struct InvertParams {
   int z0, nz;              // z rows [z0, z0 + nz) handled by this launch
   int TX, TY;              // tiles in x, y
   int window;              // index radius R of the first candidate window (widened until certified, kernels_invert.hip)
-  const unsigned* emax2;   // [rz] longest lattice edge touching each depth slice: bits of its squared length
   unsigned* todo;          // voxels (launch-relative linear index) left to k_invert_exhaustive, and their number
   unsigned* todo_count;
   unsigned long long* stats;  // [0] voxels whose window was widened, [1] voxels searched exhaustively
@@ -202,6 +201,8 @@ struct PeelParams {
   int res_bricks[3];
   const uint32_t* counters;
   const uint8_t* mask;
+  int res_super[3];            // super-cells of 4^3 bricks: ceil(res_bricks / 4)
+  uint8_t* cells;              // [num_bricks] listed | near << 1, written by launch_depth_peels before the walk (k_peel_near)
   float4* out;
 };
 void launch_depth_peels(const PeelParams& p, hipStream_t s);
@@ -217,7 +218,6 @@ void launch_fill_colors(const FillLayout& L, const float4* frame_col, const floa
 
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
-void launch_lut_edge_max(const float4* xyz, int rx, int ry, int rz, unsigned* emax2, hipStream_t s);
 void launch_invert_exhaustive(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
