@@ -245,6 +245,10 @@ def launch_ranks(n, argv, timeout=1500.0, child_cmd=None, poll_s=0.2):
             if code != 0:
                 rc = code if code > 0 else 128 - code
                 sys.stderr.write("[bench launcher] rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                # (supervisors leave on their own within moments of each other; rank 0's prints the line on its way out)
+                t_grace = time.monotonic() + (0.0 if child_cmd else 20.0)
+                while time.monotonic() < t_grace and any(procs[q].poll() is None for q in live):
+                    time.sleep(poll_s)
                 break
         if live and rc == 0:
             if time.monotonic() > deadline:
@@ -462,18 +466,18 @@ def supervise_rank(args, argv):
     if rank != 0:
         store.put("bye.%d" % rank, 1)
         return 1
+    # THE line first, the housekeeping after it: the launcher may stop this process once the other supervisors have left
+    if final is not None:
+        sys.stdout.write(json.dumps(final) + "\n")
+    else:
+        sys.stdout.write(json.dumps({"error": "every rung of the launch ladder failed", "n_gpus": world, "attempts": attempts,
+                                     "seconds": round(time.monotonic() - t_start, 1)}) + "\n")
+    sys.stdout.flush()
     t_bye = time.monotonic() + 15.0           # the other supervisors have read the last verdict: the directory can go
     while time.monotonic() < t_bye and any(store.get("bye.%d" % r) is None for r in range(1, world)):
         time.sleep(0.05)
     store.cleanup()
-    if final is not None:
-        sys.stdout.write(json.dumps(final) + "\n")
-        sys.stdout.flush()
-        return 0
-    sys.stdout.write(json.dumps({"error": "every rung of the launch ladder failed", "n_gpus": world, "attempts": attempts,
-                                 "seconds": round(time.monotonic() - t_start, 1)}) + "\n")
-    sys.stdout.flush()
-    return 1
+    return 0 if final is not None else 1
 
 
 class Watchdog:
@@ -832,6 +836,46 @@ def trial_step(rig):
         rig.exchanger = torch_exchanger(rig, reset=True)
 
 
+def choose_chain(rig, steps=12, warmup=3):
+    """Sharded or redundant pre_* chain?  Sharding saves chain time (n / k instead of n sensors per rank) and pays one
+    all-gather of the packed frames + one all-reduce of the brick counters between chain and sweep, on the critical path.
+    Which of the two is shorter depends on the interconnect (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an
+    estimated 45-140 us over xGMI, against 60-70 us of chain time saved), so the run MEASURES both schedules on its own
+    ranks before the headline and keeps the faster one (max over ranks); the line records both times."""
+    if rig.gather is None or not rig.multi:
+        return
+    torch, dist, ctx = rig.torch, rig.dist, rig.ctx
+    keep_gather, first, count = rig.gather, ctx.cfg.num_sensors // rig.slab_count * rig.slab_rank, ctx.cfg.num_sensors // rig.slab_count
+
+    ctx.set_use_bricks(False)                # the headline's sweep
+
+    def run():
+        for _ in range(warmup):
+            rig.step(False)
+        rig.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rig.step(False)
+        rig.barrier()
+        t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
+        if rig.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rig.shared["fallback"] if "fallback" in rig.shared else None)
+        return float(t[0])
+
+    ms_sharded = run()
+    ctx.set_sensor_shard(0, 0)
+    rig.gather = None
+    ms_redundant = run()
+    keep = ms_sharded <= ms_redundant
+    if os.environ.get("RGBDR_BENCH_CHAIN") in ("sharded", "redundant"):        # pin the choice (tests, A/B runs)
+        keep = os.environ["RGBDR_BENCH_CHAIN"] == "sharded"
+    if keep:
+        ctx.set_sensor_shard(first, count)
+        rig.gather = keep_gather
+    rig.chain_choice = {"ms_per_step_sharded": round(ms_sharded, 4), "ms_per_step_redundant": round(ms_redundant, 4),
+                        "kept": "sharded" if keep else "redundant", "steps_each": steps}
+
+
 def settle(rig):
     """Untimed set-up: memory a previous process released is wiped by the driver in the background for a while (a 6 GB free
     slows the sweep by 4 % for ~0.2 s).  Wait until the sweep time has settled before the warm-up and the
@@ -916,6 +960,7 @@ def headline_line(rig, dt, stats):
                    "halo_transport": rig.transport["kind"] if multi else None,
                    "pre_chain": ("sharded by sensor: %d of %d sensors per rank, packed frames all-gathered + brick counters all-reduced on "
                                  "the chain's stream" % (N // rig.slab_count, N)) if rig.gather is not None else "every sensor on every rank",
+                   "pre_chain_choice": getattr(rig, "chain_choice", None),
                    "collectives": (("library-managed RCCL (C ABI: rgbdr_halo_exchange_async, rgbdr_shard_allgather)" if rig.managed
                                     else "torch.distributed") if multi else None),
                    # which RCCL carried the exchange: the file mapped in this process, its version, and the number of ranks
@@ -968,6 +1013,9 @@ def run_rank(args, slab=None, quiet=False, shared=None):
                 trial_step(rig)
     with wd.phase("settle", 60.0):
         settle(rig)
+    if rig.multi and rig.gather is not None:
+        with wd.phase("chain choice", 60.0):
+            choose_chain(rig)
     with wd.phase("headline", 60.0 + 0.05 * (args.steps + args.warmup)):
         dt, stats = rig.timed(False, args.steps, args.warmup)
         rig.stats = stats

@@ -187,3 +187,25 @@ def test_slab_argument():
     for bad in ("4/4", "1", "0/3", "a/b"):
         with pytest.raises(SystemExit):
             b.parse_slab(bad)
+
+
+def test_file_store_and_watchdog_units(tmp_path, monkeypatch):
+    """the two small mechanisms under the ladder: values put by one process are read by another (rename, no partial reads),
+    and a phase that overruns ends the PROCESS from the side thread with the configured status"""
+    import subprocess
+    import sys
+    b = load_bench()
+    monkeypatch.setenv("RGBDR_BENCH_JOB", "unit_%d" % os.getpid())
+    st = b.FileStore()
+    assert st.get("k") is None and st.wait("k", timeout=0.2) is None
+    st.put("k", {"a": [1, 2, 3]})
+    assert b.FileStore().get("k") == {"a": [1, 2, 3]}
+    st.cleanup()
+    assert not os.path.exists(st.dir)
+    code = ("import sys, time; sys.path.insert(0, %r); import importlib.util as u; "
+            "sp = u.spec_from_file_location('bm', %r); m = u.module_from_spec(sp); sp.loader.exec_module(m)\n"
+            "wd = m.Watchdog(lambda name, budget: sys.stderr.write('expired %%s\\n' %% name))\n"
+            "with wd.phase('quick', 5.0): pass\n"
+            "with wd.phase('slow', 0.5): time.sleep(30)\n") % (ROOT, os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == b.EXIT_WATCHDOG and "watchdog: phase 'slow'" in r.stderr and "expired slow" in r.stderr

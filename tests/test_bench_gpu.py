@@ -172,12 +172,14 @@ def test_ladder_on_the_gpu_a_hung_first_rung_is_replaced_by_fresh_children():
     rung's budget is up and start rung 1 (--torch-collectives) with fresh processes, which produces the line; two ranks share
     the one GPU, so gloo carries the halos"""
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--weak", "--rung-budgets", "30,500,500",
-                  env={"RGBDR_BENCH_HANG": "0:init"})
+                  env={"RGBDR_BENCH_HANG": "0:init", "RGBDR_BENCH_CHAIN": "sharded"})
     la = j["launch"]
     assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives"] and la["line"] == "final"
     assert len(la["failed_attempts"]) == 1 and la["failed_attempts"][0]["rung"] == 0 and "budget" in la["failed_attempts"][0]["outcome"]
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["collectives"] == "torch.distributed"
     assert j["config"]["pre_chain"].startswith("sharded by sensor")
+    ch = j["config"]["pre_chain_choice"]       # both schedules were timed on the run's own ranks before the headline
+    assert ch["kept"] == "sharded" and ch["ms_per_step_sharded"] > 0 and ch["ms_per_step_redundant"] > 0
 
 
 def test_ladder_last_rung_is_the_redundant_chain_and_the_weak_run_only():
@@ -214,6 +216,20 @@ def test_a_rank_whose_managed_exchange_fails_goes_back_to_torch_distributed(wher
     rc = j["config"]["rccl"]
     assert len(rc["copies_mapped"]) == 1 and rc["path"] == rc["copies_mapped"][0] and rc["version"] > 20000 and "RTLD_NOLOAD" in rc["bound"]
     assert j["config"]["rccl_ranks"] == rc["ranks"] == 1          # one GPU stands in for its neighbours: a one-rank communicator
+
+
+def test_the_chain_schedule_is_chosen_by_measurement():
+    """sharded or redundant pre_* chain: the run times both on its own ranks and keeps the faster one; the line says which
+    and carries both times (one GPU standing in for rank 1 of 4: the gather goes to the GPU itself, so sharding wins here)"""
+    j = run_bench("--slab", "1/4", "--steps", "4", "--warmup", "2")
+    ch = j["config"]["pre_chain_choice"]
+    assert ch["kept"] in ("sharded", "redundant") and ch["steps_each"] >= 8
+    faster = "sharded" if ch["ms_per_step_sharded"] <= ch["ms_per_step_redundant"] else "redundant"
+    assert ch["kept"] == faster
+    assert j["config"]["pre_chain"].startswith("sharded by sensor") == (ch["kept"] == "sharded")
+    j = run_bench("--slab", "1/4", "--steps", "4", "--warmup", "2", env={"RGBDR_BENCH_CHAIN": "redundant"})
+    assert j["config"]["pre_chain_choice"]["kept"] == "redundant" and j["config"]["pre_chain"] == "every sensor on every rank"
+    assert j["slab"]["integrate_ms"] > 0 and "error" not in j["post_pass"]
 
 
 def test_one_slab_of_config_3_as_its_rank_would_run_it():
