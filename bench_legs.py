@@ -290,7 +290,7 @@ def leg_box(rig):
     busy = stat("gpu_busy_percent")
     if busy and busy["max"] > 0:
         res["gpu_busy_percent"] = busy
-    else:      # the driver of this pool reports 0 next to 300 W and a 2.4 GHz clock: not evidence of anything
+    else:      # 0 throughout a burst means the card read is not the one that ran it: not evidence of anything
         res["gpu_busy_percent"] = None
     sclk = stat("sclk_hwmon_MHz") or stat("sclk_MHz")
     if sclk and sclk["max"] >= 500.0:

@@ -282,13 +282,16 @@ def test_slab_loop_is_built_against_rccl_and_the_c_abi():
 
 
 @pytest.mark.gpu
-def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path):
-    """The C++ host's multi-GPU frame loop (host/slab_loop.cpp: host::HaloExchanger over
+@pytest.mark.parametrize("n", [2, 1])
+def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path, n):
+    """n = 2: the pre_* chain goes through host::FrameGather on a communicator of its own; n = 1: a single sensor cannot be
+    sharded, the loop runs the whole chain and creates no gather (it used to throw there).
+    The C++ host's multi-GPU frame loop (host/slab_loop.cpp: host::HaloExchanger over
     rgbdr_halo_begin_step / _exchange_async / _wait, RCCL bound at run time by the library) as an
     inner Z slab whose two neighbours are the process itself: four different frames with no host
     synchronisation in between; afterwards the halo layers hold the boundary layers of the LAST frame."""
     capi, synth = pkg.capi, pkg.synth
-    n, W, H, G, frames = 2, 128, 106, 96, 4
+    W, H, G, frames = 128, 106, 96, 4
     scenes = [synth.Scene(n, W, H, lut_res=(32, 27, 32), seed=1 + k, sphere_r=0.9 - 0.05 * k) for k in range(frames)]
     first = scenes[0]
     inv = first.inverse((G, G, G))
