@@ -418,7 +418,8 @@ __device__ __forceinline__ bool peel_in_grid(const PeelParams& p, const int* c)
   return !(c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= p.res_bricks[0] || c[1] >= p.res_bricks[1] || c[2] >= p.res_bricks[2]);
 }
 // (the same by linear id: the id is linear in the cell's coordinates, one cell outside the grid included)
-__device__ __forceinline__ bool peel_gt10_id(const PeelParams& p, long long id, long long nb) { return id >= 0 && id < nb && p.counters[id] > 10u; }
+// (k_peel_near keeps "counter > 10" as bit 2 of the brick's byte, so the walk needs no second array)
+__device__ __forceinline__ bool peel_gt10_id(const PeelParams& p, long long id, long long nb) { return id >= 0 && id < nb && (p.cells[id] & 4u) != 0; }
 __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
 {
   // c may lie one cell outside the grid along one axis (see above): linear id with the shader's wrap-around
@@ -431,9 +432,11 @@ __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
 // to it (the super-cell dilated by one brick, clipped to the grid).  While the walk is in a super-cell that is not near,
 // neither the cell it is in, nor the one it came from, nor the one it goes to is listed, so no face can be crossed.
 // One wavefront per super-cell finds the flag and writes a byte per brick of the super-cell: bit 0 = the brick is listed
-// (the library's mask), bit 1 = its super-cell is near -- so the walk gets both from the one byte it loads per cell.
+// (the library's mask), bit 1 = its super-cell is near, bit 2 = its counter is above 10 (the geometry shader's cull of a
+// face towards such a neighbour, bricks.gs:28-43) -- so the walk gets all three from the one byte it loads per cell.
 // Most of a frame is empty space (3 % of the bricks are occupied in SURVEY 8d's scene, 13 % of the super-cells near).
-__global__ __launch_bounds__(64) void k_peel_near(const uint8_t* mask, int rx, int ry, int rz, int sx, int sy, int sz, uint8_t* cells, int force)
+__global__ __launch_bounds__(64) void k_peel_near(const uint8_t* mask, const uint32_t* counters, int rx, int ry, int rz, int sx, int sy, int sz,
+                                                  uint8_t* cells, int force)
 {
   const int id = blockIdx.x;
   const int cx = id % sx, cy = (id / sx) % sy, cz = id / (sx * sy);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(64) void k_peel_near(const uint8_t* mask, int rx, i
   const int bx = 4 * cx + (threadIdx.x & 3), by = 4 * cy + ((threadIdx.x >> 2) & 3), bz = 4 * cz + (threadIdx.x >> 4);
   if (bx < rx && by < ry && bz < rz) {
     const size_t at = ((size_t)bz * ry + by) * rx + bx;
-    cells[at] = (uint8_t)((mask[at] != 0 ? 1u : 0u) | nearbit);
+    cells[at] = (uint8_t)((mask[at] != 0 ? 1u : 0u) | nearbit | (counters[at] > 10u ? 4u : 0u));
   }
 }
 
@@ -580,6 +583,7 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
     // this cell's faces are looked at and its byte is in flight meanwhile
     bool last_list = false;                 // was the cell the ray just left on the list?
     bool cur_list = (cur & 1u) != 0;
+    bool cur_gt10 = (cur & 4u) != 0, prev_gt10 = false, prev_known = false;   // (the byte of the cell before the first is not at hand)
     // linear ids of the cell and of the one before it, advanced by the stride of the axis stepped along
     const long long rx = p.res_bricks[0], rxy = rx * p.res_bricks[1], nb = rxy * p.res_bricks[2];
     const long long stride0 = stepi[0], stride1 = stepi[1] * rx, stride2 = stepi[2] * rxy;
@@ -595,18 +599,19 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       const long long nidx = idx + (a == 0 ? stride0 : a == 1 ? stride1 : stride2);
       const bool next_in_grid = !leaving && (unsigned)n0 < (unsigned)p.res_bricks[0] && (unsigned)n1 < (unsigned)p.res_bricks[1] &&
                                 (unsigned)n2 < (unsigned)p.res_bricks[2];
-      const bool next_list = next_in_grid && (p.cells[nidx] & 1u) != 0;
+      const unsigned next = next_in_grid ? p.cells[nidx] : 0u;
+      const bool next_list = (next & 1u) != 0;
       const bool prev_list = prev_in_grid && last_list;
       // most cells of a near super-cell are not listed themselves: one test keeps them out of the face logic
       if (cur_list || prev_list) {
         if (!(first && !(t0 > 0.0f))) {
           const float z = peel_z(p, o, d, tcur);
           if (z >= 0.0f && z <= 1.0f) {
-            if (cur_list && !peel_gt10_id(p, pidx, nb)) {
+            if (cur_list && !(prev_known ? prev_gt10 : peel_gt10_id(p, pidx, nb))) {
               r = fminf(r, z);
               gneg = fminf(gneg, -z);
             }
-            if (prev_list && !peel_gt10_id(p, idx, nb)) {
+            if (prev_list && !cur_gt10) {
               r = fminf(r, z);
               gneg = fminf(gneg, -z);
               b = fminf(b, z);
@@ -626,6 +631,9 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       if (leaving) break;
       prev_in_grid = true;
       last_list = cur_list;
+      prev_gt10 = cur_gt10;
+      prev_known = true;
+      cur_gt10 = (next & 4u) != 0;
       pidx = idx;
       idx = nidx;
       cell[0] = n0;
@@ -657,7 +665,7 @@ void launch_depth_peels(const PeelParams& p, hipStream_t s)
   // RGBDR_PEEL_ALLNEAR=1 (diagnostic, profiles/pmc_peels.sh): every super-cell counts as near, i.e. the plain walk
   static const int all_near = std::getenv("RGBDR_PEEL_ALLNEAR") ? 1 : 0;
   const int ns = p.res_super[0] * p.res_super[1] * p.res_super[2];
-  hipLaunchKernelGGL(k_peel_near, dim3((unsigned)ns), dim3(64), 0, s, p.mask, p.res_bricks[0], p.res_bricks[1],
+  hipLaunchKernelGGL(k_peel_near, dim3((unsigned)ns), dim3(64), 0, s, p.mask, p.counters, p.res_bricks[0], p.res_bricks[1],
                      p.res_bricks[2], p.res_super[0], p.res_super[1], p.res_super[2], p.cells, all_near);
   dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
   hipLaunchKernelGGL(k_depth_peels, grid, dim3(16, 16), 0, s, p);
