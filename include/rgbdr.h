@@ -210,7 +210,7 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv
  * (-1,-1,-1,-1), else the inverse-distance-weighted index of the 8 nearest cv_xyz
  * samples, (index + 0.5) / dims, 1.  The k-d tree search is replaced by a local
  * search on the warped sample grid: a (2*window+1)^3 candidate window (window <= 0
- * selects the default 3) that is accepted only with a certificate that no sample
+ * selects the default 2) that is accepted only with a certificate that no sample
  * outside it can be among the 8 nearest, widened (up to radius 8) until it has one, and
  * replaced by a scan of the whole volume for a voxel that never gets one -- the result
  * equals the exact search for every voxel (kernels_invert.hip states the argument and

@@ -30,7 +30,7 @@ sub = {
     "REFDEF": "%.3f | %.3f" % (j["reference_defaults"]["ms_per_frame"], j["reference_defaults"]["ms_per_frame_moving"]),
     "MAPPED": "%.3f" % hf["ms_per_step_mapped_buffer"], "PAGEABLE": "%.3f" % hf["ms_per_step_pageable_upload"],
     "MARCH": "%.2f" % pp["raymarch_ms"], "MARCHSKIP": "%.3f" % pp["raymarch_skip_space_ms"], "PEELS": "%.3f" % pp["brickdraw_ms"],
-    "FILL": "%.2f" % pp["holefill_ms"],
+    "FILL": "%.2f" % pp["holefill_ms"], "VIEWSKIP": "%.3f" % (pp["raymarch_skip_space_ms"] + pp["brickdraw_ms"]),
     "INV": "%.0f" % j["inverse_lut"]["inverse_lut_generate_ms"], "INVG": "%.2f" % j["inverse_lut"]["Gvoxels_per_s"],
 }
 text = open(os.path.join(root, "README.md.in")).read()

@@ -1,6 +1,6 @@
 """Developer probe: time of the on-device inverse-LUT generation at benchmark scale."""
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from __graft_entry__ import load_package
 load_package()
 from rgbd_recon_amd import capi, synth

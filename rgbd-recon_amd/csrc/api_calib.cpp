@@ -418,7 +418,9 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
   p->Y = vol_res[1];
   p->TX = (vol_res[0] + kTile - 1) / kTile;
   p->TY = (vol_res[1] + kTile - 1) / kTile;
-  p->window = window < 1 ? 3 : window;  // R = 3 certifies all but ~1e-5 of the voxels at once (R = 2: 12 % are widened)
+  // R = 2 certifies 88 % of the voxels at once and leaves 12 % to k_invert_retry (68 ms per sensor at 512^3); R = 3 certifies
+  // all but 1e-5 but scans 343 instead of 125 samples for everyone (87 ms)
+  p->window = window < 1 ? 2 : window;
   p->sensor = sensor;
   p->N = ctx->cfg.num_sensors;
 }
@@ -431,8 +433,9 @@ static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
   const int z_begin = p.z0, z_end = p.z0 + p.nz;
   const int piece = 64;
   const size_t row = (size_t)p.X * p.Y;
-  const size_t head = 6;  // [2] list length (+pad), [4] two 64-bit counters
-  const size_t words = head + row * (size_t)std::min(piece, p.nz);
+  const size_t head = 6;  // [2] the two lists' lengths, [4] two 64-bit counters
+  const size_t per_piece = row * (size_t)std::min(piece, p.nz);
+  const size_t words = head + 3 * per_piece;  // exhaustive list: a word per voxel; retry list: two
   DevScratch aux;
   HIPCHK(hipMalloc(&aux.p, words * sizeof(unsigned)));
   unsigned* base = aux.as<unsigned>();
@@ -442,6 +445,8 @@ static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
   HIPCHK(hipMemsetAsync(base, 0, head * sizeof(unsigned), ctx->stream));
   p.todo = todo;
   p.todo_count = count;
+  p.retry = todo + per_piece;
+  p.retry_count = count + 1;
   p.stats = stats;
   float* tiled = p.out_tiled;
   float4* linear = p.out_linear;
@@ -451,9 +456,11 @@ static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
     const size_t done_tiles = (size_t)((z - z_begin) / kTile) * p.TX * p.TY;
     p.out_tiled = tiled ? tiled + done_tiles * (size_t)p.N * 3 * kTileVoxels : nullptr;
     p.out_linear = linear ? linear + row * (size_t)(z - z_begin) : nullptr;
-    HIPCHK(hipMemsetAsync(count, 0, sizeof(unsigned), ctx->stream));
+    HIPCHK(hipMemsetAsync(count, 0, 2 * sizeof(unsigned), ctx->stream));
     launch_invert_lut(p, ctx->stream);
     LAUNCHCHK("invert_lut");
+    launch_invert_retry(p, ctx->stream);
+    LAUNCHCHK("invert_retry");
     launch_invert_exhaustive(p, ctx->stream);
     LAUNCHCHK("invert_exhaustive");
   }

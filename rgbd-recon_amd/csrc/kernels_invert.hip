@@ -84,6 +84,20 @@ __device__ __forceinline__ void weigh(const InvertParams& p, const Best8& b, flo
   d = (wz / tw + 0.5f) / (float)p.rz;
 }
 
+__device__ __forceinline__ void write_record(const InvertParams& p, int vx, int vy, int lz, unsigned v, float u, float w, float d)
+{
+  if (p.out_tiled) {
+    const int tile = ((lz / kTile) * p.TY + vy / kTile) * p.TX + vx / kTile;
+    const int local = ((lz % kTile) * kTile + vy % kTile) * kTile + vx % kTile;
+    float* o = p.out_tiled + ((size_t)tile * p.N + p.sensor) * 3 * kTileVoxels + local;
+    o[0] = u;
+    o[kTileVoxels] = w;
+    o[2 * kTileVoxels] = d;
+  } else {
+    p.out_linear[v] = make_float4(u, w, d, 1.0f);
+  }
+}
+
 __device__ __forceinline__ void insert8(Best8& b, float d2, int lin)
 {
   if (!nn_less(d2, lin, b.d[7], b.i[7])) return;
@@ -111,6 +125,24 @@ __device__ __forceinline__ void unit_normal(const float* a, const float* b, cons
   n[2] = sgn * cz / len;
 }
 
+// the lattice's unit normals at sample (cx, cy, cz): of the faces of constant x (pointing towards +x), y, z -- cross products of
+// the two in-face index directions (central differences, one-sided at the border)
+__device__ __forceinline__ void lattice_normals(const InvertParams& p, int cx, int cy, int cz, float* nx, float* ny, float* nz)
+{
+  const float4 xa = p.xyz[((size_t)cz * p.ry + cy) * p.rx + max(cx - 1, 0)], xb = p.xyz[((size_t)cz * p.ry + cy) * p.rx + min(cx + 1, p.rx - 1)];
+  const float4 ya = p.xyz[((size_t)cz * p.ry + max(cy - 1, 0)) * p.rx + cx], yb = p.xyz[((size_t)cz * p.ry + min(cy + 1, p.ry - 1)) * p.rx + cx];
+  const float4 za = p.xyz[((size_t)max(cz - 1, 0) * p.ry + cy) * p.rx + cx], zb = p.xyz[((size_t)min(cz + 1, p.rz - 1) * p.ry + cy) * p.rx + cx];
+  const float ex[3] = {xb.x - xa.x, xb.y - xa.y, xb.z - xa.z};
+  const float ey[3] = {yb.x - ya.x, yb.y - ya.y, yb.z - ya.z};
+  const float ez[3] = {zb.x - za.x, zb.y - za.y, zb.z - za.z};
+  unit_normal(ey, ez, ex, nx);
+  unit_normal(ez, ex, ey, ny);
+  unit_normal(ex, ey, ez, nz);
+}
+
+// R0: the radius of the first window as a compile-time constant (1, 2, 3: its loops unroll and the loads of a row of
+// samples are in flight together) or 0 = take p.window at run time
+template <int R0>
 __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
 {
   __shared__ float s_d[128];
@@ -154,6 +186,8 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
   const int seed_x = seed / ryz, seed_y = (seed / p.rz) % p.ry, seed_z = seed % p.rz;
 
   float ou[4], ov[4], od[4], ow[4];
+  int cx = seed_x, cy = seed_y, cz = seed_z;
+  bool warm = false;  // (cx, cy, cz) is the nearest sample of the lane's previous voxel, 1 / X of the box away
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     const int vx = vx0 + j;
@@ -163,10 +197,15 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
     const float py = p.start[1] + (float)vy * p.step[1];
     const float pz = p.start[2] + (float)vz * p.step[2];
     if (!inside_frustum(p, px, py, pz)) continue;
-    // ---- downhill walk to the nearest sample
-    int cx = seed_x, cy = seed_y, cz = seed_z;
+    // ---- downhill walk to the nearest sample: from the tile's seed with strides 4, 2, 1, or from the neighbouring voxel's
+    // result with stride 1 (wherever it ends, the certificate below decides whether the window is accepted)
+    if (!warm) {
+      cx = seed_x;
+      cy = seed_y;
+      cz = seed_z;
+    }
     float cd = sample_d2(p, cx, cy, cz, px, py, pz);
-    for (int stride = 4; stride >= 1; stride >>= 1) {
+    for (int stride = warm ? 1 : 4; stride >= 1; stride >>= 1) {
       for (int iter = 0; iter < 256; ++iter) {
         int bx = cx, by = cy, bz = cz;
         float bd = cd;
@@ -190,12 +229,142 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
         cd = bd;
       }
     }
-    // ---- 8 nearest of the index window, kept sorted by (d2, sample index); widened until certified
+    warm = true;
+    const int wcx = cx, wcy = cy, wcz = cz;  // where the walk ended (the next voxel starts here, whatever happens below)
+    // ---- 8 nearest of the index window, kept sorted by (d2, sample index)
+    Best8 b;
+    const int R = R0 > 0 ? R0 : p.window;
+    bool certified = false;
+    {
+      // The FIRST window: the same (2R+1)^3 offsets for every lane of the wavefront, so the loops are scalar loops, the
+      // "is this sample on face f" tests are wave-uniform, and only the outward distances of the faces an offset lies on are
+      // computed.  Offsets that fall outside the volume are skipped (that IS the clipped window of the general case below).
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        b.d[k] = __builtin_inff();
+        b.i[k] = 0x7fffffff;
+      }
+      const bool fx0 = cx - R > 0, fx1 = cx + R < p.rx - 1, fy0 = cy - R > 0, fy1 = cy + R < p.ry - 1, fz0 = cz - R > 0, fz1 = cz + R < p.rz - 1;
+      const bool any_shell = fx0 || fx1 || fy0 || fy1 || fz0 || fz1;
+      float nx[3] = {0.0f, 0.0f, 0.0f}, ny[3] = {0.0f, 0.0f, 0.0f}, nz[3] = {0.0f, 0.0f, 0.0f};
+      if (any_shell) lattice_normals(p, cx, cy, cz, nx, ny, nz);
+      float plane = __builtin_inff();  // smallest outward distance of a shell sample along its face's normal
+      if (R0 > 0) {
+        // a row of the window at a time: its 2 R + 1 loads are issued together (clamped addresses, so none is conditional),
+        // then the samples that lie inside the volume are looked at
+        constexpr int ROW = R0 > 0 ? 2 * R0 + 1 : 1;
+#pragma unroll 1
+        for (int oz = -R; oz <= R; ++oz) {
+          const int sz = cz + oz;
+          const bool zin = (unsigned)sz < (unsigned)p.rz;
+#pragma unroll 1
+          for (int oy = -R; oy <= R; ++oy) {
+            const int sy = cy + oy;
+            const bool rin = zin && (unsigned)sy < (unsigned)p.ry;
+            const float4* row = p.xyz + ((size_t)min(max(sz, 0), p.rz - 1) * p.ry + min(max(sy, 0), p.ry - 1)) * p.rx;
+            float4 sp[ROW];
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) sp[k] = row[min(max(cx + k - R, 0), p.rx - 1)];
+            // the outward distances of the faces this ROW lies on (wave-uniform tests)
+            const bool on_y = oy == -R || oy == R, on_z = oz == -R || oz == R;
+            const bool use_y = on_y && (oy == -R ? fy0 : fy1), use_z = on_z && (oz == -R ? fz0 : fz1);
+#pragma unroll
+            for (int k = 0; k < ROW; ++k) {
+              const int ox = k - R, sx = cx + ox;
+              if (!rin || (unsigned)sx >= (unsigned)p.rx) continue;
+              const float dx = px - sp[k].x, dy = py - sp[k].y, dz = pz - sp[k].z;
+              const float d2 = dx * dx + dy * dy + dz * dz;
+              if (ox == -R || ox == R) {  // compile-time
+                const float t = nx[0] * dx + nx[1] * dy + nx[2] * dz;  // n . (q - s): the outward distance of a LOW face
+                if (ox == -R ? fx0 : fx1) plane = fminf(plane, ox == -R ? t : -t);
+              }
+              if (on_y) {
+                const float t = ny[0] * dx + ny[1] * dy + ny[2] * dz;
+                if (use_y) plane = fminf(plane, oy == -R ? t : -t);
+              }
+              if (on_z) {
+                const float t = nz[0] * dx + nz[1] * dy + nz[2] * dz;
+                if (use_z) plane = fminf(plane, oz == -R ? t : -t);
+              }
+              insert8(b, d2, (sx * p.ry + sy) * p.rz + sz);
+            }
+          }
+        }
+      } else {
+  #pragma unroll 1
+        for (int oz = -R; oz <= R; ++oz)
+  #pragma unroll 1
+          for (int oy = -R; oy <= R; ++oy)
+  #pragma unroll
+            for (int ox = -R; ox <= R; ++ox) {
+              const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
+              if ((unsigned)sx >= (unsigned)p.rx || (unsigned)sy >= (unsigned)p.ry || (unsigned)sz >= (unsigned)p.rz) continue;
+              const float4 sp = p.xyz[((size_t)sz * p.ry + sy) * p.rx + sx];
+              const float dx = px - sp.x, dy = py - sp.y, dz = pz - sp.z;
+              const float d2 = dx * dx + dy * dy + dz * dz;
+              if (ox == -R || ox == R) {  // wave-uniform
+                const float t = nx[0] * dx + nx[1] * dy + nx[2] * dz;  // n . (q - s): the outward distance of a LOW face
+                if (ox == -R ? fx0 : fx1) plane = fminf(plane, ox == -R ? t : -t);
+              }
+              if (oy == -R || oy == R) {
+                const float t = ny[0] * dx + ny[1] * dy + ny[2] * dz;
+                if (oy == -R ? fy0 : fy1) plane = fminf(plane, oy == -R ? t : -t);
+              }
+              if (oz == -R || oz == R) {
+                const float t = nz[0] * dx + nz[1] * dy + nz[2] * dz;
+                if (oz == -R ? fz0 : fz1) plane = fminf(plane, oz == -R ? t : -t);
+              }
+              insert8(b, d2, (sx * p.ry + sy) * p.rz + sz);
+            }
+      }
+      // (rounded against acceptance; a NaN normal -- a degenerate lattice -- compares false: not certified)
+      certified = !any_shell || (plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f);
+    }
+    if (!certified) {  // the general case (re-centring, widening) is k_invert_retry's: a second, rarely needed kernel
+      const unsigned slot = atomicAdd(p.retry_count, 1u);
+      p.retry[2 * slot] = (unsigned)(((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx);
+      p.retry[2 * slot + 1] = (unsigned)((cx * p.ry + cy) * p.rz + cz);
+    }
+    cx = wcx;
+    cy = wcy;
+    cz = wcz;
+    weigh(p, b, ou[j], ov[j], od[j]);  // (provisional where the window was not certified: k_invert_retry overwrites it)
+    ow[j] = 1.0f;
+  }
+  if (p.out_tiled) {
+    float4* o = reinterpret_cast<float4*>(p.out_tiled + ((size_t)tile * p.N + p.sensor) * 3 * kTileVoxels) + q;
+    o[0] = make_float4(ou[0], ou[1], ou[2], ou[3]);
+    o[kTileVoxels / 4] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    o[2 * (kTileVoxels / 4)] = make_float4(od[0], od[1], od[2], od[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int vx = vx0 + j;
+      if (vx >= p.X || vy >= p.Y || vz >= p.z0 + p.nz) continue;
+      p.out_linear[((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx] = make_float4(ou[j], ov[j], od[j], ow[j]);
+    }
+  }
+}
+
+// The voxels whose first window was not certified (k_invert_lut's list: voxel, the sample its walk ended at): the general
+// search -- per-lane window bounds, re-centring on the window's nearest sample, widening up to R = 8 -- one thread per
+// voxel.  What is still uncertified then goes on the list of k_invert_exhaustive.
+__global__ __launch_bounds__(64) void k_invert_retry(InvertParams p)
+{
+  const unsigned count = *p.retry_count;
+  const int ryz = p.ry * p.rz;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+    const unsigned v = p.retry[2 * e], c = p.retry[2 * e + 1];
+    const int vx = (int)(v % (unsigned)p.X), vy = (int)((v / (unsigned)p.X) % (unsigned)p.Y), lz = (int)(v / ((unsigned)p.X * p.Y));
+    const float px = p.start[0] + (float)vx * p.step[0];
+    const float py = p.start[1] + (float)vy * p.step[1];
+    const float pz = p.start[2] + (float)(p.z0 + lz) * p.step[2];
+    int cx = (int)c / ryz, cy = ((int)c / p.rz) % p.ry, cz = (int)c % p.rz;
     Best8 b;
     int R = p.window;
     bool certified = false, recentred = false;
 #pragma unroll 1
-    for (;;) {
+    while (!certified) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         b.d[k] = __builtin_inff();
@@ -208,18 +377,8 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
       const bool fx0 = x0 > 0, fx1 = x1 < p.rx - 1, fy0 = y0 > 0, fy1 = y1 < p.ry - 1, fz0 = z0 > 0, fz1 = z1 < p.rz - 1;
       const bool any_shell = fx0 || fx1 || fy0 || fy1 || fz0 || fz1;
       float nx[3], ny[3], nz[3];
-      if (any_shell) {
-        const float4 xa = p.xyz[((size_t)cz * p.ry + cy) * p.rx + max(cx - 1, 0)], xb = p.xyz[((size_t)cz * p.ry + cy) * p.rx + min(cx + 1, p.rx - 1)];
-        const float4 ya = p.xyz[((size_t)cz * p.ry + max(cy - 1, 0)) * p.rx + cx], yb = p.xyz[((size_t)cz * p.ry + min(cy + 1, p.ry - 1)) * p.rx + cx];
-        const float4 za = p.xyz[((size_t)max(cz - 1, 0) * p.ry + cy) * p.rx + cx], zb = p.xyz[((size_t)min(cz + 1, p.rz - 1) * p.ry + cy) * p.rx + cx];
-        const float ex[3] = {xb.x - xa.x, xb.y - xa.y, xb.z - xa.z};
-        const float ey[3] = {yb.x - ya.x, yb.y - ya.y, yb.z - ya.z};
-        const float ez[3] = {zb.x - za.x, zb.y - za.y, zb.z - za.z};
-        unit_normal(ey, ez, ex, nx);  // normal of the faces of constant x, pointing towards +x
-        unit_normal(ez, ex, ey, ny);
-        unit_normal(ex, ey, ez, nz);
-      }
-      float plane = __builtin_inff();  // smallest outward distance of a shell sample along its face's normal
+      if (any_shell) lattice_normals(p, cx, cy, cz, nx, ny, nz);
+      float plane = __builtin_inff();
       for (int sz = z0; sz <= z1; ++sz)
         for (int sy = y0; sy <= y1; ++sy)
           for (int sx = x0; sx <= x1; ++sx) {
@@ -243,14 +402,13 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
         certified = true;  // the window is the whole volume
         break;
       }
-      // (rounded against acceptance; a NaN normal -- a degenerate lattice -- compares false: not certified)
       if (plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f) {
         certified = true;
         break;
       }
       const int ncx = b.i[0] / ryz, ncy = (b.i[0] / p.rz) % p.ry, ncz = b.i[0] % p.rz;
       if (!recentred && b.i[0] != 0x7fffffff && (ncx != cx || ncy != cy || ncz != cz)) {
-        recentred = true;  // the walk stopped short of the nearest sample: same radius around the better centre
+        recentred = true;
         cx = ncx;
         cy = ncy;
         cz = ncz;
@@ -261,25 +419,13 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
       recentred = false;
     }
     if (R != p.window) atomicAdd(&p.stats[0], 1ull);
-    if (!certified) {  // exhaustive scan of the whole volume, later (k_invert_exhaustive overwrites this record)
+    if (!certified) {
       const unsigned slot = atomicAdd(p.todo_count, 1u);
-      p.todo[slot] = (unsigned)(((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx);
+      p.todo[slot] = v;
     }
-    weigh(p, b, ou[j], ov[j], od[j]);
-    ow[j] = 1.0f;
-  }
-  if (p.out_tiled) {
-    float4* o = reinterpret_cast<float4*>(p.out_tiled + ((size_t)tile * p.N + p.sensor) * 3 * kTileVoxels) + q;
-    o[0] = make_float4(ou[0], ou[1], ou[2], ou[3]);
-    o[kTileVoxels / 4] = make_float4(ov[0], ov[1], ov[2], ov[3]);
-    o[2 * (kTileVoxels / 4)] = make_float4(od[0], od[1], od[2], od[3]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int vx = vx0 + j;
-      if (vx >= p.X || vy >= p.Y || vz >= p.z0 + p.nz) continue;
-      p.out_linear[((size_t)(vz - p.z0) * p.Y + vy) * p.X + vx] = make_float4(ou[j], ov[j], od[j], ow[j]);
-    }
+    float u, w, d;
+    weigh(p, b, u, w, d);
+    write_record(p, vx, vy, lz, v, u, w, d);
   }
 }
 
@@ -327,20 +473,16 @@ __global__ __launch_bounds__(256) void k_invert_exhaustive(InvertParams p)
     if (q == 0) {
       float u, w, d;
       weigh(p, b, u, w, d);
-      if (p.out_tiled) {
-        const int tile = ((lz / kTile) * p.TY + vy / kTile) * p.TX + vx / kTile;
-        const int local = ((lz % kTile) * kTile + vy % kTile) * kTile + vx % kTile;
-        float* o = p.out_tiled + ((size_t)tile * p.N + p.sensor) * 3 * kTileVoxels + local;
-        o[0] = u;
-        o[kTileVoxels] = w;
-        o[2 * kTileVoxels] = d;
-      } else {
-        p.out_linear[v] = make_float4(u, w, d, 1.0f);
-      }
+      write_record(p, vx, vy, lz, v, u, w, d);
       atomicAdd(&p.stats[1], 1ull);
     }
     __syncthreads();
   }
+}
+
+void launch_invert_retry(const InvertParams& p, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_invert_retry, dim3(4096), dim3(64), 0, s, p);
 }
 
 void launch_invert_exhaustive(const InvertParams& p, hipStream_t s)
@@ -351,7 +493,13 @@ void launch_invert_exhaustive(const InvertParams& p, hipStream_t s)
 void launch_invert_lut(const InvertParams& p, hipStream_t s)
 {
   const unsigned tz = (unsigned)((p.nz + kTile - 1) / kTile);
-  hipLaunchKernelGGL(k_invert_lut, dim3((unsigned)p.TX * p.TY * tz), dim3(128), 0, s, p);
+  const dim3 grid((unsigned)p.TX * p.TY * tz);
+  switch (p.window) {
+    case 1: hipLaunchKernelGGL(k_invert_lut<1>, grid, dim3(128), 0, s, p); break;
+    case 2: hipLaunchKernelGGL(k_invert_lut<2>, grid, dim3(128), 0, s, p); break;
+    case 3: hipLaunchKernelGGL(k_invert_lut<3>, grid, dim3(128), 0, s, p); break;
+    default: hipLaunchKernelGGL(k_invert_lut<0>, grid, dim3(128), 0, s, p); break;
+  }
 }
 
 }  // namespace rgbdr

@@ -154,6 +154,8 @@ struct InvertParams {
   int z0, nz;              // z rows [z0, z0 + nz) handled by this launch
   int TX, TY;              // tiles in x, y
   int window;              // index radius R of the first candidate window (widened until certified, kernels_invert.hip)
+  unsigned* retry;         // (voxel, sample the walk ended at) pairs whose first window was not certified: k_invert_retry
+  unsigned* retry_count;
   unsigned* todo;          // voxels (launch-relative linear index) left to k_invert_exhaustive, and their number
   unsigned* todo_count;
   unsigned long long* stats;  // [0] voxels whose window was widened, [1] voxels searched exhaustively
@@ -218,6 +220,7 @@ void launch_fill_colors(const FillLayout& L, const float4* frame_col, const floa
 
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
+void launch_invert_retry(const InvertParams& p, hipStream_t s);
 void launch_invert_exhaustive(const InvertParams& p, hipStream_t s);
 void set_gauss_table(const float* table169);  // uploads the 13x13 spatial kernel to __constant__
 void launch_u8_to_unit(const uint8_t* src, float* dst, size_t n, hipStream_t s);
