@@ -108,6 +108,63 @@ def test_four_sensors_single_gpu(pkg, orc, G):
     assert same_bits(np.concatenate(parts, axis=0), full)
 
 
+@pytest.mark.parametrize("layout", ["dense", "ring"])
+def test_dense_and_moving_frames_at_the_benchmark_size(pkg, orc, layout):
+    """bench.py's `scenes` inputs at BASELINE's size (4 sensors 512 x 424 -> 512^3): the DENSE scene (every pixel valid and
+    inside the box) and MOVING frames (two different frames in a row, then the first again), through the brick sweep, the
+    full sweep, the background skip and store elision -- images, brick table, occupied list against the oracle, TSDF bands
+    against the oracle bit for bit, and the sweeps against each other on the whole volume"""
+    orc.set_threads(16)
+    G = 512
+    scene = pkg.synth.Scene(4, W, H, lut_res=(128, 106, 128), seed=1234, layout=layout)
+    if layout == "dense":
+        assert (scene.depth > 0).all()
+    frames = [scene, scene.at_frame(2), scene]
+    ctx = make_ctx(pkg, scene, (G, G, G))
+    g = ctx.geo
+    occupied = []
+    for k, fr in enumerate(frames):
+        ctx.set_use_bricks(True)
+        ctx.set_skip_background(False)
+        ctx.set_elide_stores(False)
+        ctx.step(fr.depth, fr.color)
+        ref = orc.run_pipeline(fr, BMIN, BMAX, (G, G, G), None, brick_size=g.brick_size, bv=tuple(g.brick_voxels_axis),
+                               res_bricks=tuple(g.res_bricks))
+        for name, which in IMG.items():
+            for i in range(4):
+                got = ctx.readback_image(which, i)
+                assert same_bits(got, ref[name][i]), "frame %d %s sensor %d: %d texels differ" % (k, name, i, count_diff(got, ref[name][i]))
+        assert np.array_equal(ctx.readback_brick_counters(), ref["counters"])
+        ids, ratio = ctx.get_occupied()
+        assert np.array_equal(ids, ref["occupied"])
+        occupied.append(ratio)
+        bricked = ctx.readback_tsdf()
+        ctx.set_use_bricks(False)
+        ctx.integrate()
+        full = ctx.readback_tsdf()
+        mask = np.zeros(g.num_bricks, bool)
+        mask[ids] = True
+        vox = np.repeat(np.repeat(np.repeat(mask.reshape(g.res_bricks[2], g.res_bricks[1], g.res_bricks[0]), 8, 0), 8, 1), 8, 2)
+        assert same_bits(bricked[vox], full[vox]) and np.all(bricked[~vox] == np.float32(-0.01))
+        del bricked, vox
+        touched = 0
+        for z0 in (64, G // 2 - 8, G // 2 + 120, G - 72):
+            r = check_rows(orc, ctx, full[z0:z0 + 8], z0, 8)
+            touched += int((np.abs(r) < np.float32(0.01)).sum())
+        assert touched > 1000
+        for skip, elide in ((True, False), (True, True)):
+            ctx.set_skip_background(skip)
+            ctx.set_elide_stores(elide)
+            ctx.integrate()
+            got = ctx.readback_tsdf()
+            assert same_bits(got, full), "frame %d skip %d elide %d: %d voxels differ" % (k, skip, elide, count_diff(got, full))
+        del full
+    if layout == "dense":
+        assert min(occupied) > 0.05                      # more than twice the bricks of SURVEY 8(d)'s scene
+    assert occupied[0] != occupied[1]                     # the frames differ in what they occupy
+    ctx.close()
+
+
 def test_eight_sensors_slab_of_512(pkg, orc):
     """configs[3]: 8 sensors, 512^3 split into 4 Z slabs -- one rank's slab"""
     orc.set_threads(16)
