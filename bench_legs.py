@@ -9,7 +9,6 @@ mode, the background skip, store elision and the pre_* chain depend on what the 
 the last frame.  Those are therefore reported on three scenes: the static ring scene of SURVEY 8(d) (best case), a
 DENSE scene (every pixel valid and inside the box) and a MOVING sequence (four different frames in rotation).
 """
-import json
 import os
 import sys
 import threading
@@ -57,7 +56,7 @@ def run_all(rig, out, lean=False):
         run_leg(rig, out, "full_sweep_store_elision", lambda: leg_elision(rig))
         run_leg(rig, out, "full_sweep_background_skip", lambda: leg_background_skip(rig))
         run_leg(rig, out, "box", lambda: leg_box(rig), into=out["roofline"])
-        run_leg(rig, out, "scenes", lambda: leg_scenes(rig, out), budget=240.0)
+        run_leg(rig, out, "scenes", lambda: leg_scenes(rig), budget=240.0)
         run_leg(rig, out, "post_pass", lambda: leg_post_pass(rig))
         run_leg(rig, out, "host_fed", lambda: leg_host_fed(rig))
         run_leg(rig, out, "reference_defaults", lambda: leg_reference_defaults(rig))
@@ -345,7 +344,7 @@ def measure_modes(rig, ctx, frames, steps, warmup):
     return res
 
 
-def leg_scenes(rig, out):
+def leg_scenes(rig):
     """The data-dependent numbers on more than their best case: `static` is the headline's scene (two thirds of
     the pixels see nothing, the same frame every step); `moving` rotates four different frames of it (new noise and holes,
     the sphere displaced: occupied bricks, tile states, list sizes and elided stores change every step); `dense` is a
