@@ -153,6 +153,22 @@ def test_plain_command_line_with_two_gpus_spawns_its_own_ranks():
     assert abs(b["voxel_sensor_updates_per_s"] - 8 * b["value"] * 1e6) < 0.01 * b["voxel_sensor_updates_per_s"]
 
 
+def test_two_ranks_started_by_torch_distributed_run():
+    """the driver's other way of starting an N > 1 run: `python -m torch.distributed.run ... bench.py --gpus 2`.  Each process
+    it starts is a SUPERVISOR (never touches the GPU) whose child does the work on a rendezvous of the children's own; rank
+    0's supervisor prints the one line."""
+    port = 29500 + os.getpid() % 400
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--weak"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak" and len(j["per_rank"]["integrate_ms"]) == 2
+    assert j["launch"]["launched_by"] == "torch.distributed.run" and j["launch"]["rung"] == 0 and j["launch"]["line"] == "final"
+
+
 def test_baseline_configs_as_the_headline_of_a_two_gpu_run():
     """--baseline-configs: configs[3] (8 sensors, 512^3 over the ranks) is the headline, the fixed-work twin the extra key"""
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--baseline-configs")
