@@ -268,10 +268,12 @@ def leg_box(rig):
     rig.ctx.sync()
     sampler.start()
     t0 = time.perf_counter()
+    marks = []
     for i in range(steps):
         rig.step(False)
         if i % 64 == 63:
             rig.ctx.sync()                 # keep the queue short: the burst then lasts as long on the host as on the GPU
+            marks.append((i + 1, time.perf_counter()))
     rig.ctx.sync()
     t1 = time.perf_counter()
     sampler.stop_flag = True
@@ -283,7 +285,13 @@ def leg_box(rig):
         v = sorted(s[key] for s in mid if key in s)
         return {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)} if v else None
 
+    # The headline's 20-50 steps start from an idle GPU; under sustained load the package reaches its power limit and the
+    # clock settles lower.  The burst's second half says what a long-running loop gets per step.
+    half = [m for m in marks if m[0] >= steps // 2]
+    sustained = (half[-1][1] - half[0][1]) / (half[-1][0] - half[0][0]) * 1e3 if len(half) >= 2 else None
     res = {"burst_s": round(t1 - t0, 3), "burst_steps": steps, "samples": len(mid), "perf_level": level,
+           "sustained_ms_per_step": round(sustained, 4) if sustained else None,
+           "sustained_vs_headline": round(sustained / rig.ms_per_step, 4) if sustained else None,
            "sysfs": dev, "pci": bdf if bdf else "not matched: the first card with clocks",
            "power_W": stat("power_W"), "mclk_MHz": stat("mclk_MHz")}
     busy = stat("gpu_busy_percent")
@@ -302,6 +310,20 @@ def leg_box(rig):
 
 
 # ---- the data-dependent modes on three scenes ----------------------------------------------------------------------
+def warm_clocks(ctx, step, seconds=0.3):
+    """A leg that prepares its inputs on the CPU for a second or two leaves the GPU idle, its clocks drop, and the first
+    ~25 sweeps afterwards run 3 % longer while they ramp up again (profiles/variance_probe4.py: 1.092 instead of 1.061 ms
+    after 2 s of idle).  So such a leg runs its own step loop untimed for a moment before it times anything."""
+    t_end = time.perf_counter() + seconds
+    k = 0
+    while time.perf_counter() < t_end:
+        step(k)
+        k += 1
+        if k % 32 == 0:
+            ctx.sync()
+    ctx.sync()
+
+
 def measure_modes(rig, ctx, frames, steps, warmup):
     """full sweep, pre_* chain, brick-skipping mode, background skip and store elision of one context fed `frames`
     (a list of (depth, colour) device tensors) in rotation"""
@@ -317,6 +339,8 @@ def measure_modes(rig, ctx, frames, steps, warmup):
         ctx.integrate()
 
     res = {"frames_in_rotation": len(frames)}
+    ctx.set_use_bricks(False)
+    warm_clocks(ctx, step)
     dt, st = rig.timed(False, steps, warmup, step=step, ctx=ctx)
     res["full_sweep"] = {"ms_per_step": round(dt / steps * 1e3, 4), "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4)}
     _, st = rig.timed(False, max(4, len(frames)), 1, detail=1, step=step, ctx=ctx)
@@ -410,6 +434,7 @@ def leg_post_pass(rig):
     ctx.enable_timers(True)
     try:
         view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX)
+        warm_clocks(ctx, lambda k: rig.step(False))
         ctx.raymarch(view)
         _, depth_img, _ = ctx.raymarch(view)
         ctx.fill_colors(1280, 720)
@@ -479,6 +504,7 @@ def leg_host_fed(rig):
         return (time.perf_counter() - t0) / steps * 1e3
 
     depth_h, color_h = np.ascontiguousarray(scene.depth), np.ascontiguousarray(scene.color)
+    warm_clocks(ctx, lambda k: rig.step(False))
     pageable = fed(lambda: ctx.update(depth_h, color_h))
 
     def mapped_fill():                                  # the producer memcpys into the page-locked back buffer
@@ -544,6 +570,11 @@ def leg_reference_defaults(rig):
             rc.sync()
             return (time.perf_counter() - t0) / n * 1e3
 
+        def rs(k):
+            d, b = frames[0]
+            rc.update_device(d.data_ptr(), b.data_ptr())
+            rc.clear_occupied_bricks(); rc.process_textures(); rc.update_occupied_bricks(); rc.integrate()
+        warm_clocks(rc, rs)               # (the DXT encoding above kept the GPU idle for seconds)
         ms = run(1)
         occ = rc.occupied_ratio()
         ms_moving = run(4)
@@ -569,7 +600,8 @@ def leg_inverse_lut(rig):
     try:
         c = capi.Context(capi.make_config(1, (rig.W, rig.H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), rig.local_rank)
         c.set_calibration(0, rig.scene.xyz[0], rig.scene.lut_res, rig.scene.uv[0], rig.scene.lut_res, (0.5, 4.5))
-        c.compute_inverse_calibration(0)
+        for _ in range(3):
+            c.compute_inverse_calibration(0)     # (warm-up: the context above was built with the GPU idle)
         c.sync()
         times = []
         for _ in range(3):
