@@ -21,10 +21,19 @@ ctx.set_timer_detail(2)
 ctx.enable_timers(True)
 view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX)
 import statistics  # noqa: E402
+# busy = 1: twenty frames are queued in front of every draw, as in the frame loop (integrate, then draw) -- the GPU arrives
+# at the view pass with its clocks up; busy = 0: draws back to back with the host's download of the frame in between
+busy = int(os.environ.get("RGBDR_PROBE_BUSY", "1"))
+import torch  # noqa: E402
+dd, dc = torch.from_numpy(scene.depth).cuda(), torch.from_numpy(scene.color).cuda()
+ctx.set_use_bricks(False)
 for skip in (0, 1):
     view.skip_space = skip
     draw, peel = [], []
     for _ in range(25):
+        for _k in range(20 if busy else 0):
+            ctx.update_device(dd.data_ptr(), dc.data_ptr())
+            ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
         ctx.raymarch(view)
         draw.append(ctx.timer_ns("draw") * 1e-6)
         peel.append(ctx.timer_ns("brickdraw") * 1e-6 if skip else 0.0)
