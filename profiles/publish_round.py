@@ -30,6 +30,15 @@ for r in csv.DictReader(open(stats)):
         summary[r["Name"]]["calls"] = int(r["Calls"])
 json.dump(summary, open(f"{prof}/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 shutil.copy(stats, f"{prof}/{tag}_kernel_stats.csv")
+head = sorted(glob.glob(out + "/stats_headline/*/*kernel_stats.csv"), key=os.path.getmtime)
+if head:   # the headline alone (bench.py --no-legs): the integrate kernel's average there is the one to hold against the bench's
+    shutil.copy(head[-1], f"{prof}/{tag}_kernel_stats_headline_only.csv")
+    shutil.copy(out + "/bench_stats_headline.json", f"{prof}/{tag}_bench_headline_only_under_rocprofv3.json")
+    for r in csv.DictReader(open(head[-1])):
+        if r["Name"] in summary and "k_integrate_tiled<" in r["Name"]:
+            summary[r["Name"]]["avg_ns_headline_only"] = float(r["AverageNs"])
+            summary[r["Name"]]["calls_headline_only"] = int(r["Calls"])
+    json.dump(summary, open(f"{prof}/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 shutil.copy(out + "/bench_stats.json", f"{prof}/{tag}_bench_under_rocprofv3.json")
 shutil.copy(os.path.join(root, "gpurun_out", tag + "_bench.json"), f"{prof}/{tag}_bench.json")
 line = json.load(open(f"{prof}/{tag}_bench.json"))
@@ -37,7 +46,8 @@ name = [k for k in summary if line["roofline"]["kernel"] in k][0]
 c = summary[name]
 traffic = {"4x512": {"kernel": name, "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
                      "hbm_bytes_per_launch": int(round(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024)),
-                     "avg_launch_ns_rocprof": c["avg_ns"], "calls": c["calls"],
+                     "avg_launch_ns_rocprof": c.get("avg_ns_headline_only", c["avg_ns"]), "calls": c.get("calls_headline_only", c["calls"]),
+                     "avg_launch_ns_rocprof_all_legs": c["avg_ns"], "calls_all_legs": c["calls"],
                      "correction": "FETCH_SIZE x2 (gfx950 reports half the bytes of 16-B/lane streaming reads, MI355X_MICROARCH.md "
                                    "'HBM'); WRITE_SIZE exact; separate --pmc passes (profiles/collect_pmc.sh)",
                      "source": f"profiles/{tag}_pmc_summary.json"}}
@@ -46,6 +56,10 @@ under = json.load(open(f"{prof}/{tag}_bench_under_rocprofv3.json"))
 print("headline kernel", name)
 print("  bench (HIP events, plain run): %.4f ms; under rocprofv3: events %.4f ms, rocprofv3 average %.4f ms over %d launches"
       % (line["roofline"]["avg_launch_ms"], under["roofline"]["avg_launch_ms"], c["avg_ns"] * 1e-6, c["calls"]))
+if "avg_ns_headline_only" in c:
+    ho = json.load(open(f"{prof}/{tag}_bench_headline_only_under_rocprofv3.json"))
+    print("  headline alone (--no-legs) under rocprofv3: events %.4f ms, rocprofv3 average %.4f ms over %d launches"
+          % (ho["roofline"]["avg_launch_ms"], c["avg_ns_headline_only"] * 1e-6, c["calls_headline_only"]))
 print("  PMC traffic %.3f GB per launch (algorithmic %.3f GB)" % (traffic["4x512"]["hbm_bytes_per_launch"] / 1e9,
                                                                    line["roofline"]["bytes_per_launch"] / 1e9))
 for k, v in sorted(summary.items()):
