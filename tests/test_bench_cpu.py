@@ -209,3 +209,36 @@ def test_file_store_and_watchdog_units(tmp_path, monkeypatch):
             "with wd.phase('slow', 0.5): time.sleep(30)\n") % (ROOT, os.path.join(ROOT, "bench.py"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == b.EXIT_WATCHDOG and "watchdog: phase 'slow'" in r.stderr and "expired slow" in r.stderr
+
+
+def test_leg_isolation_units():
+    """bench_legs.run_leg without a GPU: a leg that throws leaves {"error": ...} under its key and the rig's switches are
+    put back; the legs after it still run; the test hook names a leg to fail"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_legs_mod", os.path.join(ROOT, "bench_legs.py"))
+    legs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(legs)
+    b = load_bench()
+
+    class FakeRig:
+        rank = 0
+
+        def __init__(self):
+            self.restored = 0
+            self.watchdog = b.Watchdog(lambda name, budget: None)
+
+        def restore_defaults(self):
+            self.restored += 1
+
+    rig, out = FakeRig(), {"roofline": {}}
+    legs.run_leg(rig, out, "good", lambda: {"ms": 1.0})
+    legs.run_leg(rig, out, "bad", lambda: 1 / 0)
+    legs.run_leg(rig, out, "box", lambda: {"w": 3}, into=out["roofline"])
+    assert out["good"] == {"ms": 1.0} and out["bad"]["error"].startswith("ZeroDivisionError") and out["roofline"]["box"] == {"w": 3}
+    assert rig.restored == 1
+    os.environ["RGBDR_BENCH_FAIL_LEG"] = "later"
+    try:
+        legs.run_leg(rig, out, "later", lambda: {"never": True})
+    finally:
+        del os.environ["RGBDR_BENCH_FAIL_LEG"]
+    assert out["later"] == {"error": "RuntimeError: RGBDR_BENCH_FAIL_LEG=later"} and rig.restored == 2
