@@ -193,7 +193,7 @@ class Rig:
         self.multi = self.world > 1 or self.loop
         self.out = None                      # the JSON object once the headline exists ...
         self.printed = False                 # ... and whether the line has left the process
-        self.exchanger = self.gather = self.halo = self.transport = self.rccl_info = None
+        self.exchanger = self.gather = self.halo = self.transport = self.rccl_info = self.lag = None
         self.managed = False
         self.watchdog = shared.get("watchdog") or Watchdog(self.expired, tag=" rank %d" % self.rank)
         shared["watchdog"] = self.watchdog
@@ -214,6 +214,9 @@ class Rig:
 
     def step(self, bricks=False):
         ctx = self.ctx
+        if self.lag is not None:             # dist.LaggedChain: chain + gather of this frame, sweep of the one before
+            self.lag.push(self.d_depth.data_ptr(), self.d_color.data_ptr())
+            return
         ctx.update_device(self.d_depth.data_ptr(), self.d_color.data_ptr())
         ctx.clear_occupied_bricks()
         ctx.process_textures()
@@ -356,7 +359,8 @@ def all_ranks_ok(rig, ok):
     if rig.world == 1:
         return bool(ok)
     flag = rig.torch.tensor([1 if ok else 0], dtype=rig.torch.int32)
-    rig.dist.all_reduce(flag, op=rig.dist.ReduceOp.MIN, group=rig.shared["fallback"])
+    # (the gloo side group next to an nccl job; a gloo job's own default group carries host tensors)
+    rig.dist.all_reduce(flag, op=rig.dist.ReduceOp.MIN, group=rig.shared.get("fallback"))
     return bool(int(flag[0]))
 
 
@@ -467,16 +471,21 @@ def trial_step(rig):
 
 
 def choose_chain(rig, steps=12, warmup=3):
-    """Sharded or redundant pre_* chain?  Sharding saves chain time (n / k instead of n sensors per rank) and pays one
-    all-gather of the packed frames + one all-reduce of the brick counters between chain and sweep, on the critical path.
-    Which of the two is shorter depends on the interconnect (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an
-    estimated 45-140 us over xGMI, against 60-70 us of chain time saved), so the run MEASURES both schedules on its own
-    ranks before the headline and keeps the faster one (max over ranks); the line records both times."""
+    """Which schedule for the pre_* chain of an N > 1 run?
+      sharded    rank r runs n / k sensors; one all-gather of the packed frames + one all-reduce of the brick counters sit
+                 between chain and sweep (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an estimated 45-140 us over
+                 xGMI, against 60-70 us of chain time saved);
+      redundant  every rank runs every sensor, no collective;
+      lagged     sharded on a chain-only context one frame AHEAD of the sweep, so the gather of frame k+1 travels under
+                 the sweep of frame k (dist.LaggedChain, rgbdr_import_frame): one chain + one gather + one sweep per step,
+                 like the others, one frame of latency more.
+    Which is shortest depends on the interconnect, so the run MEASURES all three on its own ranks before the headline
+    and keeps the fastest (max over ranks); the line records the three times."""
     if rig.gather is None or not rig.multi:
         return
-    torch, dist, ctx = rig.torch, rig.dist, rig.ctx
-    keep_gather, first, count = rig.gather, ctx.cfg.num_sensors // rig.slab_count * rig.slab_rank, ctx.cfg.num_sensors // rig.slab_count
-
+    torch, dist, ctx, capi, rdist = rig.torch, rig.dist, rig.ctx, rig.capi, rig.rdist
+    n = ctx.cfg.num_sensors
+    keep_gather, first, count = rig.gather, n // rig.slab_count * rig.slab_rank, n // rig.slab_count
     ctx.set_use_bricks(False)                # the headline's sweep
 
     def run():
@@ -489,21 +498,77 @@ def choose_chain(rig, steps=12, warmup=3):
         rig.barrier()
         t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
         if rig.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rig.shared["fallback"] if "fallback" in rig.shared else None)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rig.shared.get("fallback"))
         return float(t[0])
 
-    ms_sharded = run()
+    times = {"sharded": run()}
     ctx.set_sensor_shard(0, 0)
     rig.gather = None
-    ms_redundant = run()
-    keep = ms_sharded <= ms_redundant
-    if os.environ.get("RGBDR_BENCH_CHAIN") in ("sharded", "redundant"):        # pin the choice (tests, A/B runs)
-        keep = os.environ["RGBDR_BENCH_CHAIN"] == "sharded"
-    if keep:
+    times["redundant"] = run()
+    # lagged: a chain-only context (same sensors, box and brick size -> the same brick grid; one voxel per brick)
+    lag = chain = None
+    try:
+        g = rig.geo
+        chain = capi.Context(capi.make_config(n, (rig.W, rig.H), voxel_size=g.brick_size, brick_size=g.brick_size), rig.local_rank)
+        if tuple(chain.geo.res_bricks) != tuple(g.res_bricks) or chain.geo.brick_size != g.brick_size:
+            raise RuntimeError("the chain-only context's brick grid differs")
+        for i in range(n):
+            chain.set_calibration(i, rig.scene.xyz[i], rig.scene.lut_res, rig.scene.uv[i], rig.scene.lut_res, (0.5, 4.5))
+        if rig.loop:                          # (dist.FrameGather loopback: the brick counts of an unsharded frame stand for the other ranks')
+            chain.update_device(rig.d_depth.data_ptr(), rig.d_color.data_ptr())
+            chain.clear_occupied_bricks(); chain.process_textures()
+            chain.sync()
+        lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
+                                       via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
+        lag = rdist.LaggedChain(ctx, chain, rig.dev, lag_gather,
+                                before_sweep=rig.exchanger.begin_step if rig.halo is not None else None,
+                                after_sweep=rig.exchanger.exchange_async if rig.halo is not None else None)
+        rig.lag = lag
+        times["lagged"] = run()
+        lag.flush()
+        rig.barrier()
+    except Exception as e:  # noqa: BLE001 -- a schedule that does not come up is not a candidate
+        sys.stderr.write("[bench rank %d] lagged chain unavailable (%s: %s)\n" % (rig.rank, type(e).__name__, str(e)[:200]))
+        times["lagged"] = None
+    rig.lag = None
+    ok = all_ranks_ok(rig, times["lagged"] is not None)
+    cands = {k: v for k, v in times.items() if v is not None and (k != "lagged" or ok)}
+    kept = min((k for k in cands if k != "lagged"), key=cands.get)
+    if "lagged" in cands and cands["lagged"] < 0.98 * cands[kept]:   # one frame of latency more: only for a gain beyond the noise
+        kept = "lagged"
+    if os.environ.get("RGBDR_BENCH_CHAIN") in cands:        # pin the choice (tests, A/B runs)
+        kept = os.environ["RGBDR_BENCH_CHAIN"]
+    if kept == "sharded":
         ctx.set_sensor_shard(first, count)
         rig.gather = keep_gather
-    rig.chain_choice = {"ms_per_step_sharded": round(ms_sharded, 4), "ms_per_step_redundant": round(ms_redundant, 4),
-                        "kept": "sharded" if keep else "redundant", "steps_each": steps}
+    elif kept == "lagged":
+        rig.lag = lag
+    if kept != "lagged" and chain is not None:
+        chain.close()
+        lag = None
+    # the legs after the headline run on the better of the two plain schedules
+    rig.plain_chain = ("sharded", keep_gather, first, count) if times["sharded"] <= times["redundant"] else ("redundant", None, 0, 0)
+    rig.lag_keep = (lag, chain)
+    rig.chain_choice = {"ms_per_step_sharded": round(times["sharded"], 4), "ms_per_step_redundant": round(times["redundant"], 4),
+                        "ms_per_step_lagged": round(times["lagged"], 4) if times["lagged"] is not None else None,
+                        "kept": kept, "steps_each": steps}
+
+
+def leave_lagged_chain(rig):
+    """after the headline: sweep the frame still pending, close the chain-only context and put the legs on the better of
+    the two plain schedules"""
+    lag, chain = getattr(rig, "lag_keep", (None, None))
+    if rig.lag is None:
+        return
+    rig.lag.flush()
+    rig.barrier()
+    rig.lag = None
+    kind, gather, first, count = rig.plain_chain
+    if kind == "sharded":
+        rig.ctx.set_sensor_shard(first, count)
+        rig.gather = gather
+    if chain is not None:
+        chain.close()
 
 
 def settle(rig):
@@ -588,8 +653,10 @@ def headline_line(rig, dt, stats):
                    "parallelism": ("zslab%d" % world if world > 1 else "single") + (
                        " (loopback: slab %d of %d on one GPU, its own neighbour over RCCL)" % (rig.slab_rank, rig.slab_count) if loop else ""),
                    "halo_transport": rig.transport["kind"] if multi else None,
-                   "pre_chain": ("sharded by sensor: %d of %d sensors per rank, packed frames all-gathered + brick counters all-reduced on "
-                                 "the chain's stream" % (N // rig.slab_count, N)) if rig.gather is not None else "every sensor on every rank",
+                   "pre_chain": ("sharded by sensor on a chain-only context one frame ahead of the sweep: %d of %d sensors per rank, the "
+                                 "gather of frame k+1 under the sweep of frame k (dist.LaggedChain)" % (N // rig.slab_count, N)) if rig.lag is not None
+                   else ("sharded by sensor: %d of %d sensors per rank, packed frames all-gathered + brick counters all-reduced on "
+                         "the chain's stream" % (N // rig.slab_count, N)) if rig.gather is not None else "every sensor on every rank",
                    "pre_chain_choice": getattr(rig, "chain_choice", None),
                    "collectives": (("library-managed RCCL (C ABI: rgbdr_halo_exchange_async, rgbdr_shard_allgather)" if rig.managed
                                     else "torch.distributed") if multi else None),
@@ -644,7 +711,7 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     with wd.phase("settle", 60.0):
         settle(rig)
     if rig.multi and rig.gather is not None:
-        with wd.phase("chain choice", 60.0):
+        with wd.phase("chain choice", 120.0):
             choose_chain(rig)
     with wd.phase("headline", 60.0 + 0.05 * (args.steps + args.warmup)):
         dt, stats = rig.timed(False, args.steps, args.warmup)
@@ -652,6 +719,8 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     with wd.phase("after the headline", 120.0):
         out = headline_line(rig, dt, stats)
     rig.out = out
+    with wd.phase("after the headline", 60.0):
+        leave_lagged_chain(rig)
     if rig.supervised and rig.rank == 0 and not quiet:
         emit(dict(out, provisional=True))     # the supervisor keeps the LAST line: this one only if the legs never end
 

@@ -179,7 +179,8 @@ def leg_slab(rig, out):
             "host_enqueue_ms_per_step": out["host_enqueue_ms_per_step"],
             "roofline_frac": round(rig.achieved / rig.HBM_PEAK, 4), "halo_ms_to_self": rig.halo_ms,
             "frame_gather_ms_to_self": gather.last_ms() if hasattr(gather, "last_ms") else None,
-            "schedule": ("pipelined" if args.pipeline else "sequential") + (", sharded chain" if gather is not None else "") +
+            "schedule": ("pipelined" if args.pipeline else "sequential") + (
+                ", " + rig.chain_choice["kept"] + " chain" if getattr(rig, "chain_choice", None) else (", sharded chain" if gather is not None else "")) +
                         (", library-managed RCCL" if rig.managed else "") + (
                             ", RGBDR_CU_SPLIT=" + os.environ["RGBDR_CU_SPLIT"] if os.environ.get("RGBDR_CU_SPLIT") else "")}
 

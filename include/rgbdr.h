@@ -435,6 +435,16 @@ int rgbdr_set_sensor_shard(rgbdr_ctx* ctx, int first, int count);
 int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out);
 int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm);
 int rgbdr_shard_gather_done(rgbdr_ctx* ctx);
+/* The frame a context sweeps may come from ANOTHER context's pre_* chain: packed frame texels of every sensor
+ * ([num_sensors][H][W] x 8 B) and, optionally, the u32 brick counters ([num_bricks]) in device memory -- what
+ * rgbdr_shard_view of the producing context hands out after its gather.  Enqueued on the chain's stream behind
+ * wait_event (a hipEvent_t, or NULL); afterwards the context is where rgbdr_process_textures would have left it
+ * (rgbdr_update_occupied_bricks / rgbdr_integrate next).  The float images of rgbdr_readback_image are NOT part of
+ * it.  Producer and consumer must agree in sensors, image size, bounding box and brick size (the brick grid); the
+ * producer's voxel size is free.  Use: a chain-only context runs frame k+1 while this one sweeps frame k, so the
+ * all-gather of frame k+1 travels under that sweep (rgbd-recon_amd/dist.py LaggedChain; the reference has no
+ * counterpart: it is single-GPU, kinect_client.cpp:572-602). */
+int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);

@@ -218,6 +218,7 @@ SYMBOLS = {
     "rgbdr_shard_view": (C.c_int, [_P, C.POINTER(ShardDeviceView)]),
     "rgbdr_shard_allgather": (C.c_int, [_P, _P]),
     "rgbdr_shard_gather_done": (C.c_int, [_P]),
+    "rgbdr_import_frame": (C.c_int, [_P, _P, _P, _P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
@@ -645,6 +646,11 @@ class Context:
     def shard_gather_done(self):
         """the host has enqueued its own collectives on shard_view().stream: the frame is complete in stream order"""
         self._chk(lib().rgbdr_shard_gather_done(self._h))
+
+    def import_frame(self, frames_ptr, counters_ptr=None, wait_event=None):
+        """packed frames (and brick counters) of another context's chain, in device memory; wait_event: a hipEvent_t handle"""
+        self._chk(lib().rgbdr_import_frame(self._h, _P(int(frames_ptr)), _P(int(counters_ptr)) if counters_ptr else None,
+                                           _P(int(wait_event)) if wait_event else None))
 
     def shard_allgather(self, nccl_comm):
         self._chk(lib().rgbdr_shard_allgather(self._h, nccl_comm))

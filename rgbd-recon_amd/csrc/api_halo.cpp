@@ -276,6 +276,44 @@ try {
 }
 RGBDR_CONTAIN(ctx)
 
+// The frame a context sweeps need not come from its own pre_* chain: rgbdr_import_frame takes the packed frame texels of
+// every sensor and the brick counters from device memory (another context's rgbdr_shard_view, after its gather) and leaves
+// the context as rgbdr_process_textures would have.  What it is for: a rank whose CHAIN context runs frame k+1 while this
+// context still has frame k to sweep, so that the gather of frame k+1 travels under the sweep of frame k
+// (rgbd-recon_amd/dist.py LaggedChain).
+int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!packed_frames) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->occ_lazy && ctx->occ_lazy_cbuf == ctx->cbuf) {  // the counters a pending filter reads are about to change
+    int rc_ = materialise_mask(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
+  hipStream_t ps = ctx->pstream();
+  const int w = ctx->wbuf;
+  if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  if (wait_event) HIPCHK(hipStreamWaitEvent(ps, (hipEvent_t)wait_event, 0));  // e.g. the end of the source's gather
+  const size_t frame_bytes = (size_t)nsens(ctx) * ctx->cfg.depth_w * ctx->cfg.depth_h * sizeof(uint2);
+  HIPCHK(hipMemcpyAsync(ctx->frame_buf(w), packed_frames, frame_bytes, hipMemcpyDeviceToDevice, ps));
+  if (brick_counters) {
+    // every counter is overwritten: a deferred clearOccupiedBricks has nothing left to do
+    HIPCHK(hipMemcpyAsync(ctx->counters_cur(), brick_counters, (size_t)ctx->geo.num_bricks * sizeof(uint32_t), hipMemcpyDeviceToDevice, ps));
+    ctx->clear_pending = false;
+  }
+  ctx->rbuf = w;
+  if (ctx->pipelined()) {
+    HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
+    ctx->ev_pre_rec[w] = true;
+  }
+  ctx->textures_processed = true;
+  ctx->bgmax_for = -1;
+  ctx->shard_pending = false;
+  ctx->mask_valid = false;  // the occupied filter of the imported counters has not run: rgbdr_update_occupied_bricks
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
 int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;

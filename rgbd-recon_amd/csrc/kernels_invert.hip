@@ -291,11 +291,8 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
           }
         }
       } else {
-  #pragma unroll 1
         for (int oz = -R; oz <= R; ++oz)
-  #pragma unroll 1
           for (int oy = -R; oy <= R; ++oy)
-  #pragma unroll
             for (int ox = -R; ox <= R; ++ox) {
               const int sx = cx + ox, sy = cy + oy, sz = cz + oz;
               if ((unsigned)sx >= (unsigned)p.rx || (unsigned)sy >= (unsigned)p.ry || (unsigned)sz >= (unsigned)p.rz) continue;

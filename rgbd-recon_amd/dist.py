@@ -121,7 +121,8 @@ class FrameGather:
         self.foreign_counts = None
         self.timing = None           # (start, end) events of the last gather on the chain's stream
 
-    def __call__(self):
+    def __call__(self, stream=None):
+        """`stream` (a torch stream): run the collectives there instead of on the chain's stream (LaggedChain)"""
         v = self.ctx.shard_view()
         words = v.sensor_bytes // 4
         n = v.num_sensors
@@ -141,7 +142,7 @@ class FrameGather:
             torch.cuda.synchronize()
             self.ctx.shard_gather_done()
             return
-        st = torch.cuda.ExternalStream(int(v.stream), device=self.device)
+        st = stream if stream is not None else torch.cuda.ExternalStream(int(v.stream), device=self.device)
         with torch.cuda.stream(st):
             t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0.record(st)
@@ -485,6 +486,73 @@ class HaloExchanger:
         """make `stream` (default: the compute stream) wait for the newest halos"""
         if self.k:
             (stream or self.compute).wait_event(self.last)
+
+
+class LaggedChain:
+    """The sensor-sharded pre_* chain with its gather OFF the critical path: the sweep lags the chain by one frame.
+
+    In the plain sharded schedule a rank's frame is  chain(k) -> gather(k) -> sweep(k): the all-gather of the packed frames
+    (3.5 MB per rank at BASELINE configs[3]; ~20 us to the same GPU, an estimated 45-140 us over xGMI) sits between the
+    chain and the sweep.  Here a second, chain-only context (`chain_ctx`: the same sensors, calibration, bounding box and
+    brick size; its own token volume) runs frame k+1 on the SAME stream as -- so before, not under -- the sweep of frame k,
+    its gather runs on a side stream under that sweep, and the sweeping context takes the completed frame with
+    rgbdr_import_frame at the start of the next step:
+
+        main stream :  import(k) | chain(k+1) | sweep(k)          import(k+1) | chain(k+2) | sweep(k+1) ...
+        side stream :                 gather(k+1) ........              gather(k+2) ........
+
+    Only the gather (RCCL's copy kernels) shares the GPU with the sweep; the chain's kernels do not (next to a sweep that
+    refills every wave slot they take 8 x as long: profiles/r04_notes).  The volume after push(frame k+1) is frame k's;
+    flush() sweeps the last frame.  Results are those of the plain schedule, one frame later (tests/test_dist_gpu.py)."""
+
+    def __init__(self, ctx, chain_ctx, device, gather, before_sweep=None, after_sweep=None):
+        self.ctx, self.chain, self.device, self.gather = ctx, chain_ctx, device, gather
+        self.before_sweep, self.after_sweep = before_sweep, after_sweep      # halo hooks: begin_step / exchange_async
+        chain_ctx.set_stream(ctx.stream())
+        self.main = torch.cuda.ExternalStream(int(ctx.stream()), device=device)
+        self.side = torch.cuda.Stream(device)
+        self.ev_chain, self.ev_gather = torch.cuda.Event(), torch.cuda.Event()
+        self.pending = None              # (frames pointer, counters pointer) of the frame whose gather is under way
+
+    def _sweep_pending(self):
+        if self.pending is None:
+            return False
+        frames, counters = self.pending
+        self.ctx.clear_occupied_bricks()
+        self.ctx.import_frame(frames, counters, wait_event=self.ev_gather.cuda_event)
+        return True
+
+    def push(self, depth_ptr, color_ptr):
+        """one step: take over the frame pushed before (its gather has had a whole sweep to finish), run the chain of this
+        one, start its gather on the side stream, sweep the frame taken over"""
+        have = self._sweep_pending()                 # main stream: [wait gather(k)] copy frame k out of the chain context
+        a = self.chain
+        a.update_device(depth_ptr, color_ptr)
+        a.clear_occupied_bricks()
+        a.process_textures()                         # main stream, after the copy above: frame k+1 overwrites frame k there
+        v = a.shard_view()
+        self.ev_chain.record(self.main)
+        self.side.wait_event(self.ev_chain)
+        if self.gather is not None:
+            self.gather(stream=self.side)            # (marks the chain context's frame complete: shard_gather_done)
+        self.ev_gather.record(self.side)
+        self.pending = (int(v.frames), int(v.counters))
+        if have:
+            self._sweep()
+
+    def _sweep(self):
+        self.ctx.update_occupied_bricks()
+        if self.before_sweep:
+            self.before_sweep()
+        self.ctx.integrate()
+        if self.after_sweep:
+            self.after_sweep()
+
+    def flush(self):
+        """sweep the frame pushed last"""
+        if self._sweep_pending():
+            self._sweep()
+            self.pending = None
 
 
 def torch_rccl_info():

@@ -158,7 +158,64 @@ def shard_mode(out_dir, G, backend):
     dist.destroy_process_group()
 
 
+def lag_mode(out_dir, G, backend):
+    """rdist.LaggedChain: a chain-only context runs frame k+1 (sharded by sensor) before the slab context sweeps frame k;
+    the gather of frame k+1 runs on a side stream under that sweep and the slab context takes the completed frame with
+    rgbdr_import_frame.  Three different frames: after the third push the volume is the SECOND frame's, after flush()
+    the third's; both sweeps.  Dumps what shard_mode dumps, plus the volume before the flush."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dev = torch.device("cuda:0")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 4
+    scenes = [synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=s, sphere_r=r) for s, r in ((1, 0.9), (2, 0.6), (3, 0.75))]
+    inv = scenes[0].inverse((G, G, G))
+    ctx = capi.Context(capi.make_config(n, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=rank,
+                                        slab_count=world), 0)
+    # the chain-only context: same sensors, box and brick size (hence the same brick grid), a token volume of one voxel per brick
+    chain = capi.Context(capi.make_config(n, (128, 106), voxel_size=8 * 2.0 / G, brick_size=8 * 2.0 / G), 0)
+    assert tuple(chain.geo.res_bricks) == tuple(ctx.geo.res_bricks)
+    for i in range(n):
+        for c in (ctx, chain):
+            c.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    gather = rdist.FrameGather(chain, dev, rank=rank, world=world, via_host=backend != "nccl") if world > 1 or backend == "nccl" else None
+    lag = rdist.LaggedChain(ctx, chain, dev, gather)
+    frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
+    torch.cuda.synchronize()
+    before = []
+    for k, (d, c) in enumerate(frames):
+        ctx.set_use_bricks(k != 2)            # the sweep of frame k-1 happens in push k: frame 0 bricked, frame 1 full
+        lag.push(d.data_ptr(), c.data_ptr())
+        ctx.sync()
+        before.append(ctx.readback_tsdf() if k > 0 else None)
+    ctx.set_use_bricks(True)
+    lag.flush()
+    ctx.sync()
+    ctx.update_device(frames[2][0].data_ptr(), frames[2][1].data_ptr())     # (the colour frame the shading of the ray-march reads)
+    if world > 1:
+        rdist.exchange_halo_via_host(rdist.halo_views(ctx.device_tsdf(), dev), rank=rank, world=world)
+    torch.cuda.synchronize()
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=0)
+    view.skip_space = 1
+    col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=backend != "nccl")
+    np.savez(os.path.join(out_dir, "shard_r%d.npz" % rank), tsdf=ctx.readback_tsdf(), occupied=ctx.get_occupied()[0],
+             counters=ctx.readback_brick_counters(), color=col.cpu().numpy(), depth=dep.cpu().numpy(),
+             tsdf_after_push_1=before[1], tsdf_after_push_2=before[2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
+    if sys.argv[1] in ("lag", "lag_nccl"):
+        return lag_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "lag_nccl" else "gloo")
     if sys.argv[1] in ("shard", "shard_nccl"):
         return shard_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "shard_nccl" else "gloo")
     if sys.argv[1] == "loopback":

@@ -96,7 +96,7 @@ def test_async_halo_exchanger_over_rccl_loopback(tmp_path):
     assert float(z["ms"]) > 0
 
 
-@pytest.mark.parametrize("world,mode", [(2, "shard"), (4, "shard"), (1, "shard_nccl")])
+@pytest.mark.parametrize("world,mode", [(2, "shard"), (4, "shard"), (1, "shard_nccl"), (2, "lag"), (1, "lag_nccl")])
 def test_sensor_sharded_chain_over_ranks(world, mode, tmp_path, pkg):
     """rgbd_recon_amd.dist.FrameGather: the pre_* chain runs for 4 / world sensors per rank, the packed frames are
     all-gathered and the brick counters all-reduced; the slabs, the occupied bricks and the composited slab ray-march of
@@ -131,4 +131,12 @@ def test_sensor_sharded_chain_over_ranks(world, mode, tmp_path, pkg):
         assert np.array_equal(zz["occupied"], ctx.get_occupied()[0])
         assert same_bits(zz["color"], col) and same_bits(zz["depth"], dep)
     assert (dep < 1).mean() > 0.02
+    if mode.startswith("lag"):
+        # rdist.LaggedChain: the sweep lags the chain by one frame -- after push k the volume is frame k - 1's (bit for bit: the
+        # frame came through rgbdr_import_frame from the chain-only context, its gather ran on a side stream)
+        mid = synth.Scene(n, 128, 106, lut_res=(32, 27, 32), seed=2, sphere_r=0.6)
+        for frame, key, bricks in ((first, "tsdf_after_push_1", True), (mid, "tsdf_after_push_2", False)):
+            ctx.set_use_bricks(bricks)
+            ctx.step(frame.depth, frame.color)
+            assert same_bits(np.concatenate([zz[key] for zz in z], axis=0), ctx.readback_tsdf()), key
     ctx.close()
