@@ -518,11 +518,17 @@ def choose_chain(rig, steps=12, warmup=3):
             chain.update_device(rig.d_depth.data_ptr(), rig.d_color.data_ptr())
             chain.clear_occupied_bricks(); chain.process_textures()
             chain.sync()
-        lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
-                                       via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
+        raw = getattr(rig.exchanger, "comm_gather", None) if rig.managed and not rig.loop else None
+        if raw is not None:                   # the library enqueues the gather itself (rgbdr_shard_allgather_async) on the raw communicator
+            chain.set_sensor_shard(first, count)
+            lag_gather = None
+        else:                                 # torch.distributed's collectives on a side stream, or the one-GPU loopback
+            lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
+                                           via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
         lag = rdist.LaggedChain(ctx, chain, rig.dev, lag_gather,
                                 before_sweep=rig.exchanger.begin_step if rig.halo is not None else None,
-                                after_sweep=rig.exchanger.exchange_async if rig.halo is not None else None)
+                                after_sweep=rig.exchanger.exchange_async if rig.halo is not None else None,
+                                nccl_comm=raw.handle if raw is not None else None)
         rig.lag = lag
         times["lagged"] = run()
         lag.flush()

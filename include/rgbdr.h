@@ -445,6 +445,12 @@ int rgbdr_shard_gather_done(rgbdr_ctx* ctx);
  * all-gather of frame k+1 travels under that sweep (rgbd-recon_amd/dist.py LaggedChain; the reference has no
  * counterpart: it is single-GPU, kinect_client.cpp:572-602). */
 int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event);
+/* The same without a HIP type at the boundary (what a C / C++ host uses, host::LaggedChain): the gather of the producing
+ * context on a stream of that context's own -- behind its chain, with an event behind it that every later call touching
+ * the frame (on either context) waits for --, and the import straight from the producer, in the order of the producer's
+ * chain and of that gather.  Both contexts live on one device and agree in sensors, image size and brick grid. */
+int rgbdr_shard_allgather_async(rgbdr_ctx* ctx, void* nccl_comm);
+int rgbdr_import_frame_from(rgbdr_ctx* ctx, rgbdr_ctx* producer);
 /* device pointer of the packed per-sensor frame the integration kernel samples:
  * H*W 8-byte texels {f32 depth_b.r, f32 quality with (silhouette == 0) in the sign bit} */
 int rgbdr_device_frame(rgbdr_ctx* ctx, int sensor, void** ptr);

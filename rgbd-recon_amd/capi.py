@@ -219,6 +219,8 @@ SYMBOLS = {
     "rgbdr_shard_allgather": (C.c_int, [_P, _P]),
     "rgbdr_shard_gather_done": (C.c_int, [_P]),
     "rgbdr_import_frame": (C.c_int, [_P, _P, _P, _P]),
+    "rgbdr_shard_allgather_async": (C.c_int, [_P, _P]),
+    "rgbdr_import_frame_from": (C.c_int, [_P, _P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
@@ -651,6 +653,12 @@ class Context:
         """packed frames (and brick counters) of another context's chain, in device memory; wait_event: a hipEvent_t handle"""
         self._chk(lib().rgbdr_import_frame(self._h, _P(int(frames_ptr)), _P(int(counters_ptr)) if counters_ptr else None,
                                            _P(int(wait_event)) if wait_event else None))
+
+    def shard_allgather_async(self, nccl_comm):
+        self._chk(lib().rgbdr_shard_allgather_async(self._h, nccl_comm))
+
+    def import_frame_from(self, producer):
+        self._chk(lib().rgbdr_import_frame_from(self._h, producer._h))
 
     def shard_allgather(self, nccl_comm):
         self._chk(lib().rgbdr_shard_allgather(self._h, nccl_comm))

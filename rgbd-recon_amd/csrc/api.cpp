@@ -164,10 +164,18 @@ static int alloc_volume(rgbdr_ctx* ctx)
   return alloc_brick_table(ctx, ctx->cfg, g);
 }
 
+// a gather rgbdr_shard_allgather_async left on the context's gather stream: whatever touches the frame next on `st` waits
+int join_async_gather(rgbdr_ctx* ctx, hipStream_t st)
+{
+  if (ctx->gather_done_rec) HIPCHK(hipStreamWaitEvent(st, ctx->ev_gather_done, 0));
+  return RGBDR_OK;
+}
+
 // drain both streams (readbacks, setters, resizes)
 int sync_all(rgbdr_ctx* ctx)
 {
   HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->gather_stream) HIPCHK(hipStreamSynchronize(ctx->gather_stream));
   if (ctx->copy_stream) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   if (ctx->pre_stream) HIPCHK(hipStreamSynchronize(ctx->pre_stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -438,6 +446,12 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   }
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->gather_stream) {
+    (void)hipStreamSynchronize(ctx->gather_stream);
+    (void)hipStreamDestroy(ctx->gather_stream);
+  }
+  for (hipEvent_t e : {ctx->ev_gather_from, ctx->ev_gather_done, ctx->ev_export})
+    if (e) (void)hipEventDestroy(e);
   if (ctx->halo_stream) {
     (void)hipStreamSynchronize(ctx->halo_stream);
     (void)hipStreamDestroy(ctx->halo_stream);
@@ -722,6 +736,7 @@ try {
   const int w = ctx->wbuf;
   p.frame = ctx->frame_buf(w);
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }  // (an asynchronous gather still writes the frame / the counters)
   tbegin(ctx, "1preprocess", ps);
   // whichever kernel comes first performs a pending clearOccupiedBricks; the morph image of a frame that was
   // uploaded from device memory was written with the upload
@@ -777,6 +792,7 @@ try {
   HIPCHK(hipSetDevice(ctx->device));
   { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   hipStream_t ps = ctx->pstream();
+  { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }
   const int w = ctx->rbuf;  // belongs to the frame process_textures just wrote
   tbegin(ctx, "bricks", ps);
   if (!ctx->pipelined()) {
@@ -930,6 +946,7 @@ try {
     }
   }
   if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+  { int rc_ = join_async_gather(ctx, ctx->stream); if (rc_ != RGBDR_OK) return rc_; }
   tbegin(ctx, "2integrate", ctx->stream);
   if (skip_bg) {
     int rc_ = skip_sweep(ctx, p);

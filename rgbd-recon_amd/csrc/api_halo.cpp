@@ -281,19 +281,18 @@ RGBDR_CONTAIN(ctx)
 // the context as rgbdr_process_textures would have.  What it is for: a rank whose CHAIN context runs frame k+1 while this
 // context still has frame k to sweep, so that the gather of frame k+1 travels under the sweep of frame k
 // (rgbd-recon_amd/dist.py LaggedChain).
-int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event)
-try {
-  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (!packed_frames) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
-  HIPCHK(hipSetDevice(ctx->device));
+static int import_pointers(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, hipEvent_t wait_a, hipEvent_t wait_b)
+{
   if (ctx->occ_lazy && ctx->occ_lazy_cbuf == ctx->cbuf) {  // the counters a pending filter reads are about to change
     int rc_ = materialise_mask(ctx);
     if (rc_ != RGBDR_OK) return rc_;
   }
   hipStream_t ps = ctx->pstream();
+  { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }
   const int w = ctx->wbuf;
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
-  if (wait_event) HIPCHK(hipStreamWaitEvent(ps, (hipEvent_t)wait_event, 0));  // e.g. the end of the source's gather
+  if (wait_a) HIPCHK(hipStreamWaitEvent(ps, wait_a, 0));
+  if (wait_b) HIPCHK(hipStreamWaitEvent(ps, wait_b, 0));
   const size_t frame_bytes = (size_t)nsens(ctx) * ctx->cfg.depth_w * ctx->cfg.depth_h * sizeof(uint2);
   HIPCHK(hipMemcpyAsync(ctx->frame_buf(w), packed_frames, frame_bytes, hipMemcpyDeviceToDevice, ps));
   if (brick_counters) {
@@ -312,17 +311,42 @@ try {
   ctx->mask_valid = false;  // the occupied filter of the imported counters has not run: rgbdr_update_occupied_bricks
   return RGBDR_OK;
 }
-RGBDR_CONTAIN(ctx)
 
-int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
+int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event)
 try {
   if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
-  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather before process_textures");
+  if (!packed_frames) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null frame pointer");
+  HIPCHK(hipSetDevice(ctx->device));
+  return import_pointers(ctx, packed_frames, brick_counters, (hipEvent_t)wait_event, nullptr);
+}
+RGBDR_CONTAIN(ctx)
+
+// ... and straight from the context that produced it: behind its chain (whatever stream that ran on) and behind its
+// asynchronous gather, if one is under way.  No HIP type crosses the boundary: this is the form a C / C++ host uses.
+int rgbdr_import_frame_from(rgbdr_ctx* ctx, rgbdr_ctx* producer)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!producer || producer == ctx) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "the producer is another context");
+  if (!producer->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_import_frame_from: the producer has not processed a frame");
+  if (producer->shard_pending) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_import_frame_from: the producer's sensor shard has not been gathered");
+  if (producer->device != ctx->device || nsens(producer) != nsens(ctx) || producer->cfg.depth_w != ctx->cfg.depth_w ||
+      producer->cfg.depth_h != ctx->cfg.depth_h || producer->geo.num_bricks != ctx->geo.num_bricks ||
+      producer->geo.brick_size != ctx->geo.brick_size)
+    return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "producer and consumer differ in device, sensors, image size or brick grid");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!producer->ev_export) HIPCHK(hipEventCreateWithFlags(&producer->ev_export, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(producer->ev_export, producer->pstream()));  // the producer's chain, in its own stream's order
+  return import_pointers(ctx, producer->frame_buf(producer->rbuf), producer->counters_cur(), producer->ev_export,
+                         producer->gather_done_rec ? producer->ev_gather_done : nullptr);
+}
+RGBDR_CONTAIN(ctx)
+
+// the two collectives of the sharded chain on `st`
+static int gather_on(rgbdr_ctx* ctx, void* nccl_comm, hipStream_t st, const char* who)
+{
   Rccl& r = rccl();
   if (!r.lib || !r.all_gather || !r.all_reduce || !r.comm_count || !r.comm_rank)
     return ctx->fail(RGBDR_ERR_STATE, r.lib ? "the RCCL library lacks ncclAllGather / ncclAllReduce / ncclCommCount" : r.why);
-  HIPCHK(hipSetDevice(ctx->device));
   const int N = nsens(ctx);
   const int first = ctx->shard_count > 0 ? ctx->shard_first : 0, count = ctx->shard_count > 0 ? ctx->shard_count : N;
   auto chk = [&](int rc, const char* what) {
@@ -333,8 +357,7 @@ try {
   if (chk(r.comm_count(nccl_comm, &world), "ncclCommCount") || chk(r.comm_rank(nccl_comm, &rank), "ncclCommUserRank")) return RGBDR_ERR_HIP;
   // ncclAllGather puts rank r's block at r * count: the shards must be equal and in rank order
   if (count * world != N || first != rank * count)
-    return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather: rank r of a k-rank communicator must hold sensors [r n / k, (r + 1) n / k)");
-  hipStream_t st = ctx->pstream();
+    return ctx->fail(RGBDR_ERR_STATE, std::string(who) + ": rank r of a k-rank communicator must hold sensors [r n / k, (r + 1) n / k)");
   uint2* frames = ctx->frame_buf(ctx->rbuf);
   const size_t words = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * 2 * (size_t)count;  // u32 words of one shard
   tbegin(ctx, "gather", st);
@@ -344,7 +367,44 @@ try {
                         "ncclAllReduce");
   const int rc_end = chk(r.group_end(), "ncclGroupEnd");
   tend(ctx, "gather", st);
-  if (rc != 0 || rc_end != 0) return rc != 0 ? rc : rc_end;
+  return rc != 0 ? rc : rc_end;
+}
+
+int rgbdr_shard_allgather(rgbdr_ctx* ctx, void* nccl_comm)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather before process_textures");
+  HIPCHK(hipSetDevice(ctx->device));
+  { int rc_ = join_async_gather(ctx, ctx->pstream()); if (rc_ != RGBDR_OK) return rc_; }
+  const int rc = gather_on(ctx, nccl_comm, ctx->pstream(), "rgbdr_shard_allgather");
+  if (rc != RGBDR_OK) return rc;
+  ctx->shard_pending = false;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
+// The same collectives OFF the stream the chain ran on: behind an event recorded there, on a stream of the context's own,
+// with an event behind them that the consumer of the completed frame waits for -- rgbdr_import_frame_from of the context
+// that sweeps it (dist.LaggedChain / host::LaggedChain: the gather of frame k+1 under the sweep of frame k), or whatever
+// this context is asked to do with the frame next (every entry point that touches it joins the gather first).
+int rgbdr_shard_allgather_async(rgbdr_ctx* ctx, void* nccl_comm)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!nccl_comm) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null communicator");
+  if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather_async before process_textures");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->gather_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->gather_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_gather_from, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_gather_done, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(ctx->ev_gather_from, ctx->pstream()));
+  HIPCHK(hipStreamWaitEvent(ctx->gather_stream, ctx->ev_gather_from, 0));
+  const int rc = gather_on(ctx, nccl_comm, ctx->gather_stream, "rgbdr_shard_allgather_async");
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->ev_gather_done, ctx->gather_stream));
+  ctx->gather_done_rec = true;
   ctx->shard_pending = false;
   return RGBDR_OK;
 }

@@ -155,6 +155,11 @@ struct rgbdr_ctx {
   float* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int stage_target = -1;            // set the next integrate fills (-1: none)
   // managed halo exchange (api_halo.cpp): side stream, per staging set "staged" / "transfer done" events
+  // rgbdr_shard_allgather_async: the gather on a stream of its own, behind the chain (ev_gather_from) and in front of whoever
+  // reads the completed frame (ev_gather_done: rgbdr_import_frame_from of another context, or this context's next call)
+  hipStream_t gather_stream = nullptr;
+  hipEvent_t ev_gather_from = nullptr, ev_gather_done = nullptr, ev_export = nullptr;
+  bool gather_done_rec = false;
   hipStream_t halo_stream = nullptr;
   hipEvent_t ev_halo_staged[2] = {nullptr, nullptr}, ev_halo_done[2] = {nullptr, nullptr};
   bool halo_done_rec[2] = {false, false};
@@ -228,6 +233,7 @@ inline size_t npx(const rgbdr_ctx* c) { return (size_t)c->cfg.num_sensors * c->c
 // api.cpp
 int bump_clear_epoch(rgbdr_ctx* ctx);   // invalidates every recorded "this tile already holds -limit"
 int sync_all(rgbdr_ctx* ctx);           // drain both streams
+int join_async_gather(rgbdr_ctx* ctx, hipStream_t st);  // `st` waits for a gather rgbdr_shard_allgather_async left under way
 int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks

@@ -505,8 +505,11 @@ class LaggedChain:
     refills every wave slot they take 8 x as long: profiles/r04_notes).  The volume after push(frame k+1) is frame k's;
     flush() sweeps the last frame.  Results are those of the plain schedule, one frame later (tests/test_dist_gpu.py)."""
 
-    def __init__(self, ctx, chain_ctx, device, gather, before_sweep=None, after_sweep=None):
-        self.ctx, self.chain, self.device, self.gather = ctx, chain_ctx, device, gather
+    def __init__(self, ctx, chain_ctx, device, gather, before_sweep=None, after_sweep=None, nccl_comm=None):
+        """gather: a FrameGather of `chain_ctx` (torch.distributed collectives, or the one-GPU loopback), or None with
+        `nccl_comm`: a raw ncclComm_t -- then the LIBRARY enqueues the gather on the chain context's own stream and takes the
+        frame over itself (rgbdr_shard_allgather_async / rgbdr_import_frame_from: what host::LaggedChain does in C++)"""
+        self.ctx, self.chain, self.device, self.gather, self.comm = ctx, chain_ctx, device, gather, nccl_comm
         self.before_sweep, self.after_sweep = before_sweep, after_sweep      # halo hooks: begin_step / exchange_async
         chain_ctx.set_stream(ctx.stream())
         self.main = torch.cuda.ExternalStream(int(ctx.stream()), device=device)
@@ -519,7 +522,10 @@ class LaggedChain:
             return False
         frames, counters = self.pending
         self.ctx.clear_occupied_bricks()
-        self.ctx.import_frame(frames, counters, wait_event=self.ev_gather.cuda_event)
+        if self.comm is not None:
+            self.ctx.import_frame_from(self.chain)       # waits for the chain and for its asynchronous gather
+        else:
+            self.ctx.import_frame(frames, counters, wait_event=self.ev_gather.cuda_event)
         return True
 
     def push(self, depth_ptr, color_ptr):
@@ -531,11 +537,14 @@ class LaggedChain:
         a.clear_occupied_bricks()
         a.process_textures()                         # main stream, after the copy above: frame k+1 overwrites frame k there
         v = a.shard_view()
-        self.ev_chain.record(self.main)
-        self.side.wait_event(self.ev_chain)
-        if self.gather is not None:
-            self.gather(stream=self.side)            # (marks the chain context's frame complete: shard_gather_done)
-        self.ev_gather.record(self.side)
+        if self.comm is not None:
+            a.shard_allgather_async(self.comm)       # the library's gather stream, behind the chain
+        else:
+            self.ev_chain.record(self.main)
+            self.side.wait_event(self.ev_chain)
+            if self.gather is not None:
+                self.gather(stream=self.side)        # (marks the chain context's frame complete: shard_gather_done)
+            self.ev_gather.record(self.side)
         self.pending = (int(v.frames), int(v.counters))
         if have:
             self._sweep()

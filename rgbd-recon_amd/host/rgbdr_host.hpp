@@ -836,6 +836,66 @@ class FrameGather {
   void* m_comm;
 };
 
+// The sharded chain with its gather off the critical path: the sweep lags the chain by one frame.  A second, CHAIN-ONLY
+// backend (same calibration files and bounding box, brick size = the sweeping backend's, voxel size = its brick size: one
+// voxel per brick) runs NetKinectArray::processTextures for frame k+1 on the sweeping backend's stream -- hence before, not
+// under, the sweep of frame k --, its gather (rgbdr_shard_allgather_async) travels on a stream of its own under that sweep,
+// and the sweeping backend takes the completed frame with rgbdr_import_frame_from at the start of the next step:
+//     stream   :  import(k) | chain(k+1) | sweep(k)        import(k+1) | chain(k+2) | sweep(k+1) ...
+//     gather   :                 gather(k+1) ......               gather(k+2) ......
+// (rgbd-recon_amd/dist.py LaggedChain is the same in Python; no counterpart in the single-GPU reference.)  After push() of
+// frame k+1 the volume is frame k's; flush() sweeps the last frame.  Give it a communicator of its OWN.
+class LaggedChain {
+ public:
+  LaggedChain(Backend& sweep, Backend& chain, void* nccl_comm, int rank, int world) : m_sweep(sweep), m_chain(chain), m_comm(nccl_comm)
+  {
+    const int n = (int)chain.num();
+    if (world < 1 || n % world) throw std::invalid_argument("the sensors do not split evenly over the ranks");
+    check(chain.ctx(), rgbdr_set_stream(chain.ctx(), rgbdr_stream(sweep.ctx())));
+    check(chain.ctx(), rgbdr_set_sensor_shard(chain.ctx(), rank * (n / world), n / world));
+  }
+  // `chain_nka` (a NetKinectArray of the chain backend) holds the frame just uploaded; `recon` sweeps on the other backend;
+  // `halo` (may be null) is stepped around the sweep
+  template <class NKA, class Recon, class Halo>
+  void push(NKA& chain_nka, Recon& recon, Halo* halo)
+  {
+    const bool have = takeOver(recon);
+    check(m_chain.ctx(), rgbdr_clear_occupied_bricks(m_chain.ctx()));
+    chain_nka.processTextures();
+    check(m_chain.ctx(), rgbdr_shard_allgather_async(m_chain.ctx(), m_comm));
+    m_pending = true;
+    if (have) sweep(recon, halo);
+  }
+  template <class Recon, class Halo>
+  void flush(Recon& recon, Halo* halo)
+  {
+    if (takeOver(recon)) sweep(recon, halo);
+    m_pending = false;
+  }
+
+ private:
+  template <class Recon>
+  bool takeOver(Recon& recon)
+  {
+    if (!m_pending) return false;
+    recon.clearOccupiedBricks();
+    check(m_sweep.ctx(), rgbdr_import_frame_from(m_sweep.ctx(), m_chain.ctx()));
+    return true;
+  }
+  template <class Recon, class Halo>
+  void sweep(Recon& recon, Halo* halo)
+  {
+    recon.updateOccupiedBricks();
+    if (halo) halo->beginStep();
+    recon.integrate();
+    if (halo) halo->exchangeAsync();
+  }
+  Backend& m_sweep;
+  Backend& m_chain;
+  void* m_comm;
+  bool m_pending = false;
+};
+
 // process_textures() of source/kinect_client.cpp:572-580
 inline void process_textures(NetKinectArray& nka, ReconIntegration& recon, FrameGather* shard = nullptr)
 {

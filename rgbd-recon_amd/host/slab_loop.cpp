@@ -7,6 +7,8 @@
 //   slab_loop <dir> <num_sensors> <W> <H> <G> <frames> <out.bin> --loopback
 //       one GPU: this process is slab 1 of 4 (an inner slab) and both of its neighbours (RCCL
 //       accepts a send / recv pair to the own rank) -- tests/test_host_cpp.py
+//   ... --lag   (either form) the sharded chain runs one frame AHEAD of the sweep on a chain-only backend, its gather under
+//       the sweep (host::LaggedChain: rgbdr_shard_allgather_async + rgbdr_import_frame_from)
 //   slab_loop <dir> <num_sensors> <W> <H> <G> <frames> <out.bin> --rank r --world n --id <file>
 //       n processes (GPUs 0..n-1 of one node): rank 0 writes the ncclUniqueId to <file>
 // <dir> as for frame_loop (s<i>.yml / .cv_xyz / .cv_uv / .cv_xyz_inv, recordings/s<i>.stream with
@@ -42,12 +44,13 @@ int main(int argc, char** argv)
   try {
     const std::string dir = std::string(argv[1]) + "/";
     const int n = std::atoi(argv[2]), G = std::atoi(argv[5]), frames = std::atoi(argv[6]);
-    bool loopback = false;
+    bool loopback = false, lag = false;
     int rank = 0, world = 1;
     std::string id_file;
     for (int i = 8; i < argc; ++i) {
       const std::string a = argv[i];
       if (a == "--loopback") loopback = true;
+      else if (a == "--lag") lag = true;
       else if (a == "--rank" && i + 1 < argc) rank = std::atoi(argv[++i]);
       else if (a == "--world" && i + 1 < argc) world = std::atoi(argv[++i]);
       else if (a == "--id" && i + 1 < argc) id_file = argv[++i];
@@ -107,16 +110,34 @@ int main(int argc, char** argv)
     // packed frames are all-gathered); with --loopback the communicator has one rank, which holds every sensor: the
     // collectives still run (all-gather and all-reduce of one rank) and must leave the frame as it is
     std::unique_ptr<FrameGather> shard;
-    if (sharded) shard.reset(new FrameGather(be, comm_gather, loopback ? 0 : rank, gather_world));
+    // --lag: a chain-only backend with the same brick grid (one voxel per brick) and its own NetKinectArray
+    std::unique_ptr<Backend> be_chain;
+    std::unique_ptr<CalibVolumes> cv_chain;
+    std::unique_ptr<NetKinectArray> nka_chain;
+    std::unique_ptr<LaggedChain> lagged;
+    if (lag && sharded) {
+      be_chain.reset(new Backend(cf, bbox, 0.01f, 8.0f * voxel, 8.0f * voxel, device));
+      cv_chain.reset(new CalibVolumes(*be_chain, cf.filenames));
+      nka_chain.reset(new NetKinectArray(&cf, cv_chain.get()));
+      lagged.reset(new LaggedChain(be, *be_chain, comm_gather, loopback ? 0 : rank, gather_world));
+    } else if (sharded) {
+      shard.reset(new FrameGather(be, comm_gather, loopback ? 0 : rank, gather_world));
+    }
     check(be.ctx(), rgbdr_enable_timers(be.ctx(), 1));
     const size_t colorsize = (size_t)cf.widthC * cf.heightC * 3, depthsize = (size_t)cf.width * cf.height * 4;
     for (int k = 0; k < frames; ++k) {  // no host synchronisation between frames
+      if (lagged) {
+        nka_chain->readFromFiles(streams, colorsize, depthsize, (size_t)k);
+        lagged->push(*nka_chain, recon, &halo);  // the chain of frame k, the sweep of frame k - 1
+        continue;
+      }
       nka.readFromFiles(streams, colorsize, depthsize, (size_t)k);
       process_textures(nka, recon, shard.get());
       halo.beginStep();
       recon.integrate();
       halo.exchangeAsync();
     }
+    if (lagged) lagged->flush(recon, &halo);
     halo.wait();
     check(be.ctx(), rgbdr_sync(be.ctx()));
     rgbdr_geometry g;

@@ -111,7 +111,8 @@ def run(pkg, orc, seed, slab, trace):
         lambda: L.rgbdr_halo_begin_step(h), lambda: L.rgbdr_halo_exchange_async(h, None, 0, 0), lambda: L.rgbdr_halo_wait(h),
         lambda: L.rgbdr_set_sensor_shard(h, int(rng.integers(-1, 3)), int(rng.integers(-1, 4))),
         lambda: L.rgbdr_shard_view(h, C.byref(capi.ShardDeviceView())), lambda: L.rgbdr_shard_view(h, None),
-        lambda: L.rgbdr_shard_allgather(h, None), lambda: L.rgbdr_shard_gather_done(h), lambda: L.rgbdr_import_frame(h, None, None, None),
+        lambda: L.rgbdr_shard_allgather(h, None), lambda: L.rgbdr_shard_gather_done(h), lambda: L.rgbdr_import_frame(h, None, None, None), lambda: L.rgbdr_import_frame_from(h, None), lambda: L.rgbdr_import_frame_from(h, h),
+        lambda: L.rgbdr_shard_allgather_async(h, None),
         lambda: L.rgbdr_settle(h, 0.01, C.byref(f1)), lambda: L.rgbdr_settle(h, float("nan"), None),
         lambda: L.rgbdr_get_arena_probe(h, F(big), C.byref(i1), C.byref(i2)), lambda: L.rgbdr_get_arena_probe(h, None, None, None),
         lambda: L.rgbdr_set_stream(h, None),

@@ -169,7 +169,7 @@ def lag_mode(out_dir, G, backend):
     from rgbd_recon_amd import dist as rdist
 
     dev = torch.device("cuda:0")
-    if backend == "nccl":
+    if backend in ("nccl", "raw"):
         torch.cuda.set_device(dev)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -186,8 +186,14 @@ def lag_mode(out_dir, G, backend):
         for c in (ctx, chain):
             c.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
         ctx.set_inverse_calibration(i, inv[i], (G, G, G))
-    gather = rdist.FrameGather(chain, dev, rank=rank, world=world, via_host=backend != "nccl") if world > 1 or backend == "nccl" else None
-    lag = rdist.LaggedChain(ctx, chain, dev, gather)
+    raw = None
+    if backend == "raw":       # the library enqueues the gather itself on a raw communicator (the C ABI's managed form)
+        raw = rdist.RcclComm(rank, world, None, dev)
+        chain.set_sensor_shard(rank * (n // world), n // world)
+        lag = rdist.LaggedChain(ctx, chain, dev, None, nccl_comm=raw.handle)
+    else:
+        gather = rdist.FrameGather(chain, dev, rank=rank, world=world, via_host=backend != "nccl") if world > 1 or backend == "nccl" else None
+        lag = rdist.LaggedChain(ctx, chain, dev, gather)
     frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
     torch.cuda.synchronize()
     before = []
@@ -205,17 +211,20 @@ def lag_mode(out_dir, G, backend):
     torch.cuda.synchronize()
     view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX, shade_mode=0)
     view.skip_space = 1
-    col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=backend != "nccl")
+    col, dep, ns = rdist.raymarch_slabs(ctx, view, dev, via_host=backend == "gloo")
     np.savez(os.path.join(out_dir, "shard_r%d.npz" % rank), tsdf=ctx.readback_tsdf(), occupied=ctx.get_occupied()[0],
              counters=ctx.readback_brick_counters(), color=col.cpu().numpy(), depth=dep.cpu().numpy(),
              tsdf_after_push_1=before[1], tsdf_after_push_2=before[2])
+    if raw is not None:
+        ctx.sync(); chain.sync()
+        raw.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
 def main():
-    if sys.argv[1] in ("lag", "lag_nccl"):
-        return lag_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "lag_nccl" else "gloo")
+    if sys.argv[1] in ("lag", "lag_nccl", "lag_raw"):
+        return lag_mode(sys.argv[2], int(sys.argv[3]), {"lag": "gloo", "lag_nccl": "nccl", "lag_raw": "raw"}[sys.argv[1]])
     if sys.argv[1] in ("shard", "shard_nccl"):
         return shard_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "shard_nccl" else "gloo")
     if sys.argv[1] == "loopback":

@@ -282,10 +282,12 @@ def test_slab_loop_is_built_against_rccl_and_the_c_abi():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [2, 1])
-def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path, n):
+@pytest.mark.parametrize("n,lag", [(2, False), (1, False), (2, True)])
+def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path, n, lag):
     """n = 2: the pre_* chain goes through host::FrameGather on a communicator of its own; n = 1: a single sensor cannot be
-    sharded, the loop runs the whole chain and creates no gather (it used to throw there).
+    sharded, the loop runs the whole chain and creates no gather (ADVICE r4: it used to throw there); lag: host::LaggedChain --
+    a chain-only backend one frame ahead, rgbdr_shard_allgather_async on its own stream, rgbdr_import_frame_from, flush at the
+    end -- must leave the same faces.
     The C++ host's multi-GPU frame loop (host/slab_loop.cpp: host::HaloExchanger over
     rgbdr_halo_begin_step / _exchange_async / _wait, RCCL bound at run time by the library) as an
     inner Z slab whose two neighbours are the process itself: four different frames with no host
@@ -306,7 +308,7 @@ def test_cpp_halo_exchanger_over_rccl_loopback(pkg, orc, tmp_path, n):
                 f.write(scenes[k].color[i].tobytes())
                 f.write(scenes[k].depth[i].tobytes())
     out = os.path.join(d, "halo.bin")
-    r = subprocess.run([SLAB_EXE, d, str(n), str(W), str(H), str(G), str(frames), out, "--loopback"], capture_output=True,
+    r = subprocess.run([SLAB_EXE, d, str(n), str(W), str(H), str(G), str(frames), out, "--loopback"] + (["--lag"] if lag else []), capture_output=True,
                        text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     raw = np.fromfile(out, dtype=np.uint8)
