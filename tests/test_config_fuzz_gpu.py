@@ -49,7 +49,9 @@ def test_random_configuration(pkg, orc, seed):
     ctx = capi.Context(cfg, 0)
     g = ctx.geo
     res = tuple(g.res_volume)                              # (ceil(extent / voxel_size) in float: may be one more than G)
-    scene = synth.Scene(n, W, H, lut_res=lut_res, seed=seed, color_wh=color_wh, sphere_r=float(rng.choice([0.5, 0.7, 0.9])))
+    sphere_r = float(rng.choice([0.5, 0.7, 0.9]))
+    layout = "dense" if seed % 3 == 0 else "ring"          # every third configuration: every pixel valid and inside the box
+    scene = synth.Scene(n, W, H, lut_res=lut_res, seed=seed, color_wh=color_wh, sphere_r=sphere_r, layout=layout)
     inv_res = res if rng.integers(0, 3) else tuple(int(v) for v in rng.integers(8, 50, 3))
     inv = scene.inverse(inv_res)
     for i in range(n):
