@@ -528,7 +528,8 @@ def choose_chain(rig, steps=12, warmup=3):
         lag = rdist.LaggedChain(ctx, chain, rig.dev, lag_gather,
                                 before_sweep=rig.exchanger.begin_step if rig.halo is not None else None,
                                 after_sweep=rig.exchanger.exchange_async if rig.halo is not None else None,
-                                nccl_comm=raw.handle if raw is not None else None)
+                                nccl_comm=raw.handle if raw is not None else None,
+                                sweep_launches=int(os.environ.get("RGBDR_BENCH_LAG_LAUNCHES", "2")))
         rig.lag = lag
         times["lagged"] = run()
         lag.flush()
@@ -537,6 +538,7 @@ def choose_chain(rig, steps=12, warmup=3):
         sys.stderr.write("[bench rank %d] lagged chain unavailable (%s: %s)\n" % (rig.rank, type(e).__name__, str(e)[:200]))
         times["lagged"] = None
     rig.lag = None
+    ctx.set_sweep_launches(1)
     ok = all_ranks_ok(rig, times["lagged"] is not None)
     cands = {k: v for k, v in times.items() if v is not None and (k != "lagged" or ok)}
     kept = min((k for k in cands if k != "lagged"), key=cands.get)
@@ -549,6 +551,7 @@ def choose_chain(rig, steps=12, warmup=3):
         rig.gather = keep_gather
     elif kept == "lagged":
         rig.lag = lag
+        ctx.set_sweep_launches(lag.sweep_launches)
     if kept != "lagged" and chain is not None:
         chain.close()
         lag = None
@@ -566,7 +569,7 @@ def leave_lagged_chain(rig):
     lag, chain = getattr(rig, "lag_keep", (None, None))
     if rig.lag is None:
         return
-    rig.lag.flush()
+    rig.lag.close()
     rig.barrier()
     rig.lag = None
     kind, gather, first, count = rig.plain_chain

@@ -275,6 +275,11 @@ int rgbdr_set_use_bricks(rgbdr_ctx* ctx, int active);
 int rgbdr_set_pipelined(rgbdr_ctx* ctx, int on);           /* RGBDR_FLAG_PIPELINE at run time; drains both streams */
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on);        /* RGBDR_FLAG_ELIDE_STORES at run time */
 int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on);     /* RGBDR_FLAG_SKIP_BACKGROUND at run time */
+/* Issue the full sweep of rgbdr_integrate as n launches over consecutive tile ranges (default 1; the brick, listed-tile and
+ * generic sweeps ignore it).  Same stores, same order within a range; between two launches the queue drains, which is when
+ * a kernel waiting on ANOTHER queue -- the collective of a lagged frame gather -- gets onto the device: next to a single
+ * launch that refills every wave slot as it frees, such a kernel sits until the sweep ends (profiles/r05_notes). */
+int rgbdr_set_sweep_launches(rgbdr_ctx* ctx, int n);
 /* (tile, sensor) pairs of the owned slab whose LUT planes a RGBDR_FLAG_SKIP_BACKGROUND sweep of the frame
  * processed last leaves unread, and the number of pairs (diagnostic: the byte accounting of such a sweep). */
 int rgbdr_skipped_pairs(rgbdr_ctx* ctx, uint64_t* skipped, uint64_t* total);

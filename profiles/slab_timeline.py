@@ -16,7 +16,8 @@ want = sys.argv[2] if len(sys.argv) > 2 else "true>"     # the staging variant <
 sweeps = [i for i, e in enumerate(ev) if "k_integrate_tiled<" in e[3] and e[3].rstrip().endswith(want)]
 if len(sweeps) < 8:
     sweeps = [i for i, e in enumerate(ev) if "k_integrate_tiled<" in e[3]]
-sel = sweeps[10:14] if len(sweeps) > 14 else sweeps[-4:]
+# argv[3] = "last": four of the last sweeps (the timed steps of a run whose first dozens of steps try other schedules)
+sel = sweeps[-7:-3] if (len(sys.argv) > 3 and sys.argv[3] == "last" and len(sweeps) > 8) else (sweeps[10:14] if len(sweeps) > 14 else sweeps[-4:])
 t0 = ev[sel[0]][0]
 for s, e, k, n, q, st in ev[sel[0] - 8:sel[-1] + 1]:
     print("%10.1f %10.1f %8.1f us  %s %-56s q%s s%s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, k, n, q, st))

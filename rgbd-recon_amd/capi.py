@@ -182,6 +182,7 @@ SYMBOLS = {
     "rgbdr_set_pipelined": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_elide_stores": (C.c_int, [_P, C.c_int]),
     "rgbdr_set_skip_background": (C.c_int, [_P, C.c_int]),
+    "rgbdr_set_sweep_launches": (C.c_int, [_P, C.c_int]),
     "rgbdr_skipped_pairs": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rgbdr_readback_skip_tables": (C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     "rgbdr_set_min_voxels_per_brick": (C.c_int, [_P, C.c_uint32]),
@@ -477,6 +478,10 @@ class Context:
     def set_elide_stores(self, on):
         self._chk(lib().rgbdr_set_elide_stores(self._h, int(on)))
         self._flag(FLAG_ELIDE_STORES, on)
+
+    def set_sweep_launches(self, n):
+        """the full sweep as n launches (a kernel waiting on another queue gets onto the device between two)"""
+        self._chk(lib().rgbdr_set_sweep_launches(self._h, int(n)))
 
     def set_skip_background(self, on):
         self._chk(lib().rgbdr_set_skip_background(self._h, int(on)))

@@ -921,6 +921,7 @@ try {
   p.tile_state = ctx->d_tile_state;
   const bool elide = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_ELIDE_STORES) != 0;
   p.elide_stores = elide ? 1 : 0;
+  p.launches = (unsigned)ctx->sweep_launches;
   const bool skip_bg = !bricks && all_tiled && (ctx->cfg.flags & RGBDR_FLAG_SKIP_BACKGROUND) != 0 && p.limit > 0.0f;
   if (bricks && all_tiled) ctx->tile_count_parity ^= 1;
   p.skip_background = skip_bg ? 1 : 0;
@@ -1067,6 +1068,14 @@ try {
 RGBDR_CONTAIN(ctx)
 int rgbdr_set_elide_stores(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_ELIDE_STORES, on); }
 int rgbdr_set_skip_background(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_SKIP_BACKGROUND, on); }
+int rgbdr_set_sweep_launches(rgbdr_ctx* ctx, int n)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (n < 1 || n > 64) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "set_sweep_launches: 1 .. 64");
+  ctx->sweep_launches = n;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
 int rgbdr_filter_textures(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_FILTER, on); }
 int rgbdr_use_processed_depths(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_PROCESSED, on); }
 int rgbdr_refine_boundary(rgbdr_ctx* ctx, int on) { return set_flag(ctx, RGBDR_FLAG_REFINE, on); }

@@ -154,6 +154,7 @@ struct rgbdr_ctx {
   // halo staging for Z slabs: two sets of (lower face, upper face) buffers of `halo` tile layers
   float* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int stage_target = -1;            // set the next integrate fills (-1: none)
+  int sweep_launches = 1;           // rgbdr_set_sweep_launches
   // managed halo exchange (api_halo.cpp): side stream, per staging set "staged" / "transfer done" events
   // rgbdr_shard_allgather_async: the gather on a stream of its own, behind the chain (ev_gather_from) and in front of whoever
   // reads the completed frame (ev_gather_done: rgbdr_import_frame_from of another context, or this context's next call)

@@ -103,9 +103,11 @@ __global__ __launch_bounds__(128) void k_integrate_tiled(IntegrateParams p)
   // project into overlapping frame windows -> hits in that XCD's L2), and the 8
   // XCDs work on 8 adjacent chunks at a time so the concurrent LUT streams stay
   // close together in memory.
-  unsigned tile = blockIdx.x;
+  // (block_base is a multiple of 8: block b of a later launch lands on XCD b & 7 like block b of a single one)
+  const unsigned b = blockIdx.x + p.block_base;
+  unsigned tile = b;
   if (p.order_chunk) {
-    const unsigned xcd = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    const unsigned xcd = b & 7u, idx = b >> 3;
     const unsigned chunk = idx / p.order_chunk, within = idx - chunk * p.order_chunk;
     tile = (chunk * 8u + xcd) * p.order_chunk + within;
   }
@@ -263,6 +265,23 @@ __global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
   *out = make_float4(res[0], res[1], res[2], res[3]);
 }
 
+// The full sweep as p.launches launches over consecutive block ranges (whole rounds of 8 chunks each).  Between two of
+// them the queue drains: the moment a kernel waiting on ANOTHER queue gets its workgroups placed -- next to one launch
+// that refills every wave slot as it frees, RCCL's gather kernel sits until the sweep ends (profiles/r05_notes).
+template <typename Kernel>
+static void launch_in_parts(Kernel kernel, IntegrateParams p, unsigned ntiles, hipStream_t s)
+{
+  const unsigned unit = 8u * (p.order_chunk ? p.order_chunk : 1u), units = ntiles / unit;
+  const unsigned parts = p.launches > 1 ? (p.launches < units ? p.launches : (units ? units : 1u)) : 1u;
+  for (unsigned i = 0; i < parts; ++i) {
+    const unsigned b0 = (unsigned)((uint64_t)units * i / parts) * unit;
+    const unsigned b1 = i + 1 == parts ? ntiles : (unsigned)((uint64_t)units * (i + 1) / parts) * unit;
+    if (b1 == b0) continue;
+    p.block_base = b0;
+    hipLaunchKernelGGL(kernel, dim3(b1 - b0), dim3(128), 0, s, p);
+  }
+}
+
 template <int N>
 static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_t s)
 {
@@ -285,11 +304,11 @@ static void launch_tiled_n(const IntegrateParams& p, unsigned ntiles, hipStream_
   }
 #endif
   if (p.elide_stores)
-    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, true>), dim3(ntiles), dim3(128), 0, s, p);
+    launch_in_parts(k_integrate_tiled<N, 4, true, true>, p, ntiles, s);
   else if (p.stage_lo || p.stage_hi)
-    hipLaunchKernelGGL((k_integrate_tiled<N, 4, true, false, true>), dim3(ntiles), dim3(128), 0, s, p);
+    launch_in_parts(k_integrate_tiled<N, 4, true, false, true>, p, ntiles, s);
   else
-    hipLaunchKernelGGL((k_integrate_tiled<N>), dim3(ntiles), dim3(128), 0, s, p);
+    launch_in_parts(k_integrate_tiled<N>, p, ntiles, s);
 }
 
 // true when launch_integrate's kernel itself fills the halo staging buffers (plain full sweep of a

@@ -131,6 +131,8 @@ struct IntegrateParams {
   int ovx, ovy;            // BrickTables::overflow of x and y (indices past the z end leave the VBO: dropped)
   float* tsdf;             // first owned tile layer
   unsigned order_chunk;    // XCD-aware tile order: tiles per chunk handed to one XCD (0 = identity)
+  unsigned block_base;     // full sweep issued as several launches (rgbdr_set_sweep_launches): first block of this one
+  unsigned launches;       // ... and how many (0 / 1: one)
   unsigned* tile_list;     // brick-skipping sweep: owned tiles that overlap an occupied brick ...
   unsigned* tile_count;    // ... and how many (device memory, rebuilt by every sweep; zero on entry)
   unsigned* tile_count_next;  // the other of the two counters: zeroed by this sweep for the next one

@@ -502,16 +502,23 @@ class LaggedChain:
         side stream :                 gather(k+1) ........              gather(k+2) ........
 
     Only the gather (RCCL's copy kernels) shares the GPU with the sweep; the chain's kernels do not (next to a sweep that
-    refills every wave slot they take 8 x as long: profiles/r04_notes).  The volume after push(frame k+1) is frame k's;
-    flush() sweeps the last frame.  Results are those of the plain schedule, one frame later (tests/test_dist_gpu.py)."""
+    refills every wave slot they take 8 x as long: profiles/r04_notes).  RCCL's kernel does not get onto the device either
+    while ONE sweep launch refills every slot as it frees -- it ran when the sweep ended, the whole gather exposed again
+    (profiles/r05_lag_timeline_lagged.txt) --, so the sweep is issued as `sweep_launches` = 2 launches
+    (rgbdr_set_sweep_launches): the queue drains between them, the collective starts there and ends under the second half
+    (r05_lag_timeline_lagged_split.txt; the drain costs the sweep 8-19 us).  The volume after push(frame k+1) is frame
+    k's; flush() sweeps the last frame; close() puts the sweep back to one launch.  Results are those of the plain
+    schedule, one frame later (tests/test_dist_gpu.py)."""
 
-    def __init__(self, ctx, chain_ctx, device, gather, before_sweep=None, after_sweep=None, nccl_comm=None):
+    def __init__(self, ctx, chain_ctx, device, gather, before_sweep=None, after_sweep=None, nccl_comm=None, sweep_launches=2):
         """gather: a FrameGather of `chain_ctx` (torch.distributed collectives, or the one-GPU loopback), or None with
         `nccl_comm`: a raw ncclComm_t -- then the LIBRARY enqueues the gather on the chain context's own stream and takes the
         frame over itself (rgbdr_shard_allgather_async / rgbdr_import_frame_from: what host::LaggedChain does in C++)"""
         self.ctx, self.chain, self.device, self.gather, self.comm = ctx, chain_ctx, device, gather, nccl_comm
         self.before_sweep, self.after_sweep = before_sweep, after_sweep      # halo hooks: begin_step / exchange_async
         chain_ctx.set_stream(ctx.stream())
+        self.sweep_launches = sweep_launches
+        ctx.set_sweep_launches(sweep_launches)
         self.main = torch.cuda.ExternalStream(int(ctx.stream()), device=device)
         self.side = torch.cuda.Stream(device)
         self.ev_chain, self.ev_gather = torch.cuda.Event(), torch.cuda.Event()
@@ -562,6 +569,11 @@ class LaggedChain:
         if self._sweep_pending():
             self._sweep()
             self.pending = None
+
+    def close(self):
+        """flush, and the sweeping context back to one launch per sweep"""
+        self.flush()
+        self.ctx.set_sweep_launches(1)
 
 
 def torch_rccl_info():

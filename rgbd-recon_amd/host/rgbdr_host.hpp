@@ -853,7 +853,10 @@ class LaggedChain {
     if (world < 1 || n % world) throw std::invalid_argument("the sensors do not split evenly over the ranks");
     check(chain.ctx(), rgbdr_set_stream(chain.ctx(), rgbdr_stream(sweep.ctx())));
     check(chain.ctx(), rgbdr_set_sensor_shard(chain.ctx(), rank * (n / world), n / world));
+    // the sweep in two launches: RCCL's kernel gets onto the device between them (next to ONE launch it sits until the end)
+    check(sweep.ctx(), rgbdr_set_sweep_launches(sweep.ctx(), 2));
   }
+  ~LaggedChain() { rgbdr_set_sweep_launches(m_sweep.ctx(), 1); }
   // `chain_nka` (a NetKinectArray of the chain backend) holds the frame just uploaded; `recon` sweeps on the other backend;
   // `halo` (may be null) is stepped around the sweep
   template <class NKA, class Recon, class Halo>

@@ -1536,6 +1536,46 @@ def test_halo_staging_holds_the_boundary_layers(pkg, rank, count):
     ctx.close()
 
 
+@pytest.mark.parametrize("G,slab", [(64, None), (72, None), (64, (1, 2)), (40, None)])
+def test_full_sweep_in_several_launches(pkg, orc, G, slab):
+    """rgbdr_set_sweep_launches: the full sweep as n launches over consecutive tile ranges stores what one launch stores
+    (the oracle's volume, bit for bit) -- with the XCD-ordered tile mapping (64: the tile count divides into rounds of 8
+    x-rows) and without (72, 40), plain, with store elision, and with the halo staging of a slab filled by the kernel"""
+    import torch
+
+    from rgbd_recon_amd import dist as rdist
+
+    kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
+    scene, ctx, inv = build(pkg, n=3, G=G, tsdf_limit=0.1, **kw)
+    whole = build(pkg, n=3, G=G, tsdf_limit=0.1)[1] if slab else ctx
+    want = oracle_run(orc, scene, whole, inv)["tsdf"]
+    if slab:
+        whole.close()
+    if slab:
+        want = want[ctx.geo.slab_voxel_z0:ctx.geo.slab_voxel_z1]
+        lo, hi, nbytes = ctx.halo_staging(0)
+        stage_lo = rdist.wrap_device_floats(lo, nbytes // 4, torch.device("cuda:0"))     # (rank 1 of 2: the lower face has the neighbour)
+        ctx.set_halo_staging(0)
+    with pytest.raises(pkg.capi.RgbdrError):
+        ctx.set_sweep_launches(0)
+    with pytest.raises(pkg.capi.RgbdrError):
+        ctx.set_sweep_launches(65)
+    for n in (1, 2, 3, 7, 64):
+        for elide in (False, True):
+            ctx.set_sweep_launches(n)
+            ctx.set_elide_stores(elide)
+            for _ in range(2):
+                ctx.step(scene.depth, scene.color)
+            got = ctx.readback_tsdf()
+            assert same_bits(got, want), "%d launches, elide %d: %d voxels differ" % (n, elide, count_diff(got, want))
+            if slab and not elide:
+                send_lo = rdist.halo_views(ctx.device_tsdf(), torch.device("cuda:0"))[0]
+                ctx.sync()
+                assert torch.equal(stage_lo.view(torch.int32), send_lo.view(torch.int32))
+                stage_lo.fill_(7.0)
+    ctx.close()
+
+
 def test_occupied_filter_is_a_snapshot_whoever_evaluates_it(pkg, orc):
     """rgbdr_update_occupied_bricks may leave the filter to its first consumer (the brick sweep folds it into its
     first kernel): the result is that of the moment of the call -- later changes of the threshold or of the
