@@ -28,6 +28,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from bench_chain import all_ranks_ok, choose_chain, leave_lagged_chain, recheck_lagged_headline  # noqa: E402,F401
 from bench_launch import (EXIT_WATCHDOG, RUNG_BUDGETS, RUNGS, FileStore, Watchdog, budget_scale, free_port,  # noqa: E402,F401
                           launch_ranks, supervise_rank)
 
@@ -354,16 +355,6 @@ def torch_exchanger(rig, reset=False):
                                    group=rig.transport["group"], via_host=rig.transport["kind"] != "rccl", ctx=ctx, loopback=rig.loop)
 
 
-def all_ranks_ok(rig, ok):
-    """MIN over the ranks of a 0 / 1 flag, through the gloo side group (every rank takes the same road)"""
-    if rig.world == 1:
-        return bool(ok)
-    flag = rig.torch.tensor([1 if ok else 0], dtype=rig.torch.int32)
-    # (the gloo side group next to an nccl job; a gloo job's own default group carries host tensors)
-    rig.dist.all_reduce(flag, op=rig.dist.ReduceOp.MIN, group=rig.shared.get("fallback"))
-    return bool(int(flag[0]))
-
-
 def open_transport(rig):
     """The stream the exchange is ordered on and one probe of the device transport before anything is timed.  If RCCL
     point-to-point on these buffers fails on this node, say so in the JSON line and stop: a run whose halos go through host
@@ -468,116 +459,6 @@ def trial_step(rig):
             pass
         rig.gather = None
         rig.exchanger = torch_exchanger(rig, reset=True)
-
-
-def choose_chain(rig, steps=12, warmup=3):
-    """Which schedule for the pre_* chain of an N > 1 run?
-      sharded    rank r runs n / k sensors; one all-gather of the packed frames + one all-reduce of the brick counters sit
-                 between chain and sweep (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an estimated 45-140 us over
-                 xGMI, against 60-70 us of chain time saved);
-      redundant  every rank runs every sensor, no collective;
-      lagged     sharded on a chain-only context one frame AHEAD of the sweep, so the gather of frame k+1 travels under
-                 the sweep of frame k (dist.LaggedChain, rgbdr_import_frame): one chain + one gather + one sweep per step,
-                 like the others, one frame of latency more.
-    Which is shortest depends on the interconnect, so the run MEASURES all three on its own ranks before the headline
-    and keeps the fastest (max over ranks); the line records the three times."""
-    if rig.gather is None or not rig.multi:
-        return
-    torch, dist, ctx, capi, rdist = rig.torch, rig.dist, rig.ctx, rig.capi, rig.rdist
-    n = ctx.cfg.num_sensors
-    keep_gather, first, count = rig.gather, n // rig.slab_count * rig.slab_rank, n // rig.slab_count
-    ctx.set_use_bricks(False)                # the headline's sweep
-
-    def run():
-        for _ in range(warmup):
-            rig.step(False)
-        rig.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            rig.step(False)
-        rig.barrier()
-        t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64)
-        if rig.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rig.shared.get("fallback"))
-        return float(t[0])
-
-    times = {"sharded": run()}
-    ctx.set_sensor_shard(0, 0)
-    rig.gather = None
-    times["redundant"] = run()
-    # lagged: a chain-only context (same sensors, box and brick size -> the same brick grid; one voxel per brick)
-    lag = chain = None
-    try:
-        g = rig.geo
-        chain = capi.Context(capi.make_config(n, (rig.W, rig.H), voxel_size=g.brick_size, brick_size=g.brick_size), rig.local_rank)
-        if tuple(chain.geo.res_bricks) != tuple(g.res_bricks) or chain.geo.brick_size != g.brick_size:
-            raise RuntimeError("the chain-only context's brick grid differs")
-        for i in range(n):
-            chain.set_calibration(i, rig.scene.xyz[i], rig.scene.lut_res, rig.scene.uv[i], rig.scene.lut_res, (0.5, 4.5))
-        if rig.loop:                          # (dist.FrameGather loopback: the brick counts of an unsharded frame stand for the other ranks')
-            chain.update_device(rig.d_depth.data_ptr(), rig.d_color.data_ptr())
-            chain.clear_occupied_bricks(); chain.process_textures()
-            chain.sync()
-        raw = getattr(rig.exchanger, "comm_gather", None) if rig.managed and not rig.loop else None
-        if raw is not None:                   # the library enqueues the gather itself (rgbdr_shard_allgather_async) on the raw communicator
-            chain.set_sensor_shard(first, count)
-            lag_gather = None
-        else:                                 # torch.distributed's collectives on a side stream, or the one-GPU loopback
-            lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
-                                           via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
-        lag = rdist.LaggedChain(ctx, chain, rig.dev, lag_gather,
-                                before_sweep=rig.exchanger.begin_step if rig.halo is not None else None,
-                                after_sweep=rig.exchanger.exchange_async if rig.halo is not None else None,
-                                nccl_comm=raw.handle if raw is not None else None,
-                                sweep_launches=int(os.environ.get("RGBDR_BENCH_LAG_LAUNCHES", "2")))
-        rig.lag = lag
-        times["lagged"] = run()
-        lag.flush()
-        rig.barrier()
-    except Exception as e:  # noqa: BLE001 -- a schedule that does not come up is not a candidate
-        sys.stderr.write("[bench rank %d] lagged chain unavailable (%s: %s)\n" % (rig.rank, type(e).__name__, str(e)[:200]))
-        times["lagged"] = None
-    rig.lag = None
-    ctx.set_sweep_launches(1)
-    ok = all_ranks_ok(rig, times["lagged"] is not None)
-    cands = {k: v for k, v in times.items() if v is not None and (k != "lagged" or ok)}
-    kept = min((k for k in cands if k != "lagged"), key=cands.get)
-    if "lagged" in cands and cands["lagged"] < 0.98 * cands[kept]:   # one frame of latency more: only for a gain beyond the noise
-        kept = "lagged"
-    if os.environ.get("RGBDR_BENCH_CHAIN") in cands:        # pin the choice (tests, A/B runs)
-        kept = os.environ["RGBDR_BENCH_CHAIN"]
-    if kept == "sharded":
-        ctx.set_sensor_shard(first, count)
-        rig.gather = keep_gather
-    elif kept == "lagged":
-        rig.lag = lag
-        ctx.set_sweep_launches(lag.sweep_launches)
-    if kept != "lagged" and chain is not None:
-        chain.close()
-        lag = None
-    # the legs after the headline run on the better of the two plain schedules
-    rig.plain_chain = ("sharded", keep_gather, first, count) if times["sharded"] <= times["redundant"] else ("redundant", None, 0, 0)
-    rig.lag_keep = (lag, chain)
-    rig.chain_choice = {"ms_per_step_sharded": round(times["sharded"], 4), "ms_per_step_redundant": round(times["redundant"], 4),
-                        "ms_per_step_lagged": round(times["lagged"], 4) if times["lagged"] is not None else None,
-                        "kept": kept, "steps_each": steps}
-
-
-def leave_lagged_chain(rig):
-    """after the headline: sweep the frame still pending, close the chain-only context and put the legs on the better of
-    the two plain schedules"""
-    lag, chain = getattr(rig, "lag_keep", (None, None))
-    if rig.lag is None:
-        return
-    rig.lag.close()
-    rig.barrier()
-    rig.lag = None
-    kind, gather, first, count = rig.plain_chain
-    if kind == "sharded":
-        rig.ctx.set_sensor_shard(first, count)
-        rig.gather = gather
-    if chain is not None:
-        chain.close()
 
 
 def settle(rig):
@@ -725,6 +606,9 @@ def run_rank(args, slab=None, quiet=False, shared=None):
     with wd.phase("headline", 60.0 + 0.05 * (args.steps + args.warmup)):
         dt, stats = rig.timed(False, args.steps, args.warmup)
         rig.stats = stats
+    if rig.lag is not None:
+        with wd.phase("headline", 120.0 + 0.05 * (args.steps + args.warmup)):
+            dt, stats = recheck_lagged_headline(rig, dt, stats)
     with wd.phase("after the headline", 120.0):
         out = headline_line(rig, dt, stats)
     rig.out = out

@@ -32,11 +32,41 @@ chain.set_stream(ctx.stream())
 staging = os.environ.get("STAGING", "1") == "1"
 if staging:
     ctx.halo_staging(1); ctx.set_halo_staging(1)
+ex = None
+if os.environ.get("EXCH") == "1":        # the halo exchange of the bench (RCCL to this GPU itself, on a side stream)
+    import torch.distributed as tdist
+    from rgbd_recon_amd import dist as rdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    main = torch.cuda.ExternalStream(int(ctx.stream()), device=dev)
+    ex = rdist.HaloExchanger(ctx.device_tsdf(), dev, main, rank=1, world=K, ctx=ctx, loopback=True)
 
 
 def plain():
     ctx.update_device(A[0].data_ptr(), A[1].data_ptr())
-    ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+    ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks()
+    if ex and mode["exchange"]:
+        if mode.get("nowait"):
+            ex.done = [None, None]
+        ex.begin_step()
+    if mode.get("dummy_wait"):
+        e = torch.cuda.Event(); e.record(aux); main.wait_event(e)
+    ctx.integrate()
+    if ex and mode["exchange"]:
+        ex.exchange_async()
+
+
+def split_ex():
+    chain.update_device(A[0].data_ptr(), A[1].data_ptr())
+    chain.clear_occupied_bricks(); chain.process_textures()
+    v = chain.shard_view()
+    ctx.clear_occupied_bricks()
+    ctx.import_frame(int(v.frames), int(v.counters))
+    ctx.update_occupied_bricks()
+    ex.begin_step(); ctx.integrate(); ex.exchange_async()
+
+
+mode = {"exchange": False}
 
 
 def split():
@@ -72,14 +102,25 @@ def run(tag, step, steps=40, warm=10):
     ctx.sync(); torch.cuda.synchronize()
     ns, n = ctx.timer_stats("2integrate")
     ctx.enable_timer_accumulation(False); ctx.enable_timers(False); ctx.set_timer_detail(2)
-    print("%-40s sweep %.4f ms   frame %.4f ms" % (tag, ns / max(n, 1) * 1e-6, t0.elapsed_time(t1) / steps), flush=True)
+    print("%-62s sweep %.4f ms   frame %.4f ms" % (tag, ns / max(n, 1) * 1e-6, t0.elapsed_time(t1) / steps), flush=True)
 
 
 for rep in range(2):
     run("plain", plain)
     run("split", split)
     run("split, lagged order", split_lagged)
-for n in (2, 3, 4, 8, 1):
-    ctx.set_sweep_launches(n)
-    run("plain, sweep in %d launches" % n, plain)
+if ex:
+    aux = torch.cuda.Stream(dev)
+    seq = os.environ.get("SEQ", "off,dummy,nowait,split,on").split(",")
+    for rep in range(2):
+        for what in seq:
+            mode.update(exchange=what in ("on", "nowait"), nowait=what == "nowait", dummy_wait=what == "dummy")
+            torch.cuda.synchronize()
+            run({"off": "plain, exchange off", "dummy": "plain, exchange off, a cross-stream wait before the sweep",
+                 "nowait": "plain + halo exchange without its wait", "split": "split + halo exchange",
+                 "on": "plain + halo exchange"}[what], split_ex if what == "split" else plain)
+else:
+    for n in (2, 3, 4, 8, 1):
+        ctx.set_sweep_launches(n)
+        run("plain, sweep in %d launches" % n, plain)
 ctx.close(); chain.close()

@@ -292,6 +292,54 @@ class RcclComm:
             self.handle = None
 
 
+class RawLoopbackGather:
+    """One GPU standing in for rank `rank` of `world` of a sensor-sharded chain, through a raw one-rank communicator: the
+    traffic of the frame gather is reproduced by RCCL send / recv of the OTHER ranks' frame layers to this process itself
+    (same bytes; the layers hold an unsharded frame of the same static scene, which `ctx` must have processed before this
+    is created), the brick counters are all-reduced in the one-rank communicator and the other ranks' counts added back.
+    Called with a torch stream it enqueues there (dist.LaggedChain's side stream), else on the chain's stream."""
+
+    def __init__(self, ctx, device, rank, world, comm):
+        self.ctx, self.device, self.comm = ctx, device, comm
+        n = ctx.cfg.num_sensors
+        self.count, self.first = n // world, rank * (n // world)
+        v = ctx.shard_view()
+        torch.cuda.synchronize()
+        self.all_counts = wrap_device_words(v.counters, v.num_bricks, device).clone()
+        self.foreign = None
+        self.scratch = torch.empty((v.sensor_bytes // 4) * (n - self.count), dtype=torch.int32, device=device)
+        ctx.set_sensor_shard(self.first, self.count)
+
+    def __call__(self, stream=None):
+        import ctypes as C
+        L, comm = RcclComm.lib(), self.comm.handle
+        v = self.ctx.shard_view()
+        words = v.sensor_bytes // 4
+        sp = int(stream.cuda_stream) if stream is not None else int(v.stream)
+        st = C.c_void_p(sp)
+        lo_words, hi_words = self.first * words, (v.num_sensors - self.first - self.count) * words
+        base = int(v.frames)
+
+        def chk(rc, what):
+            if rc:
+                raise RuntimeError("%s failed with RCCL status %d" % (what, rc))
+        chk(L.ncclGroupStart(), "ncclGroupStart")
+        if lo_words:
+            chk(L.ncclSend(C.c_void_p(base), lo_words, 3, 0, comm, st), "ncclSend")
+            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr()), lo_words, 3, 0, comm, st), "ncclRecv")
+        if hi_words:
+            chk(L.ncclSend(C.c_void_p(base + 4 * (self.first + self.count) * words), hi_words, 3, 0, comm, st), "ncclSend")
+            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr() + 4 * lo_words), hi_words, 3, 0, comm, st), "ncclRecv")
+        chk(L.ncclAllReduce(C.c_void_p(v.counters), C.c_void_p(v.counters), v.num_bricks, 3, 0, comm, st), "ncclAllReduce")
+        chk(L.ncclGroupEnd(), "ncclGroupEnd")
+        with torch.cuda.stream(torch.cuda.ExternalStream(sp, device=self.device)):
+            counters = wrap_device_words(v.counters, v.num_bricks, self.device)
+            if self.foreign is None:
+                self.foreign = self.all_counts - counters
+            counters.add_(self.foreign)
+        self.ctx.shard_gather_done()
+
+
 class ManagedSlabExchange:
     """Per-step communication of one slab rank with everything enqueued by the LIBRARY on its own streams (the C ABI's
     managed forms): the halo exchange on the context's side stream behind events (rgbdr_halo_begin_step /
@@ -312,18 +360,15 @@ class ManagedSlabExchange:
         self.peer_lo = (me if loopback else rank - 1) if rank > 0 else -1
         self.peer_hi = (me if loopback else rank + 1) if rank < world - 1 else -1
         self.shard = None
+        self.loop_gather = None
         n = ctx.cfg.num_sensors
         if shard and n % world == 0 and world > 1:
             self.count, self.first = n // world, rank * (n // world)
-            self.all_counts = None
-            if loopback:
-                v = ctx.shard_view()
-                torch.cuda.synchronize()
-                self.all_counts = wrap_device_words(v.counters, v.num_bricks, device).clone()
-                self.foreign = None
-                self.scratch = torch.empty((v.sensor_bytes // 4) * (n - self.count), dtype=torch.int32, device=device)
             self.comm_gather = RcclComm(0 if loopback else rank, 1 if loopback else world, group, device)
-            ctx.set_sensor_shard(self.first, self.count)
+            if loopback:
+                self.loop_gather = RawLoopbackGather(ctx, device, rank, world, self.comm_gather)
+            else:
+                ctx.set_sensor_shard(self.first, self.count)
             self.shard = True
 
     def begin_step(self):
@@ -338,34 +383,10 @@ class ManagedSlabExchange:
     def gather(self):
         if not self.shard:
             return
-        if not self.loopback:
+        if self.loop_gather is not None:
+            self.loop_gather()
+        else:
             self.ctx.shard_allgather(self.comm_gather.handle)
-            return
-        import ctypes as C
-        L, comm = RcclComm.lib(), self.comm_gather.handle
-        v = self.ctx.shard_view()
-        words = v.sensor_bytes // 4
-        st = C.c_void_p(v.stream)
-        lo_words, hi_words = self.first * words, (v.num_sensors - self.first - self.count) * words
-        base = int(v.frames)
-        def chk(rc, what):
-            if rc:
-                raise RuntimeError("%s failed with RCCL status %d" % (what, rc))
-        chk(L.ncclGroupStart(), "ncclGroupStart")
-        if lo_words:
-            chk(L.ncclSend(C.c_void_p(base), lo_words, 3, 0, comm, st), "ncclSend")
-            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr()), lo_words, 3, 0, comm, st), "ncclRecv")
-        if hi_words:
-            chk(L.ncclSend(C.c_void_p(base + 4 * (self.first + self.count) * words), hi_words, 3, 0, comm, st), "ncclSend")
-            chk(L.ncclRecv(C.c_void_p(self.scratch.data_ptr() + 4 * lo_words), hi_words, 3, 0, comm, st), "ncclRecv")
-        chk(L.ncclAllReduce(C.c_void_p(v.counters), C.c_void_p(v.counters), v.num_bricks, 3, 0, comm, st), "ncclAllReduce")
-        chk(L.ncclGroupEnd(), "ncclGroupEnd")
-        with torch.cuda.stream(torch.cuda.ExternalStream(int(v.stream), device=self.device)):
-            counters = wrap_device_words(v.counters, v.num_bricks, self.device)
-            if self.foreign is None:
-                self.foreign = self.all_counts - counters
-            counters.add_(self.foreign)
-        self.ctx.shard_gather_done()
 
     def last_transfer_ms(self):
         try:

@@ -242,3 +242,40 @@ def test_leg_isolation_units():
     finally:
         del os.environ["RGBDR_BENCH_FAIL_LEG"]
     assert out["later"] == {"error": "RuntimeError: RGBDR_BENCH_FAIL_LEG=later"} and rig.restored == 2
+
+
+def test_a_lagged_headline_far_off_its_trial_is_timed_again_on_the_plain_schedule():
+    """bench_chain.recheck_lagged_headline without a GPU: the K timed steps of the lagged schedule are kept when they agree
+    with its trial (or still beat the plain schedules), otherwise the lagged chain is left and the K steps are timed again"""
+    import types
+    b = load_bench()
+
+    class FakeLag:
+        closed = 0
+
+        def close(self):
+            FakeLag.closed += 1
+
+    class FakeCtx:
+        def set_sensor_shard(self, first, count):
+            self.shard = (first, count)
+
+    def rig_with(choice):
+        r = types.SimpleNamespace(args=types.SimpleNamespace(steps=40, warmup=10), chain_choice=dict(choice), lag=FakeLag(),
+                                  lag_keep=(None, None), plain_chain=("sharded", "the gather", 2, 2), ctx=FakeCtx(), gather=None, timings=[])
+        r.barrier = lambda: None
+        r.timed = lambda bricks, steps, warmup: (r.timings.append((steps, warmup)), (steps * 0.65e-3, {"2integrate": (1, 1)}))[1]
+        return r
+
+    choice = {"ms_per_step_sharded": 0.70, "ms_per_step_redundant": 0.75, "ms_per_step_lagged": 0.67, "kept": "lagged"}
+    r = rig_with(choice)
+    dt, stats = b.recheck_lagged_headline(r, 40 * 0.66e-3, "first")          # as on the trial: kept
+    assert (dt, stats) == (40 * 0.66e-3, "first") and r.lag is not None and r.timings == []
+    r = rig_with(choice)
+    dt, stats = b.recheck_lagged_headline(r, 40 * 0.69e-3, "first")          # 3 % off the trial, below the plain ones: kept
+    assert stats == "first" and r.chain_choice["kept"] == "lagged"
+    r = rig_with(choice)
+    dt, stats = b.recheck_lagged_headline(r, 40 * 1.54e-3, "first")          # a stall: discarded
+    assert r.lag is None and FakeLag.closed == 1 and r.gather == "the gather" and r.ctx.shard == (2, 2)
+    assert r.timings == [(40, 10)] and abs(dt - 40 * 0.65e-3) < 1e-12 and stats == {"2integrate": (1, 1)}
+    assert r.chain_choice["kept"] == "sharded" and r.chain_choice["lagged_headline_discarded_ms_per_step"] == 1.54
