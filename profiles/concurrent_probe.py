@@ -51,6 +51,15 @@ def run(tag, company=None, steps=30, warm=8):
 
 run("alone")
 run("beside torch.cuda._sleep (one workgroup, ~0.4 ms)", lambda: torch.cuda._sleep(800000))
+if os.environ.get("BRICKS") == "1":      # the brick sweep: 2560 persistent blocks instead of one block per tile
+    ctx.set_use_bricks(True)
+    run("brick sweep alone")
+    run("brick sweep beside torch.cuda._sleep", lambda: torch.cuda._sleep(800000))
+    ctx.set_use_bricks(False)
+    ctx.set_skip_background(True)        # listed tiles: one block per listed tile
+    run("background-skip sweep alone")
+    run("background-skip sweep beside torch.cuda._sleep", lambda: torch.cuda._sleep(800000))
+    ctx.set_skip_background(False)
 for k in (1 << 10, 1 << 14, 1 << 18, 1 << 22):
     v = spin[:k]
     def many(v=v):
