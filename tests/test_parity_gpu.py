@@ -1407,6 +1407,7 @@ def run_random_sequence(pkg, orc, seed, slab, dxt=False):
             ctx.set_use_bricks(state["bricks"])
         elif op == 1:
             ctx.set_elide_stores(bool(rng.integers(0, 2)))
+            ctx.set_sweep_launches(int(rng.choice([1, 2, 3, 5])))      # (schedule only: the full sweep as several launches)
         elif op == 2:
             state["limit"] = np.float32(rng.choice([0.01, 0.02, 0.035]))
             ctx.set_tsdf_limit(float(state["limit"]))
