@@ -78,6 +78,7 @@ def run(pkg, orc, seed, slab, trace):
         lambda: L.rgbdr_set_voxel_size(h, float(rng.choice([0.0, -1.0, float("nan"), float("inf"), 1e-9]))),      # (invalid only: keeps the grid)
         lambda: L.rgbdr_set_use_bricks(h, flag()), lambda: L.rgbdr_set_pipelined(h, flag()), lambda: L.rgbdr_set_elide_stores(h, flag()),
         lambda: L.rgbdr_set_skip_background(h, flag()), lambda: L.rgbdr_filter_textures(h, flag()),
+        lambda: L.rgbdr_set_sweep_launches(h, int(rng.choice([1, 2, 7, 64, 0, -3, 65, 2 ** 31 - 1]))),
         lambda: L.rgbdr_use_processed_depths(h, flag()), lambda: L.rgbdr_refine_boundary(h, flag()),
         lambda: L.rgbdr_set_min_voxels_per_brick(h, int(rng.choice([0, 1, 10, 2 ** 32 - 1]))),
         lambda: L.rgbdr_skipped_pairs(h, C.byref(u64), C.byref(u64)), lambda: L.rgbdr_skipped_pairs(h, None, None),
