@@ -106,6 +106,9 @@ def parse_args(argv=None):
                     help="N > 1: every rank runs the pre_* chain for ALL sensors (rounds 1-3) instead of its n / N share followed by "
                          "the all-gather of the packed frames and the all-reduce of the brick counters (rgbdr_set_sensor_shard; "
                          "measured per rank of configs[3]: 0.68 against 0.71-0.73 ms per frame, profiles/r04_notes)")
+    ap.add_argument("--no-lagged", dest="lagged", action="store_false",
+                    help="N > 1: do not try the lagged chain schedule (the fallback rungs of the launch ladder pass this: "
+                         "after a failed rung only the plain schedules are candidates)")
     ap.add_argument("--torch-collectives", dest="managed", action="store_false",
                     help="N > 1 over RCCL: halo exchange and frame gather through torch.distributed's process group (rounds 1-3) "
                          "instead of the C ABI's managed forms, where the LIBRARY enqueues them on its own streams with a raw RCCL "

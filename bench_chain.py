@@ -58,6 +58,8 @@ def choose_chain(rig, steps=40, warmup=8):
     # lagged: a chain-only context (same sensors, box and brick size -> the same brick grid; one voxel per brick)
     lag = chain = None
     try:
+        if not getattr(rig.args, "lagged", True):
+            raise RuntimeError("--no-lagged")
         g = rig.geo
         chain = capi.Context(capi.make_config(n, (rig.W, rig.H), voxel_size=g.brick_size, brick_size=g.brick_size), rig.local_rank)
         if tuple(chain.geo.res_bricks) != tuple(g.res_bricks) or chain.geo.brick_size != g.brick_size:

@@ -16,9 +16,9 @@ BENCH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench.py")
 # below it trade features for paths that have run on more hardware.  Every rung is a FRESH set of child processes.
 RUNGS = (
     ("library-managed RCCL (C ABI) + pre_* chain sharded by sensor", []),
-    ("torch.distributed collectives + pre_* chain sharded by sensor", ["--torch-collectives"]),
+    ("torch.distributed collectives + pre_* chain sharded by sensor", ["--torch-collectives", "--no-lagged"]),
     ("torch.distributed collectives + every sensor's chain on every rank, weak-scaling run only",
-     ["--torch-collectives", "--no-shard", "--weak"]),
+     ["--torch-collectives", "--no-shard", "--no-lagged", "--weak"]),
 )
 RUNG_BUDGETS = (560.0, 420.0, 420.0)     # seconds per rung; sum + slack stays under --launch-timeout (1500) < the driver's 1800
 EXIT_WATCHDOG = 75                       # a child stopped by its own per-phase watchdog

@@ -131,12 +131,12 @@ def test_ladder_first_rung_hangs_second_succeeds(tmp_path):
     rc, line, took, err = run_ladder(["hang", "ok", "ok"], tmp_path)
     assert rc == 0 and line["value"] == 101.0 and line["legs"] == "done" and "provisional" not in line
     la = line["launch"]
-    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives"] and la["line"] == "final" and la["launched_by"] == "bench.py"
+    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives", "--no-lagged"] and la["line"] == "final" and la["launched_by"] == "bench.py"
     assert len(la["failed_attempts"]) == 1 and la["failed_attempts"][0]["rung"] == 0 and "budget" in la["failed_attempts"][0]["outcome"]
     assert took < 40
     seen = {f: json.load(open(os.path.join(str(tmp_path), f))) for f in os.listdir(str(tmp_path))}
     assert set(seen) == {"rung0.rank0", "rung0.rank1", "rung1.rank0", "rung1.rank1"}
-    assert seen["rung1.rank0"]["argv"][-1:] == ["--torch-collectives"] and "--torch-collectives" not in seen["rung0.rank0"]["argv"]
+    assert seen["rung1.rank0"]["argv"][-2:] == ["--torch-collectives", "--no-lagged"] and "--torch-collectives" not in seen["rung0.rank0"]["argv"]
     assert seen["rung0.rank0"]["port"] == seen["rung0.rank1"]["port"] != seen["rung1.rank0"]["port"] == seen["rung1.rank1"]["port"]
 
 
@@ -146,7 +146,7 @@ def test_ladder_under_torch_distributed_run(tmp_path):
     rc, line, took, err = run_ladder(["fail", "hang", "ok"], tmp_path, via_torchrun=True, timeout=180)
     assert rc == 0 and line["value"] == 102.0
     la = line["launch"]
-    assert la["rung"] == 2 and la["rung_flags"] == ["--torch-collectives", "--no-shard", "--weak"] and la["launched_by"] == "torch.distributed.run"
+    assert la["rung"] == 2 and la["rung_flags"] == ["--torch-collectives", "--no-shard", "--no-lagged", "--weak"] and la["launched_by"] == "torch.distributed.run"
     assert [a["rung"] for a in la["failed_attempts"]] == [0, 1]
     assert la["failed_attempts"][0]["child_errors"] == ["stub failure on rung 0"] and la["failed_attempts"][0]["child_status"] == 5
 

@@ -190,7 +190,7 @@ def test_ladder_on_the_gpu_a_hung_first_rung_is_replaced_by_fresh_children():
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--weak", "--rung-budgets", "30,500,500",
                   env={"RGBDR_BENCH_HANG": "0:init", "RGBDR_BENCH_CHAIN": "sharded"})
     la = j["launch"]
-    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives"] and la["line"] == "final"
+    assert la["rung"] == 1 and la["rung_flags"] == ["--torch-collectives", "--no-lagged"] and la["line"] == "final"
     assert len(la["failed_attempts"]) == 1 and la["failed_attempts"][0]["rung"] == 0 and "budget" in la["failed_attempts"][0]["outcome"]
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["collectives"] == "torch.distributed"
     assert j["config"]["pre_chain"].startswith("sharded by sensor")
@@ -200,7 +200,7 @@ def test_ladder_on_the_gpu_a_hung_first_rung_is_replaced_by_fresh_children():
 
 def test_ladder_last_rung_is_the_redundant_chain_and_the_weak_run_only():
     j = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--first-rung", "2")
-    assert j["launch"]["rung"] == 2 and j["launch"]["rung_flags"] == ["--torch-collectives", "--no-shard", "--weak"]
+    assert j["launch"]["rung"] == 2 and j["launch"]["rung_flags"] == ["--torch-collectives", "--no-shard", "--no-lagged", "--weak"]
     assert j["config"]["pre_chain"] == "every sensor on every rank" and j["config"]["collectives"] == "torch.distributed"
     assert j["scaling"] == "weak" and "baseline_configs_run" not in j and j["value"] > 0 and len(j["per_rank"]["integrate_ms"]) == 2
     assert "error" not in j["post_pass"] and "error" not in j["bricked"] and "error" not in j["halo"]
