@@ -590,13 +590,12 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
     long long idx = ((long long)cell[2] * p.res_bricks[1] + cell[1]) * rx + cell[0];
     long long pidx = ((long long)prev[2] * p.res_bricks[1] + prev[1]) * rx + prev[0];
     for (int iter = steps; iter < 4096; ++iter) {
-      int a = 0;
-      if (tmax[1] < tmax[a]) a = 1;
-      if (tmax[2] < tmax[a]) a = 2;
-      const float tnext = tmax[a];
+      // the axis crossed next: the smallest value, the lowest axis on a tie (min3 + two equality tests)
+      const float tnext = fminf(fminf(tmax[0], tmax[1]), tmax[2]);
+      const bool a0 = tmax[0] == tnext, a1 = !a0 && tmax[1] == tnext, a2 = !(a0 || a1);
       const bool leaving = !(tnext < t1);
-      const int n0 = cell[0] + (a == 0 ? stepi[0] : 0), n1 = cell[1] + (a == 1 ? stepi[1] : 0), n2 = cell[2] + (a == 2 ? stepi[2] : 0);
-      const long long nidx = idx + (a == 0 ? stride0 : a == 1 ? stride1 : stride2);
+      const int n0 = cell[0] + (a0 ? stepi[0] : 0), n1 = cell[1] + (a1 ? stepi[1] : 0), n2 = cell[2] + (a2 ? stepi[2] : 0);
+      const long long nidx = idx + (a0 ? stride0 : a1 ? stride1 : stride2);
       const bool next_in_grid = !leaving && (unsigned)n0 < (unsigned)p.res_bricks[0] && (unsigned)n1 < (unsigned)p.res_bricks[1] &&
                                 (unsigned)n2 < (unsigned)p.res_bricks[2];
       const unsigned next = next_in_grid ? p.cells[nidx] : 0u;
@@ -639,9 +638,9 @@ __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
       cell[0] = n0;
       cell[1] = n1;
       cell[2] = n2;
-      tmax[0] = a == 0 ? tmax[0] + tdelta[0] : tmax[0];
-      tmax[1] = a == 1 ? tmax[1] + tdelta[1] : tmax[1];
-      tmax[2] = a == 2 ? tmax[2] + tdelta[2] : tmax[2];
+      tmax[0] = a0 ? tmax[0] + tdelta[0] : tmax[0];
+      tmax[1] = a1 ? tmax[1] + tdelta[1] : tmax[1];
+      tmax[2] = a2 ? tmax[2] + tdelta[2] : tmax[2];
       tcur = tnext;
       if (!next_in_grid) {
         if (last_list && !peel_gt10_id(p, idx, nb)) {
