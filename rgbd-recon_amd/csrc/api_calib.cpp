@@ -110,9 +110,9 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   // RGBDR_ARENA_TRIALS candidate placements (1..16; default 16 for arenas of 1 GiB and more, else 1 = no probing)
   // and the fastest is kept.  Candidates are held while probing (otherwise the next allocation returns the same
   // place), so this transiently needs up to n x the arena; it stops at the first candidate at the fast level,
-  // when less than arena + 4 GiB is free, or after ~1 s.
+  // when less than arena + 4 GiB is free, or after 1 s + 0.12 s per GiB of arena.
   // (3 until round 4: on one box in four none of the first three candidates was fast, on one in six none of the first
-  // eight; the loop stops at the first fast one, when memory runs short, or after 1 s, so the maximum only costs where it pays)
+  // eight; the loop stops at the first fast one, when memory runs short, or when its time is up, so the maximum only costs where it pays)
   int trials = bytes >= ((size_t)1 << 30) ? 16 : 1;
   if (const char* e = std::getenv("RGBDR_ARENA_TRIALS")) trials = std::atoi(e);
   if (trials > 16) trials = 16;
@@ -164,8 +164,11 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     // (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s)
     const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
     if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) break;
+    // time budget: 1 s + 0.12 s per GiB of arena (a candidate costs its hipMalloc, which grows with its size: on one box
+    // three candidates of the 8-sensor arena -- 25.8 GB -- used up a flat 1 s, all three at the slow level)
     clock_gettime(CLOCK_MONOTONIC, &t1);
-    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > 1.0) break;
+    const double budget_s = 1.0 + 0.12 * (double)(bytes >> 30);
+    if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > budget_s) break;
   }
   if (best < 0) best = 0;
   ctx->arena_trials = got;
