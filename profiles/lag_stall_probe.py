@@ -34,6 +34,17 @@ ctx.set_use_bricks(False)
 ex = rdist.ManagedSlabExchange(ctx, dev, 1, K, loopback=True)          # halo faces to this GPU itself
 comm = rdist.RcclComm(0, 1, None, dev)
 chain.update_device(A[0].data_ptr(), A[1].data_ptr()); chain.clear_occupied_bricks(); chain.process_textures(); chain.sync()
+if os.environ.get("PLAIN_FIRST"):            # the bench's order: the plain sharded schedule first, its gather on the MAIN stream
+    shared = os.environ["PLAIN_FIRST"] == "same"      # ... through the SAME communicator the lagged gather uses afterwards
+    comm_plain = comm if shared else rdist.RcclComm(0, 1, None, dev)
+    ctx.update_device(A[0].data_ptr(), A[1].data_ptr()); ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.sync()
+    plain_gather = rdist.RawLoopbackGather(ctx, dev, 1, K, comm_plain)
+    for k in range(110):
+        ctx.update_device(A[0].data_ptr(), A[1].data_ptr()); ctx.clear_occupied_bricks(); ctx.process_textures()
+        plain_gather()
+        ctx.update_occupied_bricks(); ex.begin_step(); ctx.integrate(); ex.exchange_async()
+    ctx.sync(); torch.cuda.synchronize(); tdist.barrier(); torch.cuda.synchronize()
+    ctx.set_sensor_shard(0, 0)
 if MODE == "library":
     chain.set_sensor_shard(0, N)            # (a one-rank communicator holds every sensor: the calls of a real run, one rank wide)
     lag = rdist.LaggedChain(ctx, chain, dev, None, before_sweep=ex.begin_step, after_sweep=ex.exchange_async, nccl_comm=comm.handle)
