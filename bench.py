@@ -676,13 +676,18 @@ def placement_keys(out, ctx, int_s, bytes_launch, trials, world, args):
     frac_of_box_stream of its replay)."""
     probe_ms, kept = ctx.arena_probe()
     r = out["roofline"]
+    chunks, chunk_ms = ctx.arena_chunks()
+    if chunks:      # no candidate was fast: the arena is a range of the fastest physical chunks (rgbdr_get_arena_chunks)
+        r["arena_chunks"], r["arena_chunks_replay_ms"] = chunks, round(chunk_ms, 4)
+        probe_ms = list(probe_ms) + [round(chunk_ms, 4)]
+        kept = len(probe_ms) - 1
     if len(probe_ms) > 1 and probe_ms[0] > 0 and probe_ms[kept] > 0 and world == 1:
         first_ms = int_s * 1e3 * probe_ms[0] / probe_ms[kept]
         r["avg_launch_ms_first_placement"] = round(first_ms, 4)
         r["frac_first_placement"] = round(bytes_launch / (first_ms * 1e-3) / HBM_PEAK, 4)
         # (until round 4 bench.py probed more placements than the library's default and this key scaled the result back;
         # now the headline context runs on the library's default, so it is `frac` itself unless --arena-trials was given)
-        dflt_ms = int_s * 1e3 * min(m for m in probe_ms[:16] if m > 0) / probe_ms[kept]
+        dflt_ms = int_s * 1e3 * min(m for m in probe_ms if m > 0) / probe_ms[kept]
         r["frac_library_default"] = round(bytes_launch / (dflt_ms * 1e-3) / HBM_PEAK, 4)
         first3_ms = int_s * 1e3 * min(m for m in probe_ms[:3] if m > 0) / probe_ms[kept]
         r["frac_first_3"] = round(bytes_launch / (first3_ms * 1e-3) / HBM_PEAK, 4)   # round 3's library default

@@ -544,6 +544,14 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * the candidates' times in ms (0 where none was measured), how many were tried and which
  * one was kept. */
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen);
+/* Where no candidate allocation reached the fast level, the library assembles the arena from the fastest of a pool
+ * of 1-GiB physical chunks (HIP's virtual-memory API: every chunk timed with the sweep's streams, the fastest mapped into
+ * one range, the rest released; physical memory streams at two levels per chunk, profiles/r05_vmm_chunk_map.txt) and
+ * keeps that range if its replay beats the best plain candidate's (~25 ms of set-up per chunk of the pool, which is twice
+ * the arena or what leaves 4 GiB free).  Environment: RGBDR_ARENA_CHUNKS=0 never,
+ * =force always; RGBDR_ARENA_CHUNK_MB the chunk size.  Reports the chunks of the kept arena (0: a plain allocation) and
+ * its replay time in ms when it was assembled. */
+int rgbdr_get_arena_chunks(const rgbdr_ctx* ctx, int* chunks, float* ms);
 /* Device memory released shortly before (by this or by an earlier process) is wiped by the
  * driver in the background and slows every stream for a moment.  rgbdr_settle replays the
  * integrate kernel's LUT-read + TSDF-store stream (the volume's contents are undefined

@@ -224,6 +224,7 @@ SYMBOLS = {
     "rgbdr_import_frame_from": (C.c_int, [_P, _P]),
     "rgbdr_settle": (C.c_int, [_P, C.c_float, C.POINTER(C.c_float)]),
     "rgbdr_get_arena_probe": (C.c_int, [_P, _F, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rgbdr_get_arena_chunks": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "rgbdr_upload_view_frame": (C.c_int, [_P, C.c_int, C.c_int, _F, _F]),
     "rgbdr_raymarch_find": (C.c_int, [_P, C.POINTER(View), C.POINTER(_P)]),
     "rgbdr_raymarch_shade": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
@@ -622,6 +623,12 @@ class Context:
         n, chosen = C.c_int(), C.c_int()
         self._chk(lib().rgbdr_get_arena_probe(self._h, ms, C.byref(n), C.byref(chosen)))
         return [round(float(ms[i]), 4) for i in range(n.value)], chosen.value
+
+    def arena_chunks(self):
+        """(chunks, ms): the LUT arena as a range of the fastest physical chunks (0 chunks: a plain allocation)"""
+        n, ms = C.c_int(), C.c_float()
+        self._chk(lib().rgbdr_get_arena_chunks(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
 
     def upload_view_frame(self, color, depth):
         color = np.ascontiguousarray(color, dtype=np.float32)

@@ -75,8 +75,7 @@ static void free_volume(rgbdr_ctx* c)
   (void)hipFree(c->d_mask);
   (void)hipFree(c->d_brick_tab);
   c->d_brick_tab = nullptr;
-  (void)hipFree(c->d_lut_tiled_base);
-  c->d_lut_tiled_base = nullptr;
+  free_lut_arena(c);  // (api_calib.cpp: a plain allocation or a range of mapped chunks)
   (void)hipFree(c->d_win);
   (void)hipFree(c->d_bgmax);
   (void)hipFree(c->d_skip_mask);

@@ -5,6 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "context.hpp"
 
@@ -96,6 +99,144 @@ LutExtent rgbdr::lut_extent(const rgbdr_ctx* ctx)
 }
 extern "C" {
 
+}  // extern "C"
+// ---------------------------------------------------------------------------
+// An arena assembled from the FASTEST physical chunks (HIP's virtual-memory API).  Physical memory streams at two levels
+// per 1-GiB chunk, in contiguous runs that differ per box (profiles/r05_vmm_chunk_map.txt); where no plain candidate
+// placement reaches the fast level -- or there is no room to hold several -- a pool of chunks is created, each is timed
+// with the sweep's pair of streams, the fastest are mapped into one reserved range and the rest released.  Such a range
+// streams 0-3 % below an all-fast plain allocation and up to 10 % above a slow one, so it is only tried where no plain
+// candidate was fast, and only replaces a plain arena it beats.  Any failure on the way leaves everything as it was (returns false).
+struct ChunkPool {
+  void* va = nullptr;
+  size_t chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+namespace rgbdr {
+void free_lut_arena(rgbdr_ctx* c)
+{
+  if (c->lut_vmm_va) {
+    for (size_t i = 0; i < c->lut_vmm_handles.size(); ++i) {
+      (void)hipMemUnmap((char*)c->lut_vmm_va + i * c->lut_vmm_chunk, c->lut_vmm_chunk);
+      (void)hipMemRelease(c->lut_vmm_handles[i]);
+    }
+    (void)hipMemAddressFree(c->lut_vmm_va, c->lut_vmm_handles.size() * c->lut_vmm_chunk);
+    (void)hipGetLastError();
+    c->lut_vmm_va = nullptr;
+    c->lut_vmm_handles.clear();
+  } else {
+    (void)hipFree(c->d_lut_tiled_base);
+  }
+  c->d_lut_tiled_base = nullptr;
+}
+}  // namespace rgbdr
+// returns the base of a range of `bytes` made of the fastest chunks and its replay time, or nullptr
+static float* build_chunk_arena(rgbdr_ctx* ctx, size_t bytes, size_t head_floats, size_t ntiles, float* sink, size_t chunk,
+                                float* ms_out, std::vector<hipMemGenericAllocationHandle_t>& kept)
+{
+  const rgbdr_geometry& g = ctx->geo;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = ctx->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || chunk % gran) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const size_t need = (bytes + chunk - 1) / chunk;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return nullptr;
+  const size_t spare = (size_t)4 << 30;
+  if (free_b < spare + (need + 2) * chunk) return nullptr;
+  size_t pool_n = (free_b - spare) / chunk;
+  const size_t want = need + (need > 24 ? need : 24);        // twice the arena, at least 24 chunks more
+  if (pool_n > want) pool_n = want;
+  // chunk-level replay: per tile N x 3 planes read, one stored (the volume must hold a chunk's worth of tiles)
+  const size_t tile_bytes = (size_t)nsens(ctx) * 3 * kTileVoxels * sizeof(float);
+  size_t chunk_tiles = chunk / tile_bytes;
+  if (chunk_tiles > ntiles) chunk_tiles = ntiles;
+  if (chunk_tiles == 0) return nullptr;
+  ChunkPool pool;
+  pool.chunk = chunk;
+  if (hipMemAddressReserve(&pool.va, pool_n * chunk, 0, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  for (size_t i = 0; i < pool_n; ++i) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) break;
+    if (hipMemMap((char*)pool.va + i * chunk, chunk, 0, h, 0) != hipSuccess) {
+      (void)hipMemRelease(h);
+      break;
+    }
+    pool.handles.push_back(h);
+  }
+  (void)hipGetLastError();
+  const size_t got = pool.handles.size();
+  if (got < need || hipMemSetAccess(pool.va, got * chunk, &acc, 1) != hipSuccess) {
+    // (an address range can only be freed whole: shrink the bookkeeping to what was mapped)
+    const size_t reserved = pool_n;
+    for (size_t i = 0; i < got; ++i) {
+      (void)hipMemUnmap((char*)pool.va + i * chunk, chunk);
+      (void)hipMemRelease(pool.handles[i]);
+    }
+    (void)hipMemAddressFree(pool.va, reserved * chunk);
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::vector<std::pair<float, size_t>> rate(got);
+  for (size_t i = 0; i < got; ++i) {
+    const float ms = probe_arena_ms((const float*)((char*)pool.va + i * chunk), chunk_tiles, nsens(ctx), 0, sink, ctx->stream);
+    rate[i] = std::make_pair(ms > 0.0f ? ms : 1e30f, i);
+  }
+  std::sort(rate.begin(), rate.end());
+  std::vector<char> keep(got, 0);
+  for (size_t k = 0; k < need; ++k) keep[rate[k].second] = 1;
+  // the pool's range goes (its reservation covers pool_n chunks, mapped or not); the kept chunks move into a range of their own
+  {
+    for (size_t i = 0; i < got; ++i) {
+      (void)hipMemUnmap((char*)pool.va + i * chunk, chunk);
+      if (!keep[i]) (void)hipMemRelease(pool.handles[i]);
+    }
+    (void)hipMemAddressFree(pool.va, pool_n * chunk);
+    (void)hipGetLastError();
+  }
+  void* va = nullptr;
+  kept.clear();
+  bool ok = hipMemAddressReserve(&va, need * chunk, 0, nullptr, 0) == hipSuccess;
+  size_t mapped = 0;
+  for (size_t i = 0; ok && i < got; ++i) {
+    if (!keep[i]) continue;
+    ok = hipMemMap((char*)va + mapped * chunk, chunk, 0, pool.handles[i], 0) == hipSuccess;
+    if (ok) {
+      kept.push_back(pool.handles[i]);
+      ++mapped;
+    }
+  }
+  if (ok) ok = hipMemSetAccess(va, need * chunk, &acc, 1) == hipSuccess;
+  float ms = -1.0f;
+  if (ok) {
+    ms = probe_arena_ms((const float*)va + head_floats, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+    ok = ms > 0.0f;
+  }
+  if (!ok) {
+    for (size_t k = 0; k < mapped; ++k) (void)hipMemUnmap((char*)va + k * chunk, chunk);
+    for (size_t i = 0; i < got; ++i)
+      if (keep[i]) (void)hipMemRelease(pool.handles[i]);
+    if (va) (void)hipMemAddressFree(va, need * chunk);
+    (void)hipGetLastError();
+    kept.clear();
+    return nullptr;
+  }
+  *ms_out = ms;
+  return (float*)va;
+}
+
+extern "C" {
 static int ensure_tiled_lut(rgbdr_ctx* ctx)
 {
   if (ctx->d_lut_tiled) return RGBDR_OK;
@@ -129,7 +270,7 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
   float* sink = ctx->d_tsdf_owned;  // the probe replays the TSDF store stream too: the volume is invalidated below
   float best_ms = 0.0f;
   int best = -1, got = 0;
-  bool probed = false;
+  bool probed = false, reached_fast = false;
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   for (int t = 0; t < trials; ++t) {
@@ -163,7 +304,10 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
     // stop at the first candidate that streams at the fastest level seen on this hardware
     // (>= 6.6 TB/s for LUT reads + TSDF stores; the others are 5.9-6.5 TB/s)
     const double stream_bytes = (double)ntiles * ((double)nsens(ctx) * 3 + 1) * kTileVoxels * sizeof(float);
-    if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) break;
+    if (ms > 0.0f && stream_bytes / (ms * 1e-3) >= 6.6e12) {
+      reached_fast = true;
+      break;
+    }
     // time budget: 1 s + 0.12 s per GiB of arena (a candidate costs its hipMalloc, which grows with its size: on one box
     // three candidates of the 8-sensor arena -- 25.8 GB -- used up a flat 1 s, all three at the slow level)
     clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -179,17 +323,55 @@ static int ensure_tiled_lut(rgbdr_ctx* ctx)
       (void)hipFree(cand[t]);
       ++freed;
     }
+  // No plain candidate at the fast level (or only one could be held): an arena of the fastest physical chunks, kept if its
+  // replay beats the best plain one's (8 sensors into 1024^3, no room to shop: replay 16.52 against 16.61 ms, the sweep
+  // itself 16.91 against 17.47 -- a plain arena that is slow in parts costs the kernel more than it costs the replay).  RGBDR_ARENA_CHUNKS=0 never, =force always (tests); RGBDR_ARENA_CHUNK_MB
+  // sets the chunk size (default 1024).
+  float* base = cand[best];
+  ctx->arena_chunks = 0;
+  ctx->arena_chunk_ms = 0.0f;
+  {
+    const char* ce = std::getenv("RGBDR_ARENA_CHUNKS");
+    const bool force = ce && std::strcmp(ce, "force") == 0, never = ce && std::strcmp(ce, "0") == 0;
+    size_t chunk = (size_t)1 << 30;
+    if (const char* cm = std::getenv("RGBDR_ARENA_CHUNK_MB")) chunk = (size_t)(std::atoi(cm) > 0 ? std::atoi(cm) : 1024) << 20;
+    if (!never && (force || (trials > 1 && probed && !reached_fast)) && bytes >= chunk) {
+      float ms_c = 0.0f;
+      std::vector<hipMemGenericAllocationHandle_t> kept;
+      float* va = build_chunk_arena(ctx, bytes, layer * (size_t)ctx->halo, ntiles, sink, chunk, &ms_c, kept);
+      if (va && (force || !(best_ms > 0.0f) || ms_c < best_ms)) {
+        (void)hipFree(cand[best]);
+        ++freed;
+        base = va;
+        best_ms = ms_c;
+        ctx->lut_vmm_va = va;
+        ctx->lut_vmm_chunk = chunk;
+        ctx->lut_vmm_handles = kept;
+        ctx->arena_chunks = (int)kept.size();
+        ctx->arena_chunk_ms = ms_c;
+        probed = true;
+      } else if (va) {
+        for (size_t k = 0; k < kept.size(); ++k) {
+          (void)hipMemUnmap((char*)va + k * chunk, chunk);
+          (void)hipMemRelease(kept[k]);
+        }
+        (void)hipMemAddressFree(va, kept.size() * chunk);
+        (void)hipGetLastError();
+        ++freed;
+      }
+    }
+  }
   // Releasing that much memory slows the device down for a moment (the driver wipes released VRAM
   // in the background): wait, at most 2 s, until the kept arena streams as it did when it was chosen.
   if (freed > 0 && best_ms > 0.0f) {
     for (int k = 0; k < 40; ++k) {
-      const float ms = probe_arena_ms(cand[best] + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
+      const float ms = probe_arena_ms(base + layer * ctx->halo, ntiles, nsens(ctx), g.tiles[0], sink, ctx->stream);
       if (!(ms > best_ms * 1.01f)) break;
       struct timespec ts = {0, 50000000};
       nanosleep(&ts, nullptr);
     }
   }
-  ctx->d_lut_tiled_base = cand[best];
+  ctx->d_lut_tiled_base = base;
   ctx->d_lut_tiled = ctx->d_lut_tiled_base + layer * ctx->halo;
   if (probed) {  // the replay stored into the volume: clear it again, forget recorded clears, nothing is integrated
     HIPCHK(hipMemsetAsync(ctx->d_tsdf_owned, 0, ntiles * kTileVoxels * sizeof(float), ctx->stream));
@@ -647,6 +829,15 @@ try {
   return RGBDR_OK;
 }
 RGBDR_CONTAIN(ctx)
+
+int rgbdr_get_arena_chunks(const rgbdr_ctx* ctx, int* chunks, float* ms)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (chunks) *chunks = ctx->arena_chunks;
+  if (ms) *ms = ctx->arena_chunk_ms;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(nullptr)
 
 int rgbdr_get_arena_probe(const rgbdr_ctx* ctx, float ms[16], int* trials, int* chosen)
 try {

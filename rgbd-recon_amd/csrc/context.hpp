@@ -88,6 +88,12 @@ struct rgbdr_ctx {
   uint32_t inv_res[rgbdr::kMaxSensors][3] = {};
   float* d_lut_tiled = nullptr;       // grid-layout LUT planes of the OWNED tile layers ...
   float* d_lut_tiled_base = nullptr;  // ... inside an allocation with `halo` more layers on each side
+  // that allocation as a range of mapped physical chunks (api_calib.cpp build_chunk_arena) instead of one hipMalloc
+  void* lut_vmm_va = nullptr;
+  size_t lut_vmm_chunk = 0;
+  std::vector<hipMemGenericAllocationHandle_t> lut_vmm_handles;
+  int arena_chunks = 0;               // chunks of the kept arena (0: a plain allocation)
+  float arena_chunk_ms = 0.0f;        // its replay time when it was assembled
   // double_pbo of NetKinectArray (double_pixel_buffer.cpp:35-81): two page-locked host frame
   // sets; the producer fills the back one, upload_mapped swaps and DMAs from the front one
   void* h_depth[2] = {nullptr, nullptr};
@@ -252,5 +258,5 @@ struct LutExtent {
   float* dst;
 };
 LutExtent lut_extent(const rgbdr_ctx* ctx);
+void free_lut_arena(rgbdr_ctx* c);  // api_calib.cpp: the LUT arena, a plain allocation or a range of mapped chunks
 }  // namespace rgbdr
-

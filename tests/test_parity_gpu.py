@@ -1034,6 +1034,54 @@ def test_lut_arena_placement_probe(pkg, monkeypatch):
     small.close()
 
 
+@pytest.mark.parametrize("slab", [None, (1, 3)])
+def test_lut_arena_assembled_from_the_fastest_chunks(pkg, orc, monkeypatch, slab):
+    """The LUT arena as a range of mapped physical chunks (rgbdr_get_arena_chunks; forced here with 64-MiB chunks -- the
+    library does it on its own when no candidate allocation streams at the fast level): results are the oracle's bit for
+    bit, a resize re-assembles it, and destroy returns every byte."""
+    import torch
+
+    monkeypatch.setenv("RGBDR_ARENA_CHUNKS", "force")
+    monkeypatch.setenv("RGBDR_ARENA_CHUNK_MB", "64")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    kw = dict(slab_rank=slab[0], slab_count=slab[1]) if slab else {}
+    scene, ctx, inv = build(pkg, n=3, G=192, lut_res=(32, 27, 32), **kw)         # 3 x 192^3 x 12 B = 255 MB (a third of it per slab)
+    chunks, ms = ctx.arena_chunks()
+    g = ctx.geo
+    layers = (g.slab_tile_z1 - g.slab_tile_z0) + 2 * g.halo_tile_layers
+    arena = int(g.tiles[0]) * int(g.tiles[1]) * layers * 3 * 3 * 512 * 4
+    assert chunks == -(-arena // (64 << 20)) and ms > 0.0
+    whole = build(pkg, n=3, G=192, lut_res=(32, 27, 32))[1] if slab else ctx
+    for bricks in (False, True):
+        ctx.set_use_bricks(bricks)
+        ctx.step(scene.depth, scene.color)
+        got = ctx.readback_tsdf()
+        ref = oracle_run(orc, scene, whole, inv, use_bricks=bricks)["tsdf"]
+        if slab:
+            ref = ref[g.slab_voxel_z0:g.slab_voxel_z1]
+        assert same_bits(got, ref), "bricks %d: %d voxels differ" % (bricks, count_diff(got, ref))
+    if slab:
+        whole.close()
+    if not slab:                                                              # setVoxelSize: the arena is assembled anew
+        ctx.set_voxel_size(2.0 / 160)
+        ctx.set_brick_size(8 * 2.0 / 160)
+        inv2 = scene.inverse((160, 160, 160))
+        for i in range(3):
+            ctx.set_inverse_calibration(i, inv2[i], (160, 160, 160))
+        assert ctx.arena_chunks()[0] == -(-(160 // 8) ** 3 * 3 * 3 * 512 * 4 // (64 << 20))
+        ctx.set_use_bricks(False)
+        ctx.step(scene.depth, scene.color)
+        assert same_bits(ctx.readback_tsdf(), oracle_run(orc, scene, ctx, inv2)["tsdf"])
+    ctx.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (8 << 20), "the chunks of the arena were not returned"
+    monkeypatch.setenv("RGBDR_ARENA_CHUNKS", "0")
+    plain = build(pkg, n=3, G=192, lut_res=(32, 27, 32))[1]
+    assert plain.arena_chunks() == (0, 0.0)
+    plain.close()
+
+
 def test_brick_sweep_skips_tiles_that_are_still_cleared(pkg, orc):
     """the brick-skipping sweep rewrites -limit only where a tile does not hold it already;
     every event that invalidates that record is followed by a correct volume"""
