@@ -116,6 +116,7 @@ def run(pkg, orc, seed, slab, trace):
         lambda: L.rgbdr_shard_allgather_async(h, None),
         lambda: L.rgbdr_settle(h, 0.01, C.byref(f1)), lambda: L.rgbdr_settle(h, float("nan"), None),
         lambda: L.rgbdr_get_arena_probe(h, F(big), C.byref(i1), C.byref(i2)), lambda: L.rgbdr_get_arena_probe(h, None, None, None),
+        lambda: L.rgbdr_get_arena_chunks(h, C.byref(i1), C.byref(f1)), lambda: L.rgbdr_get_arena_chunks(h, None, None),
         lambda: L.rgbdr_set_stream(h, None),
         lambda: L.rgbdr_enable_timers(h, flag()), lambda: L.rgbdr_enable_timer_accumulation(h, flag()),
         lambda: L.rgbdr_set_timer_detail(h, int(rng.integers(-1, 4))),
