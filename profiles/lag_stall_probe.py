@@ -59,6 +59,8 @@ for k in range(int(os.environ.get("PUSHES", "400"))):
     dt = time.perf_counter() - t0
     if dt > 5e-3:
         slow.append((k, round(dt * 1e3, 1)))
+        if k > 0:                           # (CLOCK_MONOTONIC in us, the clock of AMD_LOG_LEVEL's lines: profiles/stall_log.sh)
+            print("STALL_WINDOW %d %d" % (time.monotonic_ns() // 1000 - int(dt * 1e6), time.monotonic_ns() // 1000), flush=True)
     if SYNC and k % SYNC == SYNC - 1:       # (the bench synchronises between its phases)
         ctx.sync(); torch.cuda.synchronize()
     if BARRIER and k % BARRIER == BARRIER - 1:

@@ -279,3 +279,31 @@ def test_a_lagged_headline_far_off_its_trial_is_timed_again_on_the_plain_schedul
     assert r.lag is None and FakeLag.closed == 1 and r.gather == "the gather" and r.ctx.shard == (2, 2)
     assert r.timings == [(40, 10)] and abs(dt - 40 * 0.65e-3) < 1e-12 and stats == {"2integrate": (1, 1)}
     assert r.chain_choice["kept"] == "sharded" and r.chain_choice["lagged_headline_discarded_ms_per_step"] == 1.54
+
+
+def test_a_headline_with_a_host_stall_is_timed_again():
+    """bench_chain.retime_after_a_host_stall without a GPU: a step that held the host for more than 30 ms -> the K steps are
+    timed again (at most twice) and the line keeps what was discarded; a clean run is left alone"""
+    import types
+    b = load_bench()
+
+    def rig_with(longest_first, then):
+        r = types.SimpleNamespace(args=types.SimpleNamespace(steps=40, warmup=10), world=1, longest_host_step_ms=longest_first, timings=[])
+        seq = list(then)
+
+        def timed(bricks, steps, warmup):
+            r.timings.append((steps, warmup))
+            r.longest_host_step_ms = seq.pop(0)
+            return steps * 0.65e-3, {"2integrate": (1, 1)}
+        r.timed = timed
+        return r
+
+    r = rig_with(0.4, [])
+    assert b.retime_after_a_host_stall(r, 40 * 0.66e-3, "first") == (40 * 0.66e-3, "first") and not hasattr(r, "retimed")
+    r = rig_with(81.8, [0.5])
+    dt, stats = b.retime_after_a_host_stall(r, 40 * 1.6e-3, "first")
+    assert r.timings == [(40, 10)] and abs(dt - 40 * 0.65e-3) < 1e-12 and stats == {"2integrate": (1, 1)}
+    assert r.retimed["discarded"] == [{"ms_per_step": 1.6, "longest_host_step_ms": 81.8}] and r.retimed["longest_host_step_ms_kept"] == 0.5
+    r = rig_with(81.8, [55.0, 60.0])                     # never clean: two more attempts, the last one stands
+    b.retime_after_a_host_stall(r, 40 * 1.6e-3, "first")
+    assert len(r.timings) == 2 and len(r.retimed["discarded"]) == 2
