@@ -23,6 +23,32 @@ __global__ __launch_bounds__(128) void k_pair(const v4f* __restrict__ src, v4f* 
   __builtin_nontemporal_store(acc, sink + (size_t)t * 128 + threadIdx.x);
 }
 
+// one 16-byte load per 4 KiB of the range (a test of translation, not of bandwidth), every lane of a wavefront on its own page
+__global__ __launch_bounds__(256) void k_touch(const v4f* __restrict__ src, v4f* __restrict__ sink, unsigned n, unsigned stride16)
+{
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // pages in a scattered order (a multiplicative hash modulo n, n a power of two) so that neighbouring lanes do not share a 2-MiB page
+  const unsigned j = (i * 2654435761u) & (n - 1);
+  v4f a = __builtin_nontemporal_load(src + (size_t)j * stride16);
+  if (a.x == 123.456f) sink[i] = a;
+}
+static float time_touch(const void* base, size_t bytes, void* sink, hipEvent_t e0, hipEvent_t e1)
+{
+  const unsigned n = (unsigned)(bytes / 4096);
+  float best = 1e9f;
+  for (int r = 0; r < 4; ++r) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_touch, dim3((n + 255) / 256), dim3(256), 0, 0, (const v4f*)base, (v4f*)sink, n, 256u);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (r > 0 && ms < best) best = ms;
+  }
+  return best;
+}
+
 static float time_range(const void* base, size_t bytes, void* sink, hipEvent_t e0, hipEvent_t e1)
 {
   const unsigned tiles = (unsigned)(bytes / (12 * 2048));
@@ -76,6 +102,17 @@ int main(int argc, char** argv)
   for (int i = 0; i < made; ++i) {
     rate[i] = (float)(gb / (time_range((char*)va + (size_t)i * chunk, chunk, sink, e0, e1) * 1e-3));
     printf("%5.0f%s", rate[i], (i % 10 == 9 || i == made - 1) ? "\n" : " ");
+  }
+  // translation: one load per 4 KiB, scattered, on the three fastest and the three slowest chunks
+  {
+    std::vector<int> o(made);
+    for (int i = 0; i < made; ++i) o[i] = i;
+    std::sort(o.begin(), o.end(), [&](int a, int b) { return rate[a] > rate[b]; });
+    printf("one scattered 16-byte load per 4 KiB of a chunk (262144 loads), us:  fastest chunks");
+    for (int k = 0; k < 3 && k < made; ++k) printf(" %.1f", 1e3f * time_touch((char*)va + (size_t)o[k] * chunk, chunk, sink, e0, e1));
+    printf("   slowest chunks");
+    for (int k = 0; k < 3 && k < made; ++k) printf(" %.1f", 1e3f * time_touch((char*)va + (size_t)o[made - 1 - k] * chunk, chunk, sink, e0, e1));
+    printf("\n");
   }
   // the whole mapped range at once, and the best 13 chunks remapped contiguously
   if (made >= 13) {
