@@ -54,6 +54,9 @@ static void free_volume(rgbdr_ctx* c)
   c->d_peel_near = nullptr;
   c->peel_pixels = c->peel_near_cap = 0;
   (void)hipFree(c->d_fill);
+  (void)hipFree(c->d_fill_tabs);
+  c->d_fill_tabs = nullptr;
+  c->fill_tab_w = c->fill_tab_h = 0;
   c->d_view = c->d_fill = nullptr;
   c->view_pixels = c->fill_floats = 0;
   c->view_w = c->view_h = 0;

@@ -269,8 +269,8 @@ try {
   HIPCHK(hipSetDevice(ctx->device));
   FillLayout L;
   make_fill_layout(ctx->view_w, ctx->view_h, &L);
-  const size_t na = (size_t)L.FW * L.H, npix = (size_t)L.W * L.H;
-  const size_t need = na * 10 + npix * 5;  // two atlases (rgba + depth) + the filled frame
+  const size_t nb = fill_band_texels(L), npix = (size_t)L.W * L.H;
+  const size_t need = (nb + npix) * 5 + 4;  // the atlas' LOD band (rgba + depth) + the filled frame
   if (ctx->fill_floats < need) {
     (void)hipFree(ctx->d_fill);
     ctx->d_fill = nullptr;
@@ -278,15 +278,29 @@ try {
     HIPCHK(hipMalloc((void**)&ctx->d_fill, need * sizeof(float)));
     ctx->fill_floats = need;
   }
-  float4* ncol = (float4*)ctx->d_fill;
-  float4* scol = (float4*)(ctx->d_fill + na * 4);
-  float4* ocol = (float4*)(ctx->d_fill + na * 8);
-  float* ndep = ctx->d_fill + na * 8 + npix * 4;
-  float* sdep = ndep + na;
-  float* odep = sdep + na;
+  float4* acol = (float4*)ctx->d_fill;
+  float4* ocol = (float4*)(ctx->d_fill + nb * 4);
+  float* adep = ctx->d_fill + (nb + npix) * 4;
+  float* odep = adep + nb;
+  if (ctx->fill_tab_w != L.W || ctx->fill_tab_h != L.H) {  // a new viewport size: its tap tables
+    std::vector<int> xt, yt;
+    FillTabs T;
+    make_fill_tables(L, &xt, &yt, &T);
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // a fill in flight reads the old ones
+    (void)hipFree(ctx->d_fill_tabs);
+    ctx->d_fill_tabs = nullptr;
+    ctx->fill_tab_w = ctx->fill_tab_h = 0;
+    HIPCHK(hipMalloc((void**)&ctx->d_fill_tabs, (xt.size() + yt.size() + 4) * sizeof(int)));
+    if (!xt.empty()) HIPCHK(hipMemcpy(ctx->d_fill_tabs, xt.data(), xt.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!yt.empty()) HIPCHK(hipMemcpy(ctx->d_fill_tabs + xt.size(), yt.data(), yt.size() * sizeof(int), hipMemcpyHostToDevice));
+    T.xt = (const int4*)ctx->d_fill_tabs;
+    T.yt = (const int4*)(ctx->d_fill_tabs + xt.size());
+    ctx->fill_tabs = T;
+    ctx->fill_tab_w = L.W;
+    ctx->fill_tab_h = L.H;
+  }
   tbegin(ctx, "holefill", ctx->stream);
-  launch_fill_colors(L, (const float4*)ctx->d_view, ctx->d_view + npix * 4, ncol, ndep, scol, sdep, ocol, odep,
-                     ctx->stream);
+  launch_fill_colors(L, ctx->fill_tabs, (const float4*)ctx->d_view, ctx->d_view + npix * 4, acol, adep, ocol, odep, ctx->stream);
   tend(ctx, "holefill", ctx->stream);
   LAUNCHCHK("fill_colors");
   if (color) HIPCHK(hipMemcpyAsync(color, ocol, npix * 16, hipMemcpyDeviceToHost, ctx->stream));

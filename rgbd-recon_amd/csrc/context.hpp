@@ -143,8 +143,11 @@ struct rgbdr_ctx {
   size_t peel_near_cap = 0;
   size_t peel_pixels = 0;
   int view_w = 0, view_h = 0; // size of the last ray-marched frame
-  float* d_fill = nullptr;    // hole-fill atlases (2 x colour + depth) and the filled frame
+  float* d_fill = nullptr;    // hole filling: the LOD band of the atlas (colour + depth) and the filled frame
   size_t fill_floats = 0;
+  int* d_fill_tabs = nullptr;  // tap tables of the inpaint passes for a fill_tab_w x fill_tab_h viewport (FillTabs)
+  int fill_tab_w = 0, fill_tab_h = 0;
+  rgbdr::FillTabs fill_tabs{};
   bool integrated = false;
 
   // bricks

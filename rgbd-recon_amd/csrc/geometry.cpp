@@ -10,6 +10,7 @@
 #include <cstring>
 
 #include "rgbdr_internal.hpp"
+#include "fill_taps.cuh"
 
 namespace rgbdr {
 
@@ -257,6 +258,25 @@ void make_fill_layout(int W, int H, FillLayout* L)
       L->off[i][1] = oy;
     }
   }
+}
+
+// Tap tables of the inpaint passes (FillTabs): fill_taps.cuh evaluated for every texel column / row of every LOD >= 1.
+void make_fill_tables(const FillLayout& L, std::vector<int>* xt, std::vector<int>* yt, FillTabs* T)
+{
+  xt->clear();
+  yt->clear();
+  std::memset(T->xbase, 0, sizeof(T->xbase));
+  std::memset(T->ybase, 0, sizeof(T->ybase));
+  for (int i = 1; i < L.num_lods; ++i) {
+    T->xbase[i] = (int)(xt->size() / 4);
+    T->ybase[i] = (int)(yt->size() / 4);
+    for (int fx = 0; fx < L.res[i][0]; ++fx)
+      for (int t = 0; t < 4; ++t) xt->push_back(fc_tap_column(L, i, fx, t));
+    for (int fy = 0; fy < L.res[i][1]; ++fy)
+      for (int t = 0; t < 4; ++t) yt->push_back(fc_tap_row(L, i, fy, t));
+  }
+  T->nx = (int)(xt->size() / 4);
+  T->ny = (int)(yt->size() / 4);
 }
 
 void frustum_planes(const float* xyz, const uint32_t res[3], float planes[6][4])

@@ -217,8 +217,24 @@ struct FillLayout {
   int off[20][2], res[20][2];
 };
 void make_fill_layout(int W, int H, FillLayout* L);  // geometry.cpp
-void launch_fill_colors(const FillLayout& L, const float4* frame_col, const float* frame_dep, float4* ncol, float* ndep,
-                        float4* scol, float* sdep, float4* out_col, float* out_dep, hipStream_t s);
+// Where the 4 x 4 taps of tsdf_inpaint.fs lie, per LOD i >= 1 (the pass that writes it): for texel column fx the N column of
+// the tap columns pos_int.x - 1 .. + 2 seen through framebuffer_transfer.fs's squeeze, for texel row fy the N rows.  The
+// float expressions of the two shaders, evaluated on the host once per viewport size (make_fill_tables, geometry.cpp).
+constexpr int FC_TAP_OUTSIDE = -1;      // texelFetch outside the texture: 0
+constexpr int FC_TAP_CLEAR = -2;        // a squeezed texel beyond the LOD-0 viewport: the clear colour
+constexpr int FC_ROW_CLEAR = 1 << 30;   // row flag: during pass i the band (x >= W) still holds the clear colour in this row
+struct FillTabs {
+  const int4* xt;  // [xbase[i] + fx] = N column of the 4 tap columns (or FC_TAP_*)
+  const int4* yt;  // [ybase[i] + fy] = N row of the 4 tap rows | FC_ROW_CLEAR (or FC_TAP_OUTSIDE)
+  int xbase[20], ybase[20];
+  int nx, ny;      // entries in all
+};
+// host side of the tables: xt / yt as int quadruples, bases filled in T (T->xt / yt are the caller's to set after upload)
+void make_fill_tables(const FillLayout& L, std::vector<int>* xt, std::vector<int>* yt, FillTabs* T);
+// acol / adep: the atlas' column band x >= W (the LODs >= 1), fill_band_texels(L) texels each
+size_t fill_band_texels(const FillLayout& L);
+void launch_fill_colors(const FillLayout& L, const FillTabs& T, const float4* frame_col, const float* frame_dep, float4* acol,
+                        float* adep, float4* out_col, float* out_dep, hipStream_t s);
 
 // ---- launchers (kernels_pre.hip / kernels_integrate.hip / kernels_bricks.hip / kernels_skip.hip) ----
 void launch_invert_lut(const InvertParams& p, hipStream_t s);
