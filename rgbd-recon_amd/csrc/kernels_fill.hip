@@ -17,11 +17,11 @@
 //   * where the 16 taps of a texel lie depends on the viewport alone: the N column of the 4
 //     tap columns per texel column and the N row of the 4 tap rows per texel row are tables
 //     (make_fill_tables, the shader's float expressions evaluated once per viewport size).
-//     A wavefront issues one VALU instruction per 4 cycles, so a pass with few texels lasts
-//     as long as one texel's instruction stream: 3000 instructions were 7 us per LOD.
-// Launches per frame: LOD 1 (+ clear of the band below it), one per LOD whose viewport is
-// larger than the tail's first, ONE workgroup for the tail (its LODs live in LDS between
-// __syncthreads(), no global-memory phase), colorfill.  1280 x 720: 21 -> 6 launches.
+// A texel is computed by a QUAD of lanes (fc_inpaint_quad): a pass of a few hundred texels lasts as long as one lane's
+// instruction stream, and a dependent launch costs 3.3 us before it does anything (profiles/probes_src/launch_floor_probe.hip).
+// Launches per frame: LOD 1 (+ clear of the band below it), one per LOD with more texels than the tail's first, ONE
+// workgroup for the tail (its LODs live in LDS between __syncthreads(), no global-memory phase), colorfill.
+// 1280 x 720: 21 -> 7 launches, 0.122 -> 0.062 ms.
 #include <hip/hip_runtime.h>
 
 #include "fill_taps.cuh"
@@ -66,153 +66,199 @@ struct FillLds {
   int x0, y0, w, h;
 };
 
-// tsdf_inpaint.fs for one texel of LOD i, given the N columns xe[4] / rows ye[4] of its taps (fill_taps.cuh), reading the
-// native atlas in its state before this pass: 32 loads in flight, then the shader's two sums in its order.  A tap outside
-// the atlas or on the clear colour has alpha 0 -- it takes part in nothing but the depth of the num_samples == 0 branch
-// (centre tap), so its loaded value is dropped, not replaced.  LDS: taps inside M come from there, and the global loads
-// are issued only if some lane of the wavefront has a tap elsewhere.
+// ---- one texel on a quad of lanes ---------------------------------------------------------------------------------
+// A wavefront with nothing beside it on its SIMD issues one instruction per ~7 cycles (profiles/probes_src/
+// launch_floor_probe.hip), so a pass of a few hundred texels lasts as long as ONE texel's instruction stream: 1200
+// instructions per texel were 4-6 us per LOD whatever its size.  Four lanes share a texel -- lane q owns tap row q (its four
+// taps, loads and selects) -- and the shader's two order-dependent sums run as chains over the quad (DPP quad_perm, no LDS):
+//   depth_av, order x outer / y inner: step (x, y) happens in lane y: acc = acc of lane y - 1 + s[x];
+//   the colour / depth totals, order k = x + 4 y: round y happens in lane y: four local adds onto lane y - 1's totals.
+// Every lane executes every step; only the lane whose turn it is continues the chain, the others' results are never read.
+template <int CTRL>
+__device__ __forceinline__ float fc_dpp(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int fc_dpp(int v)
+{
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+constexpr int fc_quad(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int FC_FROM_PREV = fc_quad(3, 0, 1, 2);  // lane q reads lane q - 1 (lane 0: lane 3)
+constexpr int FC_XOR1 = fc_quad(1, 0, 3, 2), FC_XOR2 = fc_quad(2, 3, 0, 1);
+template <class T>
+__device__ __forceinline__ T fc_quad_bcast(T v, int from)  // `from` is a compile-time constant at every call
+{
+  switch (from) {
+    case 0: return fc_dpp<fc_quad(0, 0, 0, 0)>(v);
+    case 1: return fc_dpp<fc_quad(1, 1, 1, 1)>(v);
+    case 2: return fc_dpp<fc_quad(2, 2, 2, 2)>(v);
+    default: return fc_dpp<fc_quad(3, 3, 3, 3)>(v);
+  }
+}
+__device__ __forceinline__ int fc_quad_sum(int v)
+{
+  v += fc_dpp<FC_XOR1>(v);
+  return v + fc_dpp<FC_XOR2>(v);
+}
+
+// tsdf_inpaint.fs for one texel of LOD i on the four lanes of a quad (q = lane & 3): xq = N column of tap column q, yq = N
+// row of tap row q (fill_taps.cuh), the native atlas read in its state before this pass.  Lane q returns component q of
+// out_FragColor in `comp`; lane 3 also gl_FragDepth in `od`.  A tap outside the atlas or on the clear colour has alpha 0:
+// it takes part in nothing but the depth of the num_samples == 0 branch (centre tap).  LDS: taps inside M come from there,
+// and the global loads are issued only if some lane of the wavefront has a tap elsewhere.
 template <bool LDS>
-__device__ __forceinline__ void fc_inpaint_texel(const FillLayout& L, const FillSrc& S, const int (&xe)[4], const int (&ye)[4],
-                                                 const FillLds& M, float4& oc, float& od)
+__device__ __forceinline__ void fc_inpaint_quad(const FillLayout& L, const FillSrc& S, int q, int xq, int yq, const FillLds& M,
+                                                float& comp, float& od)
 {
   const int AW = L.FW - L.W;
-  bool xz[4], xc[4], xb[4], xl[4], yz[4], yc[4], yl[4];
-  int colv[4], rowf[4], rowb[4], coll[4], rowl[4];
+  int xe[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    xz[t] = xe[t] == FC_TAP_OUTSIDE;
-    xc[t] = xe[t] == FC_TAP_CLEAR;
-    xb[t] = xe[t] >= L.W;
-    colv[t] = xe[t] < 0 ? 0 : (xb[t] ? xe[t] - L.W : xe[t]);
-    xl[t] = LDS && xe[t] >= M.x0 && xe[t] < M.x0 + M.w;
-    coll[t] = xe[t] - M.x0;
-    yz[t] = ye[t] < 0;
-    yc[t] = !yz[t] && (ye[t] & FC_ROW_CLEAR) != 0;
-    const int ny = yz[t] ? 0 : (ye[t] & ~FC_ROW_CLEAR);
-    rowf[t] = ny * L.W;
-    rowb[t] = ny * AW;
-    yl[t] = LDS && !yz[t] && ny >= M.y0 && ny < M.y0 + M.h;
-    rowl[t] = (ny - M.y0) * M.w;
-  }
-  float4 cs[16];
-  float ds[16];
-  bool live[16], inl[16];
+  for (int t = 0; t < 4; ++t) xe[t] = fc_quad_bcast(xq, t);
+  const bool yz = yq < 0;
+  const bool yc = !yz && (yq & FC_ROW_CLEAR) != 0;
+  const int ny = yz ? 0 : (yq & ~FC_ROW_CLEAR);
+  const bool yl = LDS && !yz && ny >= M.y0 && ny < M.y0 + M.h;
+  bool live[4], inl[4], band[4], special1[4];
+  unsigned at[4];
+  int lt[4];
   bool need_global = !LDS;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int x = k & 3, y = k >> 2;
-    const bool zero = xz[x] || yz[y];
-    const bool clear = xc[x] || (xb[x] && yc[y]);
-    live[k] = !zero && !clear;
-    inl[k] = live[k] && xl[x] && yl[y];
-    if (LDS) need_global = need_global || (live[k] && !inl[k]);
+  for (int x = 0; x < 4; ++x) {
+    const bool xz = xe[x] == FC_TAP_OUTSIDE, xc = xe[x] == FC_TAP_CLEAR;
+    band[x] = xe[x] >= L.W;
+    const int colv = xe[x] < 0 ? 0 : (band[x] ? xe[x] - L.W : xe[x]);
+    const bool zero = xz || yz;
+    const bool clear = xc || (band[x] && yc);
+    special1[x] = !zero && clear;  // reads as the clear colour (depth 1); zero && ... reads as 0
+    live[x] = !zero && !clear;
+    at[x] = (unsigned)(ny * (band[x] ? AW : L.W) + colv);  // a texel of the frame / band whatever the kind
+    inl[x] = LDS && live[x] && yl && xe[x] >= M.x0 && xe[x] < M.x0 + M.w;
+    lt[x] = inl[x] ? (ny - M.y0) * M.w + (xe[x] - M.x0) : 0;
+    if (LDS) need_global = need_global || (live[x] && !inl[x]);
   }
+  float4 cs[4];
+  float ds[4];
   if (!LDS || __builtin_amdgcn_ballot_w64(need_global) != 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int x = k & 3, y = k >> 2;
-      const unsigned at = (unsigned)((xb[x] ? rowb[y] : rowf[y]) + colv[x]);  // a texel of the frame / band whatever the kind
-      cs[k] = (xb[x] ? S.acol : S.fcol)[at];
-      ds[k] = (xb[x] ? S.adep : S.fdep)[at];
+    for (int x = 0; x < 4; ++x) {
+      cs[x] = (band[x] ? S.acol : S.fcol)[at[x]];
+      ds[x] = (band[x] ? S.adep : S.fdep)[at[x]];
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      cs[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      ds[k] = 0.0f;
+    for (int x = 0; x < 4; ++x) {
+      cs[x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      ds[x] = 0.0f;
     }
   }
   if (LDS) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int x = k & 3, y = k >> 2;
-      const int lt = inl[k] ? rowl[y] + coll[x] : 0;
-      const float4 lc = M.col[lt];
-      const float ld = M.dep[lt];
-      if (inl[k]) {
-        cs[k] = lc;
-        ds[k] = ld;
+    for (int x = 0; x < 4; ++x) {
+      const float4 lc = M.col[lt[x]];
+      const float ld = M.dep[lt[x]];
+      if (inl[x]) {
+        cs[x] = lc;
+        ds[x] = ld;
       }
     }
   }
   // a sum that starts at +0 is never -0, so adding +0 for a tap that does not count leaves the shader's sum bit for bit
-  float depth_av = 0.0f;
-  int num = 0;
+  float s[4];
+  int cnt = 0;
 #pragma unroll
-  for (int x = 0; x < 4; ++x)  // the shader's order of accumulation: x outer, y inner
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-      const int k = x + y * 4;
-      live[k] = live[k] && !(cs[k].w <= 0.0f);
-      depth_av += live[k] ? ds[k] : 0.0f;
-      num += live[k] ? 1 : 0;
-    }
-  if (num == 0) {
-    const int k = 1 + 1 * 4;  // texelFetch(texture_depth, pos_int)
-    const bool zero = xz[1] || yz[1];
-    const bool clear = xc[1] || (xb[1] && yc[1]);
-    od = zero ? 0.0f : (clear ? 1.0f : ds[k]);
-    oc = od < 1.0f ? make_float4(0.0f, 0.0f, 0.0f, -1.0f) : fc_clear_col();
-  } else {
-    depth_av /= (float)num;
-    float tr = 0.0f, tg = 0.0f, tb = 0.0f, td = 0.0f, tw = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const bool sel = live[k] && cs[k].x >= 0.0f && ds[k] >= depth_av;
-      tr += sel ? cs[k].x * 1.0f : 0.0f;
-      tg += sel ? cs[k].y * 1.0f : 0.0f;
-      tb += sel ? cs[k].z * 1.0f : 0.0f;
-      td += sel ? ds[k] * 1.0f : 0.0f;
-      tw += sel ? 1.0f : 0.0f;
-    }
-    oc = make_float4(tr / tw, tg / tw, tb / tw, 1.0f);
-    od = td / tw;
+  for (int x = 0; x < 4; ++x) {
+    live[x] = live[x] && !(cs[x].w <= 0.0f);
+    s[x] = live[x] ? ds[x] : 0.0f;
+    cnt += live[x] ? 1 : 0;
   }
+  float acc = 0.0f;
+#pragma unroll
+  for (int x = 0; x < 4; ++x)  // the shader's order of accumulation: x outer, y inner -- step (x, y) in lane y
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc = fc_dpp<FC_FROM_PREV>(acc) + s[x];
+  const int num = fc_quad_sum(cnt);
+  if (num == 0) {  // (the same in the four lanes)
+    // texelFetch(texture_depth, pos_int): tap (1, 1), lane 1
+    const float dm = fc_quad_bcast((xe[1] == FC_TAP_OUTSIDE || yz) ? 0.0f : (special1[1] ? 1.0f : ds[1]), 1);
+    od = dm;
+    comp = dm < 1.0f ? (q == 3 ? -1.0f : 0.0f) : (q == 1 ? 1.0f : 0.0f);
+    return;
+  }
+  const float depth_av = fc_quad_bcast(acc, 3) / (float)num;
+  float tr = 0.0f, tg = 0.0f, tb = 0.0f, td = 0.0f;
+  float v[4][4];
+  int nsel = 0;
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const bool sel = live[x] && cs[x].x >= 0.0f && ds[x] >= depth_av;
+    v[x][0] = sel ? cs[x].x * 1.0f : 0.0f;
+    v[x][1] = sel ? cs[x].y * 1.0f : 0.0f;
+    v[x][2] = sel ? cs[x].z * 1.0f : 0.0f;
+    v[x][3] = sel ? ds[x] * 1.0f : 0.0f;
+    nsel += sel ? 1 : 0;
+  }
+#pragma unroll
+  for (int y = 0; y < 4; ++y) {  // order k = x + 4 y: round y in lane y
+    tr = fc_dpp<FC_FROM_PREV>(tr) + v[0][0];
+    tg = fc_dpp<FC_FROM_PREV>(tg) + v[0][1];
+    tb = fc_dpp<FC_FROM_PREV>(tb) + v[0][2];
+    td = fc_dpp<FC_FROM_PREV>(td) + v[0][3];
+#pragma unroll
+    for (int x = 1; x < 4; ++x) {
+      tr += v[x][0];
+      tg += v[x][1];
+      tb += v[x][2];
+      td += v[x][3];
+    }
+  }
+  const float tw = (float)fc_quad_sum(nsel);  // a sum of ones: exact
+  // lane 3 holds the totals; lane q divides the q-th
+  const float r3 = fc_quad_bcast(tr, 3), g3 = fc_quad_bcast(tg, 3), b3 = fc_quad_bcast(tb, 3), d3 = fc_quad_bcast(td, 3);
+  const float mine = (q == 0 ? r3 : (q == 1 ? g3 : (q == 2 ? b3 : d3))) / tw;
+  od = mine;                      // lane 3: total_depth / total_weight
+  comp = q == 3 ? 1.0f : mine;    // vec4(total_color / total_weight, 1)
 }
 
-// LOD i of the band from the state before it, 32 x 8 texels per block.  TABLES: the tap positions come from the tables
-// (LOD 1, where the arithmetic of 230 000 texels counts); otherwise they are computed (the LODs in between: a few
-// thousand texels whose launch lasts as long as one texel's chain of dependent loads and instructions).  With
-// `clear_below` the launch also covers the band's rows under LOD i's viewport and sets them to the clear colour (i = 1:
-// the rows every later LOD lives in); clear_below == 2 does only that.
+// one texel's result from its quad into colour / depth arrays at texel `o`
+__device__ __forceinline__ void fc_store_quad(float4* col, float* dep, size_t o, int q, float comp, float od)
+{
+  ((float*)(col + o))[q] = comp;
+  if (q == 3) dep[o] = od;
+}
+
+// LOD i of the band from the state before it: blocks of 16 x 4 texels x 4 lanes.  TABLES: the tap positions come from the
+// tables; otherwise each lane computes its column and its row (a cold table load costs a small launch more than the
+// arithmetic).  With `clear_rows` the launch also sets the band's rows under LOD i's viewport -- one contiguous range -- to
+// the clear colour in the blocks beyond `tiles_y` (i = 1: the rows every later LOD lives in).
 template <bool TABLES>
 __global__ void __launch_bounds__(256) k_fc_inpaint(FillLayout L, FillTabs T, int i, FillSrc S, float4* __restrict__ acol,
-                                                    float* __restrict__ adep, int clear_below)
+                                                    float* __restrict__ adep, int tiles_y)
 {
   const int AW = L.FW - L.W;
-  const int fx = blockIdx.x * 32 + (threadIdx.x & 31);
-  int row = blockIdx.y * 8 + (threadIdx.x >> 5);
-  if (clear_below) {  // rows [0, off.y) of the band first, then the viewport
-    if (row < L.off[i][1]) {
-      if (fx < AW) {
-        acol[(size_t)row * AW + fx] = fc_clear_col();
-        adep[(size_t)row * AW + fx] = 1.0f;
-      }
-      return;
+  if ((int)blockIdx.y >= tiles_y) {
+    const size_t n = (size_t)L.off[i][1] * AW, stride = (size_t)gridDim.x * (gridDim.y - tiles_y) * 256;
+    for (size_t t = ((size_t)(blockIdx.y - tiles_y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x; t < n; t += stride) {
+      acol[t] = fc_clear_col();
+      adep[t] = 1.0f;
     }
-    if (clear_below == 2) return;
-    row -= L.off[i][1];
+    return;
   }
-  const int fy = row;
-  if (fx >= L.res[i][0] || fy >= L.res[i][1]) return;
-  int xe[4], ye[4];
+  const int q = threadIdx.x & 3, texel = threadIdx.x >> 2;
+  const int fx = blockIdx.x * 16 + (texel & 15), fy = blockIdx.y * 4 + (texel >> 4);
+  if (fx >= L.res[i][0] || fy >= L.res[i][1]) return;  // (a whole quad)
+  int xq, yq;
   if (TABLES) {
-    const int4 xq = T.xt[T.xbase[i] + fx], yq = T.yt[T.ybase[i] + fy];
-    xe[0] = xq.x, xe[1] = xq.y, xe[2] = xq.z, xe[3] = xq.w;
-    ye[0] = yq.x, ye[1] = yq.y, ye[2] = yq.z, ye[3] = yq.w;
+    xq = ((const int*)T.xt)[(T.xbase[i] + fx) * 4 + q];
+    yq = ((const int*)T.yt)[(T.ybase[i] + fy) * 4 + q];
   } else {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      xe[t] = fc_tap_column(L, i, fx, t);
-      ye[t] = fc_tap_row(L, i, fy, t);
-    }
+    xq = fc_tap_column(L, i, fx, q);
+    yq = fc_tap_row(L, i, fy, q);
   }
-  float4 oc;
-  float od;
-  fc_inpaint_texel<false>(L, S, xe, ye, FillLds{nullptr, nullptr, 0, 0, 0, 0}, oc, od);
-  const size_t o = (size_t)(L.off[i][1] + fy) * AW + (L.off[i][0] - L.W + fx);
-  acol[o] = oc;
-  adep[o] = od;
+  float comp, od;
+  fc_inpaint_quad<false>(L, S, q, xq, yq, FillLds{nullptr, nullptr, 0, 0, 0, 0}, comp, od);
+  fc_store_quad(acol, adep, (size_t)(L.off[i][1] + fy) * AW + (L.off[i][0] - L.W + fx), q, comp, od);
 }
 
 // The tail of the pyramid, LODs [first, num_lods), in ONE workgroup: what its passes read of N is copied to LDS once
@@ -223,15 +269,15 @@ __global__ void __launch_bounds__(1024) k_fc_inpaint_tail(FillLayout L, FillTabs
 {
   extern __shared__ int4 fc_lds[];
   const int ntx = T.nx - T.xbase[first], nty = T.ny - T.ybase[first];
-  int4* lxt = fc_lds;
-  int4* lyt = lxt + ntx;
-  float4* lcol = (float4*)(lyt + nty);
+  int* lxt = (int*)fc_lds;
+  int* lyt = lxt + 4 * ntx;
+  float4* lcol = (float4*)(lyt + 4 * nty);
   float* ldep = (float*)(lcol + cap);
   const int y1 = L.off[first][1] + L.res[first][1];  // first row above the tail's LODs
   const FillLds M{lcol, ldep, L.W - 3, L.off[L.num_lods - 1][1], L.res[first][0] + 6, y1 + 3 - L.off[L.num_lods - 1][1]};
   const int AW = L.FW - L.W;
-  for (int t = threadIdx.x; t < ntx; t += blockDim.x) lxt[t] = T.xt[T.xbase[first] + t];
-  for (int t = threadIdx.x; t < nty; t += blockDim.x) lyt[t] = T.yt[T.ybase[first] + t];
+  for (int t = threadIdx.x; t < ntx; t += blockDim.x) ((int4*)lxt)[t] = T.xt[T.xbase[first] + t];
+  for (int t = threadIdx.x; t < nty; t += blockDim.x) ((int4*)lyt)[t] = T.yt[T.ybase[first] + t];
   for (int t = threadIdx.x; t < cap; t += blockDim.x) {
     const int y = M.y0 + t / M.w, x = M.x0 + t % M.w;
     float4 c = fc_clear_col();  // the band under the LODs computed before this launch
@@ -241,36 +287,33 @@ __global__ void __launch_bounds__(1024) k_fc_inpaint_tail(FillLayout L, FillTabs
     ldep[t] = d;
   }
   __syncthreads();
+  const int q = threadIdx.x & 3;
   for (int i = first; i < L.num_lods; ++i) {
     const int rx = L.res[i][0], n = rx * L.res[i][1];
     const int xb0 = T.xbase[i] - T.xbase[first], yb0 = T.ybase[i] - T.ybase[first];
-    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    for (int t = threadIdx.x >> 2; t < n; t += blockDim.x >> 2) {  // (a quad per texel)
       const int fy = t / rx, fx = t - fy * rx;
-      const int4 xq = lxt[xb0 + fx], yq = lyt[yb0 + fy];
-      const int xe[4] = {xq.x, xq.y, xq.z, xq.w}, ye[4] = {yq.x, yq.y, yq.z, yq.w};
-      float4 oc;
-      float od;
-      fc_inpaint_texel<true>(L, S, xe, ye, M, oc, od);
-      const int lt = (L.off[i][1] + fy - M.y0) * M.w + (L.off[i][0] + fx - M.x0);
-      lcol[lt] = oc;
-      ldep[lt] = od;
-      const size_t o = (size_t)(L.off[i][1] + fy) * AW + (L.off[i][0] - L.W + fx);
-      acol[o] = oc;
-      adep[o] = od;
+      float comp, od;
+      fc_inpaint_quad<true>(L, S, q, lxt[(xb0 + fx) * 4 + q], lyt[(yb0 + fy) * 4 + q], M, comp, od);
+      fc_store_quad(lcol, ldep, (size_t)((L.off[i][1] + fy - M.y0) * M.w + (L.off[i][0] + fx - M.x0)), q, comp, od);
+      fc_store_quad(acol, adep, (size_t)(L.off[i][1] + fy) * AW + (L.off[i][0] - L.W + fx), q, comp, od);
     }
     __syncthreads();
   }
 }
 
-// MIRRORED_REPEAT: mirror((i mod 2n), n); the coordinates colorfill builds lie within a texel of the atlas, where the
-// reflection needs no division
+// MIRRORED_REPEAT: mirror(i mod 2n, n).  The coordinates colorfill builds lie within two texels of the atlas, where the
+// reflection is ~i for i < 0 and min(i, 2n - 1 - i) above; anything else takes the division.
 __device__ __forceinline__ int fc_mirror(int i, int n)
 {
-  if (i >= -n && i < 2 * n) return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
-  const int period = 2 * n;
-  int k = i % period;
-  if (k < 0) k += period;
-  return k < n ? k : period - 1 - k;
+  if (i < -n || i >= 2 * n) {
+    const int period = 2 * n;
+    int k = i % period;
+    if (k < 0) k += period;
+    return k < n ? k : period - 1 - k;
+  }
+  const int m = i ^ (i >> 31);  // -1 - i for i < 0
+  return min(m, 2 * n - 1 - m);
 }
 
 __device__ __forceinline__ float4 fc_texel(const FillLayout& L, const FillSrc& S, int x, int y)
@@ -345,9 +388,9 @@ __global__ void __launch_bounds__(256) k_fc_colorfill(FillLayout L, FillSrc S, f
   out_dep[(size_t)py * L.W + px] = d0;
 }
 
-// texels of the first LOD the tail workgroup takes, and of the copy of N it may hold in LDS (20 B each, under 64 KiB with
-// the tables)
-static constexpr int FC_TAIL_TEXELS = 1024, FC_TAIL_LDS_TEXELS = 3000;
+// texels of the first LOD the tail workgroup takes (a quad of lanes each: one round of its 1024 threads), and of the copy
+// of N it may hold in LDS (20 B each, under 64 KiB with the tables)
+static constexpr int FC_TAIL_TEXELS = 256, FC_TAIL_LDS_TEXELS = 3000;
 
 size_t fill_band_texels(const FillLayout& L) { return (size_t)(L.FW - L.W) * L.H; }
 
@@ -367,16 +410,20 @@ void launch_fill_colors(const FillLayout& L, const FillTabs& T, const float4* fr
       break;
     }
   for (int i = 1; i < first; ++i) {
-    const int rows = L.res[i][1] + (i == 1 ? L.off[1][1] : 0);
-    const dim3 grid((L.res[i][0] + 31) / 32, (rows + 7) / 8);
-    if (i == 1)
-      hipLaunchKernelGGL(k_fc_inpaint<true>, grid, dim3(256), 0, s, L, T, i, S, acol, adep, 1);
-    else
-      hipLaunchKernelGGL(k_fc_inpaint<false>, grid, dim3(256), 0, s, L, T, i, S, acol, adep, 0);
+    const int tiles_x = (L.res[i][0] + 15) / 16, tiles_y = (L.res[i][1] + 3) / 4;
+    if (i == 1) {  // + blocks that clear the rows under the viewport
+      const long long clear_blocks = ((long long)L.off[1][1] * (L.FW - L.W) + 1023) / 1024;
+      const int extra_y = (int)((clear_blocks + tiles_x - 1) / tiles_x);
+      hipLaunchKernelGGL(k_fc_inpaint<true>, dim3(tiles_x, tiles_y + extra_y), dim3(256), 0, s, L, T, i, S, acol, adep, tiles_y);
+    } else {
+      hipLaunchKernelGGL(k_fc_inpaint<false>, dim3(tiles_x, tiles_y), dim3(256), 0, s, L, T, i, S, acol, adep, tiles_y);
+    }
   }
   if (first < L.num_lods) {
-    if (first == 1)  // a frame so small that no launch above cleared the band
-      hipLaunchKernelGGL(k_fc_inpaint<false>, dim3((L.FW - L.W + 31) / 32, (L.off[1][1] + 7) / 8), dim3(256), 0, s, L, T, 1, S, acol, adep, 2);
+    if (first == 1) {  // a frame so small that no launch above cleared the band
+      const int blocks = (int)(((long long)L.off[1][1] * (L.FW - L.W) + 1023) / 1024);
+      if (blocks > 0) hipLaunchKernelGGL(k_fc_inpaint<false>, dim3(1, blocks), dim3(256), 0, s, L, T, 1, S, acol, adep, 0);
+    }
     const int cap = fc_tail_cap(L, first);
     const size_t lds = (size_t)cap * 20 + (size_t)(T.nx - T.xbase[first] + T.ny - T.ybase[first]) * 16;
     hipLaunchKernelGGL(k_fc_inpaint_tail, dim3(1), dim3(1024), lds, s, L, T, first, S, acol, adep, cap);
