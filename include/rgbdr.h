@@ -250,7 +250,22 @@ int rgbdr_upload_mapped_frame(rgbdr_ctx* ctx);
 int rgbdr_upload_frame_device(rgbdr_ctx* ctx, const void* depth_dev, const void* color_dev);
 /* ReconIntegration::clearOccupiedBricks (recon_integration.cpp:272-278) */
 int rgbdr_clear_occupied_bricks(rgbdr_ctx* ctx);
-/* NetKinectArray::processTextures (NetKinectArray.cpp:311-428) */
+/* NetKinectArray::processTextures (NetKinectArray.cpp:311-428): pre_morph, pre_depth (+ Lab), pre_boundary,
+ * pre_normal (+ mark_brick), pre_quality.
+ * Two places where the reference's shaders leave the result to the GLSL implementation; this library decides them, and a
+ * maintainer comparing against the GL path will see exactly these differences:
+ *  - pre_quality.fs:104-114 `pow(angle, 2.0)` with angle < 0 (a normal facing away from the sensor): undefined in GLSL
+ *    (4.60 section 8.2).  Here it is the product angle * angle, i.e. a small POSITIVE quality; Mesa llvmpipe -- and any
+ *    driver that lowers pow to exp2(y * log2(x)) -- returns NaN, which tsdf_integration.vs:50-55 then carries into every
+ *    voxel whose 2 x 2 LINEAR footprint touches the texel.  Observed on the 4 x 512 x 424 fixtures: <= 0.5 % of the
+ *    quality texels, 11 of 262 144 voxels on the 64^3 fixture; the comparisons with the Mesa run exclude those texels and
+ *    voxels after checking, per texel, that the angle is negative (tests/test_gl_ref.py negative_angle).
+ *  - inc_bricks.glsl:40-58 `mark_brick` of a position whose home brick lies outside the brick grid (a measurement
+ *    outside the bounding box): the shader converts a negative float to uvec3 (undefined) and increments an
+ *    out-of-range SSBO element (no effect under robust buffer access, memory corruption otherwise).  Here the position
+ *    is SKIPPED: no counter changes.  Brick counters therefore equal the GL run's on every in-grid brick.
+ * The in-grid counters themselves depend on the last bit of the world position at a brick face: at 512 x 424 they differ
+ * from the Mesa run in ~3e-4 of the increments (124 of 388 134), none of them changing the occupied list. */
 int rgbdr_process_textures(rgbdr_ctx* ctx);
 /* ReconIntegration::updateOccupiedBricks (recon_integration.cpp:431-446), device side, no readback.  The set of
  * occupied bricks is that of the moment of the call (counters and threshold as they are now); the library may
@@ -532,6 +547,18 @@ int rgbdr_draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* view, float* peels
  * of the shaders on Mesa, tests/test_gl_ref.py).  A consumer that wants the reference's window takes
  * depth < 1 ? color : its clear colour. */
 int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
+/* ReconIntegration::drawF (recon_integration.cpp:151-178), the displayed frame of the reference's main loop
+ * (kinect_client.cpp:572-617: update, process_textures, integrate, drawF): drawDepthLimits when view->skip_space
+ * ("brickdraw"), Reconstruction::drawF = the ray-march ("draw"), fillColors when fill_holes ("holefill"; m_fill_holes),
+ * the whole under "3recon".  Enqueued on the context's stream behind the frame's passes WITHOUT waiting for the device
+ * (contexts with side streams -- RGBDR_FLAG_PIPELINE, a halo or gather transfer -- are drained first); the frame stays on
+ * the device like the window's framebuffer does.  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
+ * depth [height][width] f32 of the ray-marched frame (filled = 0) or of the hole-filled one (filled = 1; RGBDR_ERR_STATE
+ * when the current frame has not been filled), valid until the next call that draws, fills or uploads a frame and ordered
+ * on rgbdr_set_stream's stream.  rgbdr_readback_view_frame copies it to the host (waits). */
+int rgbdr_draw(rgbdr_ctx* ctx, const rgbdr_view* view, int fill_holes);
+int rgbdr_device_view_frame(rgbdr_ctx* ctx, int filled, void** color, void** depth, int* width, int* height);
+int rgbdr_readback_view_frame(rgbdr_ctx* ctx, int filled, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the
  * driver placed that allocation (stable per allocation, up to 12 % apart: a zone of 13-19 GB of the device memory,

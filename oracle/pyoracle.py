@@ -105,6 +105,15 @@ def set_threads(n):
     return lib().orc_set_threads(int(n))
 
 
+def set_linear_weight_bits(bits):
+    """driver-tolerance study only (oracle/driver_weight_bound.py): LINEAR weights rounded to `bits` fractional bits, 0 = exact"""
+    lib().orc_set_linear_weight_bits(int(bits))
+
+
+def linear_weight_bits():
+    return int(lib().orc_get_linear_weight_bits())
+
+
 def tex3d(vol, u, v, w):
     vol = f32(vol)
     rz, ry, rx, ch = vol.shape

@@ -105,12 +105,27 @@ static inline int idx_from_floor(float f, int n)
   return (int)fc;
 }
 
+/* Driver-tolerance study (never set by a parity test): GL 4.4 section 8.14 lets an
+ * implementation compute the LINEAR weights in fixed point, and NVIDIA's texture units do -- the fraction of the texel
+ * coordinate is held in 9-bit fixed point with 8 fractional bits (1.0 representable; CUDA C Programming Guide,
+ * "Linear Filtering").  With g_weight_bits > 0 every LINEAR weight of the path (cv_xyz / cv_uv / cv_xyz_inv lookups,
+ * framework/calibration/CalibVolumes.cpp:76,135,140; the colour, quality and silhouette fetches, NetKinectArray.cpp:46-53)
+ * is rounded to that many fractional bits, so that exact-weight and fixed-point-weight runs of the same frame can be held
+ * against each other: the bound a maintainer comparing against the authors' driver should expect. */
+static int g_weight_bits = 0;
+ORC_API void orc_set_linear_weight_bits(int bits) { g_weight_bits = bits < 0 ? 0 : (bits > 23 ? 23 : bits); }
+ORC_API int orc_get_linear_weight_bits(void) { return g_weight_bits; }
+
 static inline void axis_linear(float s, int n, int* i0, int* i1, float* a)
 {
   float t = s * (float)n - 0.5f;
   float f = floorf(t);
   int j = idx_from_floor(f, n);
   *a = t - f;
+  if (g_weight_bits > 0) {
+    const float scale = (float)(1 << g_weight_bits);
+    *a = rintf(*a * scale) / scale; /* NaN stays NaN */
+  }
   *i0 = clampi(j, 0, n - 1);
   *i1 = clampi(j + 1, 0, n - 1);
 }

@@ -206,6 +206,9 @@ SYMBOLS = {
     "rgbdr_device_calibration": (C.c_int, [_P, C.c_int, C.POINTER(CalibrationDeviceView)]),
     "rgbdr_raymarch": (C.c_int, [_P, C.POINTER(View), _F, _F, _F]),
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
+    "rgbdr_draw": (C.c_int, [_P, _P, C.c_int]),
+    "rgbdr_device_view_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rgbdr_readback_view_frame": (C.c_int, [_P, C.c_int, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
     "rgbdr_halo_staging": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -600,6 +603,23 @@ class Context:
         color = np.empty((height, width, 4), dtype=np.float32)
         depth = np.empty((height, width), dtype=np.float32)
         self._chk(lib().rgbdr_fill_colors(self._h, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
+        return color, depth
+
+    def draw(self, view, fill_holes=True):
+        """ReconIntegration::drawF: depth peels (view.skip_space), ray-march, hole filling -- enqueued, not waited for"""
+        self._chk(lib().rgbdr_draw(self._h, C.byref(view), 1 if fill_holes else 0))
+
+    def device_view_frame(self, filled):
+        """(colour pointer, depth pointer, width, height) of the displayed frame on the device"""
+        c, d, w, h = _P(), _P(), C.c_int(), C.c_int()
+        self._chk(lib().rgbdr_device_view_frame(self._h, 1 if filled else 0, C.byref(c), C.byref(d), C.byref(w), C.byref(h)))
+        return c.value, d.value, w.value, h.value
+
+    def readback_view_frame(self, filled):
+        _, _, w, h = self.device_view_frame(filled)
+        color = np.empty((h, w, 4), dtype=np.float32)
+        depth = np.empty((h, w), dtype=np.float32)
+        self._chk(lib().rgbdr_readback_view_frame(self._h, 1 if filled else 0, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
 
     def halo_staging(self, buffer):

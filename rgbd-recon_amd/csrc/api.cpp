@@ -59,7 +59,7 @@ static void free_volume(rgbdr_ctx* c)
   c->fill_tab_w = c->fill_tab_h = 0;
   c->d_view = c->d_fill = nullptr;
   c->view_pixels = c->fill_floats = 0;
-  c->view_w = c->view_h = 0;
+  c->view_w = c->view_h = c->filled_w = c->filled_h = 0;
   c->integrated = false;
   for (int b = 0; b < 2; ++b)
     for (int f = 0; f < 2; ++f) {

@@ -36,6 +36,7 @@ static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
   ctx->d_view = nullptr;
   ctx->view_pixels = 0;
   ctx->view_w = ctx->view_h = 0;   // (the callers set the new frame's size once it is written)
+  ctx->filled_w = ctx->filled_h = 0;
   HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 7 * sizeof(float)));
   ctx->view_pixels = npix;
   return RGBDR_OK;
@@ -119,7 +120,9 @@ try {
 RGBDR_CONTAIN(ctx)
 
 // uniforms + resident data of the ray-marcher for `v`; runs the depth peels when asked
-static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp)
+// `in_stream_order`: the caller enqueues behind the frame's passes on the context's stream and returns without waiting
+// (rgbdr_draw); contexts with side streams (pipelined chain, halo / gather transfers) are drained first all the same
+static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams* pp, bool in_stream_order = false)
 {
   if (!v || !view_size_ok(v->width, v->height)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view (null, or not 1 ... 32768 pixels each way)");
   if (!view_is_finite(v)) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "bad view: a matrix or the camera position holds a NaN or an infinity");
@@ -128,7 +131,12 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   const int N = nsens(ctx);
   bool tiled = true;
   for (int i = 0; i < N; ++i) tiled = tiled && ctx->inv_tiled[i];
-  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  if (!in_stream_order || ctx->pipelined() || ctx->gather_stream || ctx->halo_stream) {
+    int rc_ = sync_all(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  } else {
+    HIPCHK(hipSetDevice(ctx->device));
+  }
   const size_t npix = (size_t)v->width * v->height;
   {
     int rc_ = ensure_view_buffers(ctx, npix);
@@ -199,6 +207,7 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   p.khit = (int*)(ctx->d_view + npix * 6);
   ctx->view_w = v->width;
   ctx->view_h = v->height;
+  ctx->filled_w = ctx->filled_h = 0;  // a new frame: the filled image no longer belongs to it
   return RGBDR_OK;
 }
 
@@ -262,11 +271,9 @@ try {
 }
 RGBDR_CONTAIN(ctx)
 
-int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
-try {
-  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
-  if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "fill_colors before raymarch");
-  HIPCHK(hipSetDevice(ctx->device));
+// fillColors of the frame in the view buffers, enqueued on the context's stream; *ocol / *odep: the filled frame
+static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out)
+{
   FillLayout L;
   make_fill_layout(ctx->view_w, ctx->view_h, &L);
   const size_t nb = fill_band_texels(L), npix = (size_t)L.W * L.H;
@@ -303,8 +310,99 @@ try {
   launch_fill_colors(L, ctx->fill_tabs, (const float4*)ctx->d_view, ctx->d_view + npix * 4, acol, adep, ocol, odep, ctx->stream);
   tend(ctx, "holefill", ctx->stream);
   LAUNCHCHK("fill_colors");
+  ctx->filled_w = L.W;
+  ctx->filled_h = L.H;
+  *ocol_out = ocol;
+  *odep_out = odep;
+  return RGBDR_OK;
+}
+
+int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "fill_colors before raymarch");
+  HIPCHK(hipSetDevice(ctx->device));
+  float4* ocol;
+  float* odep;
+  int rc = fill_view_frame(ctx, &ocol, &odep);
+  if (rc != RGBDR_OK) return rc;
+  const size_t npix = (size_t)ctx->view_w * ctx->view_h;
   if (color) HIPCHK(hipMemcpyAsync(color, ocol, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
   if (depth) HIPCHK(hipMemcpyAsync(depth, odep, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
+int rgbdr_draw(rgbdr_ctx* ctx, const rgbdr_view* v, int fill_holes)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (ctx->cfg.slab_count > 1)
+    return ctx->fail(RGBDR_ERR_STATE, "a Z slab cannot ray-march alone: use rgbdr_raymarch_find / _shade across the slabs");
+  RaymarchParams p;
+  tbegin(ctx, "3recon", ctx->stream);
+  int rc = prepare_raymarch(ctx, v, &p, true);  // (drawDepthLimits inside, when the view asks for space skipping)
+  if (rc != RGBDR_OK) return rc;
+  tbegin(ctx, "draw", ctx->stream);
+  launch_raymarch(p, 0, ctx->stream);
+  tend(ctx, "draw", ctx->stream);
+  LAUNCHCHK("raymarch");
+  ctx->filled_w = ctx->filled_h = 0;
+  if (fill_holes) {
+    float4* ocol;
+    float* odep;
+    rc = fill_view_frame(ctx, &ocol, &odep);
+    if (rc != RGBDR_OK) return rc;
+  }
+  tend(ctx, "3recon", ctx->stream);
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
+// where the displayed frame lives: the ray-marched one in the view buffers, the filled one behind the atlas band
+static int view_frame_pointers(rgbdr_ctx* ctx, int filled, float** color, float** depth)
+{
+  if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "no frame: nothing was ray-marched or uploaded");
+  const size_t npix = (size_t)ctx->view_w * ctx->view_h;
+  if (!filled) {
+    *color = ctx->d_view;
+    *depth = ctx->d_view + npix * 4;
+    return RGBDR_OK;
+  }
+  if (ctx->filled_w != ctx->view_w || ctx->filled_h != ctx->view_h || !ctx->d_fill)
+    return ctx->fail(RGBDR_ERR_STATE, "the frame in the view buffers has not been filled (rgbdr_fill_colors / rgbdr_draw with fill_holes)");
+  FillLayout L;
+  make_fill_layout(ctx->view_w, ctx->view_h, &L);
+  const size_t nb = fill_band_texels(L);
+  *color = ctx->d_fill + nb * 4;
+  *depth = ctx->d_fill + (nb + npix) * 4 + nb;
+  return RGBDR_OK;
+}
+
+int rgbdr_device_view_frame(rgbdr_ctx* ctx, int filled, void** color, void** depth, int* width, int* height)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  float *c, *d;
+  int rc = view_frame_pointers(ctx, filled, &c, &d);
+  if (rc != RGBDR_OK) return rc;
+  if (color) *color = c;
+  if (depth) *depth = d;
+  if (width) *width = ctx->view_w;
+  if (height) *height = ctx->view_h;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
+int rgbdr_readback_view_frame(rgbdr_ctx* ctx, int filled, float* color, float* depth)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  float *c, *d;
+  int rc = view_frame_pointers(ctx, filled, &c, &d);
+  if (rc != RGBDR_OK) return rc;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t npix = (size_t)ctx->view_w * ctx->view_h;
+  if (color) HIPCHK(hipMemcpyAsync(color, c, npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (depth) HIPCHK(hipMemcpyAsync(depth, d, npix * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }
@@ -324,6 +422,7 @@ try {
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->view_w = width;
   ctx->view_h = height;
+  ctx->filled_w = ctx->filled_h = 0;
   return RGBDR_OK;
 }
 RGBDR_CONTAIN(ctx)

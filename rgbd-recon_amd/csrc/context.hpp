@@ -147,6 +147,7 @@ struct rgbdr_ctx {
   size_t fill_floats = 0;
   int* d_fill_tabs = nullptr;  // tap tables of the inpaint passes for a fill_tab_w x fill_tab_h viewport (FillTabs)
   int fill_tab_w = 0, fill_tab_h = 0;
+  int filled_w = 0, filled_h = 0;  // size of the frame the filled image belongs to (0: the view buffers changed since)
   rgbdr::FillTabs fill_tabs{};
   bool integrated = false;
 

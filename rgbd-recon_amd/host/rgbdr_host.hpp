@@ -721,6 +721,28 @@ class ReconIntegration : public Reconstruction {
       if (!(m_frame.depth[i] < 1.0f))
         for (int c = 0; c < 4; ++c) m_frame.color[4 * i + c] = m_clear_color[c];
   }
+  // The same drawF() for a display loop: everything is enqueued behind the frame's passes and nothing is copied back --
+  // the frame stays on the device like the reference's stays in the window (rgbdr_draw).  deviceFrame() says where
+  // (filled = m_fill_holes); pixels of depth 1 keep the ray-march's / fill's values (the host applies its clear colour
+  // when it presents the frame).
+  void drawFOnDevice()
+  {
+    if (!m_have_view) throw std::invalid_argument("ReconIntegration::drawFOnDevice() before setView()");
+    rgbdr_view view = m_view;
+    view.skip_space = m_skip_space ? 1 : 0;
+    check(m_be.ctx(), rgbdr_draw(m_be.ctx(), &view, m_fill_holes ? 1 : 0));
+  }
+  struct DeviceFrame {
+    void* color = nullptr;  // [height][width][4] f32
+    void* depth = nullptr;  // [height][width] f32
+    int width = 0, height = 0;
+  };
+  DeviceFrame deviceFrame() const
+  {
+    DeviceFrame f;
+    check(m_be.ctx(), rgbdr_device_view_frame(m_be.ctx(), m_fill_holes ? 1 : 0, &f.color, &f.depth, &f.width, &f.height));
+    return f;
+  }
   void setClearColor(float r, float g, float b, float a)
   {
     m_clear_color[0] = r, m_clear_color[1] = g, m_clear_color[2] = b, m_clear_color[3] = a;

@@ -9,20 +9,30 @@ real OpenGL implementation (texture units, rasteriser, image stores, atomics inc
   CPU, anywhere:         oracle  vs fixtures, within the tolerances below
   GPU:                   HIP path vs fixtures, same tolerances (the HIP path is bit-identical to the oracle)
 
-Tolerances (absolute; what is observed is in DESIGN.md section 2).  They are llvmpipe-against-IEEE differences, not
-slack for the algorithm: llvmpipe evaluates pow / exp / inversesqrt / normalize with its own polynomial and Newton
-approximations and filters 8-bit textures with 8-bit weights, the oracle uses libm and float weights.
-  morph, depth_rg (float depth frames), depth_b, silhouette, brick counters     bit-exact
-  morph, depth_rg of u8 depth frames                                            1e-6   (unorm8 -> float: x * (1/255) vs x / 255)
-  Lab colour                                                                    4e-3   (pow(x, 1/3), 8-bit bilinear weights)
-  normals                                                                       5e-5   (1.3e-5 seen at 512 x 424, where the differenced positions are closest);
-                                                                                0.1 % of the components up to 1e-3 (near-degenerate cross products)
-  quality                                                                       2e-6 + 2e-5 relative; excluded: texels where llvmpipe's
-                                                                                pow(angle < 0, 2) is NaN (undefined in GLSL) or
-                                                                                a NaN normal is a bilinear neighbour (weight 0)
-  TSDF                                                                          5e-7 (2.3e-7 seen with four 512 x 424 sensors, <= 2e-9 on
-                                                                                the small scenes), same class (-limit / +limit / surface)
-                                                                                everywhere, voxels fed by such a NaN excluded"""
+Tolerances (absolute; what is observed is in DESIGN.md section 2, the same statement).  They are llvmpipe-against-IEEE
+differences, not slack for the algorithm: llvmpipe evaluates pow / exp / inversesqrt / normalize with its own polynomial
+and Newton approximations and filters 8-bit textures with 8-bit weights, the oracle uses libm and float weights.
+  morph, depth_rg (float depth frames), depth_b, silhouette     bit-exact, every scene
+  morph, depth_rg of u8 depth frames                            1e-6   (unorm8 -> float: x * (1/255) vs x / 255)
+  Lab colour                                                    4e-3   (pow(x, 1/3), 8-bit bilinear weights)
+  normals                                                       5e-5   (1.2e-5 seen at 512 x 424, where the differenced positions are closest);
+                                                                0.1 % of the components up to 1e-3 (near-degenerate cross products)
+  quality                                                       2e-6 + 2e-5 relative; excluded: texels where llvmpipe's
+                                                                pow(angle < 0, 2) is NaN (undefined in GLSL; include/rgbdr.h at
+                                                                rgbdr_process_textures) or a NaN normal is a bilinear neighbour
+                                                                (weight 0) -- each excluded texel is checked to have a negative angle
+  brick counters                                                equal on the small scenes; at 512 x 424 the sum of |differences| is
+                                                                within 1e-3 of the counter sum (124 of 388 134 seen: an increment
+                                                                lands in the neighbouring brick when the world position's last bit
+                                                                differs at a brick face); the occupied list is equal everywhere
+  TSDF                                                          5e-7 (2.3e-7 seen with four 512 x 424 sensors, <= 2e-9 on the small
+                                                                scenes), except voxels all of whose in-band sensors look at the
+                                                                surface at a grazing angle (total weight < 1e-8: each is verified to
+                                                                lie between its sensors' signed distances; at most 2e-4 of a sample --
+                                                                3 of 59 845 seen on the 512^3 bands, max 6.9e-6); voxels fed by a
+                                                                NaN-on-llvmpipe quality texel excluded
+  TSDF class (-limit / surface band / +limit)                   the same everywhere, except a voxel whose two values lie within 1e-6 of
+                                                                the same boundary (class_flips: 1 of 59 419 seen in the DXT1 sample)"""
 import os
 import sys
 
