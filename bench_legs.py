@@ -60,6 +60,7 @@ def run_all(rig, out, lean=False):
         run_leg(rig, out, "post_pass", lambda: leg_post_pass(rig))
         run_leg(rig, out, "host_fed", lambda: leg_host_fed(rig))
         run_leg(rig, out, "reference_defaults", lambda: leg_reference_defaults(rig))
+        run_leg(rig, out, "default_display_frame", lambda: leg_default_display_frame(rig))
         run_leg(rig, out, "inverse_lut", lambda: leg_inverse_lut(rig))
         if rig.rank == 0 and not rig.args.no_cpu_baseline:
             run_leg(rig, out, "cpu_baseline", lambda: cpu_baseline(rig), budget=300.0)
@@ -609,6 +610,95 @@ def leg_reference_defaults(rig):
         rc.close()
 
 
+def leg_default_display_frame(rig):
+    """ONE number for what the reference shows per frame in its default mode (source/kinect_client.cpp:572-617:
+    NetKinectArray::update, clearOccupiedBricks, processTextures, updateOccupiedBricks, integrate, drawF =
+    drawDepthLimits + ray-march + fillColors; bricks on, skip-space on, colorfill on, DXT1 1280 x 1080 colour, a
+    1280 x 720 window), end to end on one stream with no host synchronisation inside the frame (rgbdr_draw): on the
+    reference's own box (200 x 221 x 200 voxels, 10-voxel bricks, inverse LUT 286 x 315 x 286) and on the 512^3
+    benchmark grid, static and with four frames in rotation, with the stages' event timers of one more frame."""
+    torch, capi, synth = rig.torch, rig.capi, rig.synth
+    N, W, H = rig.N, rig.W, rig.H
+    sc = synth.Scene(N, W, H, lut_res=(128, 106, 128), seed=1234, color_wh=(1280, 1080))
+    frames = []
+    for k in range(4):
+        d, c = (sc.depth, sc.color) if k == 0 else sc.frame(k)
+        blocks = np.stack([synth.encode_dxt(c[i], 1) for i in range(N)])
+        frames.append((torch.from_numpy(d).to(rig.dev), torch.from_numpy(np.ascontiguousarray(blocks)).to(rig.dev)))
+    torch.cuda.synchronize()
+    out = {"window": [1280, 720], "colour": "DXT1 1280x1080", "mode": "bricks on, skip-space on, colorfill on (the reference's defaults)"}
+
+    def measure(rc, bbox_max):
+        view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, bbox_max)
+        view.skip_space = 1
+
+        def frame(k, count):
+            d, b = frames[k % count]
+            rc.update_device(d.data_ptr(), b.data_ptr())
+            rc.clear_occupied_bricks(); rc.process_textures(); rc.update_occupied_bricks(); rc.integrate()
+            rc.draw(view, True)
+
+        def run(count, n=100):
+            for k in range(8):
+                frame(k, count)
+            rc.sync()
+            t0 = time.perf_counter()
+            for k in range(n):
+                frame(k, count)
+            rc.sync()
+            return (time.perf_counter() - t0) / n * 1e3
+        warm_clocks(rc, lambda k: frame(k, 1))
+        res = {"grid": list(rc.geo.res_volume), "brick_voxels": int(rc.geo.brick_voxels)}
+        res["ms_per_frame"] = round(run(1), 4)
+        res["ms_per_frame_moving"] = round(run(4), 4)
+        res["frames_per_s"] = round(1e3 / res["ms_per_frame"], 1)
+        res["occupied_ratio"] = round(rc.occupied_ratio(), 4)
+        rc.set_timer_detail(1)
+        rc.enable_timers(True)
+        try:
+            frame(0, 1)
+            frame(1, 1)
+            rc.sync()
+            res["stages_ms"] = {name: round(rc.timer_ns(t) * 1e-6, 4) for name, t in
+                                (("pre_chain", "1preprocess"), ("integrate", "2integrate"), ("depth_peels", "brickdraw"),
+                                 ("raymarch", "draw"), ("holefill", "holefill"), ("drawF", "3recon"))}
+        finally:
+            rc.enable_timers(False)
+            rc.set_timer_detail(0)
+        _, dep = rc.readback_view_frame(True)
+        res["surface_pixels"] = round(float((dep < 1).mean()), 4)
+        return res
+
+    bmax = (1.0, 2.2, 1.0)
+    rc = capi.Context(capi.make_config(N, (W, H), color_wh=(1280, 1080), bbox_max=bmax, voxel_size=0.01, brick_size=0.1,
+                                       compress_rgb=1), rig.local_rank)
+    try:
+        for i in range(N):
+            rc.set_calibration(i, sc.xyz[i], sc.lut_res, sc.uv[i], sc.lut_res, (0.5, 4.5))
+            rc.set_inverse_calibration(i, rc.generate_inverse_lut(i, (286, 315, 286)), (286, 315, 286))
+        out["reference_box"] = measure(rc, bmax)
+    finally:
+        rc.close()
+    keep = os.environ.get("RGBDR_ARENA_TRIALS")
+    os.environ["RGBDR_ARENA_TRIALS"] = "1"            # (the brick-skipping sweep reads 3 % of the arena: placement does not matter)
+    rc = None
+    try:
+        rc = capi.Context(capi.make_config(N, (W, H), color_wh=(1280, 1080), voxel_size=2.0 / rig.G, brick_size=8 * 2.0 / rig.G,
+                                           compress_rgb=1, res_override=rig.grid), rig.local_rank)
+        for i in range(N):
+            rc.set_calibration(i, sc.xyz[i], sc.lut_res, sc.uv[i], sc.lut_res, (0.5, 4.5))
+            rc.synth_inverse_calibration(i, sc.pinhole(i))
+        out["grid_512"] = measure(rc, synth.BBOX_MAX)
+    finally:
+        if keep is None:
+            os.environ.pop("RGBDR_ARENA_TRIALS", None)
+        else:
+            os.environ["RGBDR_ARENA_TRIALS"] = keep
+        if rc is not None:
+            rc.close()
+    return out
+
+
 def leg_inverse_lut(rig):
     """f-3: the calib_inverter search (framework/calibration/calibration_inverter.cpp:99-155) on the device, at the
     benchmark grid: one sensor's 512^3 inverse LUT from its 128 x 106 x 128 forward LUT, straight into the resident layout.
@@ -743,12 +833,33 @@ def cpu_baseline(rig, reps=5):
     # comparisons with the reference's own shaders: each its own guarded sub-leg (they are not the baseline)
     for key, fn in (("reference_cpu_work", lambda: reference_cpu_work(rig, orc)),
                     ("reference_shader_text", lambda: reference_text_baseline(rig, hip, sil, db, q)),
-                    ("reference_glsl_on_mesa", lambda: reference_glsl_checks(rig))):
+                    ("reference_glsl_on_mesa", lambda: reference_glsl_checks(rig)),
+                    ("driver_weight_bound", lambda: driver_weight_bound())):
         try:
             res[key] = fn()
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return res
+
+
+def driver_weight_bound():
+    """What moves when every LINEAR weight is held with 8 fractional bits, as the authors' NVIDIA driver does (INTEGRATION.md
+    section 6): the oracle with exact against the oracle with 8-bit weights on four 512 x 424 sensors into 128^3 (the Mesa
+    sample's scene), ~6 s of CPU.  The bound a maintainer comparing against a real NVIDIA run should expect -- derived, not
+    a parity claim of the HIP path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import driver_weight_bound as dwb
+    c = dwb.case_sample()
+    t = c["tsdf"]
+    return {"what": "oracle, exact vs 8-bit LINEAR weights (GL 4.4 8.14; CalibVolumes.cpp:76,135,140), " + c["what"],
+            "tsdf_voxels_in_band": t["voxels_in_band"], "tsdf_median_abs_diff_in_band": t["median_abs_diff_in_band"],
+            "tsdf_p99_abs_diff_in_band": t["p99_abs_diff_in_band"], "tsdf_max_abs_diff": t["max_abs_diff"],
+            "tsdf_voxels_beyond_5e-7": t["voxels_beyond_5e-7"], "tsdf_voxels_beyond_1e-4": t["voxels_beyond_1e-4"],
+            "tsdf_voxels_changing_class": t["voxels_changing_class"],
+            "depth_texels_flipping_validity": c["depth_rg"]["values_differing"],
+            "brick_increments_moving": c["brick_counters"]["sum_abs_diff"], "brick_increments": c["brick_counters"]["sum"],
+            "occupied_bricks_on_one_side_only": c["occupied_list"]["only_exact"] + c["occupied_list"]["only_8bit"],
+            "all_cases": "profiles/r06_driver_weight_bound.json"}
 
 
 def reference_cpu_work(rig, orc):

@@ -266,6 +266,56 @@ def test_fill_colors_of_random_frames(pkg, orc, wh, hole_share):
     ctx.close()
 
 
+@pytest.mark.parametrize("skip", [False, True])
+def test_draw_is_drawF_without_a_host_round_trip(pkg, orc, skip):
+    """rgbdr_draw = ReconIntegration::drawF (recon_integration.cpp:151-178): depth limits when skipping, the ray-march, fillColors
+    -- enqueued behind the frame's passes with no host synchronisation, the frame left on the device.  Frame after frame (two
+    scenes alternating, so that a draw that overtook its integrate would show the other scene) the device frame equals the
+    oracle's ray-march and its hole filling bit for bit."""
+    capi, synth = pkg.capi, pkg.synth
+    scene, ctx, inv = setup(pkg, orc)
+    other = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7)
+    ctx.set_use_bricks(skip)
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 160, 90, BMIN, BMAX)
+    view.skip_space = 1 if skip else 0
+    with pytest.raises(capi.RgbdrError) as e:                # nothing drawn yet
+        ctx.readback_view_frame(False)
+    assert e.value.status == capi.ERR_STATE
+    g = ctx.geo
+    for k in range(4):
+        sc = (scene, other)[k % 2]
+        ctx.update(sc.depth, sc.color)                       # the frame's calls and the draw: nothing waits in between
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.integrate()
+        ctx.draw(view, fill_holes=(k != 1))
+        if k == 1:
+            with pytest.raises(capi.RgbdrError) as e:        # this frame was not filled: the filled image belongs to the last one
+                ctx.readback_view_frame(True)
+            assert e.value.status == capi.ERR_STATE
+        color, depth = ctx.readback_view_frame(False)
+        tsdf = ctx.readback_tsdf()
+        db = [ctx.readback_image(4, i) for i in range(2)]
+        q = [ctx.readback_image(7, i) for i in range(2)]
+        peels = None
+        if skip:
+            ids, _ = ctx.get_occupied()
+            mask = np.zeros(g.num_bricks, np.uint8)
+            mask[ids] = 1
+            peels = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+        rc, rd, _ = orc.raymarch(bytes(view), tsdf, inv, scene.uv, [sc.color[i] for i in range(2)], db, q, peels=peels)
+        assert same_bits(depth, rd) and same_bits(color, rc), (k, count_diff(color, rc))
+        if k != 1:
+            fc, fd = ctx.readback_view_frame(True)
+            oc, od = orc.fill_colors(rc, rd)
+            assert same_bits(fc, oc) and same_bits(fd, od), (k, count_diff(fc, oc))
+            cptr, dptr, w, h = ctx.device_view_frame(True)
+            assert (w, h) == (160, 90) and cptr and dptr and cptr != ctx.device_view_frame(False)[0]
+    assert (rd < 1).mean() > 0.05
+    ctx.close()
+
+
 def test_fill_colors_needs_a_frame(pkg):
     capi = pkg.capi
     ctx = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=0.5), 0)
