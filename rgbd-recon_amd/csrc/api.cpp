@@ -72,6 +72,10 @@ static void free_volume(rgbdr_ctx* c)
   c->halo_last = -1;
   (void)hipFree(c->d_tile_list);
   (void)hipFree(c->d_tile_state);
+  (void)hipFree(c->d_empty_tiles);
+  c->d_empty_tiles = nullptr;
+  c->empty_tiles_cap = 0;
+  c->tile_states_kept = false;
   c->d_tile_list = c->d_tile_state = nullptr;
   (void)hipFree(c->d_counters);
   (void)hipFree(c->d_ids);
@@ -968,6 +972,7 @@ try {
                             face_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
   ctx->integrated = true;
+  ctx->tile_states_kept = all_tiled && (bricks || elide || skip_bg);
   if (sb >= 0 && ctx->halo > 0) ctx->halo_staged = true;  // the staging set of this step holds this sweep's faces
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));

@@ -158,6 +158,27 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
     if (rc_ != RGBDR_OK) return rc_;
   }
   p.peels = (const float4*)ctx->d_peels;   // read with skip_space only
+  // the sweep's record of the tiles that hold -limit throughout: samples there are not fetched (march_ahead)
+  p.empty_bits = nullptr;
+  p.empty_words = 0;
+  {
+    const rgbdr_geometry& gg = ctx->geo;
+    const size_t ntiles = (size_t)gg.tiles[0] * gg.tiles[1] * gg.tiles[2];
+    const size_t words = (ntiles + 63) / 64 * 2;  // (a ballot of 64 tiles per store)
+    if (ctx->cfg.slab_count == 1 && ctx->tile_states_kept && ctx->d_tile_state && words * 4 <= 48 * 1024 && !std::getenv("RGBDR_NO_EMPTY_TILES")) {
+      if (ctx->empty_tiles_cap < words) {
+        (void)hipFree(ctx->d_empty_tiles);
+        ctx->d_empty_tiles = nullptr;
+        ctx->empty_tiles_cap = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_empty_tiles, words * 4));
+        ctx->empty_tiles_cap = words;
+      }
+      launch_empty_tiles(ctx->d_tile_state, ctx->clear_epoch, gg.tiles[0], gg.tiles[1], gg.tiles[2], ctx->d_empty_tiles, ctx->stream);
+      LAUNCHCHK("empty_tiles");
+      p.empty_bits = ctx->d_empty_tiles;
+      p.empty_words = (int)words;
+    }
+  }
   std::memcpy(p.projection, v->projection, 64);
   std::memcpy(p.normal_matrix, v->normal_matrix, 64);
   std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);
@@ -199,8 +220,19 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
     for (int a = 0; a < 3; ++a) p.uv_res[i][a] = (int)ctx->uv_res[i][a];
     p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
   }
-  { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }  // the shader samples the RGB8 frames
+  // the shader samples the colour frames: RGB8, or -- a DXT upload nobody has asked the decoded frame of -- its blocks
   p.color = ctx->d_color;
+  p.color_dxt = nullptr;
+  p.color_layer_bytes = 0;
+  p.color_mode = ctx->cfg.compress_rgb;
+  if (ctx->cfg.compress_rgb && !ctx->color_decoded && !std::getenv("RGBDR_DECODE_FOR_VIEW")) {
+    const size_t blocks = (size_t)((ctx->cfg.color_w + 3) / 4) * ((ctx->cfg.color_h + 3) / 4);
+    p.color_dxt = ctx->d_color_dxt;
+    p.color_layer_bytes = blocks * (ctx->cfg.compress_rgb == 1 ? 8 : 16);
+  } else {
+    int rc_ = ensure_color_decoded(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   p.out_color = (float4*)ctx->d_view;
   p.out_depth = ctx->d_view + npix * 4;
   p.out_samples = ctx->d_view + npix * 5;

@@ -160,6 +160,9 @@ struct rgbdr_ctx {
   bool clear_pending = false;       // clearOccupiedBricks was called; the zeroing rides on the next k_morph
   uint32_t* d_tile_list = nullptr;  // brick-skipping sweep: work list of owned tiles + its length (last entry)
   uint32_t* d_tile_state = nullptr; // per owned tile: epoch of the brick sweep since which it holds -limit (0: never)
+  bool tile_states_kept = false;    // the last rgbdr_integrate kept them (brick / store-eliding / background-skip sweep)
+  unsigned* d_empty_tiles = nullptr; // bit per tile: it and its +1 neighbours hold -limit (the ray-marcher's sample skip)
+  size_t empty_tiles_cap = 0;
   int tile_count_parity = 0;        // which of the two list counters the next brick sweep appends to
   // halo staging for Z slabs: two sets of (lower face, upper face) buffers of `halo` tile layers
   float* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};

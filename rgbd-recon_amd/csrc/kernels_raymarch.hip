@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "dxt.cuh"
 #include "rgbdr_internal.hpp"
 #include "sampling.cuh"
 
@@ -48,6 +49,32 @@ __device__ __forceinline__ Axis resident_rows(const RaymarchParams& p, Axis z)
   z.i0 = clampi(z.i0, p.res_z0, p.res_z1 - 1);
   z.i1 = clampi(z.i1, p.res_z0, p.res_z1 - 1);
   return z;
+}
+
+// the eight texels of texture(volume_tsdf, pos) and their blend, apart: march_ahead issues the loads of all its samples
+// before it blends any (a blend inside the branch that skips a known sample would wait for that sample's loads alone)
+struct Taps {
+  float t[8];
+};
+__device__ __forceinline__ Taps tsdf_taps(const RaymarchParams& p, const Axis& X, const Axis& Y, const Axis& Z)
+{
+  // tile-linear address = a sum of one term per axis: six terms for the eight texels
+  const unsigned x0 = (unsigned)((X.i0 >> 3) * kTileVoxels + (X.i0 & 7)), x1 = (unsigned)((X.i1 >> 3) * kTileVoxels + (X.i1 & 7));
+  const unsigned sy = (unsigned)p.TX * kTileVoxels;
+  const unsigned y0 = (unsigned)(Y.i0 >> 3) * sy + (unsigned)((Y.i0 & 7) * 8), y1 = (unsigned)(Y.i1 >> 3) * sy + (unsigned)((Y.i1 & 7) * 8);
+  const size_t sz = (size_t)p.TY * sy;
+  const float* z0 = p.tsdf + (size_t)((Z.i0 >> 3) - p.tz_alloc0) * sz + (size_t)((Z.i0 & 7) * 64);
+  const float* z1 = p.tsdf + (size_t)((Z.i1 >> 3) - p.tz_alloc0) * sz + (size_t)((Z.i1 & 7) * 64);
+  Taps r;
+  r.t[0] = z0[y0 + x0], r.t[1] = z0[y0 + x1];
+  r.t[2] = z0[y1 + x0], r.t[3] = z0[y1 + x1];
+  r.t[4] = z1[y0 + x0], r.t[5] = z1[y0 + x1];
+  r.t[6] = z1[y1 + x0], r.t[7] = z1[y1 + x1];
+  return r;
+}
+__device__ __forceinline__ float tsdf_blend(const Taps& r, float ax, float ay, float az)
+{
+  return lerpf(lerpf(lerpf(r.t[0], r.t[1], ax), lerpf(r.t[2], r.t[3], ax), ay), lerpf(lerpf(r.t[4], r.t[5], ax), lerpf(r.t[6], r.t[7], ax), ay), az);
 }
 
 // texture(volume_tsdf, pos).r
@@ -180,13 +207,30 @@ __device__ __forceinline__ void shade_fragment(const RaymarchParams& p, const fl
                                     : tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], sp[0], sp[1], sp[2]);
     const float2 pcol = tex3d_uv(p.cv_uv[i], p.uv_res[i][0], p.uv_res[i][1], p.uv_res[i][2], pcal.x, pcal.y, pcal.z);
     const Axis CX = axis_linear(pcol.x, p.Wc), CY = axis_linear(pcol.y, p.Hc);
-    const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
     float col[3];
+    if (p.color_dxt) {  // the frame as uploaded: the four texels decoded on the spot (k_pre_depth's lookup does the same)
+      const uint8_t* layer = p.color_dxt + (size_t)i * p.color_layer_bytes;
+      const int bw = (p.Wc + 3) / 4, bx0 = CX.i0 >> 2, bx1 = CX.i1 >> 2, by0 = CY.i0 >> 2, by1 = CY.i1 >> 2;
+      const uint2 b00 = dxt_block(layer, bw, p.color_mode, bx0, by0);
+      const uint2 b10 = bx1 == bx0 ? b00 : dxt_block(layer, bw, p.color_mode, bx1, by0);
+      const uint2 b01 = by1 == by0 ? b00 : dxt_block(layer, bw, p.color_mode, bx0, by1);
+      const uint2 b11 = by1 == by0 ? b10 : (bx1 == bx0 ? b01 : dxt_block(layer, bw, p.color_mode, bx1, by1));
+      int p00[3], p10[3], p01[3], p11[3];
+      dxt_texel(b00, p.color_mode, CX.i0, CY.i0, p00);
+      dxt_texel(b10, p.color_mode, CX.i1, CY.i0, p10);
+      dxt_texel(b01, p.color_mode, CX.i0, CY.i1, p01);
+      dxt_texel(b11, p.color_mode, CX.i1, CY.i1, p11);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-      const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-      col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
+      for (int k = 0; k < 3; ++k)
+        col[k] = lerpf(lerpf((float)p00[k] / 255.0f, (float)p10[k] / 255.0f, CX.a), lerpf((float)p01[k] / 255.0f, (float)p11[k] / 255.0f, CX.a), CY.a);
+    } else {
+      const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+        const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
+        col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
+      }
     }
     const uint2* frame = p.frame[i];
     const int ix = axis_nearest(pcal.x, p.W), iy = axis_nearest(pcal.y, p.H);
@@ -275,16 +319,48 @@ __device__ __forceinline__ void shade_fragment(const RaymarchParams& p, const fl
 #ifndef RGBDR_AHEAD_FULL
 #define RGBDR_AHEAD_FULL 1
 #endif
+// Tiles known to hold -limit throughout (p.empty_tiles, k_empty_tiles): a sample whose 2 x 2 x 2 footprint lies in such tiles
+// is T0 + a * (T1 - T0) of eight equal finite values -- exactly -limit for every weight -- so it is not fetched.  Its
+// position is still accumulated and it is still counted: the same additions, the same sample count, the same frame.
 template <int kAhead>
-__device__ __forceinline__ void march_ahead(const RaymarchParams& p, const Ray& r, float* sp, float& prev, unsigned& num, bool& hit)
+__device__ __forceinline__ void march_ahead(const RaymarchParams& p, const Ray& r, float* sp, float& prev, unsigned& num, bool& hit,
+                                            const unsigned* empty_bits = nullptr)
 {
+  const float held = -p.limit;
   while (num < r.max_num && !hit) {
     float pos[kAhead][3], dens[kAhead];
+    if (empty_bits) {
+      Axis X[kAhead], Y[kAhead], Z[kAhead];
+      bool known[kAhead];
 #pragma unroll
-    for (int j = 0; j < kAhead; ++j) {
+      for (int j = 0; j < kAhead; ++j) {
 #pragma unroll
-      for (int a = 0; a < 3; ++a) pos[j][a] = j == 0 ? sp[a] : pos[j - 1][a] + r.step[a];
-      dens[j] = tsdf_sample(p, pos[j][0], pos[j][1], pos[j][2]);
+        for (int a = 0; a < 3; ++a) pos[j][a] = j == 0 ? sp[a] : pos[j - 1][a] + r.step[a];
+        X[j] = axis_linear(pos[j][0], p.X);
+        Y[j] = axis_linear(pos[j][1], p.Y);
+        Z[j] = resident_rows(p, axis_linear(pos[j][2], p.Z));
+        const unsigned tile = (unsigned)(((Z[j].i0 >> 3) * p.TY + (Y[j].i0 >> 3)) * p.TX + (X[j].i0 >> 3));
+        known[j] = ((empty_bits[tile >> 5] >> (tile & 31u)) & 1u) != 0u;
+      }
+      Taps taps[kAhead];
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+        if (!known[j]) {
+          taps[j] = tsdf_taps(p, X[j], Y[j], Z[j]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) taps[j].t[k] = held;  // (the blend of eight equal values is that value)
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) dens[j] = tsdf_blend(taps[j], X[j].a, Y[j].a, Z[j].a);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kAhead; ++j) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) pos[j][a] = j == 0 ? sp[a] : pos[j - 1][a] + r.step[a];
+        dens[j] = tsdf_sample(p, pos[j][0], pos[j][1], pos[j][2]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < kAhead; ++j) {
@@ -303,6 +379,33 @@ __device__ __forceinline__ void march_ahead(const RaymarchParams& p, const Ray& 
       }
     }
   }
+}
+
+// p.empty_bits: a bit per tile = the tile and its +1 neighbours along x, y and z (a LINEAR footprint that starts in the tile
+// ends in one of those) have held -limit since a sweep of the current epoch (IntegrateParams::tile_state, k_brick_clear).
+// 32 KiB for a 512^3 volume: every workgroup of the march that has a ray to march keeps a copy in LDS.
+__global__ __launch_bounds__(256) void k_empty_tiles(const unsigned* __restrict__ tile_state, unsigned epoch, int TX, int TY, int TZ,
+                                                     unsigned long long* __restrict__ bits)
+{
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  bool all = false;
+  if (t < (unsigned)(TX * TY * TZ)) {
+    const int tx = t % TX, ty = (t / TX) % TY, tz = t / (TX * TY);
+    const int x1 = min(tx + 1, TX - 1), y1 = min(ty + 1, TY - 1), z1 = min(tz + 1, TZ - 1);
+    all = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int x = (k & 1) ? x1 : tx, y = (k & 2) ? y1 : ty, z = (k & 4) ? z1 : tz;
+      all = all && tile_state[((size_t)z * TY + y) * TX + x] == epoch;
+    }
+  }
+  const unsigned long long m = __ballot(all);   // (tiles past the end: 0)
+  if ((threadIdx.x & 63) == 0) bits[t >> 6] = m;
+}
+void launch_empty_tiles(const unsigned* tile_state, unsigned epoch, int TX, int TY, int TZ, unsigned* bits, hipStream_t s)
+{
+  const unsigned n = (unsigned)(TX * TY * TZ);
+  hipLaunchKernelGGL(k_empty_tiles, dim3((n + 255) / 256), dim3(256), 0, s, tile_state, epoch, TX, TY, TZ, (unsigned long long*)bits);
 }
 
 constexpr int kNoHit = 0x7fffffff;
@@ -324,22 +427,35 @@ __device__ __forceinline__ void wave_square_pixel(int& px, int& py)
 template <int MODE, int AHEAD = 1>
 __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
 {
+  extern __shared__ unsigned s_empty[];  // MODE 0 with p.empty_bits: the workgroup's copy of the bitmap
   int px, py;
   wave_square_pixel(px, py);
-  if (px >= p.width || py >= p.height) return;
-  const size_t o = (size_t)py * p.width + px;
+  const bool inside = px < p.width && py < p.height;
+  const size_t o = inside ? (size_t)py * p.width + px : 0;
   const float limit = p.limit;
   float4 rgba = make_float4(0.0f, 1.0f, 0.0f, 0.0f);  // ViewLod::enable clear colour
   float fdepth = 1.0f, fsamples = 0.0f;
   int khit = kNoHit;
-  Ray r = ray_setup(p, px, py, o);
+  Ray r;
+  r.covered = false;
+  r.max_num = 0u;
+  if (inside) r = ray_setup(p, px, py, o);
+  const unsigned* empty_bits = nullptr;
+  if (MODE == 0 && p.empty_bits) {  // (uniform) most workgroups of a frame have no ray to march: they skip the copy
+    if (__syncthreads_or(r.covered && r.max_num > 0u)) {
+      for (int w = threadIdx.y * 16 + threadIdx.x; w < p.empty_words; w += 256) s_empty[w] = p.empty_bits[w];
+      __syncthreads();
+      empty_bits = s_empty;
+    }
+  }
+  if (!inside) return;
   if (r.covered) {
     float sp[3] = {r.sp[0], r.sp[1], r.sp[2]};
     if (MODE == 0) {
       float prev = -limit;
       unsigned num = 0;
       bool hit = false;
-      march_ahead<AHEAD>(p, r, sp, prev, num, hit);
+      march_ahead<AHEAD>(p, r, sp, prev, num, hit, empty_bits);
       fsamples = (float)num * 0.0027f;
       if (hit) shade_fragment(p, sp, rgba, fdepth);
     } else if (MODE == 1) {
@@ -673,11 +789,12 @@ void launch_depth_peels(const PeelParams& p, hipStream_t s)
 void launch_raymarch(const RaymarchParams& p, int mode, hipStream_t s)
 {
   dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
+  const size_t lds = mode == 0 && p.empty_bits ? (size_t)p.empty_words * 4 : 0;
   if (mode == 0)
     if (p.skip_space)
-      hipLaunchKernelGGL((k_raymarch<0, RGBDR_AHEAD_SKIP>), grid, dim3(16, 16), 0, s, p);
+      hipLaunchKernelGGL((k_raymarch<0, RGBDR_AHEAD_SKIP>), grid, dim3(16, 16), lds, s, p);
     else
-      hipLaunchKernelGGL((k_raymarch<0, RGBDR_AHEAD_FULL>), grid, dim3(16, 16), 0, s, p);
+      hipLaunchKernelGGL((k_raymarch<0, RGBDR_AHEAD_FULL>), grid, dim3(16, 16), lds, s, p);
   else if (mode == 1)
     if (p.skip_space)
       hipLaunchKernelGGL((k_raymarch<1, RGBDR_AHEAD_SKIP>), grid, dim3(16, 16), 0, s, p);

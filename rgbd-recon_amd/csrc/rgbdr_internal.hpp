@@ -187,14 +187,23 @@ struct RaymarchParams {
   const float2* cv_uv[kMaxSensors];
   int uv_res[kMaxSensors][3];
   const uint8_t* color;        // [N][Hc][Wc][3]
+  const uint8_t* color_dxt;    // ... or the frames still in their DXT1 / DXT5 blocks (color_mode 1 / 5), color_layer_bytes each
+  size_t color_layer_bytes;
+  int color_mode;
   const uint2* frame[kMaxSensors];
   int skip_space;              // start positions from the depth peels (getStartPos)
   const float4* peels;
+  // whole-volume march only: bit per tile, 1 = a sample whose footprint starts in the tile reads -limit from eight texels that
+  // all hold it (launch_empty_tiles, from the brick sweep's tile states); null when the last sweep did not keep them or
+  // the map does not fit a workgroup's LDS
+  const unsigned* empty_bits;
+  int empty_words;
   float4* out_color;
   float* out_depth;
   float* out_samples;
 };
 void launch_raymarch(const RaymarchParams& p, int mode, hipStream_t s);  // 0 whole volume, 1 slab find, 2 slab shade
+void launch_empty_tiles(const unsigned* tile_state, unsigned epoch, int TX, int TY, int TZ, unsigned* bits, hipStream_t s);
 
 // ReconIntegration::drawDepthLimits (glsl/bricks.{vs,gs,fs}) per pixel
 struct PeelParams {

@@ -189,6 +189,34 @@ def test_raymarch_with_resampled_lut(pkg, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", [1, 5])
+def test_raymarch_samples_dxt_colour_frames_as_uploaded(pkg, orc, mode):
+    """compress_rgb 1 / 5 (the reference's default is DXT1): the shading's colour lookup decodes its four texels from the
+    blocks on the spot -- the frame the GL driver would have decoded into the texture (squish's arithmetic, orc.decode_dxt) --
+    without the whole-frame decode; once a consumer has asked for the RGB8 frame the lookup reads that: the same frame, bit for
+    bit, either way"""
+    capi, synth = pkg.capi, pkg.synth
+    scene, ctx, inv = setup(pkg, orc, compress_rgb=mode)
+    W, H = 128, 106
+    blocks = np.stack([synth.encode_dxt(scene.color[i], mode) for i in range(2)])
+    rng = np.random.default_rng(11)
+    blocks[1, : blocks.shape[1] // 4] = rng.integers(0, 256, blocks.shape[1] // 4, dtype=np.uint8)   # arbitrary blocks too
+    decoded = [orc.decode_dxt(blocks[i], W, H, mode) for i in range(2)]
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 96, 72, BMIN, BMAX)
+    ctx.step(scene.depth, blocks)
+    color, depth, ns = ctx.raymarch(view)                       # from the blocks
+    tsdf = ctx.readback_tsdf()
+    db = [ctx.readback_image(4, i) for i in range(2)]
+    q = [ctx.readback_image(7, i) for i in range(2)]
+    rc, rd, rn = orc.raymarch(bytes(view), tsdf, inv, scene.uv, decoded, db, q)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc), count_diff(color, rc)
+    assert (rd < 1).mean() > 0.05 and len(np.unique(color[rd < 1][:, :3])) > 50
+    assert np.array_equal(ctx.readback_color(1), decoded[1])    # now the RGB8 frame exists
+    c2, d2, n2 = ctx.raymarch(view)                             # ... and is what the lookup reads
+    assert same_bits(c2, rc) and same_bits(d2, rd) and same_bits(n2, rn)
+    ctx.close()
+
+
 def test_raymarch_errors(pkg, orc):
     capi = pkg.capi
     scene, ctx, inv = setup(pkg, orc, G=32)
