@@ -119,7 +119,11 @@ def parse_args(argv=None):
                     help="--gpus N > 1: seconds for the whole ladder (every rung together); the driver waits 1800")
     ap.add_argument("--rung-budgets", default="",
                     help="--gpus N > 1: seconds per rung of the ladder, comma separated (default %s)" % ",".join("%d" % b for b in RUNG_BUDGETS))
-    ap.add_argument("--first-rung", type=int, default=0, help="--gpus N > 1: start the ladder at this rung (0-2)")
+    ap.add_argument("--halo-transport", choices=("rccl", "peer"), default="rccl",
+                    help="N > 1 / --slab: what moves the halo faces -- RCCL send / recv (default, the transport north_star names) or "
+                         "'peer': the copy engine, every rank pulling its neighbours' staged faces from their IPC-mapped staging sets "
+                         "(rgbdr_halo_export / _set_peer / _pull_async; the gather of a sharded chain stays on RCCL)")
+    ap.add_argument("--first-rung", type=int, default=0, help="--gpus N > 1: start the ladder at this rung (0-3)")
     return ap.parse_args(argv)
 
 
@@ -378,9 +382,9 @@ def open_transport(rig):
     torch.cuda.set_stream(rig.main_stream)
     rig.transport = {"kind": "rccl" if args.backend == "nccl" else args.backend + " (host-staged)", "group": None}
     rig.managed = bool(args.managed and args.backend == "nccl")
-    if args.backend == "nccl":
-        if "fallback" not in shared:
-            shared["fallback"] = dist.new_group(backend="gloo")
+    if args.backend == "nccl" and "fallback" not in shared:
+        shared["fallback"] = dist.new_group(backend="gloo")
+    if args.backend == "nccl" and args.halo_transport != "peer":    # (the copy-engine halo does not depend on RCCL point-to-point)
         ok, why = True, ""
         try:
             ctx.sync()
@@ -443,6 +447,30 @@ def open_communicators(rig):
     if not rig.managed and want_shard:
         rig.gather = rdist.FrameGather(ctx, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
                                        via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
+
+
+class CopyEngineHalo:
+    """the exchanger of a --halo-transport peer run: the halo steps go to dist.PeerCopySlabExchange, everything else (the gather
+    of the sharded chain, its communicator) to the exchanger the run had"""
+
+    def __init__(self, peer, inner):
+        self.peer, self.inner = peer, inner
+        self.begin_step, self.exchange_async, self.wait, self.last_transfer_ms = peer.begin_step, peer.exchange_async, peer.wait, peer.last_transfer_ms
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def close(self):
+        self.peer.close()
+        if hasattr(self.inner, "close"):
+            self.inner.close()
+
+
+def use_copy_engine_halo(rig):
+    group = rig.shared.get("fallback") if rig.world > 1 else None        # the exports are Python bytes: gloo carries them
+    peer = rig.rdist.PeerCopySlabExchange(rig.ctx, rig.dev, rig.slab_rank, rig.slab_count, group=group, loopback=rig.loop)
+    rig.exchanger = CopyEngineHalo(peer, rig.exchanger)
+    rig.halo_by = "peer"
 
 
 def trial_step(rig):
@@ -552,7 +580,8 @@ def headline_line(rig, dt, stats):
                    "schedule": "pipelined (pre_* of step k+1 overlaps integrate of step k)" if args.pipeline else "sequential",
                    "parallelism": ("zslab%d" % world if world > 1 else "single") + (
                        " (loopback: slab %d of %d on one GPU, its own neighbour over RCCL)" % (rig.slab_rank, rig.slab_count) if loop else ""),
-                   "halo_transport": rig.transport["kind"] if multi else None,
+                   "halo_transport": (("copy engine (hipMemcpyAsync from the neighbours' IPC-mapped staging sets, rgbdr_halo_pull_async)"
+                                       if getattr(rig, "halo_by", "rccl") == "peer" else rig.transport["kind"]) if multi else None),
                    "pre_chain": ("sharded by sensor on a chain-only context one frame ahead of the sweep: %d of %d sensors per rank, the "
                                  "gather of frame k+1 under the sweep of frame k (dist.LaggedChain)" % (N // rig.slab_count, N)) if rig.lag is not None
                    else ("sharded by sensor: %d of %d sensors per rank, packed frames all-gathered + brick counters all-reduced on "
@@ -608,6 +637,9 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         if rig.managed:
             with wd.phase("trial step", 60.0):
                 trial_step(rig)
+    if rig.multi and args.halo_transport == "peer":
+        with wd.phase("transport", 120.0):
+            use_copy_engine_halo(rig)
     with wd.phase("settle", 60.0):
         settle(rig)
     if rig.multi and rig.gather is not None:

@@ -66,6 +66,7 @@ def run_all(rig, out, lean=False):
             run_leg(rig, out, "cpu_baseline", lambda: cpu_baseline(rig), budget=300.0)
     if rig.multi:
         run_leg(rig, out, "halo", lambda: leg_halo(rig, out))
+        run_leg(rig, out, "halo_copy_engine", lambda: leg_halo_copy_engine(rig, out))
         run_leg(rig, out, "post_pass", lambda: leg_post_pass_slabs(rig))
 
 
@@ -192,6 +193,52 @@ def leg_halo(rig, out):
     return {"layers_per_face": int(rig.geo.halo_tile_layers), "bytes_per_face": int(rig.halo[0].numel() * 4),
             "transfer_ms_rank0": rig.exchanger.last_transfer_ms(),
             "transfer_ms_max": max([h for h in per_rank["halo_ms"] if h is not None], default=None) if per_rank else rig.halo_ms}
+
+
+def leg_halo_copy_engine(rig, out):
+    """The same steps with the halo moved by the COPY ENGINE instead of RCCL's send / recv kernels (the C ABI's
+    rgbdr_halo_export / _set_peer / _pull_async; dist.PeerCopySlabExchange): every rank pulls its neighbours' staged faces
+    with device-to-device copies from their IPC-mapped staging sets.  RCCL stays the transport of the headline; this leg
+    says what the alternative gives on the same ranks (the gather of a sharded chain still runs over RCCL)."""
+    ctx, args = rig.ctx, rig.args
+    keep = rig.exchanger
+    keep.wait()
+    rig.barrier()
+    group = rig.shared.get("fallback") if rig.world > 1 else None         # exports are Python bytes: a gloo group carries them
+    peer = rig.rdist.PeerCopySlabExchange(ctx, rig.dev, rig.slab_rank, rig.slab_count, group=group, loopback=rig.loop)
+
+    class Both:                      # halo by copy engine, everything else (the gather) as before
+        begin_step, exchange_async, wait, last_transfer_ms = peer.begin_step, peer.exchange_async, peer.wait, peer.last_transfer_ms
+    rig.exchanger = Both()
+    try:
+        steps = max(8, min(args.steps, 40))
+        warm_clocks(ctx, lambda k: rig.step(False))
+        dt, st = rig.timed(False, steps, 4)
+        ctx.enable_timers(True)
+        ctx.set_timer_detail(2)
+        rig.step(False)
+        rig.step(False)
+        peer.wait()
+        ctx.sync()
+        ms = peer.last_transfer_ms()
+        ctx.enable_timers(False)
+        head = "copy_engine" if getattr(rig, "halo_by", "rccl") == "peer" else "rccl"       # what the headline ran on
+        return {"halo_transport": "copy engine: hipMemcpyAsync from the neighbours' IPC-mapped staging sets behind step words the streams "
+                                  "write / wait for (hipStreamWriteValue32 / hipStreamWaitValue32)"
+                                  + (" (loopback: this process is its own neighbour, no IPC)" if rig.loop else ""),
+                "ms_per_step": round(dt / steps * 1e3, 4), "ms_per_step_headline_" + head: out["ms_per_step"],
+                "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4),
+                "integrate_ms_headline_" + head: round(rig.int_s * 1e3, 4),
+                "transfer_ms": None if ms is None else round(ms, 4), "transfer_ms_headline_" + head: rig.halo_ms,
+                "host_enqueue_ms_per_step": round(rig.host_enqueue_ms, 4), "longest_host_step_ms": round(rig.longest_host_step_ms, 3),
+                "sweep_launches": 1}
+    finally:
+        rig.exchanger = keep
+        try:
+            peer.close()
+        except Exception:  # noqa: BLE001
+            pass
+        rig.barrier()
 
 
 # ---- clocks and power under load -----------------------------------------------------------------------------------

@@ -419,6 +419,30 @@ int rgbdr_halo_exchange(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_h
 int rgbdr_halo_begin_step(rgbdr_ctx* ctx);
 int rgbdr_halo_exchange_async(rgbdr_ctx* ctx, void* nccl_comm, int peer_lo, int peer_hi);
 int rgbdr_halo_wait(rgbdr_ctx* ctx);
+/* The same exchange by the COPY ENGINE, for the slabs of one node (SURVEY.md 8e "one exchange step per integration"; RCCL
+ * stays the default transport).  A face is one contiguous range of the tile-linear layout, so a rank can PULL its
+ * neighbours' staged faces with plain device-to-device copies from their staging sets, mapped once through HIP IPC: no
+ * send / recv kernels next to the sweep, no collective enqueue on the per-frame path.
+ *   rgbdr_halo_export(ctx, &mine)      creates the two staging sets, the interprocess events and a small POSIX shared
+ *                                      memory block, and describes them in `mine` (an rgbdr_halo_peer): plain bytes, to be carried to the two
+ *                                      neighbours by whatever rendezvous the host has (a file, a pipe, MPI, torch.distributed);
+ *   rgbdr_halo_set_peer(ctx, side, &theirs)   maps the export of the slab below (side 0) / above (side 1); NULL: no such
+ *                                      neighbour (any more).  A neighbour in the caller's own process (several contexts of
+ *                                      one host, or one context standing in for its neighbours) is used directly;
+ *   rgbdr_halo_begin_step / rgbdr_integrate / rgbdr_halo_pull_async / rgbdr_halo_wait   the step, as with RCCL: the copies
+ *                                      run on the context's side stream behind the neighbours' "staged" events and overlap the
+ *                                      next frame; every rank must call it every step (a neighbour that stops is reported as
+ *                                      RGBDR_ERR_STATE after RGBDR_PEER_TIMEOUT_S seconds, default 30, not waited for forever).
+ * Exporting (again) starts the protocol over: every rank exports at the same step of its loop, then sets its peers -- also
+ * to come back to this transport after steps over RCCL.  A resize (rgbdr_set_voxel_size / _brick_size) releases the staging
+ * sets: export and set the peers again on every rank.
+ * Same node only (shared memory, HIP IPC).  Timer "halo" brackets the copies on the side stream. */
+typedef struct {
+  uint8_t bytes[1024];
+} rgbdr_halo_peer;
+int rgbdr_halo_export(rgbdr_ctx* ctx, rgbdr_halo_peer* out);
+int rgbdr_halo_set_peer(rgbdr_ctx* ctx, int side, const rgbdr_halo_peer* peer);
+int rgbdr_halo_pull_async(rgbdr_ctx* ctx);
 
 /* The pre_* chain sharded by SENSOR over the ranks of a Z-slab job ("sensors are split across GPUs and
  * results all-gathered (ncclAllGather ...) with brick counters ncclAllReduce"; the reference is single-GPU and has no

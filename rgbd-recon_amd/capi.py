@@ -82,6 +82,9 @@ class View(C.Structure):
                 ("skip_space", C.c_int32)]
 
 
+HALO_PEER_BYTES = 1024     # sizeof(rgbdr_halo_peer)
+
+
 def make_view(eye, target, up, fovy_deg, width, height, bbox_min, bbox_max, near=0.1, far=10.0, shade_mode=0):
     """Builds the ray-marcher's uniforms the way ReconIntegration::draw does
     (recon_integration.cpp:177-241) from a look-at camera and a perspective
@@ -217,6 +220,9 @@ SYMBOLS = {
     "rgbdr_halo_exchange": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "rgbdr_halo_begin_step": (C.c_int, [_P]),
     "rgbdr_halo_exchange_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rgbdr_halo_export": (C.c_int, [_P, _P]),
+    "rgbdr_halo_set_peer": (C.c_int, [_P, C.c_int, _P]),
+    "rgbdr_halo_pull_async": (C.c_int, [_P]),
     "rgbdr_halo_wait": (C.c_int, [_P]),
     "rgbdr_set_sensor_shard": (C.c_int, [_P, C.c_int, C.c_int]),
     "rgbdr_shard_view": (C.c_int, [_P, C.POINTER(ShardDeviceView)]),
@@ -621,6 +627,22 @@ class Context:
         depth = np.empty((h, w), dtype=np.float32)
         self._chk(lib().rgbdr_readback_view_frame(self._h, 1 if filled else 0, color.ctypes.data_as(_F), depth.ctypes.data_as(_F)))
         return color, depth
+
+    # the halo by copy engine (rgbdr_halo_export / _set_peer / _pull_async): exports are plain bytes
+    def halo_export(self):
+        buf = C.create_string_buffer(HALO_PEER_BYTES)
+        self._chk(lib().rgbdr_halo_export(self._h, buf))
+        return buf.raw
+
+    def halo_set_peer(self, side, export_bytes):
+        if export_bytes is None:
+            self._chk(lib().rgbdr_halo_set_peer(self._h, side, None))
+            return
+        assert len(export_bytes) == HALO_PEER_BYTES
+        self._chk(lib().rgbdr_halo_set_peer(self._h, side, C.create_string_buffer(export_bytes, HALO_PEER_BYTES)))
+
+    def halo_pull_async(self):
+        self._chk(lib().rgbdr_halo_pull_async(self._h))
 
     def halo_staging(self, buffer):
         """(lo_ptr, hi_ptr, bytes) of halo staging set `buffer` (0 / 1)"""

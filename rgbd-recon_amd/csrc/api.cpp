@@ -66,6 +66,7 @@ static void free_volume(rgbdr_ctx* c)
       (void)hipFree(c->d_stage[b][f]);
       c->d_stage[b][f] = nullptr;
     }
+  rgbdr::destroy_peer_state(c);  // the staging sets the neighbours mapped are gone: export and set the peers again
   c->stage_target = -1;
   c->halo_begun = c->halo_staged = false;  // a resize between begin_step and exchange_async: the exchange has nothing to send
   c->halo_done_rec[0] = c->halo_done_rec[1] = false;
@@ -429,6 +430,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   if (!ctx) return;
   // drain every stream first: queued kernels still write the mapped skip counter and read the page-locked frame buffers
   (void)hipSetDevice(ctx->device);
+  rgbdr::release_peer_waits(ctx, -1);  // (a copy-engine halo step may still wait for a neighbour that is gone)
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
   if (ctx->pre_stream) (void)hipStreamSynchronize(ctx->pre_stream);
   if (ctx->halo_stream) (void)hipStreamSynchronize(ctx->halo_stream);

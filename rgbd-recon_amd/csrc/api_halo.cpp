@@ -189,6 +189,10 @@ try {
   const int b = ctx->halo_step & 1;
   { int rc_ = rgbdr_halo_staging(ctx, b, nullptr, nullptr, nullptr); if (rc_ != RGBDR_OK) return rc_; }
   if (ctx->halo_done_rec[b]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_halo_done[b], 0));
+  if (ctx->peer) {  // copy-engine transport: the neighbours read staging set b themselves (api_peer.cpp)
+    int rc_ = rgbdr::peer_begin_step(ctx, b, ctx->halo_step + 1);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   ctx->stage_target = b;
   ctx->halo_begun = true;
   ctx->halo_staged = false;  // set by the rgbdr_integrate that fills set b

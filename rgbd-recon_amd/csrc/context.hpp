@@ -33,6 +33,13 @@ struct Timer {
 };
 }  // namespace rgbdr
 
+namespace rgbdr {
+struct PeerState;  // api_peer.cpp: the halo transport by copy engine (IPC-mapped neighbour staging sets)
+void destroy_peer_state(rgbdr_ctx* ctx);
+void release_peer_waits(rgbdr_ctx* ctx, int side);  // side -1: both
+int peer_begin_step(rgbdr_ctx* ctx, int b, uint32_t absolute_step);  // (halo_step + 1)  // rgbdr_halo_begin_step's wait for the neighbours' copies
+}
+
 struct rgbdr_ctx {
   rgbdr_config cfg{};
   rgbdr_geometry geo{};
@@ -181,6 +188,7 @@ struct rgbdr_ctx {
   bool halo_staged = false;         // an rgbdr_integrate has filled the staging set since rgbdr_halo_begin_step
   unsigned halo_step = 0;
   int halo_last = -1;
+  rgbdr::PeerState* peer = nullptr;  // set by rgbdr_halo_export
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool morph_current = false;       // d_depth_morph was written with the upload (k_upload_morph): the chain skips k_morph

@@ -400,6 +400,58 @@ class ManagedSlabExchange:
             self.comm_gather.close()
 
 
+class PeerCopySlabExchange:
+    """The halo exchange of one slab rank by the COPY ENGINE (the C ABI's rgbdr_halo_export / rgbdr_halo_set_peer /
+    rgbdr_halo_pull_async): every rank pulls its neighbours' staged faces with device-to-device copies from their staging
+    sets, mapped once through HIP IPC -- no send / recv kernels next to the sweep, no collective enqueued per frame.  The
+    exports (plain bytes) travel once through torch.distributed (`group`: a group that moves Python objects, e.g. gloo).
+    Same interface as ManagedSlabExchange.  `loopback`: one context stands in for rank `rank` of `world` with itself as its
+    neighbours (a neighbour in the caller's own process is used without IPC)."""
+
+    def __init__(self, ctx, device, rank, world, group=None, loopback=False):
+        self.ctx, self.device, self.rank, self.world, self.loopback = ctx, device, rank, world, loopback
+        self.shard = None
+        mine = ctx.halo_export()
+        if loopback:
+            exports = {rank - 1: mine, rank + 1: mine}
+        else:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine, group=group)
+            exports = dict(enumerate(gathered))
+        self.sides = []
+        if rank > 0:
+            ctx.halo_set_peer(0, exports[rank - 1])
+            self.sides.append(0)
+        if rank < world - 1:
+            ctx.halo_set_peer(1, exports[rank + 1])
+            self.sides.append(1)
+        if not loopback:
+            dist.barrier(group=group)          # every rank has mapped its neighbours before anyone steps
+
+    def begin_step(self):
+        self.ctx.halo_begin_step()
+
+    def exchange_async(self):
+        self.ctx.halo_pull_async()
+
+    def wait(self):
+        self.ctx.halo_wait()
+
+    def gather(self):
+        return None
+
+    def last_transfer_ms(self):
+        try:
+            return self.ctx.timer_ns("halo") * 1e-6
+        except Exception:  # noqa: BLE001 -- timers off
+            return None
+
+    def close(self):
+        self.ctx.sync()
+        for side in self.sides:
+            self.ctx.halo_set_peer(side, None)
+
+
 class HaloExchanger:
     """The per-step halo exchange, off the critical path.
 

@@ -108,6 +108,60 @@ def exchanger_mode(out_dir, G, library_staging=False):
     dist.destroy_process_group()
 
 
+def peer_mode(out_dir, G, loopback):
+    """The halo by copy engine (rdist.PeerCopySlabExchange: rgbdr_halo_export / _set_peer / _pull_async): three frames, no host
+    synchronisation in between; the ranks are PROCESSES sharing cuda:0, so the neighbours' staging sets and events are mapped
+    through HIP IPC (loopback: one process, rank 1 of 3, with itself as both neighbours -- no IPC).  Dumps what
+    exchanger_mode dumps."""
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    load_package()
+    from rgbd_recon_amd import capi, synth
+    from rgbd_recon_amd import dist as rdist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    slab_rank, slab_count = (1, 3) if loopback else (rank, world)
+    dev = torch.device("cuda:0")
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=s, sphere_r=r) for s, r in ((1, 0.9), (2, 0.6), (3, 0.75))]
+    inv = scenes[0].inverse((G, G, G))
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=slab_rank,
+                                        slab_count=slab_count), 0)
+    for i in range(2):
+        ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    main = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(main)
+    ctx.set_stream(main.cuda_stream)
+    ctx.enable_timers(True)
+    ex = rdist.PeerCopySlabExchange(ctx, dev, slab_rank, slab_count, loopback=loopback)
+    frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
+    torch.cuda.synchronize()
+    lo, hi, rlo, rhi = rdist.halo_views(ctx.device_tsdf(), dev)
+    history = []
+    order = [0, 1, 2, 0, 1, 2] if loopback else [0, 1, 2]      # (six steps: every staging set is refilled behind its readers)
+    for n, k in enumerate(order):
+        d, c = frames[k]
+        ctx.update_device(d.data_ptr(), c.data_ptr())
+        ctx.clear_occupied_bricks()
+        ctx.process_textures()
+        ctx.update_occupied_bricks()
+        ctx.set_use_bricks(n != 1)                                    # frame 1: full sweep (stages in the kernel)
+        ex.begin_step()
+        ctx.integrate()
+        ex.exchange_async()
+        history.append((lo.clone(), hi.clone()))                  # stream-ordered snapshots, no host sync
+    ex.wait()
+    main.synchronize()
+    ms = ex.last_transfer_ms()
+    np.savez(os.path.join(out_dir, "halo_r%d.npz" % rank), send_lo=lo.cpu().numpy(), send_hi=hi.cpu().numpy(),
+             recv_lo=rlo.cpu().numpy(), recv_hi=rhi.cpu().numpy(), tsdf=ctx.readback_tsdf(),
+             hist_lo=torch.stack([h[0] for h in history]).cpu().numpy(),
+             hist_hi=torch.stack([h[1] for h in history]).cpu().numpy(), ms=-1.0 if ms is None else ms)
+    dist.barrier()
+    ex.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
 def shard_mode(out_dir, G, backend):
     """The pre_* chain sharded by sensor over the slab ranks (rdist.FrameGather): every rank runs 4 / world sensors, the
     packed frames are all-gathered and the brick counters all-reduced before updateOccupiedBricks / integrate.  Three
@@ -229,6 +283,8 @@ def main():
         return shard_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "shard_nccl" else "gloo")
     if sys.argv[1] == "loopback":
         return loopback_mode(sys.argv[2], int(sys.argv[3]))
+    if sys.argv[1] in ("peer", "peer_loopback"):
+        return peer_mode(sys.argv[2], int(sys.argv[3]), loopback=sys.argv[1] == "peer_loopback")
     if sys.argv[1] in ("exchanger", "exchanger_lib"):
         return exchanger_mode(sys.argv[2], int(sys.argv[3]), library_staging=sys.argv[1] == "exchanger_lib")
     out_dir, G, limit = sys.argv[1], int(sys.argv[2]), float(sys.argv[3])

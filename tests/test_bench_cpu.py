@@ -91,7 +91,8 @@ def test_plain_multi_gpu_command_fails_loudly_without_a_gpu_and_never_touches_to
     assert r.returncode != 0 and "needs a HIP device" in r.stderr and "[bench launcher] rank" in r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1 and "every rung" in lines[0]["error"] and "value" not in lines[0]
-    assert [a["rung"] for a in lines[0]["attempts"]] == [0, 1, 2] and lines[0]["attempts"][2]["flags"] == b_rung_flags(2)
+    assert [a["rung"] for a in lines[0]["attempts"]] == [0, 1, 2, 3] and lines[0]["attempts"][2]["flags"] == b_rung_flags(2)
+    assert lines[0]["attempts"][3]["flags"][:2] == ["--halo-transport", "peer"]      # the last rung needs no RCCL per frame
     # -X importtime lists what the PARENT imported (supervisors and ranks are started without it): no torch, so no GPU runtime
     imported = [l.split("|")[-1].strip() for l in r.stderr.splitlines() if l.startswith("import time:")]
     assert "json" in imported and "torch" not in imported
@@ -152,8 +153,8 @@ def test_ladder_under_torch_distributed_run(tmp_path):
 
 
 def test_ladder_every_rung_fails_ends_with_an_error_line(tmp_path):
-    rc, line, took, err = run_ladder(["fail", "fail", "hang"], tmp_path, budgets="4,4,4")
-    assert rc != 0 and "error" in line and "value" not in line and [a["rung"] for a in line["attempts"]] == [0, 1, 2]
+    rc, line, took, err = run_ladder(["fail", "fail", "hang", "fail"], tmp_path, budgets="4,4,4,4")
+    assert rc != 0 and "error" in line and "value" not in line and [a["rung"] for a in line["attempts"]] == [0, 1, 2, 3]
     assert took < 40
 
 
@@ -175,7 +176,7 @@ def test_ladder_a_dead_rank_ends_the_rung_early(tmp_path):
 
 def test_ladder_never_exceeds_the_launch_timeout(tmp_path):
     """--launch-timeout bounds the whole ladder: with 26 s and rungs of 20 s the second rung gets what is left or is not started"""
-    rc, line, took, err = run_ladder(["hang", "hang", "hang"], tmp_path, "--launch-timeout", "26", budgets="20,20,20")
+    rc, line, took, err = run_ladder(["hang", "hang", "hang", "hang"], tmp_path, "--launch-timeout", "26", budgets="20,20,20,20")
     assert rc != 0 and "error" in line and took < 40
     assert "not started" in line["attempts"][-1]["outcome"] or line["attempts"][-1]["seconds"] < 10
 

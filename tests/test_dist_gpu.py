@@ -76,6 +76,102 @@ def test_async_halo_exchanger(world, mode, tmp_path, pkg):
     ctx.close()
 
 
+def run_worker(world, *args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "slab_worker.py")] + [str(a) for a in args]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_by_copy_engine_between_processes(world, tmp_path, pkg):
+    """rgbdr_halo_export / rgbdr_halo_set_peer / rgbdr_halo_pull_async: the slabs are PROCESSES sharing the GPU, every rank
+    pulls its neighbours' staged faces through HIP IPC mappings behind interprocess events -- three different frames, both
+    sweeps, no host synchronisation in between; the halos hold the neighbours' boundary layers of the last frame and the
+    slabs together the whole volume of that frame"""
+    G = 64
+    run_worker(world, "peer", tmp_path, G)
+    z = [np.load(os.path.join(str(tmp_path), "halo_r%d.npz" % k)) for k in range(world)]
+    for k in range(world - 1):
+        up = [same_bits(z[k]["recv_hi"], z[k + 1]["hist_lo"][f]) for f in range(3)]
+        down = [same_bits(z[k + 1]["recv_lo"], z[k]["hist_hi"][f]) for f in range(3)]
+        assert up[2] and down[2], (k, up, down)                  # the halos hold the last frame
+        assert not same_bits(z[k + 1]["hist_lo"][1], z[k + 1]["hist_lo"][2])
+        assert np.nanmax(np.abs(z[k]["send_hi"])) > 0 and float(z[k]["ms"]) > 0
+    capi, synth = pkg.capi, pkg.synth
+    last = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=3, sphere_r=0.75)
+    first = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=1, sphere_r=0.9)
+    ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), 0)
+    inv = first.inverse((G, G, G))
+    for i in range(2):
+        ctx.set_calibration(i, first.xyz[i], first.lut_res, first.uv[i], first.lut_res, (0.5, 4.5))
+        ctx.set_inverse_calibration(i, inv[i], (G, G, G))
+    ctx.step(last.depth, last.color)
+    assert same_bits(np.concatenate([zz["tsdf"] for zz in z], axis=0), ctx.readback_tsdf())
+    ctx.close()
+
+
+def test_halo_by_copy_engine_loopback(tmp_path):
+    """the same transport with one context as its own two neighbours (slab 1 of 3; a neighbour in the caller's process is
+    used without IPC): six steps, so that each staging set is refilled twice behind its readers"""
+    run_worker(1, "peer_loopback", tmp_path, 96)
+    z = np.load(os.path.join(str(tmp_path), "halo_r0.npz"))
+    lo_matches = [same_bits(z["recv_hi"], z["hist_lo"][f]) for f in range(6)]      # lower face -> own upper halo
+    hi_matches = [same_bits(z["recv_lo"], z["hist_hi"][f]) for f in range(6)]
+    assert lo_matches[5] and hi_matches[5], (lo_matches, hi_matches)
+    assert not same_bits(z["hist_lo"][4], z["hist_lo"][5]) and float(z["ms"]) > 0
+
+
+def test_the_copy_engine_halo_reports_a_neighbour_that_stopped(pkg, monkeypatch):
+    """a neighbour that does not stage its step is an error after RGBDR_PEER_TIMEOUT_S, not a hang; calls out of order are
+    refused"""
+    capi, synth = pkg.capi, pkg.synth
+    monkeypatch.setenv("RGBDR_PEER_TIMEOUT_S", "0.5")
+    G = 64
+    scene = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=1)
+    inv = scene.inverse((G, G, G))
+    ctxs = []
+    for r in range(2):
+        c = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / G, brick_size=8 * 2.0 / G, slab_rank=r, slab_count=2), 0)
+        for i in range(2):
+            c.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
+            c.set_inverse_calibration(i, inv[i], (G, G, G))
+        ctxs.append(c)
+    a, b = ctxs
+    with pytest.raises(capi.RgbdrError) as e:
+        a.halo_set_peer(1, b"x" * capi.HALO_PEER_BYTES)          # before its own export
+    assert e.value.status == capi.ERR_STATE
+    ea, eb = a.halo_export(), b.halo_export()
+    with pytest.raises(capi.RgbdrError) as e:
+        a.halo_set_peer(1, b"x" * capi.HALO_PEER_BYTES)          # not an export
+    assert e.value.status == capi.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.RgbdrError) as e:
+        a.halo_set_peer(2, eb)
+    assert e.value.status == capi.ERR_OUT_OF_RANGE
+    a.halo_set_peer(1, eb)
+    b.halo_set_peer(0, ea)
+    with pytest.raises(capi.RgbdrError) as e:
+        a.halo_pull_async()                                      # before begin_step + integrate
+    assert e.value.status == capi.ERR_STATE
+    a.halo_begin_step()
+    a.step(scene.depth, scene.color)
+    # b never steps.  a's side stream waits for b's faces on the device; the HOST gives the neighbour up once it is more than
+    # a couple of dozen steps behind what is being enqueued, instead of queueing for ever
+    steps = 0
+    with pytest.raises(capi.RgbdrError) as e:
+        for steps in range(1, 200):
+            a.halo_pull_async()
+            a.halo_begin_step()
+            a.integrate()
+    assert e.value.status == capi.ERR_STATE and "neighbour" in str(e.value) and 8 < steps < 64, steps
+    for c in ctxs:
+        c.close()                                                # (releases the waits a's streams still sit in: no hang)
+
+
 def test_async_halo_exchanger_over_rccl_loopback(tmp_path):
     """the stream-ordered path as it runs on a multi-GPU node -- RCCL send/recv on the library's
     staging sets, side stream, events, no host synchronisation between four frames -- with
