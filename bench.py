@@ -567,6 +567,11 @@ def headline_line(rig, dt, stats):
         "frames_per_s": round(args.steps / dt, 2),
         "host_enqueue_ms_per_step": round(rig.host_enqueue_ms, 4),   # when this approaches ms_per_step the host loop is the limit
         "headline_retimed": getattr(rig, "retimed", None),           # bench_chain.retime_after_a_host_stall
+        # ... and when that happened, what the FIRST measurement read (a stall inside the collective library is a property
+        # of the N > 1 path: a product loop cannot time itself again)
+        "value_first_measurement": (round(V_total / (rig.retimed["discarded"][0]["ms_per_step"] * 1e-3) / 1e6, 1)
+                                    if getattr(rig, "retimed", None) else None),
+        "ms_per_step_first_measurement": rig.retimed["discarded"][0]["ms_per_step"] if getattr(rig, "retimed", None) else None,
         "higher_is_better": True,
         "scaling": rig.scaling if world > 1 else None,      # one GPU: nothing scales
         "vs_baseline": None,

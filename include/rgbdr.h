@@ -214,9 +214,12 @@ int rgbdr_load_calibration_files(rgbdr_ctx* ctx, int sensor, const char* path_cv
  * outside it can be among the 8 nearest, widened (up to radius 8) until it has one, and
  * replaced by a scan of the whole volume for a voxel that never gets one -- the result
  * equals the exact search for every voxel (kernels_invert.hip states the argument and
- * its assumption: a convex sampled region whose lattice does not fold).
- * rgbdr_inverse_search_stats: how many voxels of the sensor's last search needed a wider
- * window / the exhaustive scan.
+ * its assumption: a convex sampled region whose lattice does not fold).  Whether the lattice
+ * folds -- its cells change orientation somewhere: a distortion model strong enough to turn the
+ * image back on itself, a damaged file -- is checked when the calibration is set; such a volume
+ * is searched exhaustively throughout (exact, and slow: one workgroup per voxel).
+ * rgbdr_inverse_search_stats: how many voxels of the sensor's last search -- the whole call,
+ * however many chunks it worked in -- needed a wider window / the exhaustive scan.
  *   compute_inverse_calibration: directly at this context's grid resolution into the
  *     resident grid layout (what `calib_inverter` + loadInverseCalibs would produce
  *     for a LUT at 1:1); with RGBDR_FLAG_NO_RESAMPLE -- every sensor of a context is resident in
@@ -487,7 +490,12 @@ int rgbdr_shard_gather_done(rgbdr_ctx* ctx);
  * it.  Producer and consumer must agree in sensors, image size, bounding box and brick size (the brick grid); the
  * producer's voxel size is free.  Use: a chain-only context runs frame k+1 while this one sweeps frame k, so the
  * all-gather of frame k+1 travels under that sweep (rgbd-recon_amd/dist.py LaggedChain; the reference has no
- * counterpart: it is single-GPU, kinect_client.cpp:572-602). */
+ * counterpart: it is single-GPU, kinect_client.cpp:572-602).
+ * Ordering: the copies are enqueued on the stream THIS context's chain runs on (its second stream under
+ * RGBDR_FLAG_PIPELINE).  With the pointer form the caller keeps the source unchanged until they have run -- producer and
+ * consumer on one stream, or an event recorded behind this call that the source's next writer waits for;
+ * rgbdr_import_frame_from does both sides itself: the copies wait for the producer's chain and gather, and the producer's
+ * next rgbdr_process_textures / rgbdr_import_frame* / rgbdr_shard_allgather waits for the copies, whatever the streams. */
 int rgbdr_import_frame(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, void* wait_event);
 /* The same without a HIP type at the boundary (what a C / C++ host uses, host::LaggedChain): the gather of the producing
  * context on a stream of that context's own -- behind its chain, with an event behind it that every later call touching

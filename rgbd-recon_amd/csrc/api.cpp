@@ -458,7 +458,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     (void)hipStreamSynchronize(ctx->gather_stream);
     (void)hipStreamDestroy(ctx->gather_stream);
   }
-  for (hipEvent_t e : {ctx->ev_gather_from, ctx->ev_gather_done, ctx->ev_export})
+  for (hipEvent_t e : {ctx->ev_gather_from, ctx->ev_gather_done, ctx->ev_export, ctx->ev_imported})
     if (e) (void)hipEventDestroy(e);
   if (ctx->halo_stream) {
     (void)hipStreamSynchronize(ctx->halo_stream);
@@ -745,6 +745,8 @@ try {
   p.frame = ctx->frame_buf(w);
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
   { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }  // (an asynchronous gather still writes the frame / the counters)
+  // another context may still be copying the LAST frame out of these buffers (rgbdr_import_frame_from on a stream of its own)
+  if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_imported, 0));
   tbegin(ctx, "1preprocess", ps);
   // whichever kernel comes first performs a pending clearOccupiedBricks; the morph image of a frame that was
   // uploaded from device memory was written with the upload

@@ -61,6 +61,7 @@ try {
   ctx->max_ds[sensor] = xyz->depth_limits[1];
   camera_position((const float*)xyz->data, xyz->res, ctx->cam_pos[sensor]);
   frustum_planes((const float*)xyz->data, xyz->res, ctx->planes[sensor]);
+  ctx->lattice_folded[sensor] = lattice_folds((const float*)xyz->data, xyz->res);
   {  // the lookups of pre_depth.fs that depend on the pixel only (kernels_pre.hip k_pre_cache)
     PreParams p{};
     p.W = ctx->cfg.depth_w;
@@ -150,7 +151,10 @@ static float* build_chunk_arena(rgbdr_ctx* ctx, size_t bytes, size_t head_floats
   const size_t spare = (size_t)4 << 30;
   if (free_b < spare + (need + 2) * chunk) return nullptr;
   size_t pool_n = (free_b - spare) / chunk;
-  const size_t want = need + (need > 24 ? need : 24);        // twice the arena, at least 24 chunks more
+  // the pool: the arena plus as many chunks again, but between 8 and 24 -- a 26-GiB arena used to take 52 + GiB of
+  // transient memory here, enough to fail another context of the process that allocated in that window
+  const size_t extra = need < 8 ? 8 : (need > 24 ? 24 : need);
+  const size_t want = need + extra;
   if (pool_n > want) pool_n = want;
   // chunk-level replay: per tile N x 3 planes read, one stored (the volume must hold a chunk's worth of tiles)
   const size_t tile_bytes = (size_t)nsens(ctx) * 3 * kTileVoxels * sizeof(float);
@@ -606,6 +610,7 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
   // R = 2 certifies 88 % of the voxels at once and leaves 12 % to k_invert_retry (68 ms per sensor at 512^3); R = 3 certifies
   // all but 1e-5 but scans 343 instead of 125 samples for everyone (87 ms)
   p->window = window < 1 ? 2 : window;
+  p->folded = ctx->lattice_folded[sensor] ? 1 : 0;
   p->sensor = sensor;
   p->N = ctx->cfg.num_sensors;
 }
@@ -613,7 +618,10 @@ static void fill_invert_params(rgbdr_ctx* ctx, int sensor, const int32_t vol_res
 // One certified search over the z rows [p.z0, p.z0 + p.nz): the local search and the exhaustive scan of whatever it could
 // not certify (kernels_invert.hip).  Rows are taken in pieces of at most 64 so that the list of uncertified voxels (one
 // word per voxel of a piece: it can never overflow) stays small.
-static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
+// An API call that searches in several chunks (rgbdr_generate_inverse_lut streams 64 rows at a time to the host) hands in
+// one scratch allocation for all of them (`shared`, sized by the first = largest chunk) and the counters of
+// rgbdr_inverse_search_stats add up over the chunks: the entry point zeroes them, not this function.
+static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor, DevScratch* shared = nullptr)
 {
   const int z_begin = p.z0, z_end = p.z0 + p.nz;
   const int piece = 64;
@@ -621,8 +629,9 @@ static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
   const size_t head = 6;  // [2] the two lists' lengths, [4] two 64-bit counters
   const size_t per_piece = row * (size_t)std::min(piece, p.nz);
   const size_t words = head + 3 * per_piece;  // exhaustive list: a word per voxel; retry list: two
-  DevScratch aux;
-  HIPCHK(hipMalloc(&aux.p, words * sizeof(unsigned)));
+  DevScratch own;
+  DevScratch& aux = shared ? *shared : own;
+  if (!aux.p) HIPCHK(hipMalloc(&aux.p, words * sizeof(unsigned)));
   unsigned* base = aux.as<unsigned>();
   unsigned* count = base;
   unsigned long long* stats = (unsigned long long*)(base + 2);  // 8-byte aligned
@@ -652,8 +661,8 @@ static int run_invert(rgbdr_ctx* ctx, InvertParams p, int sensor)
   unsigned long long h[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->inv_search_widened[sensor] = h[0];
-  ctx->inv_search_exhaustive[sensor] = h[1];
+  ctx->inv_search_widened[sensor] += h[0];
+  ctx->inv_search_exhaustive[sensor] += h[1];
   return RGBDR_OK;
 }
 
@@ -700,6 +709,7 @@ try {
     p.nz = hi - lo + 1;
     p.out_linear = ctx->d_lut_generic[sensor];
     p.out_tiled = nullptr;
+    ctx->inv_search_widened[sensor] = ctx->inv_search_exhaustive[sensor] = 0;
     { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
     for (int a = 0; a < 3; ++a) ctx->inv_res[sensor][a] = (uint32_t)g.res_volume[a];
     ctx->zoff[sensor] = lo;
@@ -714,6 +724,7 @@ try {
   p.z0 = ext.vz0;
   p.nz = ext.vz1 - ext.vz0;
   p.out_tiled = ext.dst;
+  ctx->inv_search_widened[sensor] = ctx->inv_search_exhaustive[sensor] = 0;
   { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
   launch_tile_windows(ctx->d_lut_tiled, ctx->cfg.depth_w, ctx->cfg.depth_h,
                       g.tiles[0] * g.tiles[1] * (g.slab_tile_z1 - g.slab_tile_z0), sensor, nsens(ctx), ctx->d_win,
@@ -745,13 +756,14 @@ try {
   fill_invert_params(ctx, sensor, vr, window, &p);
   const size_t row = (size_t)res[0] * res[1];
   const int chunk = 64;
-  DevScratch tmp;
+  DevScratch tmp, aux;
   HIPCHK(hipMalloc(&tmp.p, row * chunk * sizeof(float4)));
+  ctx->inv_search_widened[sensor] = ctx->inv_search_exhaustive[sensor] = 0;  // "the sensor's last search": this whole call
   for (int z = 0; z < (int)res[2]; z += chunk) {
     p.z0 = z;
     p.nz = z + chunk <= (int)res[2] ? chunk : (int)res[2] - z;
     p.out_linear = tmp.as<float4>();
-    { int rc_ = run_invert(ctx, p, sensor); if (rc_ != RGBDR_OK) return rc_; }
+    { int rc_ = run_invert(ctx, p, sensor, &aux); if (rc_ != RGBDR_OK) return rc_; }
     HIPCHK(hipMemcpyAsync(dst + row * 4 * (size_t)z, tmp.p, row * (size_t)p.nz * sizeof(float4), hipMemcpyDeviceToHost,
                           ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

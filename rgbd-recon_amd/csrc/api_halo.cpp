@@ -295,6 +295,7 @@ static int import_pointers(rgbdr_ctx* ctx, const void* packed_frames, const void
   { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }
   const int w = ctx->wbuf;
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_imported, 0));  // a context still copying out of this one's buffers
   if (wait_a) HIPCHK(hipStreamWaitEvent(ps, wait_a, 0));
   if (wait_b) HIPCHK(hipStreamWaitEvent(ps, wait_b, 0));
   const size_t frame_bytes = (size_t)nsens(ctx) * ctx->cfg.depth_w * ctx->cfg.depth_h * sizeof(uint2);
@@ -340,8 +341,15 @@ try {
   HIPCHK(hipSetDevice(ctx->device));
   if (!producer->ev_export) HIPCHK(hipEventCreateWithFlags(&producer->ev_export, hipEventDisableTiming));
   HIPCHK(hipEventRecord(producer->ev_export, producer->pstream()));  // the producer's chain, in its own stream's order
-  return import_pointers(ctx, producer->frame_buf(producer->rbuf), producer->counters_cur(), producer->ev_export,
-                         producer->gather_done_rec ? producer->ev_gather_done : nullptr);
+  int rc = import_pointers(ctx, producer->frame_buf(producer->rbuf), producer->counters_cur(), producer->ev_export,
+                           producer->gather_done_rec ? producer->ev_gather_done : nullptr);
+  if (rc != RGBDR_OK) return rc;
+  // ... and the other way round: the producer's next chain (or gather, or import) overwrites these buffers only behind the
+  // copies just enqueued, whatever streams the two contexts run on (a pipelined consumer copies on its second stream)
+  if (!producer->ev_imported) HIPCHK(hipEventCreateWithFlags(&producer->ev_imported, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(producer->ev_imported, ctx->pstream()));
+  producer->imported_rec = true;
+  return RGBDR_OK;
 }
 RGBDR_CONTAIN(ctx)
 
@@ -381,6 +389,7 @@ try {
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_allgather before process_textures");
   HIPCHK(hipSetDevice(ctx->device));
   { int rc_ = join_async_gather(ctx, ctx->pstream()); if (rc_ != RGBDR_OK) return rc_; }
+  if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ctx->pstream(), ctx->ev_imported, 0));
   const int rc = gather_on(ctx, nccl_comm, ctx->pstream(), "rgbdr_shard_allgather");
   if (rc != RGBDR_OK) return rc;
   ctx->shard_pending = false;

@@ -87,6 +87,7 @@ struct rgbdr_ctx {
   float cam_pos[rgbdr::kMaxSensors][3] = {};
   float planes[rgbdr::kMaxSensors][6][4] = {};  // Frustum::getPlanes of cv_xyz
   bool have_calib[rgbdr::kMaxSensors] = {};
+  bool lattice_folded[rgbdr::kMaxSensors] = {};  // cv_xyz's cells change orientation somewhere: the inverse search scans exhaustively
 
   // inverse calibration
   bool inv_set[rgbdr::kMaxSensors] = {};
@@ -181,6 +182,10 @@ struct rgbdr_ctx {
   hipStream_t gather_stream = nullptr;
   hipEvent_t ev_gather_from = nullptr, ev_gather_done = nullptr, ev_export = nullptr;
   bool gather_done_rec = false;
+  // write-after-read side of rgbdr_import_frame_from: recorded on the CONSUMER's stream behind its copies out of this
+  // (producer) context's frame buffer and counters; this context's next chain / import / gather waits for it
+  hipEvent_t ev_imported = nullptr;
+  bool imported_rec = false;
   hipStream_t halo_stream = nullptr;
   hipEvent_t ev_halo_staged[2] = {nullptr, nullptr}, ev_halo_done[2] = {nullptr, nullptr};
   bool halo_done_rec[2] = {false, false};

@@ -279,6 +279,39 @@ void make_fill_tables(const FillLayout& L, std::vector<int>* xt, std::vector<int
   T->ny = (int)(yt->size() / 4);
 }
 
+// Does the sampled lattice of a cv_xyz volume fold?  The certificate of the device's inverse search (kernels_invert.hip) is
+// argued for a lattice whose cells all have the same orientation: the triple product of a cell's three index directions
+// keeps its sign.  A lens model that lets it change sign somewhere (a barrel distortion strong enough to turn the image
+// back on itself) or a damaged file does not fit the argument; the search then scans exhaustively (still exact, slow).
+// Volumes thinner than two samples along an axis have no cells: not folded.
+bool lattice_folds(const float* xyz, const uint32_t res[3])
+{
+  if (res[0] < 2 || res[1] < 2 || res[2] < 2) return false;
+  const size_t sx = 3, sy = (size_t)res[0] * 3, sz = (size_t)res[0] * res[1] * 3;
+  bool pos = false, neg = false;
+  for (uint32_t z = 0; z + 1 < res[2]; ++z)
+    for (uint32_t y = 0; y + 1 < res[1]; ++y)
+      for (uint32_t x = 0; x + 1 < res[0]; ++x) {
+        const float* o = xyz + z * sz + y * sy + x * sx;
+        double e[3][3];
+        for (int k = 0; k < 3; ++k) {
+          e[0][k] = (double)o[sx + k] - o[k];
+          e[1][k] = (double)o[sy + k] - o[k];
+          e[2][k] = (double)o[sz + k] - o[k];
+        }
+        const double det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                           e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+        if (det > 0.0)
+          pos = true;
+        else if (det < 0.0)
+          neg = true;
+        else
+          return true;  // a degenerate (or NaN) cell
+        if (pos && neg) return true;
+      }
+  return false;
+}
+
 void frustum_planes(const float* xyz, const uint32_t res[3], float planes[6][4])
 {
   const uint32_t ex = res[0] - 1, ey = res[1] - 1, ez = res[2] - 1;

@@ -34,7 +34,10 @@
 // max(1, R/2), up to 8); a voxel still uncertified at R = 8 is appended to a list and
 // k_invert_exhaustive scans the WHOLE volume for it, one workgroup per voxel.  So the
 // result equals the exact search for every voxel (tests/test_inverter_gpu.py asserts
-// equality, not a fraction).
+// equality, not a fraction).  The argument needs a lattice whose cells all have one orientation; the host checks that when
+// the calibration is set (geometry.cpp lattice_folds) and, where a cv_xyz volume folds, p.folded sends every voxel to the
+// exhaustive scan (a radial distortion of k = -0.3 folds near the corners: 6 of 168 000 voxels were wrong with a
+// "certificate" there, tests/test_inverter_gpu.py).
 #include <hip/hip_runtime.h>
 
 #include "rgbdr_internal.hpp"
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(128) void k_invert_lut(InvertParams p)
             }
       }
       // (rounded against acceptance; a NaN normal -- a degenerate lattice -- compares false: not certified)
-      certified = !any_shell || (plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f);
+      certified = !any_shell || (!p.folded && plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f);
     }
     if (!certified) {  // the general case (re-centring, widening) is k_invert_retry's: a second, rarely needed kernel
       const unsigned slot = atomicAdd(p.retry_count, 1u);
@@ -399,10 +402,11 @@ __global__ __launch_bounds__(64) void k_invert_retry(InvertParams p)
         certified = true;  // the window is the whole volume
         break;
       }
-      if (plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f) {
+      if (!p.folded && plane > 0.0f && sqrtf(b.d[7]) * 1.00001f < plane * 0.99999f) {
         certified = true;
         break;
       }
+      if (p.folded) break;  // no certificate holds on a lattice that folds: straight to the exhaustive scan
       const int ncx = b.i[0] / ryz, ncy = (b.i[0] / p.rz) % p.ry, ncz = b.i[0] % p.rz;
       if (!recentred && b.i[0] != 0x7fffffff && (ncx != cx || ncy != cy || ncz != cz)) {
         recentred = true;

@@ -36,6 +36,7 @@ int compute_brick_tables(const rgbdr_config& cfg, const rgbdr_geometry& g, Brick
 void camera_position(const float* cv_xyz, const uint32_t res[3], float out[3]);
 // Frustum::getPlanes of the 8 corner samples of cv_xyz (frustum.cpp:113-177)
 void frustum_planes(const float* cv_xyz, const uint32_t res[3], float planes[6][4]);
+bool lattice_folds(const float* cv_xyz, const uint32_t res[3]);  // geometry.cpp
 // true when an inverse LUT of resolution `lut_res` maps every voxel centre of a
 // `vol_res` grid onto exactly one texel with zero interpolation weights
 bool lut_is_one_to_one(const uint32_t lut_res[3], const int32_t vol_res[3]);
@@ -156,6 +157,7 @@ struct InvertParams {
   int z0, nz;              // z rows [z0, z0 + nz) handled by this launch
   int TX, TY;              // tiles in x, y
   int window;              // index radius R of the first candidate window (widened until certified, kernels_invert.hip)
+  int folded;              // the lattice folds (geometry.cpp lattice_folds): no window is certified, every voxel is scanned exhaustively
   unsigned* retry;         // (voxel, sample the walk ended at) pairs whose first window was not certified: k_invert_retry
   unsigned* retry_count;
   unsigned* todo;          // voxels (launch-relative linear index) left to k_invert_exhaustive, and their number

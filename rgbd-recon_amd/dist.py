@@ -594,7 +594,7 @@ class LaggedChain:
         ctx.set_sweep_launches(sweep_launches)
         self.main = torch.cuda.ExternalStream(int(ctx.stream()), device=device)
         self.side = torch.cuda.Stream(device)
-        self.ev_chain, self.ev_gather = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_chain, self.ev_gather, self.ev_imported = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.pending = None              # (frames pointer, counters pointer) of the frame whose gather is under way
 
     def _sweep_pending(self):
@@ -606,6 +606,13 @@ class LaggedChain:
             self.ctx.import_frame_from(self.chain)       # waits for the chain and for its asynchronous gather
         else:
             self.ctx.import_frame(frames, counters, wait_event=self.ev_gather.cuda_event)
+            # the pointer form orders read-after-write only (include/rgbdr.h): a sweeping context on its two-stream
+            # schedule copies on its SECOND stream, and the chain of the next frame -- on the main stream -- must not
+            # overwrite the source before that copy has run
+            ps = int(self.ctx.shard_view().stream or 0)
+            if ps and ps != int(self.ctx.stream()):
+                self.ev_imported.record(torch.cuda.ExternalStream(ps, device=self.device))
+                self.main.wait_event(self.ev_imported)
         return True
 
     def push(self, depth_ptr, color_ptr):

@@ -212,7 +212,7 @@ def shard_mode(out_dir, G, backend):
     dist.destroy_process_group()
 
 
-def lag_mode(out_dir, G, backend):
+def lag_mode(out_dir, G, backend, pipelined=False):
     """rdist.LaggedChain: a chain-only context runs frame k+1 (sharded by sensor) before the slab context sweeps frame k;
     the gather of frame k+1 runs on a side stream under that sweep and the slab context takes the completed frame with
     rgbdr_import_frame.  Three different frames: after the third push the volume is the SECOND frame's, after flush()
@@ -251,6 +251,16 @@ def lag_mode(out_dir, G, backend):
     frames = [(torch.from_numpy(s.depth).to(dev), torch.from_numpy(s.color).to(dev)) for s in scenes]
     torch.cuda.synchronize()
     before = []
+    if pipelined:
+        # the SWEEPING context on its two-stream schedule: its import copies run on its second stream while the chain context
+        # already works on the next frame on another one (rgbdr_import_frame_from orders both directions itself).  Twelve
+        # frames without a host synchronisation, so that a copy overtaken by the next chain would show as a torn frame.
+        ctx.set_pipelined(True)
+        for k in range(9):
+            d, c = frames[k % 3]
+            ctx.set_use_bricks(k % 2 == 0)
+            lag.push(d.data_ptr(), c.data_ptr())
+        ctx.sync()
     for k, (d, c) in enumerate(frames):
         ctx.set_use_bricks(k != 2)            # the sweep of frame k-1 happens in push k: frame 0 bricked, frame 1 full
         lag.push(d.data_ptr(), c.data_ptr())
@@ -277,8 +287,9 @@ def lag_mode(out_dir, G, backend):
 
 
 def main():
-    if sys.argv[1] in ("lag", "lag_nccl", "lag_raw"):
-        return lag_mode(sys.argv[2], int(sys.argv[3]), {"lag": "gloo", "lag_nccl": "nccl", "lag_raw": "raw"}[sys.argv[1]])
+    if sys.argv[1] in ("lag", "lag_nccl", "lag_raw", "lag_pipe", "lag_raw_pipe"):
+        return lag_mode(sys.argv[2], int(sys.argv[3]), {"lag": "gloo", "lag_nccl": "nccl", "lag_raw": "raw", "lag_pipe": "gloo",
+                                                         "lag_raw_pipe": "raw"}[sys.argv[1]], pipelined=sys.argv[1].endswith("_pipe"))
     if sys.argv[1] in ("shard", "shard_nccl"):
         return shard_mode(sys.argv[2], int(sys.argv[3]), "nccl" if sys.argv[1] == "shard_nccl" else "gloo")
     if sys.argv[1] == "loopback":

@@ -192,7 +192,8 @@ def test_async_halo_exchanger_over_rccl_loopback(tmp_path):
     assert float(z["ms"]) > 0
 
 
-@pytest.mark.parametrize("world,mode", [(2, "shard"), (4, "shard"), (1, "shard_nccl"), (2, "lag"), (1, "lag_nccl"), (1, "lag_raw")])
+@pytest.mark.parametrize("world,mode", [(2, "shard"), (4, "shard"), (1, "shard_nccl"), (2, "lag"), (1, "lag_nccl"), (1, "lag_raw"),
+                                        (2, "lag_pipe"), (1, "lag_raw_pipe")])
 def test_sensor_sharded_chain_over_ranks(world, mode, tmp_path, pkg):
     """rgbd_recon_amd.dist.FrameGather: the pre_* chain runs for 4 / world sensors per rank, the packed frames are
     all-gathered and the brick counters all-reduced; the slabs, the occupied bricks and the composited slab ray-march of

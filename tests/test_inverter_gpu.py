@@ -60,6 +60,44 @@ def test_an_irregular_lattice_falls_back_to_the_exhaustive_scan_and_stays_exact(
     ctx.close()
 
 
+@pytest.mark.parametrize("k", [0.45, -0.12, -0.3])
+def test_a_radially_distorted_lattice_with_voxels_outside_the_sampled_hull_stays_exact(pkg, orc, k):
+    """The certificate of kernels_invert.hip is argued for a query inside a convex, non-folding sampled region.  A lens with
+    strong radial distortion bends the lattice: with k > 0 its sides cave in between the corners (pincushion), so voxels that
+    pass the frustum test -- its planes come from the eight corner samples -- lie OUTSIDE the hull of the samples; with k < 0
+    it bulges (k = -0.12), and at k = -0.3 the lattice FOLDS near the corners (the Jacobian 1 + 8 k + 12 k^2 of the map at (1, 1) is negative below k = -1/6) -- the library notices
+    that when the calibration is set and scans exhaustively.  Every voxel must equal the exhaustive search."""
+    capi, synth = pkg.capi, pkg.synth
+    lut_res = (20, 17, 12)
+    scene = synth.Scene(1, 64, 53, lut_res=lut_res)
+    xyz = scene.xyz[0].copy()                                   # [z][y][x][3]
+    nz, ny, nx = xyz.shape[:3]
+    u = np.linspace(-1.0, 1.0, nx, dtype=np.float32)[None, None, :]
+    v = np.linspace(-1.0, 1.0, ny, dtype=np.float32)[None, :, None]
+    r2 = u * u + v * v
+    scale = (1.0 + k * r2) / (1.0 + k * 2.0)                    # the four corner columns (r2 = 2) stay: the frustum planes do too
+    axis = xyz[:, ny // 2:ny // 2 + 1, nx // 2:nx // 2 + 1, :]  # the central column of every depth slice
+    xyz = (axis + (xyz - axis) * scale[..., None]).astype(np.float32)
+    for corner in ((0, 0), (0, -1), (-1, 0), (-1, -1)):
+        assert np.allclose(xyz[:, corner[0], corner[1]], scene.xyz[0][:, corner[0], corner[1]], atol=1e-5)
+        xyz[:, corner[0], corner[1]] = scene.xyz[0][:, corner[0], corner[1]]       # (to the bit)
+    ctx = capi.Context(capi.make_config(1, (64, 53), voxel_size=2.0 / 32, brick_size=8 * 2.0 / 32), 0)
+    ctx.set_calibration(0, xyz, lut_res, scene.uv[0], lut_res, (0.5, 4.5))
+    res = (36, 36, 130) if k != -0.3 else (20, 20, 66)          # (several chunks of z rows: the statistics add up over them)
+    got = ctx.generate_inverse_lut(0, res)
+    ref = orc.inverse_volume(xyz, BMIN, BMAX, res)
+    inside = ref[..., 3] > 0
+    assert 0.1 < inside.mean() < 1.0
+    assert np.array_equal(got, ref), int((got != ref).any(axis=-1).sum())
+    widened, exhaustive = ctx.inverse_search_stats(0)
+    assert widened <= inside.sum() and exhaustive <= inside.sum()
+    if k == -0.3:
+        assert exhaustive == inside.sum()                       # a folded lattice: every voxel of the whole call, not of its last chunk
+    else:
+        assert 0 < widened and exhaustive < inside.sum()       # (a lattice this coarse and this bent certifies less than half)
+    ctx.close()
+
+
 @pytest.mark.parametrize("lut_res", [(1, 1, 1), (2, 2, 2), (3, 1, 2), (1, 5, 1), (8, 8, 8)])
 @pytest.mark.parametrize("window", [0, 1, 8])
 def test_inverter_on_calibration_volumes_with_fewer_than_eight_samples_per_axis(pkg, orc, lut_res, window):
