@@ -67,7 +67,15 @@ enum {
    * resampled once, at upload, at the voxel centres (the LINEAR lookup of
    * tsdf_integration.vs:31 is static between frames) so that integrate() streams it
    * like a 1:1 LUT.  This flag keeps the file's volume resident instead and evaluates
-   * the 8-tap lookup per frame (less HBM for LUTs much coarser than the grid). */
+   * the 8-tap lookup per frame: a MEMORY-saving mode, with a measured price (profiles/r06_pmc_generic*.json; the
+   * same volume bit for bit).  Four 512 x 424 sensors, full sweep:
+   *   512^3 grid, 256^3 LUT (2 x coarser)     LUTs 1.16 GiB instead of 6.18; HBM 3.2 GB per sweep instead of 7.0;
+   *                                           2.82 ms instead of 1.21 (VALU-bound: 1.8 G wavefront instructions against 0.53)
+   *   the reference's 200 x 221 x 200 grid,   LUTs 1.70 GiB instead of 0.57 (this LUT is FINER than the grid: nothing
+   *   286 x 315 x 286 LUT                     is saved); 0.58 ms instead of 0.11
+   * The LUT box a tile touches is staged in LDS (k_integrate_generic_lds; 2.4 / 11 ms with plain global gathers); a LUT
+   * more than ~2.5 x finer than the grid does not fit and falls back to those.  Use it where the arena is the problem
+   * (1024^3 and eight sensors: 96 GiB resampled), not for speed. */
   RGBDR_FLAG_NO_RESAMPLE = 32u,
   /* Full sweep only (the brick-skipping sweep always works this way): a tile whose 512 voxels
    * all come out as -limit is not stored again when it has held -limit since an earlier sweep

@@ -265,6 +265,111 @@ __global__ __launch_bounds__(128) void k_integrate_generic(IntegrateParams p)
   *out = make_float4(res[0], res[1], res[2], res[3]);
 }
 
+// The same sweep with the LUT block of a tile staged in LDS (RGBDR_FLAG_NO_RESAMPLE at a LUT that is not much finer than
+// the grid).  The plain kernel above gathers 8 x 16 B per voxel and sensor from global memory in tile order: 15.8 GB of HBM
+// traffic for a 512^3 sweep whose four 256^3 LUTs hold 1.07 GB (profiles/r06_pmc_generic.json), 9 x the time of the
+// resampled sweep.  Here the texels a tile's 512 voxels can touch -- the index box from the first voxel's lower to the last
+// voxel's upper texel, per sensor -- are loaded once, row by row (.xyz only: 12 B), and the eight taps come from LDS with
+// tex3d_xyz's expressions (bit-identical).  The fold over the sensors stays sequential per voxel.  bx * by * bz: the largest
+// box over all tiles and sensors, found on the host (launch_integrate).
+template <bool BRICKS>
+__global__ __launch_bounds__(128) void k_integrate_generic_lds(IntegrateParams p, int box_texels)
+{
+  extern __shared__ float s_box[];  // [nz][ny][nx][3] of the current sensor
+  unsigned tile = blockIdx.x;
+  if (p.order_chunk) {  // XCD-aware order like the tiled sweep: neighbouring tiles share LUT rows in one XCD's L2
+    const unsigned xcd = tile & 7u, k = tile >> 3, chunk = p.order_chunk;
+    tile = (k / chunk) * 8u * chunk + xcd * chunk + k % chunk;
+  }
+  const int q = threadIdx.x;
+  const int lz = q >> 4, ly = (q >> 1) & 7, lx0 = (q & 1) * 4;
+  const int tx = tile % p.TX;
+  const int ty = (tile / p.TX) % p.TY;
+  const int tzl = tile / (p.TX * p.TY);
+  const int vz = (p.tz0 + tzl) * kTile + lz, vy = ty * kTile + ly, vx0 = tx * kTile + lx0;
+  float4* out = reinterpret_cast<float4*>(p.tsdf + (size_t)tile * kTileVoxels) + q;
+  const float limit = p.limit;
+  const float pz = ((float)vz + 0.5f) * p.stepZ, py = ((float)vy + 0.5f) * p.stepY;
+  float tsd[4], wsum[4];
+  bool live[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int vx = vx0 + j;
+    tsd[j] = limit;
+    wsum[j] = 0.0f;
+    live[j] = !(BRICKS && !voxel_occupied(p, vx, vy, vz)) && !(vx >= p.X || vy >= p.Y || vz >= p.Z);
+  }
+  // the tile's voxel range along every axis (a partial tile ends at the grid's last voxel)
+  const int tvx0 = tx * kTile, tvy0 = ty * kTile, tvz0 = (p.tz0 + tzl) * kTile;
+  const int tvx1 = min(tvx0 + kTile - 1, p.X - 1), tvy1 = min(tvy0 + kTile - 1, p.Y - 1), tvz1 = min(tvz0 + kTile - 1, p.Z - 1);
+  for (int i = 0; i < p.N; ++i) {
+    const int rx = p.rx[i], ry = p.ry[i], rz = p.rz[i];
+    // index box: monotone in the voxel index, so the first voxel's i0 and the last voxel's i1 bound every tap
+    const int X0 = axis_linear(((float)tvx0 + 0.5f) * p.stepX, rx).i0, X1 = axis_linear(((float)tvx1 + 0.5f) * p.stepX, rx).i1;
+    const int Y0 = axis_linear(((float)tvy0 + 0.5f) * p.stepY, ry).i0, Y1 = axis_linear(((float)tvy1 + 0.5f) * p.stepY, ry).i1;
+    const int Z0 = axis_linear(((float)tvz0 + 0.5f) * p.stepZ, rz).i0, Z1 = axis_linear(((float)tvz1 + 0.5f) * p.stepZ, rz).i1;
+    const int nx = X1 - X0 + 1, ny = Y1 - Y0 + 1, nz = Z1 - Z0 + 1;
+    const int n = nx * ny * nz;
+    __syncthreads();  // the previous sensor's taps are all read
+    if (n <= box_texels) {
+      const float4* __restrict__ lut = p.lut[i];
+      for (int t = q; t < n; t += 128) {
+        const int x = t % nx, y = (t / nx) % ny, z = t / (nx * ny);
+        const float4 v = lut[((size_t)(Z0 + z - p.zoff[i]) * ry + (Y0 + y)) * rx + (X0 + x)];
+        s_box[3 * t] = v.x;
+        s_box[3 * t + 1] = v.y;
+        s_box[3 * t + 2] = v.z;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!live[j]) continue;
+      const float px = ((float)(vx0 + j) + 0.5f) * p.stepX;
+      float3 pc;
+      if (n <= box_texels) {
+        const Axis AX = axis_linear(px, rx), AY = axis_linear(py, ry), AZ = axis_linear(pz, rz);
+        auto at = [&](int x, int y, int z) {
+          const float* t = s_box + 3 * (((z - Z0) * ny + (y - Y0)) * nx + (x - X0));
+          return make_float3(t[0], t[1], t[2]);
+        };
+        const float3 c00 = lerp3(at(AX.i0, AY.i0, AZ.i0), at(AX.i1, AY.i0, AZ.i0), AX.a), c10 = lerp3(at(AX.i0, AY.i1, AZ.i0), at(AX.i1, AY.i1, AZ.i0), AX.a);
+        const float3 c01 = lerp3(at(AX.i0, AY.i0, AZ.i1), at(AX.i1, AY.i0, AZ.i1), AX.a), c11 = lerp3(at(AX.i0, AY.i1, AZ.i1), at(AX.i1, AY.i1, AZ.i1), AX.a);
+        pc = lerp3(lerp3(c00, c10, AY.a), lerp3(c01, c11, AY.a), AZ.a);
+      } else {  // (a tile whose box outgrows LDS: a LUT much finer than the grid)
+        pc = tex3d_xyz(p.lut[i], rx, ry, rz, p.zoff[i], px, py, pz);
+      }
+      float ax, ay;
+      const int jx = footprint(pc.x, p.W, ax), jy = footprint(pc.y, p.H, ay);
+      uint2 p00, p10, p01, p11;
+      fetch_global(p.frame[i], p.W, p.H, jx, jy, p00, p10, p01, p11);
+      fold_taps(p00, p10, p01, p11, ax, ay, pc.z, limit, tsd[j], wsum[j]);
+    }
+  }
+  float res[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) res[j] = live[j] ? tsd[j] : -limit;
+  *out = make_float4(res[0], res[1], res[2], res[3]);
+}
+
+// largest LUT index box of a tile along one axis (the kernel's own arithmetic, on the host: same floats)
+static int generic_box_extent(int tiles, int voxels, float step, int r)
+{
+  auto i01 = [&](int v, bool upper) {
+    const float t = ((float)v + 0.5f) * step * (float)r - 0.5f;
+    const float f = std::floor(t);
+    const int j = (int)std::fmin(std::fmax(f, -1.0f), (float)r);
+    const int k = upper ? j + 1 : j;
+    return k < 0 ? 0 : (k > r - 1 ? r - 1 : k);
+  };
+  int ext = 1;
+  for (int t = 0; t < tiles; ++t) {
+    const int v0 = t * kTile, v1 = std::min(v0 + kTile - 1, voxels - 1);
+    ext = std::max(ext, i01(v1, true) - i01(v0, false) + 1);
+  }
+  return ext;
+}
+
 // The full sweep as p.launches launches over consecutive block ranges (whole rounds of 8 chunks each).  Between two of
 // them the queue drains: the moment a kernel waiting on ANOTHER queue gets its workgroups placed -- next to one launch
 // that refills every wave slot as it frees, RCCL's gather kernel sits until the sweep ends (profiles/r05_notes).
@@ -338,6 +443,25 @@ void launch_integrate(const IntegrateParams& p_in, bool one_to_one, hipStream_t 
 #endif
   p.order_chunk = (chunk && ntiles % (8 * chunk) == 0) ? chunk : 0;
   if (!one_to_one) {
+    // the LUT box of a tile in LDS when it fits (k_integrate_generic_lds); RGBDR_GENERIC_GLOBAL=1: the plain gathers
+    static const bool global_only = getenv("RGBDR_GENERIC_GLOBAL") != nullptr;
+    int box = 0;
+    for (int i = 0; i < p.N && !global_only; ++i) {
+      const int e = generic_box_extent(p.TX, p.X, p.stepX, p.rx[i]) * generic_box_extent(p.TY, p.Y, p.stepY, p.ry[i]) *
+                    generic_box_extent(p.tz0 + p.ntz, p.Z, p.stepZ, p.rz[i]);
+      box = std::max(box, e);
+    }
+    const size_t lds = (size_t)box * 3 * sizeof(float);
+    if (box > 0 && lds <= 96 * 1024) {
+      if (p.use_bricks) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_integrate_generic_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_integrate_generic_lds<true>), dim3(ntiles), dim3(128), lds, s, p, box);
+      } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_integrate_generic_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_integrate_generic_lds<false>), dim3(ntiles), dim3(128), lds, s, p, box);
+      }
+      return;
+    }
     if (p.use_bricks)
       hipLaunchKernelGGL((k_integrate_generic<true>), dim3(ntiles), dim3(128), 0, s, p);
     else
