@@ -642,6 +642,18 @@ def run_rank(args, slab=None, quiet=False, shared=None):
         if rig.managed:
             with wd.phase("trial step", 60.0):
                 trial_step(rig)
+    # The "once per process, ~230 frames in, the host is held for 36-100 ms" of rounds 4-5 was Python's cyclic collector:
+    # a generation-2 pass over everything the set-up left on the heap (scene arrays, ctypes objects, torch), triggered by
+    # the allocation count of the step loop -- outside any HIP or RCCL call (profiles/stall_trace.sh, r06_notes/host_stall.md:
+    # with the collector off or the heap frozen the gap is gone).  The set-up's objects are moved out of the collector's
+    # reach here; RGBDR_BENCH_GC=on leaves it as it was.
+    if os.environ.get("RGBDR_BENCH_GC", "freeze") != "on":
+        import gc
+        gc.collect()
+        if os.environ.get("RGBDR_BENCH_GC") == "off":
+            gc.disable()
+        else:
+            gc.freeze()
     if rig.multi and args.halo_transport == "peer":
         with wd.phase("transport", 120.0):
             use_copy_engine_halo(rig)

@@ -629,6 +629,10 @@ class Context:
         return color, depth
 
     # the halo by copy engine (rgbdr_halo_export / _set_peer / _pull_async): exports are plain bytes
+    def halo_exchange(self, nccl_comm, peer_lo, peer_hi, buffer=-1, hip_stream=None):
+        """one grouped send / recv of the boundary layers on a stream (rgbdr_halo_exchange)"""
+        self._chk(lib().rgbdr_halo_exchange(self._h, nccl_comm, peer_lo, peer_hi, buffer, _P(hip_stream) if hip_stream else None))
+
     def halo_export(self):
         buf = C.create_string_buffer(HALO_PEER_BYTES)
         self._chk(lib().rgbdr_halo_export(self._h, buf))
