@@ -1,4 +1,5 @@
-"""bench.py's choice of the pre_* chain schedule of an N > 1 run: sharded by sensor, redundant, or sharded and one frame ahead
+"""bench.py's choice of the pre_* chain schedule of an N > 1 run: sharded by sensor, redundant, or sharded and one
+frame ahead
 of the sweep (dist.LaggedChain) -- timed on the run's own ranks before the headline."""
 import os
 import sys
@@ -17,12 +18,15 @@ def all_ranks_ok(rig, ok):
 
 def choose_chain(rig, steps=40, warmup=8):
     """Which schedule for the pre_* chain of an N > 1 run?
-      sharded    rank r runs n / k sensors; one all-gather of the packed frames + one all-reduce of the brick counters sit
-                 between chain and sweep (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an estimated 45-140 us over
+      sharded    rank r runs n / k sensors; one all-gather of the packed frames + one all-reduce of the brick counters
+      sit
+                 between chain and sweep (3.5 MB per rank at configs[3]: ~20 us to the same GPU, an estimated 45-140 us
+                 over
                  xGMI, against 60-70 us of chain time saved);
       redundant  every rank runs every sensor, no collective;
       lagged     sharded on a chain-only context one frame AHEAD of the sweep, so the gather of frame k+1 travels under
-                 the sweep of frame k (dist.LaggedChain, rgbdr_import_frame): one chain + one gather + one sweep per step,
+                 the sweep of frame k (dist.LaggedChain, rgbdr_import_frame): one chain + one gather + one sweep per
+                 step,
                  like the others, one frame of latency more.
     Which is shortest depends on the interconnect, so the run MEASURES all three on its own ranks before the headline
     and keeps the fastest (max over ranks); the line records the three times.  (Timed like the headline -- host clock
@@ -37,7 +41,8 @@ def choose_chain(rig, steps=40, warmup=8):
     ctx.set_use_bricks(False)                # the headline's sweep
 
     def run():
-        for attempt in range(3):             # (a trial that contains the collective library's one-off host stall is run again)
+        # (a trial that contains the collective library's one-off host stall is run again)
+        for attempt in range(3):
             for _ in range(warmup):
                 rig.step(False)
             rig.barrier()
@@ -56,10 +61,12 @@ def choose_chain(rig, steps=40, warmup=8):
                 break
         return float(t[0])
 
-    slow_transport = rig.args.backend == "gloo"       # (host-staged debugging transport: tens of ms per step -- short trials)
+    # (host-staged debugging transport: tens of ms per step -- short trials)
+    slow_transport = rig.args.backend == "gloo"
     if slow_transport:
         steps, warmup = 6, 2
-    for _ in range(0 if slow_transport else 60):      # clocks up first: the schedule tried first is not to pay the ramp (3 % over ~25 frames)
+    # clocks up first: the schedule tried first is not to pay the ramp (3 % over ~25 frames)
+    for _ in range(0 if slow_transport else 60):
         rig.step(False)
     times = {"sharded": run()}
     ctx.set_sensor_shard(0, 0)
@@ -71,23 +78,30 @@ def choose_chain(rig, steps=40, warmup=8):
         if not getattr(rig.args, "lagged", True):
             raise RuntimeError("--no-lagged")
         g = rig.geo
-        chain = capi.Context(capi.make_config(n, (rig.W, rig.H), voxel_size=g.brick_size, brick_size=g.brick_size), rig.local_rank)
+        chain = capi.Context(capi.make_config(n, (rig.W, rig.H), voxel_size=g.brick_size, brick_size=g.brick_size),
+            rig.local_rank)
         if tuple(chain.geo.res_bricks) != tuple(g.res_bricks) or chain.geo.brick_size != g.brick_size:
             raise RuntimeError("the chain-only context's brick grid differs")
         for i in range(n):
-            chain.set_calibration(i, rig.scene.xyz[i], rig.scene.lut_res, rig.scene.uv[i], rig.scene.lut_res, (0.5, 4.5))
-        if rig.loop:                          # (dist.FrameGather loopback: the brick counts of an unsharded frame stand for the other ranks')
+            chain.set_calibration(i, rig.scene.xyz[i], rig.scene.lut_res, rig.scene.uv[i], rig.scene.lut_res, (0.5,
+                4.5))
+        # (dist.FrameGather loopback: the brick counts of an unsharded frame stand for the other ranks')
+        if rig.loop:
             chain.update_device(rig.d_depth.data_ptr(), rig.d_color.data_ptr())
             chain.clear_occupied_bricks(); chain.process_textures()
             chain.sync()
         raw = getattr(rig.exchanger, "comm_gather", None) if rig.managed and not rig.loop else None
-        if raw is not None:                   # the library enqueues the gather itself (rgbdr_shard_allgather_async) on the raw communicator
+        # the library enqueues the gather itself (rgbdr_shard_allgather_async) on the raw communicator
+        if raw is not None:
             chain.set_sensor_shard(first, count)
             lag_gather = None
         elif rig.managed and getattr(rig.exchanger, "comm_gather", None) is not None:     # one GPU, raw RCCL to itself
-            lag_gather = rdist.RawLoopbackGather(chain, rig.dev, rig.slab_rank, rig.slab_count, rig.exchanger.comm_gather)
-        else:                                 # torch.distributed's collectives on a side stream, or the one-GPU loopback
-            lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count, group=rig.transport["group"],
+            lag_gather = rdist.RawLoopbackGather(chain, rig.dev, rig.slab_rank, rig.slab_count,
+                rig.exchanger.comm_gather)
+        # torch.distributed's collectives on a side stream, or the one-GPU loopback
+        else:
+            lag_gather = rdist.FrameGather(chain, rig.dev, rank=rig.slab_rank, world=rig.slab_count,
+                group=rig.transport["group"],
                                            via_host=rig.transport["kind"] != "rccl", loopback=rig.loop)
         lag = rdist.LaggedChain(ctx, chain, rig.dev, lag_gather,
                                 before_sweep=rig.exchanger.begin_step if rig.halo is not None else None,
@@ -99,14 +113,16 @@ def choose_chain(rig, steps=40, warmup=8):
         lag.flush()
         rig.barrier()
     except Exception as e:  # noqa: BLE001 -- a schedule that does not come up is not a candidate
-        sys.stderr.write("[bench rank %d] lagged chain unavailable (%s: %s)\n" % (rig.rank, type(e).__name__, str(e)[:200]))
+        sys.stderr.write("[bench rank %d] lagged chain unavailable (%s: %s)\n" % (rig.rank, type(e).__name__,
+            str(e)[:200]))
         times["lagged"] = None
     rig.lag = None
     ctx.set_sweep_launches(1)
     ok = all_ranks_ok(rig, times["lagged"] is not None)
     cands = {k: v for k, v in times.items() if v is not None and (k != "lagged" or ok)}
     kept = min((k for k in cands if k != "lagged"), key=cands.get)
-    if "lagged" in cands and cands["lagged"] < 0.98 * cands[kept]:   # one frame of latency more: only for a gain beyond the noise
+    # one frame of latency more: only for a gain beyond the noise
+    if "lagged" in cands and cands["lagged"] < 0.98 * cands[kept]:
         kept = "lagged"
     if os.environ.get("RGBDR_BENCH_CHAIN") in cands:        # pin the choice (tests, A/B runs)
         kept = os.environ["RGBDR_BENCH_CHAIN"]
@@ -120,9 +136,11 @@ def choose_chain(rig, steps=40, warmup=8):
         chain.close()
         lag = None
     # the legs after the headline run on the better of the two plain schedules
-    rig.plain_chain = ("sharded", keep_gather, first, count) if times["sharded"] <= times["redundant"] else ("redundant", None, 0, 0)
+    rig.plain_chain = ("sharded", keep_gather, first,
+        count) if times["sharded"] <= times["redundant"] else ("redundant", None, 0, 0)
     rig.lag_keep = (lag, chain)
-    rig.chain_choice = {"ms_per_step_sharded": round(times["sharded"], 4), "ms_per_step_redundant": round(times["redundant"], 4),
+    rig.chain_choice = {"ms_per_step_sharded": round(times["sharded"], 4),
+        "ms_per_step_redundant": round(times["redundant"], 4),
                         "ms_per_step_lagged": round(times["lagged"], 4) if times["lagged"] is not None else None,
                         "kept": kept, "steps_each": steps}
 
@@ -145,7 +163,8 @@ def leave_lagged_chain(rig):
 
 
 def recheck_lagged_headline(rig, dt, stats):
-    """The lagged schedule was kept on its trial, but its K timed steps took 10 % longer per step than the trial AND longer
+    """The lagged schedule was kept on its trial, but its K timed steps took 10 % longer per step than the trial AND
+    longer
     than the better plain schedule's trial (seen on one GPU: a single 50-100 ms stall of the host inside RCCL's enqueue
     under this schedule, profiles/r05_notes/scaling_tail.md): leave it, time the K steps again on the plain schedule and
     report those -- the line keeps what the discarded attempt read.  (dt and the trials are maxima over the ranks: every
@@ -158,7 +177,8 @@ def recheck_lagged_headline(rig, dt, stats):
     leave_lagged_chain(rig)
     c["lagged_headline_discarded_ms_per_step"] = round(ms, 4)
     c["kept"] = rig.plain_chain[0]
-    c["why"] = "the lagged schedule's timed steps took more than 1.1 x its trial: timed again on the better plain schedule"
+    c["why"] = ("the lagged schedule's timed steps took more than 1.1 x its trial: "
+                "timed again on the better plain schedule")
     dt, stats = rig.timed(False, rig.args.steps, rig.args.warmup)
     rig.stats = stats
     return dt, stats
@@ -169,7 +189,8 @@ STALL_MS = 30.0
 
 def retime_after_a_host_stall(rig, dt, stats):
     """Once per process (70-300 frames in) the host is held for 36-100 ms inside RCCL's enqueue -- no HIP call in
-    progress, whichever schedule runs, the device idle meanwhile (profiles/r05_notes/scaling_tail.md, lag_stall_probe.py,
+    progress, whichever schedule runs, the device idle meanwhile (profiles/r05_notes/scaling_tail.md,
+    lag_stall_probe.py,
     stall_log.sh).  A run of K = 40 steps that contains it reads two to three times its steady state.  The criterion is
     the host's own clock: a single step of the timed loop that took the host more than 30 ms (a frame is 0.6-2.4 ms) on
     ANY rank -> every rank times its K steps again, at most twice; the line keeps what the discarded attempts read."""
@@ -178,11 +199,13 @@ def retime_after_a_host_stall(rig, dt, stats):
         stalled = getattr(rig, "longest_host_step_ms", 0.0) > STALL_MS
         if all_ranks_ok(rig, not stalled):
             break
-        discarded.append({"ms_per_step": round(dt / rig.args.steps * 1e3, 4), "longest_host_step_ms": round(rig.longest_host_step_ms, 1)})
+        discarded.append({"ms_per_step": round(dt / rig.args.steps * 1e3, 4),
+            "longest_host_step_ms": round(rig.longest_host_step_ms, 1)})
         dt, stats = rig.timed(False, rig.args.steps, rig.args.warmup)
         rig.stats = stats
     if discarded:
-        rig.retimed = {"why": "a step of the timed loop held the host for more than %.0f ms on some rank (a one-off stall "
+        rig.retimed = {"why": "a step of the timed loop held the host for more than %.0f ms on some rank (a one-off "
+            "stall "
                               "inside the collective library's enqueue): the K steps were timed again" % STALL_MS,
                        "discarded": discarded, "longest_host_step_ms_kept": round(rig.longest_host_step_ms, 1)}
     return dt, stats

@@ -24,7 +24,8 @@ RUNGS = (
     ("copy-engine halo (HIP IPC peer copies) + every sensor's chain on every rank, weak-scaling run only",
      ["--halo-transport", "peer", "--torch-collectives", "--no-shard", "--no-lagged", "--weak"]),
 )
-RUNG_BUDGETS = (470.0, 330.0, 330.0, 300.0)   # seconds per rung; sum + slack stays under --launch-timeout (1500) < the driver's 1800
+# seconds per rung; sum + slack stays under --launch-timeout (1500) < the driver's 1800
+RUNG_BUDGETS = (470.0, 330.0, 330.0, 300.0)
 EXIT_WATCHDOG = 75                       # a child stopped by its own per-phase watchdog
 
 
@@ -80,7 +81,8 @@ def launch_ranks(n, argv, timeout=1500.0, child_cmd=None, poll_s=0.2):
     procs, lines = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+            text=(r == 0) or None))
 
     def pump():
         for ln in procs[0].stdout:
@@ -102,7 +104,8 @@ def launch_ranks(n, argv, timeout=1500.0, child_cmd=None, poll_s=0.2):
             live.discard(r)
             if code != 0:
                 rc = code if code > 0 else 128 - code
-                sys.stderr.write("[bench launcher] rank %d exited with status %d; stopping the other ranks\n" % (r, code))
+                sys.stderr.write("[bench launcher] rank %d exited with status %d; stopping the other ranks\n" % (r,
+                    code))
                 # (supervisors leave on their own within moments of each other; rank 0's prints the line on its way out)
                 t_grace = time.monotonic() + (0.0 if child_cmd else 20.0)
                 while time.monotonic() < t_grace and any(procs[q].poll() is None for q in live):
@@ -111,7 +114,8 @@ def launch_ranks(n, argv, timeout=1500.0, child_cmd=None, poll_s=0.2):
         if live and rc == 0:
             if time.monotonic() > deadline:
                 rc = 124
-                sys.stderr.write("[bench launcher] %d rank(s) still running after %.0f s; stopping them\n" % (len(live), timeout))
+                sys.stderr.write("[bench launcher] %d rank(s) still running after %.0f s; stopping them\n" % (len(live),
+                    timeout))
                 break
             time.sleep(poll_s)
     if rc != 0:
@@ -132,8 +136,10 @@ def launch_ranks(n, argv, timeout=1500.0, child_cmd=None, poll_s=0.2):
 
 
 class FileStore:
-    """What the supervisors of one job on one node agree through: small JSON files in a directory of the temp dir, written
-    by rename.  (torch.distributed.run's own store would do, but a supervisor must not import torch: it never touches the
+    """What the supervisors of one job on one node agree through: small JSON files in a directory of the temp dir,
+    written
+    by rename.  (torch.distributed.run's own store would do, but a supervisor must not import torch: it never touches
+    the
     GPU and costs nothing.)  The directory name is unique per job: our launcher's job id, or the launching agent's pid +
     start time + rendezvous port."""
 
@@ -194,10 +200,13 @@ def headline_of(lines):
 def supervise_rank(args, argv):
     """The supervisor of one rank of an N > 1 run (started by launch_ranks or by torch.distributed.run; it never touches
     the GPU, so it may start FRESH children as often as it likes).  It walks RUNGS: per rung every supervisor starts one
-    child (this script, role "rank", a fresh rendezvous port chosen by rank 0's supervisor), and rank 0's supervisor decides
-    the rung's verdict: ok as soon as its child has printed a line with a headline and ended (or the rung's budget ran out
+    child (this script, role "rank", a fresh rendezvous port chosen by rank 0's supervisor), and rank 0's supervisor
+    decides
+    the rung's verdict: ok as soon as its child has printed a line with a headline and ended (or the rung's budget ran
+    out
     with the provisional line in hand), failed otherwise.  Children bound their own phases (Watchdog) and leave with
-    os._exit; the supervisors bound the rung.  The verdict travels through a FileStore.  Rank 0's supervisor prints THE line:
+    os._exit; the supervisors bound the rung.  The verdict travels through a FileStore.  Rank 0's supervisor prints THE
+    line:
     the child's, plus `launch` = which rung produced it and what failed before; or {"error": ..., "attempts": [...]} and
     a non-zero status when every rung failed.  Total time <= --launch-timeout."""
     import subprocess
@@ -220,9 +229,11 @@ def supervise_rank(args, argv):
         name, flags = RUNGS[k]
         budget = min(budgets[min(k, len(budgets) - 1)], t_end - time.monotonic())
         if rank == 0:
-            # rank 0's supervisor alone decides whether a rung starts (the others would round the same clock differently)
+            # rank 0's supervisor alone decides whether a rung starts (the others would round the same clock
+            # differently)
             if budget < min(60.0, budgets[min(k, len(budgets) - 1)]):
-                attempts.append({"rung": k, "name": name, "outcome": "not started: %.0f s of the run's budget left" % max(budget, 0.0)})
+                attempts.append({"rung": k, "name": name,
+                    "outcome": "not started: %.0f s of the run's budget left" % max(budget, 0.0)})
                 store.put("rung%d.port" % k, -1)
                 break
             port = free_port()
@@ -234,12 +245,15 @@ def supervise_rank(args, argv):
                 return 1
             if port < 0:
                 break
-        env = dict(os.environ, RGBDR_BENCH_ROLE="rank", RGBDR_BENCH_RUNG=str(k), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RGBDR_BENCH_ROLE="rank", RGBDR_BENCH_RUNG=str(k), MASTER_ADDR="127.0.0.1",
+            MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         for key in [e for e in env if e.startswith("TORCHELASTIC_") or e in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",)]:
-            env.pop(key)                                    # the children rendezvous among themselves, not through the agent
+            # the children rendezvous among themselves, not through the agent
+            env.pop(key)
         t0 = time.monotonic()
-        child = subprocess.Popen(base_cmd + list(argv) + flags, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr,
+        child = subprocess.Popen(base_cmd + list(argv) + flags, env=env,
+            stdout=subprocess.PIPE if rank == 0 else sys.stderr,
                                  text=True if rank == 0 else None)
         lines = []
         if rank == 0:
@@ -261,7 +275,8 @@ def supervise_rank(args, argv):
                     reported = True
                 verdict = store.get("rung%d.verdict" % k)
                 if verdict is None and now > deadline + 45.0:
-                    log("rung %d: no verdict from rank 0's supervisor %.0f s after the rung's budget; giving up" % (k, now - deadline))
+                    log("rung %d: no verdict from rank 0's supervisor %.0f s after the rung's budget; giving up" % (k,
+                        now - deadline))
                     stop_process(child)
                     return 1
             else:
@@ -273,7 +288,8 @@ def supervise_rank(args, argv):
                 elif now > deadline:
                     line = headline_of(lines)
                     verdict = "ok" if line else "failed"
-                    why = "the rung's budget of %.0f s ran out %s" % (budget, "with the provisional line in hand" if line else "before a headline")
+                    why = "the rung's budget of %.0f s ran out %s" % (budget,
+                        "with the provisional line in hand" if line else "before a headline")
                 else:
                     # another rank's child died without a headline on our side: the job cannot complete; a short grace
                     # (its own watchdog or the broken collective will usually end our child first), then stop
@@ -301,10 +317,13 @@ def supervise_rank(args, argv):
             line = headline_of(lines)
             if verdict == "ok" and line:
                 final = line
-                final["launch"] = {"rung": k, "rung_name": name, "rung_flags": flags, "rung_s": took, "child_status": code,
-                                   "line": "provisional (the child did not reach its end)" if line.get("provisional") else "final",
+                final["launch"] = {"rung": k, "rung_name": name, "rung_flags": flags, "rung_s": took,
+                    "child_status": code,
+                                   "line": "provisional (the child did not reach its "
+                                   "end)" if line.get("provisional") else "final",
                                    "note": why or None, "failed_attempts": attempts,
-                                   "launched_by": "torch.distributed.run" if "RGBDR_BENCH_JOB" not in os.environ else "bench.py"}
+                                   "launched_by": "torch.distributed.run"
+                                   if "RGBDR_BENCH_JOB" not in os.environ else "bench.py"}
                 final.pop("provisional", None)
                 break
             errs = []
@@ -332,7 +351,8 @@ def supervise_rank(args, argv):
     if final is not None:
         sys.stdout.write(json.dumps(final) + "\n")
     else:
-        sys.stdout.write(json.dumps({"error": "every rung of the launch ladder failed", "n_gpus": world, "attempts": attempts,
+        sys.stdout.write(json.dumps({"error": "every rung of the launch ladder failed", "n_gpus": world,
+            "attempts": attempts,
                                      "seconds": round(time.monotonic() - t_start, 1)}) + "\n")
     sys.stdout.flush()
     store.put("printed", 1)

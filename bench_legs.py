@@ -113,7 +113,8 @@ def leg_other_schedule(rig):
     finally:
         ctx.set_pipelined(bool(args.pipeline))
     oi_ns, oi_n = stats_o["2integrate"]
-    return {"schedule": "sequential" if args.pipeline else "pipelined (pre_* of step k+1 on a second stream under integrate of step k)",
+    return {"schedule": "sequential" if args.pipeline else "pipelined (pre_* of step k+1 on a second stream under "
+        "integrate of step k)",
             "ms_per_step": round(dto / args.steps * 1e3, 4), "value": round(rig.V_total / (dto / args.steps) / 1e6, 1),
             "integrate_ms": round(oi_ns / max(oi_n, 1) * 1e-6, 4)}
 
@@ -128,7 +129,8 @@ def leg_elision(rig):
         ctx.set_elide_stores(False)
     ei_ns, ei_n = stats_e["2integrate"]
     return {"ms_per_step": round(dte / args.steps * 1e3, 4), "value": round(rig.V_total / (dte / args.steps) / 1e6, 1),
-            "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4), "scene": "static ring scene (best case; dense / moving under `scenes`)"}
+            "integrate_ms": round(ei_ns / max(ei_n, 1) * 1e-6, 4),
+            "scene": "static ring scene (best case; dense / moving under `scenes`)"}
 
 
 def skip_summary(rig, ctx, dts, stats_s, steps):
@@ -148,7 +150,8 @@ def skip_summary(rig, ctx, dts, stats_s, steps):
 
 
 def leg_background_skip(rig):
-    """RGBDR_FLAG_SKIP_BACKGROUND: LUT planes of (tile, sensor) pairs whose frame window decides the outcome stay unread,
+    """RGBDR_FLAG_SKIP_BACKGROUND: LUT planes of (tile, sensor) pairs whose frame window decides the outcome stay
+    unread,
     tiles that are constants are not rewritten while they hold their constant"""
     ctx, args = rig.ctx, rig.args
     ctx.set_skip_background(True)
@@ -182,9 +185,11 @@ def leg_slab(rig, out):
             "roofline_frac": round(rig.achieved / rig.HBM_PEAK, 4), "halo_ms_to_self": rig.halo_ms,
             "frame_gather_ms_to_self": gather.last_ms() if hasattr(gather, "last_ms") else None,
             "schedule": ("pipelined" if args.pipeline else "sequential") + (
-                ", " + rig.chain_choice["kept"] + " chain" if getattr(rig, "chain_choice", None) else (", sharded chain" if gather is not None else "")) +
+                ", " + rig.chain_choice["kept"] + " chain" if getattr(rig, "chain_choice",
+                None) else (", sharded chain" if gather is not None else "")) +
                         (", library-managed RCCL" if rig.managed else "") + (
-                            ", RGBDR_CU_SPLIT=" + os.environ["RGBDR_CU_SPLIT"] if os.environ.get("RGBDR_CU_SPLIT") else "")}
+                            ", RGBDR_CU_SPLIT="
+                            + os.environ["RGBDR_CU_SPLIT"] if os.environ.get("RGBDR_CU_SPLIT") else "")}
 
 
 def leg_halo(rig, out):
@@ -192,28 +197,34 @@ def leg_halo(rig, out):
     per_rank = out.get("per_rank")
     return {"layers_per_face": int(rig.geo.halo_tile_layers), "bytes_per_face": int(rig.halo[0].numel() * 4),
             "transfer_ms_rank0": rig.exchanger.last_transfer_ms(),
-            "transfer_ms_max": max([h for h in per_rank["halo_ms"] if h is not None], default=None) if per_rank else rig.halo_ms}
+            "transfer_ms_max": max([h for h in per_rank["halo_ms"] if h is not None],
+            default=None) if per_rank else rig.halo_ms}
 
 
 def leg_halo_copy_engine(rig, out):
     """The same steps with the halo moved by the COPY ENGINE instead of RCCL's send / recv kernels (the C ABI's
-    rgbdr_halo_export / _set_peer / _pull_async; dist.PeerCopySlabExchange): every rank pulls its neighbours' staged faces
+    rgbdr_halo_export / _set_peer / _pull_async; dist.PeerCopySlabExchange): every rank pulls its neighbours' staged
+    faces
     with device-to-device copies from their IPC-mapped staging sets.  RCCL stays the transport of the headline; this leg
     says what the alternative gives on the same ranks (the gather of a sharded chain still runs over RCCL)."""
     ctx, args = rig.ctx, rig.args
     keep = rig.exchanger
     keep.wait()
     rig.barrier()
-    group = rig.shared.get("fallback") if rig.world > 1 else None         # exports are Python bytes: a gloo group carries them
+    # exports are Python bytes: a gloo group carries them
+    group = rig.shared.get("fallback") if rig.world > 1 else None
     peer = rig.rdist.PeerCopySlabExchange(ctx, rig.dev, rig.slab_rank, rig.slab_count, group=group, loopback=rig.loop)
 
     class Both:                      # halo by copy engine, everything else (the gather) as before
-        begin_step, exchange_async, wait, last_transfer_ms = peer.begin_step, peer.exchange_async, peer.wait, peer.last_transfer_ms
+        begin_step, exchange_async = peer.begin_step, peer.exchange_async
+        wait, last_transfer_ms = peer.wait, peer.last_transfer_ms
     rig.exchanger = Both()
     try:
         steps = max(8, min(args.steps, 40))
-        warm_clocks(ctx, lambda k: rig.step(False))
-        dt, st = rig.timed(False, steps, 4)
+        # (every rank the same number of steps: a loop by the clock would leave the neighbours of the rank that stops
+        # first
+        # waiting for faces that never come)
+        dt, st = rig.timed(False, steps, 24 if rig.args.backend == "nccl" else 4)
         ctx.enable_timers(True)
         ctx.set_timer_detail(2)
         rig.step(False)
@@ -222,15 +233,19 @@ def leg_halo_copy_engine(rig, out):
         ctx.sync()
         ms = peer.last_transfer_ms()
         ctx.enable_timers(False)
-        head = "copy_engine" if getattr(rig, "halo_by", "rccl") == "peer" else "rccl"       # what the headline ran on
-        return {"halo_transport": "copy engine: hipMemcpyAsync from the neighbours' IPC-mapped staging sets behind step words the streams "
+        # what the headline ran on
+        head = "copy_engine" if getattr(rig, "halo_by",
+            "rccl") == "peer" else ("rccl" if rig.transport["kind"] == "rccl" else "host_staged")
+        return {"halo_transport": "copy engine: hipMemcpyAsync from the neighbours' IPC-mapped staging sets behind "
+            "step words the streams "
                                   "write / wait for (hipStreamWriteValue32 / hipStreamWaitValue32)"
                                   + (" (loopback: this process is its own neighbour, no IPC)" if rig.loop else ""),
                 "ms_per_step": round(dt / steps * 1e3, 4), "ms_per_step_headline_" + head: out["ms_per_step"],
                 "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4),
                 "integrate_ms_headline_" + head: round(rig.int_s * 1e3, 4),
                 "transfer_ms": None if ms is None else round(ms, 4), "transfer_ms_headline_" + head: rig.halo_ms,
-                "host_enqueue_ms_per_step": round(rig.host_enqueue_ms, 4), "longest_host_step_ms": round(rig.longest_host_step_ms, 3),
+                "host_enqueue_ms_per_step": round(rig.host_enqueue_ms, 4),
+                "longest_host_step_ms": round(rig.longest_host_step_ms, 3),
                 "sweep_launches": 1}
     finally:
         rig.exchanger = keep
@@ -243,7 +258,8 @@ def leg_halo_copy_engine(rig, out):
 
 # ---- clocks and power under load -----------------------------------------------------------------------------------
 def gpu_sysfs(torch, index=0):
-    """the sysfs directory of HIP device `index`: matched by PCI address (a box shows the cards of every GPU of the node,
+    """the sysfs directory of HIP device `index`: matched by PCI address (a box shows the cards of every GPU of the
+    node,
     the process sees one of them); the first card with clocks when the address cannot be matched"""
     import glob
     cards = [d for d in sorted(glob.glob("/sys/class/drm/card*/device")) if os.path.exists(d + "/pp_dpm_mclk")]
@@ -301,9 +317,11 @@ class BoxSampler(threading.Thread):
 
 
 def leg_box(rig):
-    """roofline.box: clocks, power and busy percentage of the GPU UNDER LOAD -- an untimed burst of the same step loop of
+    """roofline.box: clocks, power and busy percentage of the GPU UNDER LOAD -- an untimed burst of the same step loop
+    of
     at least one second with sysfs sampled from a side thread every 20 ms; the statistics are over the samples of the
-    middle 60 % of the burst.  (Round 4 took one sample after enqueueing a 23 ms timed region and read an idle clock.)  A
+    middle 60 % of the burst.  (Round 4 took one sample after enqueueing a 23 ms timed region and read an idle clock.) 
+    A
     clock that still reads idle next to a busy GPU is a stale sysfs marker, and is dropped rather than printed."""
     dev, bdf = gpu_sysfs(rig.torch, rig.local_rank)
     if dev is None:
@@ -323,7 +341,8 @@ def leg_box(rig):
     for i in range(steps):
         rig.step(False)
         if i % 64 == 63:
-            rig.ctx.sync()                 # keep the queue short: the burst then lasts as long on the host as on the GPU
+            # keep the queue short: the burst then lasts as long on the host as on the GPU
+            rig.ctx.sync()
             marks.append((i + 1, time.perf_counter()))
     rig.ctx.sync()
     t1 = time.perf_counter()
@@ -336,7 +355,8 @@ def leg_box(rig):
         v = sorted(s[key] for s in mid if key in s)
         return {"min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)} if v else None
 
-    # The headline's 20-50 steps start from an idle GPU; under sustained load the package reaches its power limit and the
+    # The headline's 20-50 steps start from an idle GPU; under sustained load the package reaches its power limit and
+    # the
     # clock settles lower.  The burst's second half says what a long-running loop gets per step.
     half = [m for m in marks if m[0] >= steps // 2]
     sustained = (half[-1][1] - half[0][1]) / (half[-1][0] - half[0][0]) * 1e3 if len(half) >= 2 else None
@@ -355,21 +375,23 @@ def leg_box(rig):
         res["sclk_MHz"] = sclk
     else:
         res["sclk_MHz"] = None
-        res["sclk_note"] = "dropped: sysfs reads %s MHz during the burst (a stale DPM marker, not the clock the kernels ran at)" % (
-            sclk["max"] if sclk else "nothing")
+        res["sclk_note"] = ("dropped: sysfs reads %s MHz during the burst (a stale DPM marker, not the clock the "
+                            "kernels ran at)" % (sclk["max"] if sclk else "nothing"))
     return res
 
 
 # ---- the data-dependent modes on three scenes ----------------------------------------------------------------------
 def profiled():
-    """a profiler is preloaded (rocprofv3 sets ROCP* / ROCPROF* variables): every dispatch becomes a row of its output, so
+    """a profiler is preloaded (rocprofv3 sets ROCP* / ROCPROF* variables): every dispatch becomes a row of its output,
+    so
     the legs keep their untimed loops short"""
     return any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
 def warm_clocks(ctx, step, seconds=0.3):
     """A leg that prepares its inputs on the CPU for a second or two leaves the GPU idle, its clocks drop, and the first
-    ~25 sweeps afterwards run 3 % longer while they ramp up again (profiles/variance_probe4.py: 1.092 instead of 1.061 ms
+    ~25 sweeps afterwards run 3 % longer while they ramp up again (profiles/variance_probe4.py: 1.092 instead of 1.061
+    ms
     after 2 s of idle).  So such a leg runs its own step loop untimed for a moment before it times anything."""
     t_end = time.perf_counter() + (0.01 if profiled() else seconds)
     k = 0
@@ -416,9 +438,11 @@ def measure_modes(rig, ctx, frames, steps, warmup):
     _, st = rig.timed(False, max(4, len(frames)), 1, detail=1, step=step, ctx=ctx)
     res["pre_chain_ms"] = round(st["1preprocess"][0] / max(st["1preprocess"][1], 1) * 1e-6, 4)
     _, st = rig.timed(False, max(4, len(frames)), 1, detail=2, step=step, ctx=ctx)
-    res["pre_passes_ms"] = {n: round(st[n][0] / max(st[n][1], 1) * 1e-6, 4) for n in ("morph", "bilateral", "boundary", "normal", "quality")}
+    res["pre_passes_ms"] = {n: round(st[n][0] / max(st[n][1], 1) * 1e-6, 4) for n in ("morph", "bilateral", "boundary",
+        "normal", "quality")}
     dt, st = rig.timed(True, steps, warmup, step=step, ctx=ctx)
-    res["bricked"] = {"ms_per_step": round(dt / steps * 1e3, 4), "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4),
+    res["bricked"] = {"ms_per_step": round(dt / steps * 1e3, 4),
+        "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4),
                       "occupied_ratio": round(ctx.occupied_ratio(), 4)}
     ctx.set_use_bricks(False)
     ctx.set_skip_background(True)
@@ -427,20 +451,24 @@ def measure_modes(rig, ctx, frames, steps, warmup):
         sk = skip_summary(rig, ctx, dt, st, steps)
     finally:
         ctx.set_skip_background(False)
-    res["background_skip"] = {key: sk[key] for key in ("ms_per_step", "integrate_ms", "frac_decided", "tiles_listed", "tiles")}
+    res["background_skip"] = {key: sk[key] for key in ("ms_per_step", "integrate_ms", "frac_decided", "tiles_listed",
+        "tiles")}
     ctx.set_elide_stores(True)
     try:
         dt, st = rig.timed(False, steps, warmup, step=step, ctx=ctx)
     finally:
         ctx.set_elide_stores(False)
-    res["store_elision"] = {"ms_per_step": round(dt / steps * 1e3, 4), "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4)}
+    res["store_elision"] = {"ms_per_step": round(dt / steps * 1e3, 4),
+        "integrate_ms": round(st["2integrate"][0] / max(st["2integrate"][1], 1) * 1e-6, 4)}
     res["valid_pixels"] = None
     return res
 
 
 def leg_scenes(rig):
-    """The data-dependent numbers on more than their best case: `static` is the headline's scene (two thirds of
-    the pixels see nothing, the same frame every step); `moving` rotates four different frames of it (new noise and holes,
+    """The data-dependent numbers on more than their best case: `static` is the headline's scene (two thirds
+    of
+    the pixels see nothing, the same frame every step); `moving` rotates four different frames of it (new noise and
+    holes,
     the sphere displaced: occupied bricks, tile states, list sizes and elided stores change every step); `dense` is a
     scene whose every pixel is valid and inside the box (pre_* runs its 169 taps everywhere, nothing is background);
     `dense_moving` rotates four frames of that."""
@@ -472,7 +500,8 @@ def leg_scenes(rig):
         cfg = capi.make_config(N, (W, H), voxel_size=2.0 / rig.G, brick_size=8 * 2.0 / rig.G, res_override=rig.grid)
         dctx = capi.Context(cfg, rig.local_rank)
         for i in range(N):
-            dctx.set_calibration(i, dense_scene.xyz[i], dense_scene.lut_res, dense_scene.uv[i], dense_scene.lut_res, (0.5, 4.5))
+            dctx.set_calibration(i, dense_scene.xyz[i], dense_scene.lut_res, dense_scene.uv[i], dense_scene.lut_res,
+                (0.5, 4.5))
             dctx.synth_inverse_calibration(i, dense_scene.pinhole(i))
         dense = resident(dense_scene, 4)
         res["dense"] = measure_modes(rig, dctx, dense[:1], steps, warmup)
@@ -484,10 +513,13 @@ def leg_scenes(rig):
             dctx.close()
     fr = [res[k]["full_sweep"]["frac_of_box_stream"] for k in ("static", "moving", "dense", "dense_moving") if k in res]
     res["full_sweep_frac_of_box_stream_spread"] = round(max(fr) - min(fr), 4) if fr and None not in fr else None
-    res["note"] = ("ms per step of the same 4-sensor 512^3 job; `static` is the best case every other key of this line is "
-                   "quoted on, `dense` / `dense_moving` bound the pre_* chain and the skipping modes from above; full_sweep."
+    res["note"] = ("ms per step of the same 4-sensor 512^3 job; `static` is the best case every other key of this "
+        "line is "
+                   "quoted on, `dense` / `dense_moving` bound the pre_* chain and the skipping modes from above; "
+                   "full_sweep."
                    "roofline_frac is the headline's arithmetic on each input, frac_of_box_stream holds it against the "
-                   "context's own stream replay (static / moving share the headline's arena, the dense pair has its own, "
+                   "context's own stream replay (static / moving share the headline's arena, the dense pair has its "
+                   "own, "
                    "placed by the same policy)")
     return res
 
@@ -502,7 +534,8 @@ def leg_post_pass(rig):
     ctx.set_timer_detail(2)
     ctx.enable_timers(True)
     try:
-        view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX)
+        view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
+            synth.BBOX_MAX)
         warm_clocks(ctx, lambda k: rig.step(False))
         ctx.raymarch(view)
         _, depth_img, _ = ctx.raymarch(view)
@@ -525,13 +558,15 @@ def leg_post_pass(rig):
 
 def leg_post_pass_slabs(rig):
     """post-pass across the slabs (BASELINE configs[4]): slab ray-march (find, all-reduce MIN, shade, composite) +
-    tsdf_inpaint / tsdf_colorfill of the composited frame; --loopback / --slab run it too (one slab's share of the frame)"""
+    tsdf_inpaint / tsdf_colorfill of the composited frame; --loopback / --slab run it too (one slab's share of the
+    frame)"""
     ctx, capi, synth, rdist = rig.ctx, rig.capi, rig.synth, rig.rdist
     ctx.set_use_bricks(False)
     rig.step(False)
     rig.exchanger.wait()
     rig.barrier()
-    view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, synth.BBOX_MAX)
+    view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
+        synth.BBOX_MAX)
     vh = rig.transport["kind"] != "rccl"
     group = rig.transport["group"]
     rdist.raymarch_slabs(ctx, view, rig.dev, group=group, via_host=vh)
@@ -673,10 +708,12 @@ def leg_default_display_frame(rig):
         blocks = np.stack([synth.encode_dxt(c[i], 1) for i in range(N)])
         frames.append((torch.from_numpy(d).to(rig.dev), torch.from_numpy(np.ascontiguousarray(blocks)).to(rig.dev)))
     torch.cuda.synchronize()
-    out = {"window": [1280, 720], "colour": "DXT1 1280x1080", "mode": "bricks on, skip-space on, colorfill on (the reference's defaults)"}
+    out = {"window": [1280, 720], "colour": "DXT1 1280x1080",
+        "mode": "bricks on, skip-space on, colorfill on (the reference's defaults)"}
 
     def measure(rc, bbox_max):
-        view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, bbox_max)
+        view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN,
+            bbox_max)
         view.skip_space = 1
 
         def frame(k, count):
@@ -707,7 +744,8 @@ def leg_default_display_frame(rig):
             frame(1, 1)
             rc.sync()
             res["stages_ms"] = {name: round(rc.timer_ns(t) * 1e-6, 4) for name, t in
-                                (("pre_chain", "1preprocess"), ("integrate", "2integrate"), ("depth_peels", "brickdraw"),
+                                (("pre_chain", "1preprocess"), ("integrate", "2integrate"), ("depth_peels",
+                                "brickdraw"),
                                  ("raymarch", "draw"), ("holefill", "holefill"), ("drawF", "3recon"))}
         finally:
             rc.enable_timers(False)
@@ -727,10 +765,12 @@ def leg_default_display_frame(rig):
     finally:
         rc.close()
     keep = os.environ.get("RGBDR_ARENA_TRIALS")
-    os.environ["RGBDR_ARENA_TRIALS"] = "1"            # (the brick-skipping sweep reads 3 % of the arena: placement does not matter)
+    # (the brick-skipping sweep reads 3 % of the arena: placement does not matter)
+    os.environ["RGBDR_ARENA_TRIALS"] = "1"
     rc = None
     try:
-        rc = capi.Context(capi.make_config(N, (W, H), color_wh=(1280, 1080), voxel_size=2.0 / rig.G, brick_size=8 * 2.0 / rig.G,
+        rc = capi.Context(capi.make_config(N, (W, H), color_wh=(1280, 1080), voxel_size=2.0 / rig.G,
+            brick_size=8 * 2.0 / rig.G,
                                            compress_rgb=1, res_override=rig.grid), rig.local_rank)
         for i in range(N):
             rc.set_calibration(i, sc.xyz[i], sc.lut_res, sc.uv[i], sc.lut_res, (0.5, 4.5))
@@ -748,7 +788,8 @@ def leg_default_display_frame(rig):
 
 def leg_inverse_lut(rig):
     """f-3: the calib_inverter search (framework/calibration/calibration_inverter.cpp:99-155) on the device, at the
-    benchmark grid: one sensor's 512^3 inverse LUT from its 128 x 106 x 128 forward LUT, straight into the resident layout.
+    benchmark grid: one sensor's 512^3 inverse LUT from its 128 x 106 x 128 forward LUT, straight into the resident
+    layout.
     Its own context (it overwrites that sensor's LUT)."""
     capi = rig.capi
     G = rig.G
@@ -756,7 +797,8 @@ def leg_inverse_lut(rig):
     os.environ["RGBDR_ARENA_TRIALS"] = "1"
     c = None
     try:
-        c = capi.Context(capi.make_config(1, (rig.W, rig.H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G), rig.local_rank)
+        c = capi.Context(capi.make_config(1, (rig.W, rig.H), voxel_size=2.0 / G, brick_size=8 * 2.0 / G),
+            rig.local_rank)
         c.set_calibration(0, rig.scene.xyz[0], rig.scene.lut_res, rig.scene.uv[0], rig.scene.lut_res, (0.5, 4.5))
         for _ in range(3):
             c.compute_inverse_calibration(0)     # (warm-up: the context above was built with the GPU idle)
@@ -769,7 +811,8 @@ def leg_inverse_lut(rig):
             times.append(time.perf_counter() - t0)
         t = sorted(times)[1]
         return {"grid": [G, G, G], "forward_lut": list(rig.scene.lut_res), "inverse_lut_generate_ms": round(t * 1e3, 2),
-                "Gvoxels_per_s": round(G ** 3 / t / 1e9, 2), "window": "library default (exact: widened until certified)",
+                "Gvoxels_per_s": round(G ** 3 / t / 1e9, 2),
+                "window": "library default (exact: widened until certified)",
                 "what": "rgbdr_compute_inverse_calibration of one sensor, median of 3 after one warm-up"}
     finally:
         if keep is None:
@@ -818,10 +861,12 @@ def median(v):
 
 def cpu_baseline(rig, reps=5):
     """Times the CPU oracle ("port") on this box's host cores over the benchmark workload itself: the whole
-    pre_* chain for the frame set (median of `reps` runs after one warm-up) plus integrate() of the volume, taken in chunks
+    pre_* chain for the frame set (median of `reps` runs after one warm-up) plus integrate() of the volume, taken in
+    chunks
     of 64 z rows (the 1:1 LUT rows of a chunk are read back from the device first, untimed): every chunk is run once as
     warm-up -- that run is also compared with the HIP TSDF bit for bit, so a default bench run is a full-volume parity
-    check at the benchmark size -- and then `reps` times; the chunk's time is the median of those.  --cpu-rows bounds the
+    check at the benchmark size -- and then `reps` times; the chunk's time is the median of those.  --cpu-rows bounds
+    the
     sample to that many rows mid-volume and extrapolates."""
     ctx, scene, capi, synth = rig.ctx, rig.scene, rig.capi, rig.synth
     N, rows, V_total = rig.N, rig.args.cpu_rows, rig.V_total
@@ -868,12 +913,17 @@ def cpu_baseline(rig, reps=5):
     t_pre = median(times)
     t_full = t_pre + t_int * (Z / done)
     res = {"value": round(V_total / t_full / 1e6, 2), "unit": "Mvoxels/s", "cores": threads,
-           "cpu_model": cpu_model(), "nproc": os.cpu_count(),      # the box's CPU and its logical CPU count
+           # the box's CPU and its logical CPU count
+           "cpu_model": cpu_model(), "nproc": os.cpu_count(),
            "kind": "port", "repetitions": reps,
-           "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota) on the benchmark workload: full "
-                     "pre_* chain of the %d-sensor frame (median of %d after one warm-up: %.3f s) + integrate of %s in chunks of 64 rows, "
+           "sample": "oracle (OpenMP, %d threads = CPUs granted by affinity and cgroup quota) on the benchmark "
+           "workload: full "
+                     "pre_* chain of the %d-sensor frame (median of %d after one warm-up: %.3f s) + integrate of %s "
+                     "in chunks of 64 rows, "
                      "each chunk the median of %d runs after one warm-up (sum %.2f s)"
-                     % (threads, N, reps, t_pre, "all %d z rows" % Z if done == Z else "%d of %d z rows mid-volume, extrapolated to the grid" % (done, Z),
+                     % (threads, N, reps, t_pre,
+                     "all %d z rows" % Z if done == Z else "%d of %d z rows mid-volume, extrapolated to the "
+                     "grid" % (done, Z),
                         reps, t_int),
            "integrate_mvoxels_per_s": round(g.res_volume[0] * g.res_volume[1] * done / t_int / 1e6, 2),
            "parity_rows_bit_exact": parity, "parity_rows": done}
@@ -890,9 +940,12 @@ def cpu_baseline(rig, reps=5):
 
 
 def driver_weight_bound():
-    """What moves when every LINEAR weight is held with 8 fractional bits, as the authors' NVIDIA driver does (INTEGRATION.md
-    section 6): the oracle with exact against the oracle with 8-bit weights on four 512 x 424 sensors into 128^3 (the Mesa
-    sample's scene), ~6 s of CPU.  The bound a maintainer comparing against a real NVIDIA run should expect -- derived, not
+    """What moves when every LINEAR weight is held with 8 fractional bits, as the authors' NVIDIA driver does
+    (INTEGRATION.md
+    section 6): the oracle with exact against the oracle with 8-bit weights on four 512 x 424 sensors into 128^3 (the
+    Mesa
+    sample's scene), ~6 s of CPU.  The bound a maintainer comparing against a real NVIDIA run should expect -- derived,
+    not
     a parity claim of the HIP path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import driver_weight_bound as dwb
@@ -904,7 +957,8 @@ def driver_weight_bound():
             "tsdf_voxels_beyond_5e-7": t["voxels_beyond_5e-7"], "tsdf_voxels_beyond_1e-4": t["voxels_beyond_1e-4"],
             "tsdf_voxels_changing_class": t["voxels_changing_class"],
             "depth_texels_flipping_validity": c["depth_rg"]["values_differing"],
-            "brick_increments_moving": c["brick_counters"]["sum_abs_diff"], "brick_increments": c["brick_counters"]["sum"],
+            "brick_increments_moving": c["brick_counters"]["sum_abs_diff"],
+            "brick_increments": c["brick_counters"]["sum"],
             "occupied_bricks_on_one_side_only": c["occupied_list"]["only_exact"] + c["occupied_list"]["only_8bit"],
             "all_cases": "profiles/r06_driver_weight_bound.json"}
 
@@ -926,7 +980,8 @@ def reference_glsl_checks(rig):
         ref_glsl["baseline_sensor_size"] = reference_glsl_sample_check(capi, synth)
         ref_glsl["default_mode_bricks_on"] = reference_glsl_mode_check(capi, synth)
         ref_glsl["headline_grid_z_bands"] = reference_glsl_big_check(capi, synth, "four_sensors_512x424_into_512_bands")
-        ref_glsl["default_mode_dxt1_bricks_at_sensor_size"] = reference_glsl_big_check(capi, synth, "default_mode_dxt1_bricks_512x424_into_128")
+        ref_glsl["default_mode_dxt1_bricks_at_sensor_size"] = reference_glsl_big_check(capi, synth,
+            "default_mode_dxt1_bricks_512x424_into_128")
     return ref_glsl
 
 
@@ -968,7 +1023,8 @@ def reference_glsl_fixture_check(capi, synth, name="four_sensors_128x106_into_64
 
         def cls(v):
             return np.where(v <= -lim, -1, np.where(v >= lim, 1, 0))
-        return {"what": "HIP path vs the reference's GLSL run on Mesa llvmpipe (committed fixture gl_passes_%s.npz)" % name,
+        return {"what": "HIP path vs the reference's GLSL run on Mesa llvmpipe (committed fixture "
+            "gl_passes_%s.npz)" % name,
                 "max_abs_diff": {k: float("%.3g" % v) for k, v in out.items()}, "brick_counters_equal": counters_equal,
                 "tsdf_max_abs_diff": float("%.3g" % np.abs(t.astype(np.float64) - r)[ok].max()),
                 "tsdf_voxels_differing": int((t != r)[ok].sum()), "tsdf_voxels": int(t.size),
@@ -988,15 +1044,19 @@ def _tsdf_summary(t, r, limit):
         return np.where(v <= -lim, -1, np.where(v >= lim, 1, 0))
     flips = (cls(t) != cls(r)) & ok
     # a voxel whose two values lie within 1e-6 of the SAME boundary: a last-bit difference of sdist against +-limit
-    # (tsdf_integration.vs:41-46) turns exactly -limit into a weighted mean a hair above it -- tests/test_gl_ref.py class_flips
+    # (tsdf_integration.vs:41-46) turns exactly -limit into a weighted mean a hair above it -- tests/test_gl_ref.py
+    # class_flips
     tie = (np.abs(np.abs(t) - lim) <= 1e-6) & (np.abs(np.abs(r) - lim) <= 1e-6) & (np.sign(t) == np.sign(r))
-    return {"tsdf_max_abs_diff": float("%.3g" % (d.max() if d.size else 0.0)), "tsdf_voxels_beyond_5e-7": int((d > 5e-7).sum()),
+    return {"tsdf_max_abs_diff": float("%.3g" % (d.max() if d.size else 0.0)),
+        "tsdf_voxels_beyond_5e-7": int((d > 5e-7).sum()),
             "tsdf_voxels_compared": int(ok.sum()), "tsdf_voxels_in_band": int((np.abs(r[ok]) < lim).sum()),
-            "tsdf_voxels_changing_class": int(flips.sum()), "tsdf_voxels_changing_class_at_a_boundary_tie": int((flips & tie).sum())}
+            "tsdf_voxels_changing_class": int(flips.sum()),
+            "tsdf_voxels_changing_class_at_a_boundary_tie": int((flips & tie).sum())}
 
 
 def reference_glsl_mode_check(capi, synth, name="bricks_reference_box_5_voxel_bricks"):
-    """The library in the reference's DEFAULT mode (bricks on) against the Mesa run of the same mode: the reference's own
+    """The library in the reference's DEFAULT mode (bricks on) against the Mesa run of the same mode: the reference's
+    own
     box (-1,0,-1)-(1,2.2,1) with 5-voxel bricks that share rows, tsdf_integration.vs drawn through the occupied bricks'
     containedVoxels index lists (tests/golden/gl_passes_<name>.npz)."""
     try:
@@ -1015,9 +1075,12 @@ def reference_glsl_mode_check(capi, synth, name="bricks_reference_box_5_voxel_br
             ctx.set_calibration(i, scene.xyz[i], scene.lut_res, scene.uv[i], scene.lut_res, (0.5, 4.5))
             ctx.set_inverse_calibration(i, inv[i], inv_res)
         ctx.step(scene.depth, scene.color)
-        out = {"what": "HIP path with RGBDR_FLAG_USE_BRICKS vs the reference's GLSL drawn through the occupied bricks' index lists on "
-                       "Mesa (gl_passes_%s.npz: grid %s, %d of %d bricks occupied)" % (name, "x".join(str(v) for v in geo.res_volume),
-                                                                                       fx["occupied"].size, fx["counters"].size),
+        out = {"what": "HIP path with RGBDR_FLAG_USE_BRICKS vs the reference's GLSL drawn through the occupied "
+            "bricks' index lists on "
+                       "Mesa (gl_passes_%s.npz: grid %s, %d of %d bricks occupied)" % (name,
+                       "x".join(str(v) for v in geo.res_volume),
+                                                                                       fx["occupied"].size,
+                                                                                       fx["counters"].size),
                "brick_counters_equal": bool(np.array_equal(ctx.readback_brick_counters(), fx["counters"])),
                "occupied_bricks_equal": bool(np.array_equal(ctx.get_occupied()[0], fx["occupied"]))}
         out.update(_tsdf_summary(ctx.readback_tsdf(), fx["tsdf"], cfg.tsdf_limit))
@@ -1028,7 +1091,8 @@ def reference_glsl_mode_check(capi, synth, name="bricks_reference_box_5_voxel_br
 
 
 def reference_glsl_big_check(capi, synth, name):
-    """The larger Mesa samples of tests/golden/make_gl_golden.py BIG_SAMPLES: z bands of the 512^3 HEADLINE grid from four
+    """The larger Mesa samples of tests/golden/make_gl_golden.py BIG_SAMPLES: z bands of the 512^3 HEADLINE grid from
+    four
     512 x 424 sensors; the default mode (DXT1 1280 x 1080 colour, bricks on) at that sensor size."""
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -1059,14 +1123,17 @@ def reference_glsl_big_check(capi, synth, name):
         n, H, W = 4, 424, 512
         imgs = {}
         for k, which in {"depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}.items():
-            got = np.stack([ctx.readback_image(which, i) for i in range(n)]).reshape(n * H * W, -1)[tex].astype(np.float64)
+            got = np.stack([ctx.readback_image(which, i) for i in range(n)]).reshape(n * H * W,
+                -1)[tex].astype(np.float64)
             want = fx[k].astype(np.float64)
             fin = np.isfinite(got) & np.isfinite(want)
             imgs[k] = float("%.3g" % np.abs(got - want)[fin].max())
-        out = {"what": "%s: %d sampled texels per image (every edge-class texel of pre_boundary among them), %d sampled voxels" % (
+        out = {"what": "%s: %d sampled texels per image (every edge-class texel of pre_boundary among them), %d "
+            "sampled voxels" % (
                    name, tex.size, fx["voxels"].size),
                "max_abs_diff": imgs,
-               "brick_counts_differing": int(np.abs(ctx.readback_brick_counters().astype(np.int64) - fx["counters"].astype(np.int64)).sum()),
+               "brick_counts_differing": int(np.abs(ctx.readback_brick_counters().astype(np.int64)
+                                                    - fx["counters"].astype(np.int64)).sum()),
                "brick_counts": int(fx["counters"].sum())}
         if "occupied" in fx.files:
             out["occupied_bricks_equal"] = bool(np.array_equal(ctx.get_occupied()[0], fx["occupied"]))
@@ -1079,7 +1146,8 @@ def reference_glsl_big_check(capi, synth, name):
 
 
 def reference_glsl_sample_check(capi, synth, name="four_sensors_512x424_into_128"):
-    """the same at BASELINE's sensor size: four 512 x 424 sensors into 128^3, against the committed SAMPLE of the Mesa run
+    """the same at BASELINE's sensor size: four 512 x 424 sensors into 128^3, against the committed SAMPLE of the Mesa
+    run
     (tests/golden/gl_sample_<name>.npz: 19 814 texels of every image, 59 413 voxels, every brick counter)"""
     try:
         path = os.path.join(ROOT, "tests", "golden", "gl_sample_%s.npz" % name)
@@ -1098,8 +1166,10 @@ def reference_glsl_sample_check(capi, synth, name="four_sensors_512x424_into_128
         c.step(scene.depth, scene.color)
         tex = fx["texels"].astype(np.int64)
         out = {}
-        for k, which in {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6, "quality": 7}.items():
-            got = np.stack([c.readback_image(which, i) for i in range(n)]).reshape(n * H * W, -1)[tex].astype(np.float64)
+        for k, which in {"morph": 1, "depth_rg": 2, "lab": 3, "depth_b": 4, "sil": 5, "normal": 6,
+            "quality": 7}.items():
+            got = np.stack([c.readback_image(which, i) for i in range(n)]).reshape(n * H * W,
+                -1)[tex].astype(np.float64)
             want = fx[k].astype(np.float64)
             fin = np.isfinite(got) & np.isfinite(want)
             out[k] = float("%.3g" % np.abs(got - want)[fin].max())
@@ -1109,7 +1179,8 @@ def reference_glsl_sample_check(capi, synth, name="four_sensors_512x424_into_128
         r = fx["tsdf"]
         ok = ~(np.isnan(t) | np.isnan(r))
         lim = np.float32(cfg.tsdf_limit)
-        return {"what": "4 sensors 512 x 424 into 128^3, %d sampled texels per image, %d sampled voxels (%d in the band)"
+        return {"what": "4 sensors 512 x 424 into 128^3, %d sampled texels per image, %d sampled voxels (%d in the "
+            "band)"
                         % (tex.size, t.size, int((np.abs(r[ok]) < lim).sum())),
                 "max_abs_diff": out, "brick_counts_differing": int(np.abs(cnt - fx["counters"].astype(np.int64)).sum()),
                 "brick_counts": int(fx["counters"].sum()),
@@ -1161,10 +1232,13 @@ def reference_text_baseline(rig, hip, sil, db, q, rows=32):
     frame = shader_ref.run_frame(one, synth.BBOX_MIN, synth.BBOX_MAX, (X, Y, Z), None, brick_size=g.brick_size,
                                  res_bricks=tuple(g.res_bricks))
     t_pre = time.perf_counter() - t0
-    same_img = all(bool(np.all((frame[k][0] == ctx.readback_image(w, 0)) | (np.isnan(frame[k][0]) & np.isnan(ctx.readback_image(w, 0)))))
-                   for k, w in (("depth_b", capi.IMG_DEPTH_B_RG), ("sil", capi.IMG_SILHOUETTE), ("quality", capi.IMG_QUALITY),
+    same_img = all(bool(np.all((frame[k][0] == ctx.readback_image(w,
+        0)) | (np.isnan(frame[k][0]) & np.isnan(ctx.readback_image(w, 0)))))
+                   for k, w in (("depth_b", capi.IMG_DEPTH_B_RG), ("sil", capi.IMG_SILHOUETTE), ("quality",
+                   capi.IMG_QUALITY),
                                 ("normal", capi.IMG_NORMAL), ("lab", capi.IMG_LAB)))
-    return {"what": "the reference's shader text compiled as C++ (stand-in samplers), 1 thread: tsdf_integration.vs on %d of %d "
+    return {"what": "the reference's shader text compiled as C++ (stand-in samplers), 1 thread: tsdf_integration.vs "
+        "on %d of %d "
                     "z rows, pre_* chain of 1 of %d sensors" % (rows, Z, N),
             "integrate_mvoxels_per_s": round(X * Y * rows / t_int / 1e6, 2), "integrate_s": round(t_int, 2),
             "pre_chain_one_sensor_s": round(t_pre, 2),

@@ -11,13 +11,47 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*args, env=None):
+LINE_BYTES = 6000      # the one stdout line: the driver's fields, roofline, cpu_baseline (flat) and <= 10 keys more
+
+
+def merged(line):
+    """the line plus what it moved to bench_extra.json (bench.py split_line): the object the assertions below read.  Nested
+    tables of roofline / cpu_baseline come back under their old keys."""
+    j = dict(line)
+    ex = line.get("extra")
+    if not ex:
+        return j
+    assert "error" not in ex, ex
+    extra = json.load(open(ex["file"]))
+    assert sorted(extra) == ex["keys"]
+    for k, v in extra.items():
+        if k == "cpu_baseline":
+            j["cpu_baseline"] = dict(j.get("cpu_baseline") or {}, **v)
+        elif k == "roofline_box":
+            j["roofline"] = dict(j["roofline"], box=v)
+        elif k == "roofline_tables":
+            j["roofline"] = dict(j["roofline"], **v)
+        else:
+            j[k] = v                     # (default_display_frame / post_pass: the whole table replaces the compact one)
+    return j
+
+
+def run_bench(*args, env=None, tmp_extra=None):
+    extra_file = os.path.join(tmp_extra or __import__("tempfile").mkdtemp(), "bench_extra.json")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, **env) if env else None)
+                       env=dict(os.environ, RGBDR_BENCH_EXTRA=extra_file, **(env or {})))
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+    line = json.loads(lines[0])
+    if "roofline" in line:
+        assert len(lines[0]) < LINE_BYTES, len(lines[0])
+        assert len([k for k in line if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")]) <= 10, sorted(line)
+        assert all(not isinstance(v, (dict, list)) for v in line["roofline"].values()), "roofline is flat on the line"
+        if "cpu_baseline" in line:
+            assert all(not isinstance(v, (dict, list)) for v in line["cpu_baseline"].values()), "cpu_baseline is flat on the line"
+    return merged(line)
 
 
 def test_bench_line_contract():
@@ -82,6 +116,20 @@ def test_bench_line_contract():
     # the data-dependent modes on more than their best case: static / moving / dense / dense + moving
     sc = j["scenes"]
     assert "error" not in sc, sc
+    # the headline's roofline arithmetic per scene, on the line itself (flat, so that the driver's record keeps it)
+    for name in ("static", "moving", "dense", "dense_moving"):
+        assert r["frac_scene_" + name] == sc[name]["full_sweep"]["roofline_frac"] and 0.5 < r["frac_scene_" + name] < 1.0
+        assert 0.9 < r["frac_of_box_stream_scene_" + name] < 1.1
+    assert abs(r["frac_scene_static"] - r["frac"]) < 0.08 and r["frac_scene_dense"] > 0.9 * r["frac_scene_static"]     # (a 6-step headline on cold clocks)
+    c0 = j["cpu_baseline"]
+    assert c0["glsl_on_mesa_tsdf_max_abs_diff"] <= 5e-7 and c0["glsl_on_mesa_brick_counters_equal"] is True
+    assert 1e-5 < c0["driver_weight_bound_tsdf_p99_abs_diff_in_band"] < 1e-3        # the derived 8-bit-weight bound
+    dd = j["default_display_frame"]
+    assert "error" not in dd, dd
+    for g in ("reference_box", "grid_512"):
+        st = dd[g]["stages_ms"]
+        assert 0.1 < dd[g]["ms_per_frame"] < 2.0 and dd[g]["ms_per_frame_moving"] > 0 and 0 < st["holefill"] < 0.09 and st["raymarch"] > 0
+        assert st["drawF"] >= st["raymarch"] + st["holefill"] and dd[g]["ms_per_frame"] > st["drawF"]
     assert sc["static"]["valid_pixels"] < 0.5 and sc["dense"]["valid_pixels"] == 1.0 and sc["dense_moving"]["valid_pixels"] > 0.98
     assert sc["moving"]["frames_in_rotation"] == 4 and sc["dense_moving"]["frames_in_rotation"] == 4
     for name in ("static", "moving", "dense", "dense_moving"):
@@ -164,8 +212,9 @@ def test_two_ranks_started_by_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    j = json.loads(lines[0])
+    j = merged(json.loads(lines[0]))          # (bench_extra_n2.json beside bench.py: the per-rank tables)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["scaling"] == "weak" and len(j["per_rank"]["integrate_ms"]) == 2
+    assert j["roofline"]["frac_slowest_rank"] == min(j["per_rank"]["roofline_frac"]) and j["roofline"]["ranks"] == 2
     assert j["launch"]["launched_by"] == "torch.distributed.run" and j["launch"]["rung"] == 0 and j["launch"]["line"] == "final"
 
 
