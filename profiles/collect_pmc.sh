@@ -8,6 +8,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/pmc_$TAG
 rm -rf $OUT && mkdir -p $OUT   # a tag is one run: never mix counter files of two runs
 ROOT=$PWD
+export RGBDR_BENCH_EXTRA=$OUT/bench_extra_of_the_profiled_runs.json   # (what each run's line moved out of itself; not the round's record)
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 # the timing pass uses the default step count so that the bench's own average (HIP events over the

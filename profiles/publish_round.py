@@ -41,6 +41,9 @@ if head:   # the headline alone (bench.py --no-legs): the integrate kernel's ave
     json.dump(summary, open(f"{prof}/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
 shutil.copy(out + "/bench_stats.json", f"{prof}/{tag}_bench_under_rocprofv3.json")
 shutil.copy(os.path.join(root, "gpurun_out", tag + "_bench.json"), f"{prof}/{tag}_bench.json")
+extra = os.path.join(root, "gpurun_out", tag + "_bench_extra.json")     # what the line moved out of itself (bench.py split_line)
+if os.path.exists(extra):
+    shutil.copy(extra, f"{prof}/{tag}_bench_extra.json")
 line = json.load(open(f"{prof}/{tag}_bench.json"))
 name = [k for k in summary if line["roofline"]["kernel"] in k][0]
 c = summary[name]
