@@ -211,6 +211,8 @@ try {
   if (side < 0 || side > 1) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "rgbdr_halo_set_peer: side is 0 (lower neighbour) or 1 (upper)");
   if (ctx->halo <= 0) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_set_peer needs a Z-slab context (slab_count > 1)");
   if (!ctx->peer || !ctx->peer->exported) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_set_peer before rgbdr_halo_export of this context");
+  if (peer && (side == 0 ? ctx->cfg.slab_rank <= 0 : ctx->cfg.slab_rank >= ctx->cfg.slab_count - 1))
+    return ctx->fail(RGBDR_ERR_STATE, "rgbdr_halo_set_peer: this slab has no neighbour on that side (the first slab has none below, the last none above)");
   HIPCHK(hipSetDevice(ctx->device));
   PeerLink& l = ctx->peer->link[side];
   if (!peer) release_peer_waits(ctx, side);  // the neighbour is gone: nothing queued may wait for it any longer

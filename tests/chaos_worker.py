@@ -49,7 +49,32 @@ def run(pkg, orc, seed, slab, trace):
         return v
 
     ids = np.array([0, 1, 5, 2 ** 31], np.uint32)
+    peer_buf = C.create_string_buffer(capi.HALO_PEER_BYTES)
+    garbage = C.create_string_buffer(bytes(rng.integers(0, 256, capi.HALO_PEER_BYTES, dtype=np.uint8)), capi.HALO_PEER_BYTES)
+
+    def peers_to_self():
+        """export; a middle slab then becomes its own neighbour on BOTH sides (a face whose neighbour never writes would leave
+        the side stream waiting for ever -- as a send without a receive does --, so a context stands in for one neighbour only
+        if it also stands in for the other); an edge slab checks that the side it lacks is refused"""
+        rc = L.rgbdr_halo_export(h, peer_buf)
+        if rc == 0 and slab:
+            if 0 < slab[0] < slab[1] - 1:
+                assert L.rgbdr_halo_set_peer(h, 0, peer_buf) == 0 and L.rgbdr_halo_set_peer(h, 1, peer_buf) == 0
+            else:
+                assert L.rgbdr_halo_set_peer(h, 0 if slab[0] == 0 else 1, peer_buf) == capi.ERR_STATE
+        return rc
+
+    def no_peers():
+        return min(L.rgbdr_halo_set_peer(h, 0, None), L.rgbdr_halo_set_peer(h, 1, None))
+
     calls = [
+        lambda: L.rgbdr_draw(h, C.byref(view()), flag()), lambda: L.rgbdr_draw(h, None, 1),
+        lambda: L.rgbdr_device_view_frame(h, flag(), C.byref(vp), C.byref(vp), C.byref(i1), C.byref(i2)),
+        lambda: L.rgbdr_device_view_frame(h, 0, None, None, None, None),
+        lambda: L.rgbdr_readback_view_frame(h, flag(), F(big), F(big[1 << 20:])), lambda: L.rgbdr_readback_view_frame(h, 1, None, None),
+        peers_to_self, lambda: L.rgbdr_halo_export(h, None),
+        lambda: L.rgbdr_halo_set_peer(h, int(rng.integers(-1, 3)), garbage), no_peers,
+        lambda: L.rgbdr_halo_pull_async(h),
         lambda: L.rgbdr_set_calibration(h, sensor(), C.byref(luts["xyz"][0]), C.byref(luts["uv"][0])),
         lambda: L.rgbdr_set_calibration(h, 0, None, C.byref(luts["uv"][0])),
         lambda: L.rgbdr_set_inverse_calibration(h, sensor(), C.byref(luts["inv"][0])),
