@@ -68,4 +68,8 @@ if not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):     # timing
     st = {n: round(rc.timer_ns(t) * 1e-6, 4) for n, t in (("pre_chain", "1preprocess"), ("integrate", "2integrate"), ("depth_peels", "brickdraw"),
                                                             ("raymarch", "draw"), ("holefill", "holefill"), ("drawF", "3recon"))}
     print("%s grid %s: %.4f ms per displayed frame (500 back to back); stages of one more frame: %s" % (which, list(rc.geo.res_volume), ms, st))
+elif os.environ.get("RGBDR_DISPLAY_SPLIT"):   # under the profiler: the march alone (k_raymarch<1,8>) and the shading alone (k_raymarch<2,1>)
+    for _ in range(10):
+        rc.raymarch_find(view)
+        rc.raymarch_shade(view)
 rc.close()

@@ -179,6 +179,9 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
       p.empty_words = (int)words;
     }
   }
+  // (developer knob, read per call: 1 = every ray still marching after a round goes to march_whole_wave, 2 = none does)
+  const char* whole_wave = std::getenv("RGBDR_WHOLE_WAVE_MARCH");
+  p.whole_wave = whole_wave ? std::atoi(whole_wave) : 0;
   std::memcpy(p.projection, v->projection, 64);
   std::memcpy(p.normal_matrix, v->normal_matrix, 64);
   std::memcpy(p.gl_normal_matrix_inv, v->gl_normal_matrix_inv, 64);

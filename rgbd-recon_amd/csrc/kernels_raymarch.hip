@@ -324,10 +324,10 @@ __device__ __forceinline__ void shade_fragment(const RaymarchParams& p, const fl
 // position is still accumulated and it is still counted: the same additions, the same sample count, the same frame.
 template <int kAhead>
 __device__ __forceinline__ void march_ahead(const RaymarchParams& p, const Ray& r, float* sp, float& prev, unsigned& num, bool& hit,
-                                            const unsigned* empty_bits = nullptr)
+                                            const unsigned* empty_bits = nullptr, int max_rounds = 0x7fffffff)
 {
   const float held = -p.limit;
-  while (num < r.max_num && !hit) {
+  for (int round = 0; round < max_rounds && num < r.max_num && !hit; ++round) {
     float pos[kAhead][3], dens[kAhead];
     if (empty_bits) {
       Axis X[kAhead], Y[kAhead], Z[kAhead];
@@ -414,6 +414,57 @@ constexpr int kNoHit = 0x7fffffff;
 // MODE 1 (Z slab, "find"): index of the first sample this slab owns whose density is > 0.
 // MODE 2 (Z slab, "shade"): with the minimum of those indices over all slabs in khit, the
 //         slab that owns that sample refines and shades it; the others mark the pixel kNoHit.
+// The whole wavefront marches the ray of ONE of its lanes, `owner`: lane j takes sample j of the ray's next 64.  The
+// positions are the march's own chain of additions (lane j runs j of them), a sample past the ray's budget is not fetched,
+// the first lane with a positive density is the hit and the lane before it (or the round before) holds `prev`: the same
+// values in the same order as march_ahead, 64 samples per round trip to memory instead of kAhead.  All 64 lanes call it.
+__device__ __forceinline__ void march_whole_wave(const RaymarchParams& p, const Ray& r, int owner, int lane, float* sp, float& prev, unsigned& num,
+                                                 bool& hit)
+{
+  auto from_owner = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), owner)); };
+  float osp[3] = {from_owner(sp[0]), from_owner(sp[1]), from_owner(sp[2])};
+  const float ostep[3] = {from_owner(r.step[0]), from_owner(r.step[1]), from_owner(r.step[2])};
+  float oprev = from_owner(prev);
+  unsigned onum = (unsigned)__builtin_amdgcn_readlane((int)num, owner);
+  const unsigned omax = (unsigned)__builtin_amdgcn_readlane((int)r.max_num, owner);
+  bool ohit = false;
+  while (onum < omax && !ohit) {
+    float pos[3] = {osp[0], osp[1], osp[2]};
+    for (int k = 0; k < 63; ++k) {
+      const bool on = k < lane;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) pos[a] = on ? pos[a] + ostep[a] : pos[a];
+    }
+    const unsigned left = omax - onum;
+    const bool valid = (unsigned)lane < left;
+    float dens = 0.0f;
+    if (valid) dens = tsdf_sample(p, pos[0], pos[1], pos[2]);
+    const unsigned long long hits = __ballot(valid && dens > 0.0f);
+    auto from_lane = [&](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    if (hits) {
+      const int f = __ffsll((long long)hits) - 1;
+      const float density = from_lane(dens, f), before = f == 0 ? oprev : from_lane(dens, f - 1);
+      const float fr = before / (density - before);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) osp[a] = (from_lane(pos[a], f) - ostep[a]) - ostep[a] * fr;
+      onum += (unsigned)f + 1u;
+      ohit = true;
+    } else {
+      const int last = (int)(left < 64u ? left : 64u) - 1;
+      oprev = from_lane(dens, last);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) osp[a] = from_lane(pos[a], last) + ostep[a];
+      onum += (unsigned)last + 1u;
+    }
+  }
+  if (lane == owner) {
+    sp[0] = osp[0], sp[1] = osp[1], sp[2] = osp[2];
+    prev = oprev;
+    num = onum;
+    hit = ohit;
+  }
+}
+
 // A wavefront covers an 8 x 8 pixel square of the block's 16 x 16 (not 16 x 4 rows of the launch order): its rays stay closer
 // together in the volume, so a gather instruction touches fewer cache lines -- the march is bound by the vector L1's rate
 // of one line per cycle per CU (profiles/r04_notes: 457 M line accesses per 1280 x 720 frame = 0.74 ms).
@@ -424,10 +475,31 @@ __device__ __forceinline__ void wave_square_pixel(int& px, int& py)
   py = blockIdx.y * 16 + (w >> 1) * 8 + (l >> 3);
 }
 
+#ifdef RGBDR_TRACE_BLOCKS
+// Developer build (make trace, profiles/march_waves_probe.py): when every wavefront of the whole-volume march went through its
+// stages.  Per wavefront {s_memrealtime (100 MHz) at entry, after the ray set-up, after the march, at exit, rounds marched lane
+// by lane, rays taken by the whole wavefront, HW_ID, XCC_ID}.
+struct MarchTrace {
+  uint32_t t[4], rounds, whole, hw_id, xcc_id;
+};
+__device__ MarchTrace g_march_trace[16384];
+extern "C" int rgbdr_debug_march_trace(void* dst, size_t bytes)
+{
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_march_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define MARCH_STAMP(k) trace_t[k] = (uint32_t)wall_clock64()
+#else
+#define MARCH_STAMP(k)
+#endif
+
 template <int MODE, int AHEAD = 1>
 __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
 {
   extern __shared__ unsigned s_empty[];  // MODE 0 with p.empty_bits: the workgroup's copy of the bitmap
+#ifdef RGBDR_TRACE_BLOCKS
+  uint32_t trace_t[4], trace_rounds = 0, trace_whole = 0;
+  MARCH_STAMP(0);
+#endif
   int px, py;
   wave_square_pixel(px, py);
   const bool inside = px < p.width && py < p.height;
@@ -448,17 +520,68 @@ __global__ __launch_bounds__(256) void k_raymarch(RaymarchParams p)
       empty_bits = s_empty;
     }
   }
-  if (!inside) return;
-  if (r.covered) {
+  if (MODE == 0) {
+    // A wavefront lasts as long as its longest lane, a round of AHEAD samples is ~3 us of dependent instructions for a lane,
+    // and a frame has a handful of rays that march 200-300 samples next to neighbours that take ten
+    // (profiles/march_samples_probe.py): the frame would wait 0.1 ms for them.  So the wavefront's lanes march on their own,
+    // round by round, while that is the shorter way; once a few long rays are all that is left, the whole wavefront
+    // takes them one after the other, 64 samples a round.  (No lane has left the kernel: all 64 take part.)
+    const int lane = (threadIdx.y * 16 + threadIdx.x) & 63;
+    const bool marching = inside && r.covered;
     float sp[3] = {r.sp[0], r.sp[1], r.sp[2]};
-    if (MODE == 0) {
-      float prev = -limit;
-      unsigned num = 0;
-      bool hit = false;
-      march_ahead<AHEAD>(p, r, sp, prev, num, hit, empty_bits);
+    float prev = -limit;
+    unsigned num = 0;
+    bool hit = false;
+    MARCH_STAMP(1);
+    for (int round = 0;; ++round) {
+      const bool live = marching && !hit && num < r.max_num;
+      unsigned long long todo = __ballot(live);
+      if (!todo) break;
+      bool whole_wave = p.whole_wave == 1 && round >= 1;
+      if (p.whole_wave == 0 && round >= 2 && __popcll(todo) <= 8) {  // rounds left either way (64 samples of the wavefront take about as long as 8 of a lane)
+        const unsigned left = r.max_num - num;
+        unsigned longest = 0, summed = 0;
+        for (unsigned long long m = todo; m; m &= m - 1) {
+          const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)left, __ffsll((long long)m) - 1);
+          longest = l > longest ? l : longest;
+          summed += (l + 63u) >> 6;
+        }
+        whole_wave = summed < (longest + 7u) / 8u;
+      }
+      if (whole_wave) {
+#ifdef RGBDR_TRACE_BLOCKS
+        trace_whole = (uint32_t)__popcll(todo);
+#endif
+        for (; todo; todo &= todo - 1) march_whole_wave(p, r, __ffsll((long long)todo) - 1, lane, sp, prev, num, hit);
+        break;
+      }
+      if (live) march_ahead<AHEAD>(p, r, sp, prev, num, hit, empty_bits, 1);
+#ifdef RGBDR_TRACE_BLOCKS
+      trace_rounds = (uint32_t)round + 1;
+#endif
+    }
+    MARCH_STAMP(2);
+    if (marching) {
       fsamples = (float)num * 0.0027f;
       if (hit) shade_fragment(p, sp, rgba, fdepth);
-    } else if (MODE == 1) {
+    }
+#ifdef RGBDR_TRACE_BLOCKS
+    MARCH_STAMP(3);
+    if (lane == 0) {
+      MarchTrace& t = g_march_trace[((blockIdx.y * gridDim.x + blockIdx.x) * 4 + ((threadIdx.y * 16 + threadIdx.x) >> 6)) % 16384];
+      for (int k = 0; k < 4; ++k) t.t[k] = trace_t[k];
+      t.rounds = trace_rounds;
+      t.whole = trace_whole;
+      t.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      t.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
+    if (!inside) return;
+  } else if (!inside) {
+    return;
+  } else if (r.covered) {
+    float sp[3] = {r.sp[0], r.sp[1], r.sp[2]};
+    if (MODE == 1) {
       // as in march_ahead: AHEAD samples in flight, looked at in order (a sample this slab does not own is fetched from the
       // nearest resident rows and not looked at)
       for (unsigned k0 = 0; k0 < r.max_num && khit == kNoHit; k0 += AHEAD) {

@@ -200,6 +200,7 @@ struct RaymarchParams {
   // the map does not fit a workgroup's LDS
   const unsigned* empty_bits;
   int empty_words;
+  int whole_wave;              // the whole wavefront takes over its last long rays (march_whole_wave): 0 when that is shorter, 1 always, 2 never
   float4* out_color;
   float* out_depth;
   float* out_samples;

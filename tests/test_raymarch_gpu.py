@@ -50,6 +50,32 @@ def test_raymarch_matches_oracle(pkg, orc, shade_mode, eye):
     ctx.close()
 
 
+@pytest.mark.parametrize("whole_wave", ["1", "2"])
+def test_rays_marched_by_the_whole_wavefront(pkg, orc, monkeypatch, whole_wave):
+    """the march hands a wavefront's last long rays to all of its 64 lanes, 64 samples a round (march_whole_wave): with every ray
+    that is still marching after a round taken that way (RGBDR_WHOLE_WAVE_MARCH=1), and with none (2), the frames equal the
+    oracle's -- through the whole cube and from the brick peels, in a viewport that leaves lanes of its wavefronts without a pixel"""
+    monkeypatch.setenv("RGBDR_WHOLE_WAVE_MARCH", whole_wave)
+    scene, ctx, inv = setup(pkg, orc)
+    view = pkg.capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 130, 75, BMIN, BMAX)
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images(orc, ctx, scene, inv, view)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc)
+    assert (depth < 1.0).mean() > 0.02 and ns.max() / 0.0027 > 64          # rays of more than one round of the wavefront
+    ctx.set_use_bricks(True)
+    ctx.step(scene.depth, scene.color)
+    g = ctx.geo
+    ids, _ = ctx.get_occupied()
+    mask = np.zeros(g.num_bricks, np.uint8)
+    mask[ids] = 1
+    peels = orc.depth_peels(bytes(view), BMIN, g.brick_size, tuple(g.res_bricks), ctx.readback_brick_counters(), mask)
+    view.skip_space = 1
+    color, depth, ns = ctx.raymarch(view)
+    rc, rd, rn = oracle_images_skip(orc, ctx, scene, inv, view, peels)
+    assert same_bits(ns, rn) and same_bits(depth, rd) and same_bits(color, rc)
+    ctx.close()
+
+
 @pytest.mark.parametrize("wh", [(1, 1), (7, 3), (17, 9), (63, 65), (129, 1)])
 def test_viewports_off_the_block_size(pkg, orc, wh):
     """viewports of one pixel, narrower than the 8 x 8 square a wavefront covers, one row high, one past a block edge: the
