@@ -16,6 +16,8 @@ load_package()
 import torch  # noqa: E402
 from rgbd_recon_amd import capi, synth  # noqa: E402
 
+if os.environ.get("RGBDR_PROBE_LIB"):   # A/B of two builds of the library in one session (profiles/ab_display.sh)
+    capi.LIB_PATH = os.environ["RGBDR_PROBE_LIB"]
 N, W, H = 4, 512, 424
 which = os.environ.get("RGBDR_DISPLAY_GRID", "ref")
 os.environ.setdefault("RGBDR_ARENA_TRIALS", "1")
