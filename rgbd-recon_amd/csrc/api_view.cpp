@@ -60,7 +60,7 @@ static void mat4_product(const float* a, const float* b, float* o)  // glm assoc
 }
 
 // ReconIntegration::drawDepthLimits into the peel image of the view buffers
-static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
+static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out, bool with_empty_tiles = false)
 {
   { int rc_ = flush_clear(ctx); if (rc_ != RGBDR_OK) return rc_; }
   if (!ctx->mask_valid) return ctx->fail(RGBDR_ERR_STATE, "depth limits before update_occupied_bricks");
@@ -94,6 +94,7 @@ static int draw_depth_limits(rgbdr_ctx* ctx, const rgbdr_view* v, float4* out)
   }
   p.cells = ctx->d_peel_near;
   p.out = out;
+  if (with_empty_tiles) p.empty_tiles = {ctx->d_tile_state, ctx->clear_epoch, ctx->geo.tiles[0], ctx->geo.tiles[1], ctx->geo.tiles[2], ctx->d_empty_tiles};
   tbegin(ctx, "brickdraw", ctx->stream);
   launch_depth_peels(p, ctx->stream);
   tend(ctx, "brickdraw", ctx->stream);
@@ -151,16 +152,10 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   RaymarchParams& p = *pp;
   p = RaymarchParams{};
   p.skip_space = v->skip_space ? 1 : 0;
-  if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
-    int rc_ = ensure_peel_buffer(ctx, npix);
-    if (rc_ != RGBDR_OK) return rc_;
-    rc_ = draw_depth_limits(ctx, v, (float4*)ctx->d_peels);
-    if (rc_ != RGBDR_OK) return rc_;
-  }
-  p.peels = (const float4*)ctx->d_peels;   // read with skip_space only
   // the sweep's record of the tiles that hold -limit throughout: samples there are not fetched (march_ahead)
   p.empty_bits = nullptr;
   p.empty_words = 0;
+  bool want_empty_tiles = false;
   {
     const rgbdr_geometry& gg = ctx->geo;
     const size_t ntiles = (size_t)gg.tiles[0] * gg.tiles[1] * gg.tiles[2];
@@ -173,12 +168,22 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
         HIPCHK(hipMalloc((void**)&ctx->d_empty_tiles, words * 4));
         ctx->empty_tiles_cap = words;
       }
-      launch_empty_tiles(ctx->d_tile_state, ctx->clear_epoch, gg.tiles[0], gg.tiles[1], gg.tiles[2], ctx->d_empty_tiles, ctx->stream);
-      LAUNCHCHK("empty_tiles");
+      want_empty_tiles = true;
       p.empty_bits = ctx->d_empty_tiles;
       p.empty_words = (int)words;
     }
   }
+  if (p.skip_space) {  // m_skip_space && m_use_bricks: drawDepthLimits first (recon_integration.cpp:153-156)
+    int rc_ = ensure_peel_buffer(ctx, npix);
+    if (rc_ != RGBDR_OK) return rc_;
+    rc_ = draw_depth_limits(ctx, v, (float4*)ctx->d_peels, want_empty_tiles);  // (the bitmap rides in the peels' first launch)
+    if (rc_ != RGBDR_OK) return rc_;
+  } else if (want_empty_tiles) {
+    const rgbdr_geometry& gg = ctx->geo;
+    launch_empty_tiles(ctx->d_tile_state, ctx->clear_epoch, gg.tiles[0], gg.tiles[1], gg.tiles[2], ctx->d_empty_tiles, ctx->stream);
+    LAUNCHCHK("empty_tiles");
+  }
+  p.peels = (const float4*)ctx->d_peels;   // read with skip_space only
   // (developer knob, read per call: 1 = every ray still marching after a round goes to march_whole_wave, 2 = none does)
   const char* whole_wave = std::getenv("RGBDR_WHOLE_WAVE_MARCH");
   p.whole_wave = whole_wave ? std::atoi(whole_wave) : 0;

@@ -384,10 +384,10 @@ __device__ __forceinline__ void march_ahead(const RaymarchParams& p, const Ray& 
 // p.empty_bits: a bit per tile = the tile and its +1 neighbours along x, y and z (a LINEAR footprint that starts in the tile
 // ends in one of those) have held -limit since a sweep of the current epoch (IntegrateParams::tile_state, k_brick_clear).
 // 32 KiB for a 512^3 volume: every workgroup of the march that has a ray to march keeps a copy in LDS.
-__global__ __launch_bounds__(256) void k_empty_tiles(const unsigned* __restrict__ tile_state, unsigned epoch, int TX, int TY, int TZ,
-                                                     unsigned long long* __restrict__ bits)
+__device__ __forceinline__ void empty_tiles_block(const unsigned* __restrict__ tile_state, unsigned epoch, int TX, int TY, int TZ,
+                                                  unsigned long long* __restrict__ bits, unsigned block, unsigned lane256)
 {
-  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned t = block * 256u + lane256;
   bool all = false;
   if (t < (unsigned)(TX * TY * TZ)) {
     const int tx = t % TX, ty = (t / TX) % TY, tz = t / (TX * TY);
@@ -400,7 +400,12 @@ __global__ __launch_bounds__(256) void k_empty_tiles(const unsigned* __restrict_
     }
   }
   const unsigned long long m = __ballot(all);   // (tiles past the end: 0)
-  if ((threadIdx.x & 63) == 0) bits[t >> 6] = m;
+  if ((lane256 & 63u) == 0) bits[t >> 6] = m;
+}
+__global__ __launch_bounds__(256) void k_empty_tiles(const unsigned* __restrict__ tile_state, unsigned epoch, int TX, int TY, int TZ,
+                                                     unsigned long long* __restrict__ bits)
+{
+  empty_tiles_block(tile_state, epoch, TX, TY, TZ, bits, blockIdx.x, threadIdx.x);
 }
 void launch_empty_tiles(const unsigned* tile_state, unsigned epoch, int TX, int TY, int TZ, unsigned* bits, hipStream_t s)
 {
@@ -674,22 +679,28 @@ __device__ __forceinline__ bool peel_gt10(const PeelParams& p, const int* c)
 // (the library's mask), bit 1 = its super-cell is near, bit 2 = its counter is above 10 (the geometry shader's cull of a
 // face towards such a neighbour, bricks.gs:28-43) -- so the walk gets all three from the one byte it loads per cell.
 // Most of a frame is empty space (3 % of the bricks are occupied in SURVEY 8d's scene, 13 % of the super-cells near).
-__global__ __launch_bounds__(64) void k_peel_near(const uint8_t* mask, const uint32_t* counters, int rx, int ry, int rz, int sx, int sy, int sz,
-                                                  uint8_t* cells, int force)
+__global__ __launch_bounds__(256) void k_peel_near(const uint8_t* mask, const uint32_t* counters, int rx, int ry, int rz, int sx, int sy, int sz,
+                                                   uint8_t* cells, int force, unsigned near_blocks, PeelParams::EmptyTiles et)
 {
-  const int id = blockIdx.x;
+  if (blockIdx.x >= near_blocks) {  // (k_empty_tiles' work: one dependent launch less in front of the march)
+    empty_tiles_block(et.tile_state, et.epoch, et.TX, et.TY, et.TZ, (unsigned long long*)et.bits, blockIdx.x - near_blocks, threadIdx.x);
+    return;
+  }
+  const int id = (int)(blockIdx.x * 4u + (threadIdx.x >> 6));  // a wavefront per super-cell
+  if (id >= sx * sy * sz) return;
+  const int lane = threadIdx.x & 63;
   const int cx = id % sx, cy = (id / sx) % sy, cz = id / (sx * sy);
   const int x0 = max(4 * cx - 1, 0), x1 = min(4 * cx + 4, rx - 1);
   const int y0 = max(4 * cy - 1, 0), y1 = min(4 * cy + 4, ry - 1);
   const int z0 = max(4 * cz - 1, 0), z1 = min(4 * cz + 4, rz - 1);
   const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, n = nx * ny * (z1 - z0 + 1);
   unsigned any = 0;
-  for (int k = threadIdx.x; k < n; k += 64) {
+  for (int k = lane; k < n; k += 64) {
     const int x = x0 + k % nx, y = y0 + (k / nx) % ny, z = z0 + k / (nx * ny);
     any |= mask[((size_t)z * ry + y) * rx + x];
   }
   const unsigned nearbit = (__ballot(any != 0) != 0 || force) ? 2u : 0u;
-  const int bx = 4 * cx + (threadIdx.x & 3), by = 4 * cy + ((threadIdx.x >> 2) & 3), bz = 4 * cz + (threadIdx.x >> 4);
+  const int bx = 4 * cx + (lane & 3), by = 4 * cy + ((lane >> 2) & 3), bz = 4 * cz + (lane >> 4);
   if (bx < rx && by < ry && bz < rz) {
     const size_t at = ((size_t)bz * ry + by) * rx + bx;
     cells[at] = (uint8_t)((mask[at] != 0 ? 1u : 0u) | nearbit | (counters[at] > 10u ? 4u : 0u));
@@ -903,8 +914,10 @@ void launch_depth_peels(const PeelParams& p, hipStream_t s)
   // RGBDR_PEEL_ALLNEAR=1 (diagnostic, profiles/pmc_peels.sh): every super-cell counts as near, i.e. the plain walk
   static const int all_near = std::getenv("RGBDR_PEEL_ALLNEAR") ? 1 : 0;
   const int ns = p.res_super[0] * p.res_super[1] * p.res_super[2];
-  hipLaunchKernelGGL(k_peel_near, dim3((unsigned)ns), dim3(64), 0, s, p.mask, p.counters, p.res_bricks[0], p.res_bricks[1],
-                     p.res_bricks[2], p.res_super[0], p.res_super[1], p.res_super[2], p.cells, all_near);
+  const unsigned near_blocks = ((unsigned)ns + 3u) / 4u;
+  const unsigned et_blocks = p.empty_tiles.bits ? ((unsigned)(p.empty_tiles.TX * p.empty_tiles.TY * p.empty_tiles.TZ) + 255u) / 256u : 0u;
+  hipLaunchKernelGGL(k_peel_near, dim3(near_blocks + et_blocks), dim3(256), 0, s, p.mask, p.counters, p.res_bricks[0], p.res_bricks[1],
+                     p.res_bricks[2], p.res_super[0], p.res_super[1], p.res_super[2], p.cells, all_near, near_blocks, p.empty_tiles);
   dim3 grid((p.width + 15) / 16, (p.height + 15) / 16);
   hipLaunchKernelGGL(k_depth_peels, grid, dim3(16, 16), 0, s, p);
 }

@@ -220,6 +220,14 @@ struct PeelParams {
   int res_super[3];            // super-cells of 4^3 bricks: ceil(res_bricks / 4)
   uint8_t* cells;              // [num_bricks] listed | near << 1, written by launch_depth_peels before the walk (k_peel_near)
   float4* out;
+  // the ray-marcher's bitmap of empty tiles (launch_empty_tiles), formed by extra workgroups of k_peel_near's launch when the
+  // march follows the peels: one dependent launch less in front of it (bits == null: not wanted)
+  struct EmptyTiles {
+    const unsigned* tile_state;
+    unsigned epoch;
+    int TX, TY, TZ;
+    unsigned* bits;
+  } empty_tiles;
 };
 void launch_depth_peels(const PeelParams& p, hipStream_t s);
 
