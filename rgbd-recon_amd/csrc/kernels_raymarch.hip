@@ -202,56 +202,154 @@ __device__ __forceinline__ void shade_fragment(const RaymarchParams& p, const fl
   const float3 vn = normalize3(vn4.x, vn4.y, vn4.z);
   const float4 vp = mat4_mul(p.mv_vol_to_world, sp[0], sp[1], sp[2], 1.0f);
   float tc[3] = {0, 0, 0}, tc2[3] = {0, 0, 0}, tw = 0.0f, tw2 = 0.0f, cw[3] = {0, 0, 0}, cwt = 0.0f;
-  for (int i = 0; i < p.N; ++i) {
-    const float3 pcal = p.lut_tiled ? lut_planes_sample(p, i, sp[0], sp[1], sp[2])
-                                    : tex3d_xyz(p.lut[i], p.rx[i], p.ry[i], p.rz[i], p.zoff[i], sp[0], sp[1], sp[2]);
-    const float2 pcol = tex3d_uv(p.cv_uv[i], p.uv_res[i][0], p.uv_res[i][1], p.uv_res[i][2], pcal.x, pcal.y, pcal.z);
-    const Axis CX = axis_linear(pcol.x, p.Wc), CY = axis_linear(pcol.y, p.Hc);
-    float col[3];
-    if (p.color_dxt) {  // the frame as uploaded: the four texels decoded on the spot (k_pre_depth's lookup does the same)
-      const uint8_t* layer = p.color_dxt + (size_t)i * p.color_layer_bytes;
-      const int bw = (p.Wc + 3) / 4, bx0 = CX.i0 >> 2, bx1 = CX.i1 >> 2, by0 = CY.i0 >> 2, by1 = CY.i1 >> 2;
-      const uint2 b00 = dxt_block(layer, bw, p.color_mode, bx0, by0);
-      const uint2 b10 = bx1 == bx0 ? b00 : dxt_block(layer, bw, p.color_mode, bx1, by0);
-      const uint2 b01 = by1 == by0 ? b00 : dxt_block(layer, bw, p.color_mode, bx0, by1);
-      const uint2 b11 = by1 == by0 ? b10 : (bx1 == bx0 ? b01 : dxt_block(layer, bw, p.color_mode, bx1, by1));
-      int p00[3], p10[3], p01[3], p11[3];
-      dxt_texel(b00, p.color_mode, CX.i0, CY.i0, p00);
-      dxt_texel(b10, p.color_mode, CX.i1, CY.i0, p10);
-      dxt_texel(b01, p.color_mode, CX.i0, CY.i1, p01);
-      dxt_texel(b11, p.color_mode, CX.i1, CY.i1, p11);
+  // blendColors' loop over the sensors, four at a time, as three rounds of gathers.  A sensor's lookups depend on each other
+  // (calibration volume -> colour lookup volume -> colour texels; calibration volume -> depth -> quality), the sensors' do not,
+  // and a wavefront that shades spends its time waiting: ~17 dependent round trips to memory at two wavefronts per SIMD
+  // (profiles/r06_notes/raymarch.md).  So every gather of a round -- for all four sensors -- is issued before any of their
+  // results is looked at (the scheduling barriers keep the compiler from sinking the loads back to their uses): three round
+  // trips per group of four sensors.  Nothing is loaded behind a branch (a sensor index past N reads sensor N - 1 again,
+  // the quality texels are read whatever the depth test says; every address is clamped into its image); the sums are
+  // formed in the shader's order.
+  constexpr int G = 4;
+  const Axis LX = axis_linear(sp[0], p.X), LY = axis_linear(sp[1], p.Y), LZ = resident_rows(p, axis_linear(sp[2], p.Z));
+  for (int i0 = 0; i0 < p.N; i0 += G) {
+    int sensor[G];
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        col[k] = lerpf(lerpf((float)p00[k] / 255.0f, (float)p10[k] / 255.0f, CX.a), lerpf((float)p01[k] / 255.0f, (float)p11[k] / 255.0f, CX.a), CY.a);
-    } else {
-      const uint8_t* img = p.color + (size_t)i * p.Wc * p.Hc * 3;
+    for (int g = 0; g < G; ++g) sensor[g] = min(i0 + g, p.N - 1);
+    // round 1: texture(cv_xyz_inv[i], pos).xyz -- eight texels of three planes (or eight 16-byte records) per sensor
+    float lt[G][3][8];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float c00 = (float)img[((size_t)CY.i0 * p.Wc + CX.i0) * 3 + k] / 255.0f, c10 = (float)img[((size_t)CY.i0 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-        const float c01 = (float)img[((size_t)CY.i1 * p.Wc + CX.i0) * 3 + k] / 255.0f, c11 = (float)img[((size_t)CY.i1 * p.Wc + CX.i1) * 3 + k] / 255.0f;
-        col[k] = lerpf(lerpf(c00, c10, CX.a), lerpf(c01, c11, CX.a), CY.a);
+    for (int g = 0; g < G; ++g) {
+      if (p.lut_tiled) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int x = (k & 1) ? LX.i1 : LX.i0, y = (k & 2) ? LY.i1 : LY.i0, z = (k & 4) ? LZ.i1 : LZ.i0;
+          const size_t tile = (size_t)(((z >> 3) - p.tz_alloc0) * p.TY + (y >> 3)) * p.TX + (x >> 3);
+          const float* at = p.lut_tiled + ((tile * p.N + sensor[g]) * 3) * kTileVoxels + ((z & 7) * 64 + (y & 7) * 8 + (x & 7));
+#pragma unroll
+          for (int c = 0; c < 3; ++c) lt[g][c][k] = at[c * kTileVoxels];
+        }
+      } else {
+        const int i = sensor[g];
+        const Axis X = axis_linear(sp[0], p.rx[i]), Y = axis_linear(sp[1], p.ry[i]), Z = axis_linear(sp[2], p.rz[i]);
+        const size_t sy = (size_t)p.rx[i], sz = (size_t)p.rx[i] * p.ry[i];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 v = p.lut[i][(size_t)(((k & 4) ? Z.i1 : Z.i0) - p.zoff[i]) * sz + ((k & 2) ? Y.i1 : Y.i0) * sy + ((k & 1) ? X.i1 : X.i0)];
+          lt[g][0][k] = v.x, lt[g][1][k] = v.y, lt[g][2][k] = v.z;
+        }
       }
     }
-    const uint2* frame = p.frame[i];
-    const int ix = axis_nearest(pcal.x, p.W), iy = axis_nearest(pcal.y, p.H);
-    const float depth = __uint_as_float(frame[(size_t)iy * p.W + ix].x);
-    const float dist = fabsf(depth - pcal.z);
-    float q = 0.0f;
-    if (dist < limit) {
-      const Axis QX = axis_linear(pcal.x, p.W), QY = axis_linear(pcal.y, p.H);
-      const float q00 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i0].y & 0x7fffffffu), q10 = __uint_as_float(frame[(size_t)QY.i0 * p.W + QX.i1].y & 0x7fffffffu);
-      const float q01 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i0].y & 0x7fffffffu), q11 = __uint_as_float(frame[(size_t)QY.i1 * p.W + QX.i1].y & 0x7fffffffu);
-      q = lerpf(lerpf(q00, q10, QX.a), lerpf(q01, q11, QX.a), QY.a);
+    __builtin_amdgcn_sched_barrier(0);
+    float3 pcal[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float r[3];
+      if (p.lut_tiled) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          r[c] = lerpf(lerpf(lerpf(lt[g][c][0], lt[g][c][1], LX.a), lerpf(lt[g][c][2], lt[g][c][3], LX.a), LY.a),
+                       lerpf(lerpf(lt[g][c][4], lt[g][c][5], LX.a), lerpf(lt[g][c][6], lt[g][c][7], LX.a), LY.a), LZ.a);
+      } else {  // (tex3d_xyz's order: the x blends of the three components, then y, then z)
+        const int i = sensor[g];
+        const Axis X = axis_linear(sp[0], p.rx[i]), Y = axis_linear(sp[1], p.ry[i]), Z = axis_linear(sp[2], p.rz[i]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          r[c] = lerpf(lerpf(lerpf(lt[g][c][0], lt[g][c][1], X.a), lerpf(lt[g][c][2], lt[g][c][3], X.a), Y.a),
+                       lerpf(lerpf(lt[g][c][4], lt[g][c][5], X.a), lerpf(lt[g][c][6], lt[g][c][7], X.a), Y.a), Z.a);
+      }
+      pcal[g] = make_float3(r[0], r[1], r[2]);
+    }
+    // round 2: texture(cv_uv[i], pcal) -- eight float2 texels -- and the depth and quality texels of the sensor's frame
+    float2 ut[G][8];
+    Axis UX[G], UY[G], UZ[G], QX[G], QY[G];
+    float depth[G], q4[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int i = sensor[g];
+      UX[g] = axis_linear(pcal[g].x, p.uv_res[i][0]), UY[g] = axis_linear(pcal[g].y, p.uv_res[i][1]), UZ[g] = axis_linear(pcal[g].z, p.uv_res[i][2]);
+      const size_t sy = (size_t)p.uv_res[i][0], sz = (size_t)p.uv_res[i][0] * p.uv_res[i][1];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        ut[g][k] = p.cv_uv[i][(size_t)((k & 4) ? UZ[g].i1 : UZ[g].i0) * sz + ((k & 2) ? UY[g].i1 : UY[g].i0) * sy + ((k & 1) ? UX[g].i1 : UX[g].i0)];
+      const uint2* frame = p.frame[i];
+      const int ix = axis_nearest(pcal[g].x, p.W), iy = axis_nearest(pcal[g].y, p.H);
+      depth[g] = __uint_as_float(frame[(size_t)iy * p.W + ix].x);
+      QX[g] = axis_linear(pcal[g].x, p.W), QY[g] = axis_linear(pcal[g].y, p.H);
+      q4[g][0] = __uint_as_float(frame[(size_t)QY[g].i0 * p.W + QX[g].i0].y & 0x7fffffffu);
+      q4[g][1] = __uint_as_float(frame[(size_t)QY[g].i0 * p.W + QX[g].i1].y & 0x7fffffffu);
+      q4[g][2] = __uint_as_float(frame[(size_t)QY[g].i1 * p.W + QX[g].i0].y & 0x7fffffffu);
+      q4[g][3] = __uint_as_float(frame[(size_t)QY[g].i1 * p.W + QX[g].i1].y & 0x7fffffffu);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float2 pcol[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float ax = UX[g].a, ay = UY[g].a, az = UZ[g].a;
+      pcol[g].x = lerpf(lerpf(lerpf(ut[g][0].x, ut[g][1].x, ax), lerpf(ut[g][2].x, ut[g][3].x, ax), ay),
+                        lerpf(lerpf(ut[g][4].x, ut[g][5].x, ax), lerpf(ut[g][6].x, ut[g][7].x, ax), ay), az);
+      pcol[g].y = lerpf(lerpf(lerpf(ut[g][0].y, ut[g][1].y, ax), lerpf(ut[g][2].y, ut[g][3].y, ax), ay),
+                        lerpf(lerpf(ut[g][4].y, ut[g][5].y, ax), lerpf(ut[g][6].y, ut[g][7].y, ax), ay), az);
+    }
+    // round 3: the four colour texels around pcol, from the frame's DXT blocks as uploaded or from the decoded frame
+    float col[G][3];
+    Axis CX[G], CY[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) CX[g] = axis_linear(pcol[g].x, p.Wc), CY[g] = axis_linear(pcol[g].y, p.Hc);
+    if (p.color_dxt) {
+      uint2 blk[G][4];
+      const int bw = (p.Wc + 3) / 4;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint8_t* layer = p.color_dxt + (size_t)sensor[g] * p.color_layer_bytes;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) blk[g][k] = dxt_block(layer, bw, p.color_mode, ((k & 1) ? CX[g].i1 : CX[g].i0) >> 2, ((k & 2) ? CY[g].i1 : CY[g].i0) >> 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        int t4[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dxt_texel(blk[g][k], p.color_mode, (k & 1) ? CX[g].i1 : CX[g].i0, (k & 2) ? CY[g].i1 : CY[g].i0, t4[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          col[g][k] = lerpf(lerpf((float)t4[0][k] / 255.0f, (float)t4[1][k] / 255.0f, CX[g].a), lerpf((float)t4[2][k] / 255.0f, (float)t4[3][k] / 255.0f, CX[g].a),
+                            CY[g].a);
+      }
+    } else {
+      uint8_t c4[G][4][3];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const uint8_t* img = p.color + (size_t)sensor[g] * p.Wc * p.Hc * 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) c4[g][k][c] = img[((size_t)((k & 2) ? CY[g].i1 : CY[g].i0) * p.Wc + ((k & 1) ? CX[g].i1 : CX[g].i0)) * 3 + c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          col[g][k] = lerpf(lerpf((float)c4[g][0][k] / 255.0f, (float)c4[g][1][k] / 255.0f, CX[g].a),
+                            lerpf((float)c4[g][2][k] / 255.0f, (float)c4[g][3][k] / 255.0f, CX[g].a), CY[g].a);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      tc[k] += col[k] * q / (dist + 0.01f);
-      tc2[k] += col[k] / dist;
-      if (i < 5) cw[k] += (c_camera_colors[i][k] / 255.0f) * q;
+    for (int g = 0; g < G; ++g) {
+      const int i = i0 + g;
+      if (i >= p.N) break;
+      const float dist = fabsf(depth[g] - pcal[g].z);
+      const float q = dist < limit ? lerpf(lerpf(q4[g][0], q4[g][1], QX[g].a), lerpf(q4[g][2], q4[g][3], QX[g].a), QY[g].a) : 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        tc[k] += col[g][k] * q / (dist + 0.01f);
+        tc2[k] += col[g][k] / dist;
+        if (i < 5) cw[k] += (c_camera_colors[i][k] / 255.0f) * q;
+      }
+      tw += q / (dist + 0.01f);
+      tw2 += 1.0f / dist;
+      cwt += q;
     }
-    tw += q / (dist + 0.01f);
-    tw2 += 1.0f / dist;
-    cwt += q;
   }
   if (p.shade_mode == 3) {
     rgba = make_float4(cwt <= 0.0f ? 1.0f : cw[0] / cwt, cwt <= 0.0f ? 1.0f : cw[1] / cwt, cwt <= 0.0f ? 1.0f : cw[2] / cwt, 1.0f);
