@@ -39,6 +39,55 @@ int main()
       if (rep == 2) printf("empty kernel, %5d blocks of 256: %.2f us per launch (8 in a row)\n", blocks, ms * 1e3 / 8);
     }
   }
+  // (c) the same chains replayed from a hipGraph (stream capture of 8 / 64 launches): does a graph's dependent launch cost less?
+  for (int len : {8, 64})
+    for (int blocks : {1, 1024}) {
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+      for (int k = 0; k < len; ++k) hipLaunchKernelGGL(k_empty, dim3(blocks), dim3(256), 0, s, out);
+      hipStreamEndCapture(s, &g);
+      if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) {
+        printf("graph instantiate failed\n");
+        continue;
+      }
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, s);
+        for (int k = 0; k < 4; ++k) hipGraphLaunch(ge, s);
+        hipEventRecord(e1, s);
+        hipStreamSynchronize(s);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep == 3) printf("graph of %2d empty kernels, %5d blocks of 256: %.2f us per kernel (4 graph launches in a row)\n", len, blocks, ms * 1e3 / (4 * len));
+      }
+      hipGraphExecDestroy(ge);
+      hipGraphDestroy(g);
+    }
+  // (d) ... and behind a kernel that keeps the GPU busy for ~0.1 ms (a graph launch has a fixed cost: does it hide behind the
+  // kernel in front of it?): the long kernel alone, + 8 stream launches, + one graph of the same 8
+  {
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, out);
+    hipStreamEndCapture(s, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    for (int mode = 0; mode < 3; ++mode) {
+      float best = 1e9f;
+      for (int rep = 0; rep < 6; ++rep) {
+        hipEventRecord(e0, s);
+        hipLaunchKernelGGL(k_chain, dim3(4096), dim3(64), 0, s, out, 4096, 0.5f);
+        if (mode == 1) for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_empty, dim3(1024), dim3(256), 0, s, out);
+        if (mode == 2) hipGraphLaunch(ge, s);
+        hipEventRecord(e1, s);
+        hipStreamSynchronize(s);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (rep >= 2 && ms < best) best = ms;
+      }
+      printf("long kernel %s: %.2f us\n", mode == 0 ? "alone" : mode == 1 ? "+ 8 stream launches (1024 blocks)" : "+ a graph of the 8", best * 1e3);
+    }
+  }
   for (int blocks : {1, 256, 1024, 4096})
     for (int n : {64, 256, 1024}) {
       for (int rep = 0; rep < 3; ++rep) {
