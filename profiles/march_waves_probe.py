@@ -49,7 +49,7 @@ fn = capi.lib().rgbdr_debug_march_trace
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_size_t]
 nw = (1280 // 16) * (720 // 16) * 4
-buf = np.zeros((16384, 8), dtype=np.uint32)
+buf = np.zeros((32768, 8), dtype=np.uint32)
 assert fn(buf.ctypes.data, buf.nbytes) == 0
 t = buf[:nw, :4].astype(np.int64)
 t0 = t[:, 0].min()
@@ -73,4 +73,15 @@ busy = [(int(((start <= e) & (end > e)).sum()), int(((start <= e) & (end > e) & 
 print("  wavefronts in flight every 10 us (all, marching):", busy)
 per_round = march[work] / np.maximum(rounds[work], 1)
 print("  march time per round of the marching wavefronts: median %.2f us, 90 %% %.2f" % (np.median(per_round), np.percentile(per_round, 90)))
+# k_depth_peels of the same frame: entry and exit of every wavefront
+pt = buf[16384:16384 + nw][:, [0, 3]].astype(np.int64)
+p0 = pt[:, 0].min()
+ps, pe = (pt[:, 0] - p0) / 100.0, (pt[:, 1] - p0) / 100.0
+stay = pe - ps
+print("k_depth_peels: %d wavefronts, first entry to last exit %.1f us; entry times median %.1f, last %.1f us" % (nw, pe.max(), np.median(ps), ps.max()))
+print("  a wavefront's stay: 50 %% %.1f  90 %% %.1f  99 %% %.1f  max %.1f us; summed %.0f wavefront-us = %.1f us on 2048 / %.1f us on 8192 slots" %
+      (np.percentile(stay, 50), np.percentile(stay, 90), np.percentile(stay, 99), stay.max(), stay.sum(), stay.sum() / 2048, stay.sum() / 8192))
+edges = np.arange(0, pe.max() + 5, 5)
+print("  wavefronts in flight every 5 us:", [int(((ps <= e) & (pe > e)).sum()) for e in edges])
+print("  the five that leave last (entry, stay, exit us):", [(round(float(ps[k]), 1), round(float(stay[k]), 1), round(float(pe[k]), 1)) for k in np.argsort(-pe)[:5]])
 rc.close()

@@ -585,7 +585,7 @@ __device__ __forceinline__ void wave_square_pixel(int& px, int& py)
 struct MarchTrace {
   uint32_t t[4], rounds, whole, hw_id, xcc_id;
 };
-__device__ MarchTrace g_march_trace[16384];
+__device__ MarchTrace g_march_trace[32768];  // [0, 16384): k_raymarch<0>, [16384, 32768): k_depth_peels (entry and exit only)
 extern "C" int rgbdr_debug_march_trace(void* dst, size_t bytes)
 {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_march_trace), bytes, 0, hipMemcpyDeviceToHost);
@@ -807,6 +807,20 @@ __global__ __launch_bounds__(256) void k_peel_near(const uint8_t* mask, const ui
 
 __global__ __launch_bounds__(256) void k_depth_peels(PeelParams p)
 {
+#ifdef RGBDR_TRACE_BLOCKS
+  const uint32_t trace_t0 = (uint32_t)wall_clock64();
+  struct PeelStamp {
+    uint32_t t0;
+    __device__ ~PeelStamp()
+    {
+      const int t = threadIdx.y * 16 + threadIdx.x;
+      if (t & 63) return;
+      MarchTrace& m = g_march_trace[16384 + ((blockIdx.y * gridDim.x + blockIdx.x) * 4 + (t >> 6)) % 16384];
+      m.t[0] = t0;
+      m.t[3] = (uint32_t)wall_clock64();
+    }
+  } peel_stamp{trace_t0};
+#endif
   int px, py;
   wave_square_pixel(px, py);
   if (px >= p.width || py >= p.height) return;
