@@ -736,6 +736,13 @@ def leg_default_display_frame(rig):
         res["ms_per_frame"] = round(run(1), 4)
         res["ms_per_frame_moving"] = round(run(4), 4)
         res["frames_per_s"] = round(1e3 / res["ms_per_frame"], 1)
+        # the same frames with RGBDR_FLAG_PIPELINE: the pre_* chain of frame k + 1 on the second stream under the view
+        # pass of frame k (throughput of a host that keeps enqueuing; a frame's latency is the sequential figure)
+        rc.set_pipelined(True)
+        try:
+            res["ms_per_frame_pipelined"] = round(run(4), 4)
+        finally:
+            rc.set_pipelined(False)
         res["occupied_ratio"] = round(rc.occupied_ratio(), 4)
         rc.set_timer_detail(1)
         rc.enable_timers(True)

@@ -36,6 +36,8 @@ for i in range(N):
         rc.set_inverse_calibration(i, rc.generate_inverse_lut(i, (286, 315, 286)), (286, 315, 286))
     else:
         rc.synth_inverse_calibration(i, sc.pinhole(i))
+if os.environ.get("RGBDR_DISPLAY_PIPELINE"):   # the pre_* chain of frame k + 1 on the second stream, under the view pass of frame k
+    rc.set_pipelined(True)
 view = capi.make_view((2.4, 1.8, 2.1), (0.0, 0.7, 0.0), (0.0, 1.0, 0.0), 45.0, 1280, 720, synth.BBOX_MIN, bmax)
 view.skip_space = 1
 import time  # noqa: E402

@@ -384,6 +384,10 @@ try {
       ctx->err = "hipEventCreate failed";
       return cleanup(RGBDR_ERR_HIP);
     }
+  if (hipEventCreateWithFlags(&ctx->ev_color_read, hipEventDisableTiming) != hipSuccess) {
+    ctx->err = "hipEventCreate failed";
+    return cleanup(RGBDR_ERR_HIP);
+  }
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)cfg->num_sensors * cfg->color_w * cfg->color_h * 3;
   struct {
@@ -452,6 +456,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     if (ctx->ev_pre[b]) (void)hipEventDestroy(ctx->ev_pre[b]);
     if (ctx->ev_int[b]) (void)hipEventDestroy(ctx->ev_int[b]);
   }
+  if (ctx->ev_color_read) (void)hipEventDestroy(ctx->ev_color_read);
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->gather_stream) {
@@ -493,6 +498,8 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
+  // a view pass of the frame before (rgbdr_draw on the other stream of a pipelined context) may still read the colour frame
+  if (ctx->pipelined() && ctx->ev_color_read_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));
   ctx->morph_current = false;
   ctx->frame_uploaded = false;  // until every launch below is enqueued: an upload that fails part-way leaves no frame
   // a sensor shard (rgbdr_set_sensor_shard) copies and morphs the raw depth of its own layers only
@@ -744,6 +751,7 @@ try {
   const int w = ctx->wbuf;
   p.frame = ctx->frame_buf(w);
   if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  if (ctx->pipelined() && ctx->ev_color_read_rec && ctx->view_read_buf == w) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));  // ... a view pass
   { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }  // (an asynchronous gather still writes the frame / the counters)
   // another context may still be copying the LAST frame out of these buffers (rgbdr_import_frame_from on a stream of its own)
   if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_imported, 0));
@@ -785,6 +793,7 @@ try {
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
     ctx->ev_pre_rec[w] = true;
+    ++ctx->pre_serial;
   }
   ctx->textures_processed = true;
   ctx->bgmax_for = -1;
@@ -821,6 +830,7 @@ try {
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
     ctx->ev_pre_rec[w] = true;
+    ++ctx->pre_serial;
   }
   ctx->mask_valid = true;
   return RGBDR_OK;
@@ -956,7 +966,10 @@ try {
       copy_faces = true;
     }
   }
-  if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+  if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf]) {
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+    ctx->pre_joined = ctx->pre_serial;
+  }
   { int rc_ = join_async_gather(ctx, ctx->stream); if (rc_ != RGBDR_OK) return rc_; }
   tbegin(ctx, "2integrate", ctx->stream);
   if (skip_bg) {

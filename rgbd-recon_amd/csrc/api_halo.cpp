@@ -308,6 +308,7 @@ static int import_pointers(rgbdr_ctx* ctx, const void* packed_frames, const void
   ctx->rbuf = w;
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
+    ++ctx->pre_serial;
     ctx->ev_pre_rec[w] = true;
   }
   ctx->textures_processed = true;

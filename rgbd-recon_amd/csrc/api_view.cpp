@@ -132,11 +132,19 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
   const int N = nsens(ctx);
   bool tiled = true;
   for (int i = 0; i < N; ++i) tiled = tiled && ctx->inv_tiled[i];
-  if (!in_stream_order || ctx->pipelined() || ctx->gather_stream || ctx->halo_stream) {
+  if (!in_stream_order || ctx->gather_stream || ctx->halo_stream) {
     int rc_ = sync_all(ctx);
     if (rc_ != RGBDR_OK) return rc_;
   } else {
     HIPCHK(hipSetDevice(ctx->device));
+    // a pipelined context: the frame's images, brick counters and mask come from the chain's stream (the sweep has waited
+    // for them already if there was one); what the NEXT frame's chain overwrites while this pass runs is the other half of
+    // every double buffer, and the colour frame only behind ev_color_read (rgbdr_draw)
+    // (a wait or a record on a stream is a bubble of ~10 us between its kernels: none that is not needed)
+    if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf] && ctx->pre_joined != ctx->pre_serial) {
+      HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
+      ctx->pre_joined = ctx->pre_serial;
+    }
   }
   const size_t npix = (size_t)v->width * v->height;
   {
@@ -387,6 +395,13 @@ try {
   launch_raymarch(p, 0, ctx->stream);
   tend(ctx, "draw", ctx->stream);
   LAUNCHCHK("raymarch");
+  if (ctx->pipelined()) {
+    // the pass has read the frame: its colour (the next upload waits), its images, counters and mask (the chain of the frame
+    // after the next waits for ev_int before it refills this half of the double buffers -- behind the sweep until now)
+    HIPCHK(hipEventRecord(ctx->ev_color_read, ctx->stream));
+    ctx->ev_color_read_rec = true;
+    ctx->view_read_buf = ctx->rbuf;  // (one record for both: process_textures waits for it too when it refills that half)
+  }
   ctx->filled_w = ctx->filled_h = 0;
   if (fill_holes) {
     float4* ocol;

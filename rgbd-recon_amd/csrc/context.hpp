@@ -54,6 +54,12 @@ struct rgbdr_ctx {
   std::vector<uint32_t> side_cu_mask;  // RGBDR_CU_SPLIT: the CUs of the second stream (and of the halo stream); empty: no split
   int wbuf = 0, rbuf = 0;            // buffer the next process_textures writes / the latest one written
   hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
+  // pipelined contexts: behind the last kernel of a view pass (rgbdr_draw) that reads the colour frame -- the one buffer of a
+  // frame that is not double-buffered: the next upload, on the chain's stream, waits for it
+  hipEvent_t ev_color_read = nullptr;
+  bool ev_color_read_rec = false;
+  int view_read_buf = -1;            // the half of the double buffers that view pass read
+  unsigned pre_serial = 0, pre_joined = 0;  // records of ev_pre / the last one the sweep's stream has waited for
   bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
   bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
   hipStream_t pstream() const { return pipelined() ? pre_stream : stream; }

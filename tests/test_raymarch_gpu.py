@@ -369,6 +369,50 @@ def test_draw_is_drawF_without_a_host_round_trip(pkg, orc, skip):
     assert (rd < 1).mean() > 0.05
     ctx.close()
 
+@pytest.mark.parametrize("compress_rgb", [0, 1])
+def test_draw_on_a_pipelined_context(pkg, orc, compress_rgb):
+    """a context with RGBDR_FLAG_PIPELINE runs the pre_* chain of frame k + 1 on its second stream while rgbdr_draw of frame k
+    is still on the first: the view pass is ordered by events (no host synchronisation), the next upload waits for its last
+    read of the colour frame.  Bursts of 2 .. 6 frames of two alternating scenes, nothing read back inside a burst: the last
+    displayed frame of every burst equals, bit for bit, the one a sequential context displays for the same frames."""
+    capi, synth = pkg.capi, pkg.synth
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), color_wh=(128, 106)),
+              synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7, color_wh=(128, 106))]
+    frames = [(sc.depth, np.stack([synth.encode_dxt(sc.color[i], 1) for i in range(2)]) if compress_rgb else sc.color) for sc in scenes]
+    inv = scenes[0].inverse((64, 64, 64))
+    ctxs = []
+    for pipelined in (False, True):
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64, compress_rgb=compress_rgb), 0)
+        for i in range(2):
+            ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
+        ctx.set_use_bricks(True)
+        ctx.set_pipelined(pipelined)
+        ctxs.append(ctx)
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 320, 180, BMIN, BMAX)
+    view.skip_space = 1
+    k = 0
+    for burst in (2, 3, 4, 5, 6):
+        shown = []
+        for ctx in ctxs:
+            kk = k
+            for _ in range(burst):
+                depth, color = frames[kk % 2]
+                kk += 1
+                ctx.update(depth, color)
+                ctx.clear_occupied_bricks()
+                ctx.process_textures()
+                ctx.update_occupied_bricks()
+                ctx.integrate()
+                ctx.draw(view, True)
+            shown.append(ctx.readback_view_frame(True) + ctx.readback_view_frame(False))
+        k += burst
+        for a, b in zip(*shown):
+            assert same_bits(a, b), (burst, count_diff(a, b))
+        assert (shown[0][3] < 1).mean() > 0.05
+    for ctx in ctxs:
+        ctx.close()
+
 
 def test_fill_colors_needs_a_frame(pkg):
     capi = pkg.capi
