@@ -593,8 +593,8 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * the whole under "3recon".  Enqueued on the context's stream behind the frame's passes WITHOUT waiting for the device
  * (contexts with a halo or gather transfer on a side stream are drained first); the frame stays on the device like the
  * window's framebuffer does.  With RGBDR_FLAG_PIPELINE the pass is ordered against the chain's stream by events: the
- * pre_* chain of the NEXT frame runs under it (it reads the halves of the double buffers that chain does not write; the
- * next upload waits for the pass's last read of the colour frame, the one buffer of a frame there is one of).  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
+ * pre_* chain of the NEXT frame, its upload included, runs under it (the pass reads the halves of the double buffers --
+ * images, brick counters and masks, colour frame -- that chain does not write).  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
  * depth [height][width] f32 of the ray-marched frame (filled = 0) or of the hole-filled one (filled = 1; RGBDR_ERR_STATE
  * when the current frame has not been filled), valid until the next call that draws, fills or uploads a frame and ordered
  * on rgbdr_set_stream's stream.  rgbdr_readback_view_frame copies it to the host (waits). */

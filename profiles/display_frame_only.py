@@ -62,8 +62,14 @@ if not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):     # timing
     t0 = time.perf_counter()
     for _ in range(500):
         frame()
+    host_ms = (time.perf_counter() - t0) / 500 * 1e3     # what the host needs to enqueue a frame (it runs ahead of the device)
     rc.sync()
     ms = (time.perf_counter() - t0) / 500 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):     # ... and with the queue empty: the host's own cost per frame
+        frame()
+    host_idle_ms = (time.perf_counter() - t0) / 20 * 1e3
+    rc.sync()
     rc.set_timer_detail(1)
     rc.enable_timers(True)
     frame()
@@ -71,7 +77,8 @@ if not any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):     # timing
     rc.sync()
     st = {n: round(rc.timer_ns(t) * 1e-6, 4) for n, t in (("pre_chain", "1preprocess"), ("integrate", "2integrate"), ("depth_peels", "brickdraw"),
                                                             ("raymarch", "draw"), ("holefill", "holefill"), ("drawF", "3recon"))}
-    print("%s grid %s: %.4f ms per displayed frame (500 back to back); stages of one more frame: %s" % (which, list(rc.geo.res_volume), ms, st))
+    print("%s grid %s: %.4f ms per displayed frame (500 back to back); stages of one more frame: %s; the host enqueues a frame in %.3f ms (%.3f into an empty queue)" %
+          (which, list(rc.geo.res_volume), ms, st, host_ms, host_idle_ms))
 elif os.environ.get("RGBDR_DISPLAY_SPLIT"):   # under the profiler: the march alone (k_raymarch<1,8>) and the shading alone (k_raymarch<2,1>)
     for _ in range(10):
         rc.raymarch_find(view)

@@ -397,10 +397,12 @@ try {
                 {(void**)&ctx->d_depth_rg, n * 8},    {(void**)&ctx->d_lab, n * 12},
                 {(void**)&ctx->d_depth_b, n * 8},     {(void**)&ctx->d_sil, n * 4},
                 {(void**)&ctx->d_normal, n * 12},     {(void**)&ctx->d_quality, n * 4},
-                {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol},
+                {(void**)&ctx->d_frame, n * 8 * 2},      {(void**)&ctx->d_color, ncol * 2},
                 {(void**)&ctx->d_count, 32},
-                {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors},
+                {(void**)&ctx->d_color_dxt, color_frame_bytes(*cfg) * cfg->num_sensors * 2},
                 {(void**)&ctx->d_cc_far, n * 8},         {(void**)&ctx->d_box_flags, n}};
+  ctx->color_half_bytes = ncol;
+  ctx->dxt_half_bytes = color_frame_bytes(*cfg) * cfg->num_sensors;
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) {
       ctx->err = "hipMalloc of image buffers failed";
@@ -498,25 +500,32 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)nsens(ctx) * ctx->cfg.color_w * ctx->cfg.color_h * 3;
   hipStream_t ps = ctx->pstream();
-  // a view pass of the frame before (rgbdr_draw on the other stream of a pipelined context) may still read the colour frame
-  if (ctx->pipelined() && ctx->ev_color_read_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));
+  // The colour half this frame goes to: on a pipelined context the one the frame before does not live in (its view pass,
+  // rgbdr_draw on the other stream, may still read that; a zero-copy view of the colour image pins the half it was given
+  // for); a frame no pre_* chain has looked at is simply replaced.  Whoever read the target last has to be done with it.
+  int ch = ctx->color_up;
+  if (ctx->pipelined() && !ctx->color_view_out && ctx->color_consumed) ch ^= 1;
+  if (ctx->pipelined() && ctx->ev_color_read_rec && ctx->view_read_color == ch) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));
+  ctx->color_up = ch;
+  ctx->color_consumed = false;
+  uint8_t *const d_color = ctx->color_half(ch), *const d_color_dxt = ctx->dxt_half(ch);
   ctx->morph_current = false;
   ctx->frame_uploaded = false;  // until every launch below is enqueued: an upload that fails part-way leaves no frame
   // a sensor shard (rgbdr_set_sensor_shard) copies and morphs the raw depth of its own layers only
   const int first = ctx->shard_count > 0 ? ctx->shard_first : 0, count = ctx->shard_count > 0 ? ctx->shard_count : nsens(ctx);
   if (!ctx->cfg.compress_depth && !ctx->cfg.compress_rgb &&
       launch_upload_morph(ctx->cfg.depth_w, ctx->cfg.depth_h, first, count, depth, ctx->d_depth_raw, ctx->d_depth_morph, color,
-                          ctx->d_color, ncol, ps)) {
+                          d_color, ncol, ps)) {
     LAUNCHCHK("upload_morph");
     ctx->morph_current = true;
-    ctx->color_decoded = true;
+    ctx->color_decoded[ch] = true;
     ctx->frame_uploaded = true;
     return RGBDR_OK;
   }
   // Compressed colour stays in its DXT blocks: pre_depth decodes the four taps of its bilinear lookup itself, and the
   // whole frame is only decoded when a consumer of the RGB8 image asks (ensure_color_decoded).
   const size_t layer = color_frame_bytes(ctx->cfg);
-  void* cdst = ctx->cfg.compress_rgb ? (void*)ctx->d_color_dxt : (void*)ctx->d_color;
+  void* cdst = ctx->cfg.compress_rgb ? (void*)d_color_dxt : (void*)d_color;
   const size_t cbytes = ctx->cfg.compress_rgb ? layer * nsens(ctx) : ncol;
   bool color_done = false;
   if (ctx->cfg.compress_depth) {
@@ -530,15 +539,15 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
     HIPCHK(hipMemcpyAsync(ctx->d_depth_raw, depth, n * 4, hipMemcpyDeviceToDevice, ps));
   }
   if (!color_done) HIPCHK(hipMemcpyAsync(cdst, color, cbytes, hipMemcpyDeviceToDevice, ps));
-  ctx->color_decoded = !ctx->cfg.compress_rgb;
+  ctx->color_decoded[ch] = !ctx->cfg.compress_rgb;
   ctx->frame_uploaded = true;
   // a zero-copy view of the RGB8 frame is out (rgbdr_device_image(RGBDR_IMG_COLOR)): it is documented as rewritten
   // by every upload, so the decode rides behind the copy on the same stream -- no host synchronisation
-  if (!ctx->color_decoded && ctx->color_view_out) {
-    launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
-                      color_frame_bytes(ctx->cfg), ctx->d_color, ps);
+  if (!ctx->color_decoded[ch] && ctx->color_view_out) {
+    launch_decode_dxt(d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
+                      color_frame_bytes(ctx->cfg), d_color, ps);
     LAUNCHCHK("decode_dxt");
-    ctx->color_decoded = true;
+    ctx->color_decoded[ch] = true;
   }
   return RGBDR_OK;
 }
@@ -653,15 +662,16 @@ RGBDR_CONTAIN(ctx)
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
 // the RGB8 colour frame for consumers other than pre_depth (which reads DXT blocks directly)
-int rgbdr::ensure_color_decoded(rgbdr_ctx* ctx)
+int rgbdr::ensure_color_decoded(rgbdr_ctx* ctx, int half)
 {
-  if (ctx->color_decoded) return RGBDR_OK;
+  const int h = half < 0 ? ctx->color_up : half;  // (the image getters: the last uploaded frame)
+  if (ctx->color_decoded[h]) return RGBDR_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  launch_decode_dxt(ctx->d_color_dxt, ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
-                    color_frame_bytes(ctx->cfg), ctx->d_color, ctx->pstream());
+  launch_decode_dxt(ctx->dxt_half(h), ctx->cfg.color_w, ctx->cfg.color_h, ctx->cfg.compress_rgb, nsens(ctx),
+                    color_frame_bytes(ctx->cfg), ctx->color_half(h), ctx->pstream());
   LAUNCHCHK("decode_dxt");
   if (ctx->pipelined()) HIPCHK(hipStreamSynchronize(ctx->pstream()));  // consumers may sit on the other stream
-  ctx->color_decoded = true;
+  ctx->color_decoded[h] = true;
   return RGBDR_OK;
 }
 // the filter of a lazy rgbdr_update_occupied_bricks, for consumers other than the brick sweep and before
@@ -726,8 +736,8 @@ try {
   }
   p.brick_size = ctx->geo.brick_size;
   p.brick_counters = ctx->counters_cur();
-  p.color = ctx->d_color;
-  p.color_dxt = ctx->color_decoded ? nullptr : ctx->d_color_dxt;
+  p.color = ctx->color_half(ctx->color_up);
+  p.color_dxt = ctx->color_decoded[ctx->color_up] ? nullptr : ctx->dxt_half(ctx->color_up);
   p.color_layer_bytes = color_frame_bytes(ctx->cfg);
   p.color_mode = ctx->cfg.compress_rgb;
   p.depth_morph = ctx->d_depth_morph;
@@ -790,6 +800,8 @@ try {
   tend(ctx, "1preprocess", ps);
   LAUNCHCHK("process_textures");
   ctx->rbuf = w;
+  ctx->color_of[w] = ctx->color_up;
+  ctx->color_consumed = true;
   if (ctx->pipelined()) {
     HIPCHK(hipEventRecord(ctx->ev_pre[w], ps));
     ctx->ev_pre_rec[w] = true;
@@ -1221,7 +1233,7 @@ try {
       v.height = ctx->cfg.color_h;
       v.channels = 3;
       v.element_bytes = 1;
-      v.ptr = ctx->d_color + (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3 * sensor;
+      v.ptr = ctx->color_half(ctx->color_up) + (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3 * sensor;  // (uploads stay in this half from now on)
       break;
     default: return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "unknown image id");
   }
@@ -1240,7 +1252,7 @@ try {
   { int rc_ = ensure_color_decoded(ctx); if (rc_ != RGBDR_OK) return rc_; }
   { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t img = (size_t)ctx->cfg.color_w * ctx->cfg.color_h * 3;
-  HIPCHK(hipMemcpyAsync(dst, ctx->d_color + img * sensor, img, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst, ctx->color_half(ctx->color_up) + img * sensor, img, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RGBDR_OK;
 }

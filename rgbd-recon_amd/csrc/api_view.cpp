@@ -237,16 +237,17 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
     p.frame[i] = ctx->frame_buf(ctx->rbuf) + img * i;
   }
   // the shader samples the colour frames: RGB8, or -- a DXT upload nobody has asked the decoded frame of -- its blocks
-  p.color = ctx->d_color;
+  const int ch = ctx->color_of[ctx->rbuf];  // the colour half of the frame whose images the pass reads
+  p.color = ctx->color_half(ch);
   p.color_dxt = nullptr;
   p.color_layer_bytes = 0;
   p.color_mode = ctx->cfg.compress_rgb;
-  if (ctx->cfg.compress_rgb && !ctx->color_decoded && !std::getenv("RGBDR_DECODE_FOR_VIEW")) {
+  if (ctx->cfg.compress_rgb && !ctx->color_decoded[ch] && !std::getenv("RGBDR_DECODE_FOR_VIEW")) {
     const size_t blocks = (size_t)((ctx->cfg.color_w + 3) / 4) * ((ctx->cfg.color_h + 3) / 4);
-    p.color_dxt = ctx->d_color_dxt;
+    p.color_dxt = ctx->dxt_half(ch);
     p.color_layer_bytes = blocks * (ctx->cfg.compress_rgb == 1 ? 8 : 16);
   } else {
-    int rc_ = ensure_color_decoded(ctx);
+    int rc_ = ensure_color_decoded(ctx, ch);
     if (rc_ != RGBDR_OK) return rc_;
   }
   p.out_color = (float4*)ctx->d_view;
@@ -401,6 +402,7 @@ try {
     HIPCHK(hipEventRecord(ctx->ev_color_read, ctx->stream));
     ctx->ev_color_read_rec = true;
     ctx->view_read_buf = ctx->rbuf;  // (one record for both: process_textures waits for it too when it refills that half)
+    ctx->view_read_color = ctx->color_of[ctx->rbuf];
   }
   ctx->filled_w = ctx->filled_h = 0;
   if (fill_holes) {

@@ -58,7 +58,7 @@ struct rgbdr_ctx {
   // frame that is not double-buffered: the next upload, on the chain's stream, waits for it
   hipEvent_t ev_color_read = nullptr;
   bool ev_color_read_rec = false;
-  int view_read_buf = -1;            // the half of the double buffers that view pass read
+  int view_read_buf = -1, view_read_color = -1;  // the halves of the frame buffers / of the colour frame that view pass read
   unsigned pre_serial = 0, pre_joined = 0;  // records of ev_pre / the last one the sweep's stream has waited for
   bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
   bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
@@ -74,7 +74,16 @@ struct rgbdr_ctx {
   uint2* d_frame = nullptr;
   float2* d_cc_far = nullptr;            // per pixel: frame-independent lookups of pre_depth.fs (k_pre_cache, set_calibration)
   unsigned char* d_box_flags = nullptr;
+  // The colour frame has two halves (each of d_color / d_color_dxt holds both): a pipelined context uploads frame k + 1 into
+  // the half the view pass of frame k does not read (everything else of a frame that two streams touch is double-buffered
+  // by wbuf / rbuf / cbuf); a sequential context only ever uses half 0.
   uint8_t *d_color = nullptr, *d_color_dxt = nullptr;
+  size_t color_half_bytes = 0, dxt_half_bytes = 0;
+  int color_up = 0;             // the half the last upload wrote: what the next pre_* chain and the image getters read
+  int color_of[2] = {0, 0};     // the half that belongs to the frame in half b of the frame buffers (the view pass's)
+  bool color_consumed = false;  // a pre_* chain has read half color_up (the next upload of a pipelined context takes the other)
+  uint8_t* color_half(int h) const { return d_color + (size_t)h * color_half_bytes; }
+  uint8_t* dxt_half(int h) const { return d_color_dxt + (size_t)h * dxt_half_bytes; }
   bool frame_uploaded = false, textures_processed = false;
   // Sensor shard of the pre_* chain (rgbdr_set_sensor_shard): process_textures works on the layers
   // [shard_first, shard_first + shard_count) only; the packed frames of the other sensors and the other ranks' brick
@@ -203,7 +212,7 @@ struct rgbdr_ctx {
   uint32_t clear_epoch = 1;         // bumped whenever the volume may have been written by anything else
   uint8_t* d_mask = nullptr;
   bool morph_current = false;       // d_depth_morph was written with the upload (k_upload_morph): the chain skips k_morph
-  bool color_decoded = true;        // d_color holds the uploaded frame (false: only d_color_dxt does)
+  bool color_decoded[2] = {true, true};  // half h of d_color holds the frame uploaded into it (false: only d_color_dxt does)
   bool color_view_out = false;      // a device view of d_color was handed out: uploads keep it current
   bool mask_valid = false;
   // rgbdr_update_occupied_bricks only noted the threshold: mask_buf(rbuf) is to be rebuilt from the counters by
@@ -271,7 +280,7 @@ int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
 int materialise_mask(rgbdr_ctx* ctx);
-int ensure_color_decoded(rgbdr_ctx* ctx);  // RGB8 frame of a DXT upload, decoded on demand   // perform a pending (lazy) updateOccupiedBricks filter
+int ensure_color_decoded(rgbdr_ctx* ctx, int half = -1);  // RGB8 frame of a DXT upload, decoded on demand   // perform a pending (lazy) updateOccupiedBricks filter
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);
 void tend(rgbdr_ctx* c, const char* name, hipStream_t st);
