@@ -50,6 +50,7 @@ for key, g in (("DISPLAY_REF", "reference_box"), ("DISPLAY_512", "grid_512")):
     st = d["stages_ms"]
     sub[key] = "**%.3f** / %.3f | %.3f | %.3f | %.3f | %.3f | %.3f" % (d["ms_per_frame"], d["ms_per_frame_moving"], st["pre_chain"], st["integrate"],
                                                                         st["depth_peels"], st["raymarch"], st["holefill"])
+    sub[key + "_PIPE"] = "%.3f" % d["ms_per_frame_pipelined"] if "ms_per_frame_pipelined" in d else "n/a"
 text = open(os.path.join(root, "README.md.in")).read()
 for k, v in sub.items():
     text = text.replace("@%s@" % k, v)
