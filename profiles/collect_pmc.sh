@@ -23,6 +23,10 @@ rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- 
 rocprofv3 --pmc WRITE_SIZE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU --output-format csv -d $OUT/write -- $BENCH > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/tcc -- $BENCH > /dev/null 2>&1
 rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*/*_agent_info.csv   # (tens of MiB of per-dispatch rows nobody reads; gpurun_out is capped at 64 MiB)
+# ... and the counter rows of the displayed-frame leg's kernels (hundreds of frames x 16 launches; profiles/pmc_view_pass.sh is their pass)
+for f in $OUT/*/*/*counter_collection.csv; do
+  grep -v -e "k_fc_" -e "k_raymarch" -e "k_depth_peels" -e "k_peel_near" -e "k_empty_tiles" -e "k_upload_morph" "$f" > "$f.keep" && mv "$f.keep" "$f"
+done
 python3 - $OUT <<'PY'
 import csv, glob, sys, json, collections
 out = sys.argv[1]
