@@ -320,6 +320,52 @@ def test_fill_colors_of_random_frames(pkg, orc, wh, hole_share):
     ctx.close()
 
 
+def test_an_upload_ahead_of_the_draw_on_a_pipelined_context(pkg, orc):
+    """the next frame may be uploaded before the current one is drawn: a pipelined context keeps the colour frame in two halves, so
+    the view pass still shades with the colours of the frame it shows (a sequential context has one half: there the draw would
+    see the new colours, as before); with a zero-copy view of the colour image handed out the uploads stay in the half the
+    view points to and the pass waits for them instead"""
+    capi, synth = pkg.capi, pkg.synth
+    a = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), color_wh=(128, 106))
+    b = synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7, color_wh=(128, 106))
+    inv = a.inverse((64, 64, 64))
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 160, 90, BMIN, BMAX)
+
+    def context(pipelined):
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64), 0)
+        for i in range(2):
+            ctx.set_calibration(i, a.xyz[i], a.lut_res, a.uv[i], a.lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
+        ctx.set_pipelined(pipelined)
+        return ctx
+
+    def frame(ctx, sc, ahead=None):
+        ctx.update(sc.depth, sc.color)
+        ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+        if ahead is not None:
+            ctx.update(ahead.depth, ahead.color)
+        ctx.draw(view, False)
+        return ctx.readback_view_frame(False)
+
+    seq, pipe = context(False), context(True)
+    want_a = frame(seq, a)
+    for k in range(3):                                       # (both halves take their turn)
+        got = frame(pipe, a, ahead=b)
+        assert same_bits(got[0], want_a[0]) and same_bits(got[1], want_a[1]), k
+    want_b = frame(seq, b)
+    got = frame(pipe, b)
+    assert same_bits(got[0], want_b[0]) and same_bits(got[1], want_b[1])
+    assert not same_bits(want_a[0], want_b[0])
+    v0 = pipe.device_image(capi.IMG_COLOR, 0)                # from here on the colour frame stays where this view points
+    for k in range(3):
+        sc, want = ((a, want_a), (b, want_b))[k % 2]
+        got = frame(pipe, sc)
+        assert same_bits(got[0], want[0]) and same_bits(got[1], want[1]), k
+        assert pipe.device_image(capi.IMG_COLOR, 0).ptr == v0.ptr
+    seq.close()
+    pipe.close()
+
+
 @pytest.mark.parametrize("skip", [False, True])
 def test_draw_is_drawF_without_a_host_round_trip(pkg, orc, skip):
     """rgbdr_draw = ReconIntegration::drawF (recon_integration.cpp:151-178): depth limits when skipping, the ray-march, fillColors
