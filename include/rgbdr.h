@@ -594,7 +594,12 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * (contexts with a halo or gather transfer on a side stream are drained first); the frame stays on the device like the
  * window's framebuffer does.  With RGBDR_FLAG_PIPELINE the pass is ordered against the chain's stream by events: the
  * pre_* chain of the NEXT frame, its upload included, runs under it (the pass reads the halves of the double buffers --
- * images, brick counters and masks, colour frame -- that chain does not write).  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
+ * images, brick counters and masks, colour frame -- that chain does not write), and the hole filling runs on a stream of
+ * its own, the next frame's sweep, peels and march under it (the view buffers have two halves as well).  The filled frame
+ * is then ordered on that stream: rgbdr_device_view_frame, rgbdr_readback_view_frame and rgbdr_fill_colors make the
+ * context's stream wait for it, so what they return is ordered on rgbdr_set_stream's stream as ever -- a host that asks
+ * for every frame this way gets the frames one after the other; one that lets frames go by (or presents from its own
+ * queue behind an event it records after the call) gets the overlap.  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
  * depth [height][width] f32 of the ray-marched frame (filled = 0) or of the hole-filled one (filled = 1; RGBDR_ERR_STATE
  * when the current frame has not been filled), valid until the next call that draws, fills or uploads a frame and ordered
  * on rgbdr_set_stream's stream.  rgbdr_readback_view_frame copies it to the host (waits). */

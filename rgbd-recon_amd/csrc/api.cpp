@@ -47,7 +47,12 @@ static void free_volume(rgbdr_ctx* c)
 {
   (void)hipFree(c->d_tsdf_base);
   (void)hipFree(c->d_linear);
-  (void)hipFree(c->d_view);
+  if (c->fill_stream) (void)hipStreamSynchronize(c->fill_stream);
+  c->fill_side = false;
+  c->ev_fill_rec[0] = c->ev_fill_rec[1] = false;
+  (void)hipFree(c->d_view_base);
+  c->d_view_base = nullptr;
+  c->vbuf = 0;
   (void)hipFree(c->d_peels);
   (void)hipFree(c->d_peel_near);
   c->d_peels = nullptr;
@@ -186,6 +191,8 @@ int sync_all(rgbdr_ctx* ctx)
   if (ctx->copy_stream) HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   if (ctx->pre_stream) HIPCHK(hipStreamSynchronize(ctx->pre_stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->fill_stream) HIPCHK(hipStreamSynchronize(ctx->fill_stream));
+  ctx->fill_side = false;
   if (ctx->halo_stream) HIPCHK(hipStreamSynchronize(ctx->halo_stream));
   return RGBDR_OK;
 }
@@ -459,6 +466,9 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     if (ctx->ev_int[b]) (void)hipEventDestroy(ctx->ev_int[b]);
   }
   if (ctx->ev_color_read) (void)hipEventDestroy(ctx->ev_color_read);
+  for (hipEvent_t e : ctx->ev_fill)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->gather_stream) {

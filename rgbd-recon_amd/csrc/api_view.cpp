@@ -32,13 +32,27 @@ extern "C" {
 static int ensure_view_buffers(rgbdr_ctx* ctx, size_t npix)
 {
   if (ctx->view_pixels >= npix) return RGBDR_OK;
-  (void)hipFree(ctx->d_view);
-  ctx->d_view = nullptr;
+  if (ctx->fill_stream) HIPCHK(hipStreamSynchronize(ctx->fill_stream));  // (a side-stream fill reads the old buffers)
+  ctx->fill_side = false;
+  ctx->ev_fill_rec[0] = ctx->ev_fill_rec[1] = false;
+  (void)hipFree(ctx->d_view_base);
+  ctx->d_view_base = ctx->d_view = nullptr;
   ctx->view_pixels = 0;
+  ctx->vbuf = 0;
   ctx->view_w = ctx->view_h = 0;   // (the callers set the new frame's size once it is written)
   ctx->filled_w = ctx->filled_h = 0;
-  HIPCHK(hipMalloc((void**)&ctx->d_view, npix * 7 * sizeof(float)));
+  HIPCHK(hipMalloc((void**)&ctx->d_view_base, npix * 7 * 2 * sizeof(float)));  // two halves (context.hpp)
+  ctx->d_view = ctx->d_view_base;
   ctx->view_pixels = npix;
+  return RGBDR_OK;
+}
+// a hole filling on the side stream (rgbdr_draw of a pipelined context) is in flight: what follows on the context's stream and
+// touches the frame, the atlas or the filled image comes after it
+static int join_side_fill(rgbdr_ctx* ctx)
+{
+  if (!ctx->fill_side) return RGBDR_OK;
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_fill[ctx->vbuf], 0));
+  ctx->fill_side = false;
   return RGBDR_OK;
 }
 // the depth peels of a viewport: RGBA32F per pixel, their own allocation (context.hpp)
@@ -321,8 +335,13 @@ try {
 RGBDR_CONTAIN(ctx)
 
 // fillColors of the frame in the view buffers, enqueued on the context's stream; *ocol / *odep: the filled frame
-static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out)
+static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out, hipStream_t s = nullptr)
 {
+  if (!s) {
+    s = ctx->stream;
+    int rc_ = join_side_fill(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   FillLayout L;
   make_fill_layout(ctx->view_w, ctx->view_h, &L);
   const size_t nb = fill_band_texels(L), npix = (size_t)L.W * L.H;
@@ -343,6 +362,7 @@ static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out)
     FillTabs T;
     make_fill_tables(L, &xt, &yt, &T);
     HIPCHK(hipStreamSynchronize(ctx->stream));  // a fill in flight reads the old ones
+    if (ctx->fill_stream) HIPCHK(hipStreamSynchronize(ctx->fill_stream));
     (void)hipFree(ctx->d_fill_tabs);
     ctx->d_fill_tabs = nullptr;
     ctx->fill_tab_w = ctx->fill_tab_h = 0;
@@ -355,9 +375,9 @@ static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out)
     ctx->fill_tab_w = L.W;
     ctx->fill_tab_h = L.H;
   }
-  tbegin(ctx, "holefill", ctx->stream);
-  launch_fill_colors(L, ctx->fill_tabs, (const float4*)ctx->d_view, ctx->d_view + npix * 4, acol, adep, ocol, odep, ctx->stream);
-  tend(ctx, "holefill", ctx->stream);
+  tbegin(ctx, "holefill", s);
+  launch_fill_colors(L, ctx->fill_tabs, (const float4*)ctx->d_view, ctx->d_view + npix * 4, acol, adep, ocol, odep, s);
+  tend(ctx, "holefill", s);
   LAUNCHCHK("fill_colors");
   ctx->filled_w = L.W;
   ctx->filled_h = L.H;
@@ -389,6 +409,27 @@ try {
   if (ctx->cfg.slab_count > 1)
     return ctx->fail(RGBDR_ERR_STATE, "a Z slab cannot ray-march alone: use rgbdr_raymarch_find / _shade across the slabs");
   RaymarchParams p;
+  // A pipelined context marches this frame into the other half of the view buffers and fills its holes on a stream of its
+  // own: the sweep, the peels and the march of the NEXT frame run under that filling (seven small launches that wait on
+  // each other).  The filled frame is then ordered on that stream: rgbdr_device_view_frame / rgbdr_readback_view_frame /
+  // rgbdr_fill_colors make the context's stream wait for it.  (Not with the timers on: "3recon" brackets one stream.)
+  const bool side_fill = ctx->pipelined() && fill_holes && !ctx->timers && ctx->d_view_base && v &&
+                         (size_t)v->width * v->height <= ctx->view_pixels;
+  if (side_fill) {
+    if (!ctx->fill_stream) {
+      HIPCHK(hipSetDevice(ctx->device));
+      HIPCHK(hipStreamCreateWithFlags(&ctx->fill_stream, hipStreamNonBlocking));
+      for (hipEvent_t& e : ctx->ev_fill) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const int nb = ctx->vbuf ^ 1;
+    if (ctx->ev_fill_rec[nb]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_fill[nb], 0));  // the fill that read that half: two frames ago
+    ctx->vbuf = nb;
+    ctx->d_view = ctx->d_view_base + (size_t)nb * ctx->view_pixels * 7;
+    ctx->fill_side = false;  // (fills are in order on their stream: the one of the frame before needs no join)
+  } else {
+    int rc_ = join_side_fill(ctx);
+    if (rc_ != RGBDR_OK) return rc_;
+  }
   tbegin(ctx, "3recon", ctx->stream);
   int rc = prepare_raymarch(ctx, v, &p, true);  // (drawDepthLimits inside, when the view asks for space skipping)
   if (rc != RGBDR_OK) return rc;
@@ -408,8 +449,17 @@ try {
   if (fill_holes) {
     float4* ocol;
     float* odep;
-    rc = fill_view_frame(ctx, &ocol, &odep);
-    if (rc != RGBDR_OK) return rc;
+    if (side_fill) {
+      HIPCHK(hipStreamWaitEvent(ctx->fill_stream, ctx->ev_color_read, 0));  // (recorded behind the march just above)
+      rc = fill_view_frame(ctx, &ocol, &odep, ctx->fill_stream);
+      if (rc != RGBDR_OK) return rc;
+      HIPCHK(hipEventRecord(ctx->ev_fill[ctx->vbuf], ctx->fill_stream));
+      ctx->ev_fill_rec[ctx->vbuf] = true;
+      ctx->fill_side = true;
+    } else {
+      rc = fill_view_frame(ctx, &ocol, &odep);
+      if (rc != RGBDR_OK) return rc;
+    }
   }
   tend(ctx, "3recon", ctx->stream);
   return RGBDR_OK;
@@ -420,6 +470,7 @@ RGBDR_CONTAIN(ctx)
 static int view_frame_pointers(rgbdr_ctx* ctx, int filled, float** color, float** depth)
 {
   if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "no frame: nothing was ray-marched or uploaded");
+  { int rc_ = join_side_fill(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)ctx->view_w * ctx->view_h;
   if (!filled) {
     *color = ctx->d_view;

@@ -157,6 +157,16 @@ struct rgbdr_ctx {
   int halo = 0;
   float* d_linear = nullptr;  // readback scratch
   size_t linear_floats = 0;
+  // The view buffers have two halves (d_view_base): d_view points at the one that holds the last ray-marched frame.  A
+  // pipelined context marches frame k + 1 into the other half while the hole filling of frame k, on fill_stream, still
+  // reads its own (rgbdr_draw); ev_fill[b]: behind the last side-stream fill that read half b; fill_side: such a fill is in
+  // flight and whoever touches the frame or the filled image on the context's stream joins it first (join_side_fill).
+  float* d_view_base = nullptr;
+  int vbuf = 0;
+  hipStream_t fill_stream = nullptr;
+  hipEvent_t ev_fill[2] = {nullptr, nullptr};
+  bool ev_fill_rec[2] = {false, false};
+  bool fill_side = false;
   float* d_view = nullptr;    // the last ray-marched frame: rgba, depth, samples (+ the first-hit indices of the slab protocol)
   size_t view_pixels = 0;
   // the depth peels have a buffer of their own (the reference draws them into m_view_depth, not into the window): a

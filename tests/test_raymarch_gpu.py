@@ -456,6 +456,32 @@ def test_draw_on_a_pipelined_context(pkg, orc, compress_rgb):
         for a, b in zip(*shown):
             assert same_bits(a, b), (burst, count_diff(a, b))
         assert (shown[0][3] < 1).mean() > 0.05
+    # the hole filling of a pipelined context runs on a stream of its own (the next frame's sweep and march under it): a
+    # fill asked for on the context's stream (rgbdr_fill_colors) comes after it, viewports of another size re-make the buffers
+    # under it, and switching the pipeline off drains it
+    for wh in ((320, 180), (96, 54), (640, 360), (320, 180)):
+        v2 = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, wh[0], wh[1], BMIN, BMAX)
+        v2.skip_space = 1
+        shown = []
+        for ctx in ctxs:
+            for kk in (k, k + 1, k + 2):
+                depth, color = frames[kk % 2]
+                ctx.update(depth, color)
+                ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+                ctx.draw(v2, True)
+            shown.append(ctx.fill_colors(wh[0], wh[1]) + ctx.readback_view_frame(True))
+        k += 3
+        for a, b in zip(*shown):
+            assert same_bits(a, b), (wh, count_diff(a, b))
+        assert same_bits(shown[1][0], shown[1][2]) and same_bits(shown[1][1], shown[1][3])      # the two fills agree
+    ctxs[1].set_pipelined(False)
+    for ctx in ctxs:
+        depth, color = frames[k % 2]
+        ctx.update(depth, color)
+        ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+        ctx.draw(view, True)
+    a, b = ctxs[0].readback_view_frame(True), ctxs[1].readback_view_frame(True)
+    assert same_bits(a[0], b[0]) and same_bits(a[1], b[1])
     for ctx in ctxs:
         ctx.close()
 
