@@ -598,8 +598,8 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * its own, the next frame's sweep, peels and march under it (the view buffers have two halves as well).  The filled frame
  * is then ordered on that stream: rgbdr_device_view_frame, rgbdr_readback_view_frame and rgbdr_fill_colors make the
  * context's stream wait for it, so what they return is ordered on rgbdr_set_stream's stream as ever -- a host that asks
- * for every frame this way gets the frames one after the other; one that lets frames go by (or presents from its own
- * queue behind an event it records after the call) gets the overlap.  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
+ * for every frame this way gets the frames one after the other (that wait sits in front of the next frame's sweep); the
+ * overlap is for a host that lets frames go by -- a throughput run, a recorder that keeps every n-th frame.  rgbdr_device_view_frame returns where: colour [height][width][4] f32 and
  * depth [height][width] f32 of the ray-marched frame (filled = 0) or of the hole-filled one (filled = 1; RGBDR_ERR_STATE
  * when the current frame has not been filled), valid until the next call that draws, fills or uploads a frame and ordered
  * on rgbdr_set_stream's stream.  rgbdr_readback_view_frame copies it to the host (waits). */
