@@ -605,6 +605,12 @@ int rgbdr_fill_colors(rgbdr_ctx* ctx, float* color, float* depth);
  * on rgbdr_set_stream's stream.  rgbdr_readback_view_frame copies it to the host (waits). */
 int rgbdr_draw(rgbdr_ctx* ctx, const rgbdr_view* view, int fill_holes);
 int rgbdr_device_view_frame(rgbdr_ctx* ctx, int filled, void** color, void** depth, int* width, int* height);
+/* The same for a host that presents from a queue of its own: nothing is made to wait; *ready_event (a hipEvent_t owned by
+ * the context) completes when the frame is written -- behind the hole filling on its stream, or behind what the
+ * context's stream holds -- and the host's queue waits for it (hipStreamWaitEvent) before it reads.  The filled image
+ * and the view buffers have two halves: the pointers of frame k stay untouched until the rgbdr_draw of frame k + 2 is
+ * called, so a presenter that is done with frame k by then overlaps with the library frame after frame. */
+int rgbdr_device_view_frame_async(rgbdr_ctx* ctx, int filled, void** color, void** depth, int* width, int* height, void** ready_event);
 int rgbdr_readback_view_frame(rgbdr_ctx* ctx, int filled, float* color, float* depth);
 
 /* Placement of the inverse-LUT arena.  The integrate sweep time depends on where the

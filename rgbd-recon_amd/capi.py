@@ -211,6 +211,7 @@ SYMBOLS = {
     "rgbdr_fill_colors": (C.c_int, [_P, _F, _F]),
     "rgbdr_draw": (C.c_int, [_P, _P, C.c_int]),
     "rgbdr_device_view_frame": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rgbdr_device_view_frame_async": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_P)]),
     "rgbdr_readback_view_frame": (C.c_int, [_P, C.c_int, _F, _F]),
     "rgbdr_map_frame_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "rgbdr_upload_mapped_frame": (C.c_int, [_P]),
@@ -620,6 +621,13 @@ class Context:
         c, d, w, h = _P(), _P(), C.c_int(), C.c_int()
         self._chk(lib().rgbdr_device_view_frame(self._h, 1 if filled else 0, C.byref(c), C.byref(d), C.byref(w), C.byref(h)))
         return c.value, d.value, w.value, h.value
+
+    def device_view_frame_async(self, filled):
+        """the same without making the context's stream wait: (colour pointer, depth pointer, width, height, hipEvent_t) -- the
+        caller's own queue waits for the event before it reads"""
+        c, d, w, h, e = _P(), _P(), C.c_int(), C.c_int(), _P()
+        self._chk(lib().rgbdr_device_view_frame_async(self._h, 1 if filled else 0, C.byref(c), C.byref(d), C.byref(w), C.byref(h), C.byref(e)))
+        return c.value, d.value, w.value, h.value, e.value
 
     def readback_view_frame(self, filled):
         _, _, w, h = self.device_view_frame(filled)

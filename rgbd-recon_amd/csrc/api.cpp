@@ -468,6 +468,7 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
   if (ctx->ev_color_read) (void)hipEventDestroy(ctx->ev_color_read);
   for (hipEvent_t e : ctx->ev_fill)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_view_ready) (void)hipEventDestroy(ctx->ev_view_ready);
   if (ctx->fill_stream) (void)hipStreamDestroy(ctx->fill_stream);
   if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

@@ -350,12 +350,13 @@ static int fill_view_frame(rgbdr_ctx* ctx, float4** ocol_out, float** odep_out, 
     (void)hipFree(ctx->d_fill);
     ctx->d_fill = nullptr;
     ctx->fill_floats = 0;
-    HIPCHK(hipMalloc((void**)&ctx->d_fill, need * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&ctx->d_fill, need * 2 * sizeof(float)));  // two halves, like the view buffers (half vbuf: this frame's)
     ctx->fill_floats = need;
   }
-  float4* acol = (float4*)ctx->d_fill;
-  float4* ocol = (float4*)(ctx->d_fill + nb * 4);
-  float* adep = ctx->d_fill + (nb + npix) * 4;
+  float* const fill = ctx->d_fill + (size_t)ctx->vbuf * ctx->fill_floats;
+  float4* acol = (float4*)fill;
+  float4* ocol = (float4*)(fill + nb * 4);
+  float* adep = fill + (nb + npix) * 4;
   float* odep = adep + nb;
   if (ctx->fill_tab_w != L.W || ctx->fill_tab_h != L.H) {  // a new viewport size: its tap tables
     std::vector<int> xt, yt;
@@ -467,10 +468,11 @@ try {
 RGBDR_CONTAIN(ctx)
 
 // where the displayed frame lives: the ray-marched one in the view buffers, the filled one behind the atlas band
-static int view_frame_pointers(rgbdr_ctx* ctx, int filled, float** color, float** depth)
+// (`join`: what follows on the context's stream comes after a hole filling still in flight on its own stream)
+static int view_frame_pointers(rgbdr_ctx* ctx, int filled, float** color, float** depth, bool join = true)
 {
   if (ctx->view_w < 1 || !ctx->d_view) return ctx->fail(RGBDR_ERR_STATE, "no frame: nothing was ray-marched or uploaded");
-  { int rc_ = join_side_fill(ctx); if (rc_ != RGBDR_OK) return rc_; }
+  if (join) { int rc_ = join_side_fill(ctx); if (rc_ != RGBDR_OK) return rc_; }
   const size_t npix = (size_t)ctx->view_w * ctx->view_h;
   if (!filled) {
     *color = ctx->d_view;
@@ -482,8 +484,9 @@ static int view_frame_pointers(rgbdr_ctx* ctx, int filled, float** color, float*
   FillLayout L;
   make_fill_layout(ctx->view_w, ctx->view_h, &L);
   const size_t nb = fill_band_texels(L);
-  *color = ctx->d_fill + nb * 4;
-  *depth = ctx->d_fill + (nb + npix) * 4 + nb;
+  float* const fill = ctx->d_fill + (size_t)ctx->vbuf * ctx->fill_floats;
+  *color = fill + nb * 4;
+  *depth = fill + (nb + npix) * 4 + nb;
   return RGBDR_OK;
 }
 
@@ -493,6 +496,28 @@ try {
   float *c, *d;
   int rc = view_frame_pointers(ctx, filled, &c, &d);
   if (rc != RGBDR_OK) return rc;
+  if (color) *color = c;
+  if (depth) *depth = d;
+  if (width) *width = ctx->view_w;
+  if (height) *height = ctx->view_h;
+  return RGBDR_OK;
+}
+RGBDR_CONTAIN(ctx)
+
+int rgbdr_device_view_frame_async(rgbdr_ctx* ctx, int filled, void** color, void** depth, int* width, int* height, void** ready_event)
+try {
+  if (!ctx) return RGBDR_ERR_INVALID_ARGUMENT;
+  if (!ready_event) return ctx->fail(RGBDR_ERR_INVALID_ARGUMENT, "null event pointer");
+  float *c, *d;
+  int rc = view_frame_pointers(ctx, filled, &c, &d, false);
+  if (rc != RGBDR_OK) return rc;
+  if (filled && ctx->fill_side) {
+    *ready_event = (void*)ctx->ev_fill[ctx->vbuf];  // behind the filling on its own stream
+  } else {  // the frame is ordered on the context's stream: an event behind what is enqueued there
+    if (!ctx->ev_view_ready) HIPCHK(hipEventCreateWithFlags(&ctx->ev_view_ready, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->ev_view_ready, ctx->stream));
+    *ready_event = (void*)ctx->ev_view_ready;
+  }
   if (color) *color = c;
   if (depth) *depth = d;
   if (width) *width = ctx->view_w;

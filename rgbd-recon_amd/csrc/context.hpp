@@ -167,6 +167,7 @@ struct rgbdr_ctx {
   hipEvent_t ev_fill[2] = {nullptr, nullptr};
   bool ev_fill_rec[2] = {false, false};
   bool fill_side = false;
+  hipEvent_t ev_view_ready = nullptr;  // rgbdr_device_view_frame_async of a frame that is ordered on the context's stream
   float* d_view = nullptr;    // the last ray-marched frame: rgba, depth, samples (+ the first-hit indices of the slab protocol)
   size_t view_pixels = 0;
   // the depth peels have a buffer of their own (the reference draws them into m_view_depth, not into the window): a

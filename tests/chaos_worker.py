@@ -71,6 +71,8 @@ def run(pkg, orc, seed, slab, trace):
         lambda: L.rgbdr_draw(h, C.byref(view()), flag()), lambda: L.rgbdr_draw(h, None, 1),
         lambda: L.rgbdr_device_view_frame(h, flag(), C.byref(vp), C.byref(vp), C.byref(i1), C.byref(i2)),
         lambda: L.rgbdr_device_view_frame(h, 0, None, None, None, None),
+        lambda: L.rgbdr_device_view_frame_async(h, flag(), C.byref(vp), C.byref(vp), C.byref(i1), C.byref(i2), C.byref(vp)),
+        lambda: L.rgbdr_device_view_frame_async(h, flag(), None, None, None, None, None),
         lambda: L.rgbdr_readback_view_frame(h, flag(), F(big), F(big[1 << 20:])), lambda: L.rgbdr_readback_view_frame(h, 1, None, None),
         peers_to_self, lambda: L.rgbdr_halo_export(h, None),
         lambda: L.rgbdr_halo_set_peer(h, int(rng.integers(-1, 3)), garbage), no_peers,

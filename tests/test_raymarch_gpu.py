@@ -366,6 +366,68 @@ def test_an_upload_ahead_of_the_draw_on_a_pipelined_context(pkg, orc):
     pipe.close()
 
 
+def test_a_presenter_on_its_own_queue(pkg, orc):
+    """rgbdr_device_view_frame_async: a host that presents from its own queue takes the pointers of frame k and an event, enqueues
+    frame k + 1 at once, and lets its queue wait for the event before it copies the frame out -- nothing on the context's
+    streams waits for it.  Ten frames of two alternating scenes on a pipelined context (hole filling on its own stream, filled
+    image and view buffers in two halves): every frame the presenter copied equals the one a sequential context shows."""
+    import ctypes as C
+    import torch
+    capi, synth = pkg.capi, pkg.synth
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), color_wh=(128, 106)),
+              synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7, color_wh=(128, 106))]
+    inv = scenes[0].inverse((64, 64, 64))
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 320, 180, BMIN, BMAX)
+    view.skip_space = 1
+    ctxs = []
+    for pipelined in (False, True):
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64), 0)
+        for i in range(2):
+            ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
+        ctx.set_use_bricks(True)
+        ctx.set_pipelined(pipelined)
+        ctxs.append(ctx)
+
+    def enqueue(ctx, k):
+        sc = scenes[k % 2]
+        ctx.update(sc.depth, sc.color)
+        ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+        ctx.draw(view, True)
+
+    K, npix = 10, 320 * 180
+    want = []
+    for k in range(K):
+        enqueue(ctxs[0], k)
+        want.append(ctxs[0].readback_view_frame(True))
+    present = torch.cuda.Stream()
+    got = [(torch.empty(npix * 4, dtype=torch.float32, device="cuda"), torch.empty(npix, dtype=torch.float32, device="cuda")) for _ in range(K)]
+    copied = [None] * K
+    for k in range(K):
+        if k >= 2:
+            copied[k - 2].synchronize()                      # the presenter is done with frame k - 2: its half is free again
+        enqueue(ctxs[1], k)
+        c, d, w, h, ev = ctxs[1].device_view_frame_async(True)
+        assert (w, h) == (320, 180) and ev
+        assert hip.hipStreamWaitEvent(C.c_void_p(present.cuda_stream), C.c_void_p(ev), 0) == 0
+        assert hip.hipMemcpyAsync(C.c_void_p(got[k][0].data_ptr()), C.c_void_p(c), npix * 16, 3, C.c_void_p(present.cuda_stream)) == 0
+        assert hip.hipMemcpyAsync(C.c_void_p(got[k][1].data_ptr()), C.c_void_p(d), npix * 4, 3, C.c_void_p(present.cuda_stream)) == 0
+        copied[k] = torch.cuda.Event()
+        copied[k].record(present)
+    present.synchronize()
+    for k in range(K):
+        assert same_bits(got[k][0].cpu().numpy().reshape(180, 320, 4), want[k][0]), k
+        assert same_bits(got[k][1].cpu().numpy().reshape(180, 320), want[k][1]), k
+    # ... and on the sequential context the event is behind what its stream holds
+    c, d, w, h, ev = ctxs[0].device_view_frame_async(True)
+    assert ev and c == ctxs[0].device_view_frame(True)[0]
+    for ctx in ctxs:
+        ctx.close()
+
+
 @pytest.mark.parametrize("skip", [False, True])
 def test_draw_is_drawF_without_a_host_round_trip(pkg, orc, skip):
     """rgbdr_draw = ReconIntegration::drawF (recon_integration.cpp:151-178): depth limits when skipping, the ray-march, fillColors
