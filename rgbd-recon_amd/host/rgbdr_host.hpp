@@ -736,11 +736,19 @@ class ReconIntegration : public Reconstruction {
     void* color = nullptr;  // [height][width][4] f32
     void* depth = nullptr;  // [height][width] f32
     int width = 0, height = 0;
+    void* ready = nullptr;  // deviceFrameAsync: the hipEvent_t the presenter's queue waits for before it reads
   };
   DeviceFrame deviceFrame() const
   {
     DeviceFrame f;
     check(m_be.ctx(), rgbdr_device_view_frame(m_be.ctx(), m_fill_holes ? 1 : 0, &f.color, &f.depth, &f.width, &f.height));
+    return f;
+  }
+  // for a presenter with a queue of its own (a pipelined context's hole filling runs beside the next frame): nothing waits
+  DeviceFrame deviceFrameAsync() const
+  {
+    DeviceFrame f;
+    check(m_be.ctx(), rgbdr_device_view_frame_async(m_be.ctx(), m_fill_holes ? 1 : 0, &f.color, &f.depth, &f.width, &f.height, &f.ready));
     return f;
   }
   void setClearColor(float r, float g, float b, float a)
