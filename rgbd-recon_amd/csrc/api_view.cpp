@@ -424,16 +424,27 @@ try {
     }
     const int nb = ctx->vbuf ^ 1;
     if (ctx->ev_fill_rec[nb]) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_fill[nb], 0));  // the fill that read that half: two frames ago
-    ctx->vbuf = nb;
-    ctx->d_view = ctx->d_view_base + (size_t)nb * ctx->view_pixels * 7;
-    ctx->fill_side = false;  // (fills are in order on their stream: the one of the frame before needs no join)
   } else {
     int rc_ = join_side_fill(ctx);
     if (rc_ != RGBDR_OK) return rc_;
   }
+  const int vbuf_before = ctx->vbuf;
+  const bool side_before = ctx->fill_side;
+  if (side_fill) {
+    ctx->vbuf ^= 1;
+    ctx->d_view = ctx->d_view_base + (size_t)ctx->vbuf * ctx->view_pixels * 7;
+    ctx->fill_side = false;  // (fills are in order on their stream: the one of the frame before needs no join)
+  }
   tbegin(ctx, "3recon", ctx->stream);
   int rc = prepare_raymarch(ctx, v, &p, true);  // (drawDepthLimits inside, when the view asks for space skipping)
-  if (rc != RGBDR_OK) return rc;
+  if (rc != RGBDR_OK) {
+    if (side_fill && ctx->d_view_base) {  // a view the library refuses leaves the last frame where it was
+      ctx->vbuf = vbuf_before;
+      ctx->d_view = ctx->d_view_base + (size_t)ctx->vbuf * ctx->view_pixels * 7;
+      ctx->fill_side = side_before;
+    }
+    return rc;
+  }
   tbegin(ctx, "draw", ctx->stream);
   launch_raymarch(p, 0, ctx->stream);
   tend(ctx, "draw", ctx->stream);

@@ -518,6 +518,14 @@ def test_draw_on_a_pipelined_context(pkg, orc, compress_rgb):
         for a, b in zip(*shown):
             assert same_bits(a, b), (burst, count_diff(a, b))
         assert (shown[0][3] < 1).mean() > 0.05
+    bad = capi.View.from_buffer_copy(bytes(view))          # a view the library refuses leaves the last frame where it was
+    bad.shade_mode = 7
+    for ctx in ctxs:
+        with pytest.raises(capi.RgbdrError):
+            ctx.draw(bad, True)
+    again = [ctx.readback_view_frame(True) + ctx.readback_view_frame(False) for ctx in ctxs]
+    for a, b, c in zip(again[0], again[1], shown[0]):
+        assert same_bits(a, b) and same_bits(a, c)
     # the hole filling of a pipelined context runs on a stream of its own (the next frame's sweep and march under it): a
     # fill asked for on the context's stream (rgbdr_fill_colors) comes after it, viewports of another size re-make the buffers
     # under it, and switching the pipeline off drains it
