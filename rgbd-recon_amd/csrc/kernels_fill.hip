@@ -18,7 +18,8 @@
 //     tap columns per texel column and the N row of the 4 tap rows per texel row are tables
 //     (make_fill_tables, the shader's float expressions evaluated once per viewport size).
 // A texel is computed by a QUAD of lanes (fc_inpaint_quad): a pass of a few hundred texels lasts as long as one lane's
-// instruction stream, and a dependent launch costs 3.3 us before it does anything (profiles/probes_src/launch_floor_probe.hip).
+// instruction stream, and a dependent launch costs 1.7 us (queue filled ahead) to 3.3 us (host-bound) before it does anything
+// (profiles/probes_src/launch_floor_probe.hip).
 // Launches per frame: LOD 1 (+ clear of the band below it), one per LOD with more texels than the tail's first, ONE
 // workgroup for the tail (its LODs live in LDS between __syncthreads(), no global-memory phase), colorfill.
 // 1280 x 720: 21 -> 7 launches, 0.122 -> 0.062 ms.
