@@ -60,8 +60,10 @@ enum {
   RGBDR_FLAG_USE_BRICKS = 8u,
   RGBDR_FLAGS_DEFAULT = 15u,
   /* not a reference setting: overlap the upload + pre_* chain of frame k+1 (second
-   * HIP stream, double-buffered packed frame / occupied mask) with integrate of
-   * frame k.  Results are identical; only the schedule changes. */
+   * HIP stream, double-buffered packed frame / occupied mask / colour frame) with integrate
+   * and rgbdr_draw of frame k, and the hole filling of frame k (third stream, double-buffered
+   * view buffers / filled image) with integrate and the march of frame k+1.  Results are
+   * identical; only the schedule changes. */
   RGBDR_FLAG_PIPELINE = 16u,
   /* An inverse LUT whose resolution differs from the TSDF grid is normally
    * resampled once, at upload, at the voxel centres (the LINEAR lookup of
