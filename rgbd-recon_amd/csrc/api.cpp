@@ -391,10 +391,11 @@ try {
       ctx->err = "hipEventCreate failed";
       return cleanup(RGBDR_ERR_HIP);
     }
-  if (hipEventCreateWithFlags(&ctx->ev_color_read, hipEventDisableTiming) != hipSuccess) {
-    ctx->err = "hipEventCreate failed";
-    return cleanup(RGBDR_ERR_HIP);
-  }
+  for (int b = 0; b < 2; ++b)
+    if (hipEventCreateWithFlags(&ctx->ev_view_read[b], hipEventDisableTiming) != hipSuccess) {
+      ctx->err = "hipEventCreate failed";
+      return cleanup(RGBDR_ERR_HIP);
+    }
   const size_t n = npx(ctx);
   const size_t ncol = (size_t)cfg->num_sensors * cfg->color_w * cfg->color_h * 3;
   struct {
@@ -465,7 +466,8 @@ void rgbdr_destroy(rgbdr_ctx* ctx)
     if (ctx->ev_pre[b]) (void)hipEventDestroy(ctx->ev_pre[b]);
     if (ctx->ev_int[b]) (void)hipEventDestroy(ctx->ev_int[b]);
   }
-  if (ctx->ev_color_read) (void)hipEventDestroy(ctx->ev_color_read);
+  for (hipEvent_t e : ctx->ev_view_read)
+    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_fill)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_view_ready) (void)hipEventDestroy(ctx->ev_view_ready);
@@ -516,7 +518,8 @@ static int upload_device(rgbdr_ctx* ctx, const void* depth, const void* color)
   // for); a frame no pre_* chain has looked at is simply replaced.  Whoever read the target last has to be done with it.
   int ch = ctx->color_up;
   if (ctx->pipelined() && !ctx->color_view_out && ctx->color_consumed) ch ^= 1;
-  if (ctx->pipelined() && ctx->ev_color_read_rec && ctx->view_read_color == ch) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));
+  for (int b = 0; b < 2; ++b)
+    if (ctx->pipelined() && ctx->ev_view_rec[b] && ctx->view_color[b] == ch) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_view_read[b], 0));
   ctx->color_up = ch;
   ctx->color_consumed = false;
   uint8_t *const d_color = ctx->color_half(ch), *const d_color_dxt = ctx->dxt_half(ch);
@@ -673,6 +676,21 @@ RGBDR_CONTAIN(ctx)
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
 // the RGB8 colour frame for consumers other than pre_depth (which reads DXT blocks directly)
+// the sweep and the view pass of the frame that lives in half w of the frame buffers (images, mask, counts) read it on the
+// first stream: the chain's stream waits for them before it writes there
+int rgbdr::wait_last_readers(rgbdr_ctx* ctx, int w, hipStream_t ps)
+{
+  if (!ctx->pipelined()) return RGBDR_OK;
+  if (ctx->int_unrecorded[w]) {  // its sweep left the record to a draw that did not come: behind what the first stream holds now
+    HIPCHK(hipEventRecord(ctx->ev_int[w], ctx->stream));
+    ctx->ev_int_rec[w] = true;
+    ctx->int_unrecorded[w] = false;
+    ctx->draw_expected = false;
+  }
+  if (ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));
+  if (ctx->ev_view_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_view_read[w], 0));
+  return RGBDR_OK;
+}
 int rgbdr::ensure_color_decoded(rgbdr_ctx* ctx, int half)
 {
   const int h = half < 0 ? ctx->color_up : half;  // (the image getters: the last uploaded frame)
@@ -771,8 +789,7 @@ try {
   hipStream_t ps = ctx->pstream();
   const int w = ctx->wbuf;
   p.frame = ctx->frame_buf(w);
-  if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
-  if (ctx->pipelined() && ctx->ev_color_read_rec && ctx->view_read_buf == w) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_color_read, 0));  // ... a view pass
+  { int rc_ = wait_last_readers(ctx, w, ps); if (rc_ != RGBDR_OK) return rc_; }
   { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }  // (an asynchronous gather still writes the frame / the counters)
   // another context may still be copying the LAST frame out of these buffers (rgbdr_import_frame_from on a stream of its own)
   if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_imported, 0));
@@ -1015,8 +1032,13 @@ try {
   ctx->tile_states_kept = all_tiled && (bricks || elide || skip_bg);
   if (sb >= 0 && ctx->halo > 0) ctx->halo_staged = true;  // the staging set of this step holds this sweep's faces
   if (ctx->pipelined()) {
-    HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
-    ctx->ev_int_rec[ctx->rbuf] = true;
+    if (ctx->draw_expected) {  // (rgbdr_draw's record will cover this sweep: context.hpp)
+      ctx->int_unrecorded[ctx->rbuf] = true;
+    } else {
+      HIPCHK(hipEventRecord(ctx->ev_int[ctx->rbuf], ctx->stream));
+      ctx->ev_int_rec[ctx->rbuf] = true;
+      ctx->int_unrecorded[ctx->rbuf] = false;
+    }
     ctx->wbuf = ctx->rbuf ^ 1;  // the next frame's pre_* chain may run while this sweep reads rbuf
   }
   return RGBDR_OK;
@@ -1110,6 +1132,8 @@ try {
   if (rc != RGBDR_OK) return rc;
   ctx->wbuf = ctx->rbuf;  // keep reading what was written last
   ctx->ev_pre_rec[0] = ctx->ev_pre_rec[1] = ctx->ev_int_rec[0] = ctx->ev_int_rec[1] = false;
+  ctx->int_unrecorded[0] = ctx->int_unrecorded[1] = ctx->draw_expected = false;  // (everything has completed)
+  ctx->ev_view_rec[0] = ctx->ev_view_rec[1] = false;
   return set_flag(ctx, RGBDR_FLAG_PIPELINE, on);
 }
 RGBDR_CONTAIN(ctx)

@@ -294,7 +294,7 @@ static int import_pointers(rgbdr_ctx* ctx, const void* packed_frames, const void
   hipStream_t ps = ctx->pstream();
   { int rc_ = join_async_gather(ctx, ps); if (rc_ != RGBDR_OK) return rc_; }
   const int w = ctx->wbuf;
-  if (ctx->pipelined() && ctx->ev_int_rec[w]) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_int[w], 0));  // last reader of buffer w
+  { int rc_ = wait_last_readers(ctx, w, ps); if (rc_ != RGBDR_OK) return rc_; }  // last readers of buffer w
   if (ctx->imported_rec) HIPCHK(hipStreamWaitEvent(ps, ctx->ev_imported, 0));  // a context still copying out of this one's buffers
   if (wait_a) HIPCHK(hipStreamWaitEvent(ps, wait_a, 0));
   if (wait_b) HIPCHK(hipStreamWaitEvent(ps, wait_b, 0));

@@ -153,7 +153,7 @@ static int prepare_raymarch(rgbdr_ctx* ctx, const rgbdr_view* v, RaymarchParams*
     HIPCHK(hipSetDevice(ctx->device));
     // a pipelined context: the frame's images, brick counters and mask come from the chain's stream (the sweep has waited
     // for them already if there was one); what the NEXT frame's chain overwrites while this pass runs is the other half of
-    // every double buffer, and the colour frame only behind ev_color_read (rgbdr_draw)
+    // every double buffer (ev_view_read orders the refills of this one, context.hpp)
     // (a wait or a record on a stream is a bubble of ~10 us between its kernels: none that is not needed)
     if (ctx->pipelined() && ctx->ev_pre_rec[ctx->rbuf] && ctx->pre_joined != ctx->pre_serial) {
       HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_pre[ctx->rbuf], 0));
@@ -450,19 +450,20 @@ try {
   tend(ctx, "draw", ctx->stream);
   LAUNCHCHK("raymarch");
   if (ctx->pipelined()) {
-    // the pass has read the frame: its colour (the next upload waits), its images, counters and mask (the chain of the frame
-    // after the next waits for ev_int before it refills this half of the double buffers -- behind the sweep until now)
-    HIPCHK(hipEventRecord(ctx->ev_color_read, ctx->stream));
-    ctx->ev_color_read_rec = true;
-    ctx->view_read_buf = ctx->rbuf;  // (one record for both: process_textures waits for it too when it refills that half)
-    ctx->view_read_color = ctx->color_of[ctx->rbuf];
+    // the pass has read the frame -- its images, counters, mask and colour: whoever refills those halves waits for this record
+    // (context.hpp: the chain of the frame after the next, an upload into that colour half, the hole filling below)
+    HIPCHK(hipEventRecord(ctx->ev_view_read[ctx->rbuf], ctx->stream));
+    ctx->ev_view_rec[ctx->rbuf] = true;
+    ctx->view_color[ctx->rbuf] = ctx->color_of[ctx->rbuf];
+    ctx->int_unrecorded[ctx->rbuf] = false;  // ... and it covers the sweep of this frame, earlier on this stream
+    ctx->draw_expected = true;
   }
   ctx->filled_w = ctx->filled_h = 0;
   if (fill_holes) {
     float4* ocol;
     float* odep;
     if (side_fill) {
-      HIPCHK(hipStreamWaitEvent(ctx->fill_stream, ctx->ev_color_read, 0));  // (recorded behind the march just above)
+      HIPCHK(hipStreamWaitEvent(ctx->fill_stream, ctx->ev_view_read[ctx->rbuf], 0));  // (recorded behind the march just above)
       rc = fill_view_frame(ctx, &ocol, &odep, ctx->fill_stream);
       if (rc != RGBDR_OK) return rc;
       HIPCHK(hipEventRecord(ctx->ev_fill[ctx->vbuf], ctx->fill_stream));

@@ -54,13 +54,20 @@ struct rgbdr_ctx {
   std::vector<uint32_t> side_cu_mask;  // RGBDR_CU_SPLIT: the CUs of the second stream (and of the halo stream); empty: no split
   int wbuf = 0, rbuf = 0;            // buffer the next process_textures writes / the latest one written
   hipEvent_t ev_pre[2] = {nullptr, nullptr}, ev_int[2] = {nullptr, nullptr};
-  // pipelined contexts: behind the last kernel of a view pass (rgbdr_draw) that reads the colour frame -- the one buffer of a
-  // frame that is not double-buffered: the next upload, on the chain's stream, waits for it
-  hipEvent_t ev_color_read = nullptr;
-  bool ev_color_read_rec = false;
-  int view_read_buf = -1, view_read_color = -1;  // the halves of the frame buffers / of the colour frame that view pass read
+  // pipelined contexts: ev_view_read[b] is recorded behind the march of a view pass (rgbdr_draw) of the frame that lives in half
+  // b of the frame buffers -- the last kernel that reads that frame's images, counters, mask and colour (half view_color[b] of
+  // the colour frame).  The chain waits for it before it refills half b (two frames later), an upload before it rewrites that
+  // colour half, the hole filling on its stream before it starts.
+  hipEvent_t ev_view_read[2] = {nullptr, nullptr};
+  bool ev_view_rec[2] = {false, false};
+  int view_color[2] = {-1, -1};
   unsigned pre_serial = 0, pre_joined = 0;  // records of ev_pre / the last one the sweep's stream has waited for
   bool ev_pre_rec[2] = {false, false}, ev_int_rec[2] = {false, false};
+  // A record on a stream costs ~20 us of its time (profiles/r06_notes/display_pipeline.md), and the one behind the sweep is
+  // superseded when rgbdr_draw follows (its own record, behind the march, covers the sweep of the same frame): once a draw
+  // has followed a sweep the next sweep leaves its record out (int_unrecorded), and the chain that refills that half of the
+  // frame buffers records late -- behind whatever the first stream holds by then -- should no draw have come after all.
+  bool draw_expected = false, int_unrecorded[2] = {false, false};
   bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
   hipStream_t pstream() const { return pipelined() ? pre_stream : stream; }
   uint2* frame_buf(int b) const { return d_frame + (size_t)b * cfg.num_sensors * cfg.depth_w * cfg.depth_h; }
@@ -291,6 +298,7 @@ int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
 int materialise_mask(rgbdr_ctx* ctx);
+int wait_last_readers(rgbdr_ctx* ctx, int w, hipStream_t ps);  // before the chain's stream refills half w of the frame buffers
 int ensure_color_decoded(rgbdr_ctx* ctx, int half = -1);  // RGB8 frame of a DXT upload, decoded on demand   // perform a pending (lazy) updateOccupiedBricks filter
 // api_timers.cpp
 void tbegin(rgbdr_ctx* c, const char* name, hipStream_t st);

@@ -366,6 +366,50 @@ def test_an_upload_ahead_of_the_draw_on_a_pipelined_context(pkg, orc):
     pipe.close()
 
 
+def test_a_host_far_ahead_of_a_pipelined_context(pkg, orc):
+    """sixteen frames of two alternating scenes enqueued without the host ever waiting (frames uploaded from device memory, every
+    ray-marched frame copied aside by a device-to-device copy on the context's stream): the chain of frame k + 2 refills the
+    buffers frame k lives in, and must not do so before the view pass of frame k has read them -- every frame equals the
+    sequential context's"""
+    import ctypes as C
+    import torch
+    capi, synth = pkg.capi, pkg.synth
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), color_wh=(128, 106)),
+              synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7, color_wh=(128, 106))]
+    dev = [(torch.from_numpy(sc.depth).cuda(), torch.from_numpy(np.ascontiguousarray(sc.color)).cuda()) for sc in scenes]
+    inv = scenes[0].inverse((64, 64, 64))
+    view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 640, 360, BMIN, BMAX)
+    view.skip_space = 1
+    K, npix = 16, 640 * 360
+    frames = []
+    for pipelined in (False, True):
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64), 0)
+        for i in range(2):
+            ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
+            ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
+        ctx.set_use_bricks(True)
+        ctx.set_pipelined(pipelined)
+        stream = capi.lib().rgbdr_stream(ctx._h)
+        got = [torch.empty(npix * 5, dtype=torch.float32, device="cuda") for _ in range(K)]
+        torch.cuda.synchronize()
+        for k in range(K):
+            d, c = dev[k % 2]
+            ctx.update_device(d.data_ptr(), c.data_ptr())
+            ctx.clear_occupied_bricks(); ctx.process_textures(); ctx.update_occupied_bricks(); ctx.integrate()
+            ctx.draw(view, True)
+            cp, dp, w, h = ctx.device_view_frame(False)
+            assert hip.hipMemcpyAsync(C.c_void_p(got[k].data_ptr()), C.c_void_p(cp), npix * 16, 3, C.c_void_p(stream)) == 0
+            assert hip.hipMemcpyAsync(C.c_void_p(got[k].data_ptr() + npix * 16), C.c_void_p(dp), npix * 4, 3, C.c_void_p(stream)) == 0
+        ctx.sync()
+        frames.append([g.cpu().numpy() for g in got])
+        ctx.close()
+    for k in range(K):
+        assert same_bits(frames[0][k], frames[1][k]), (k, count_diff(frames[0][k], frames[1][k]))
+    assert not same_bits(frames[0][0], frames[0][1])
+
+
 def test_a_presenter_on_its_own_queue(pkg, orc):
     """rgbdr_device_view_frame_async: a host that presents from its own queue takes the pointers of frame k and an event, enqueues
     frame k + 1 at once, and lets its queue wait for the event before it copies the frame out -- nothing on the context's
