@@ -383,16 +383,20 @@ try {
     ctx->err = "hipStreamCreate failed";
     return cleanup(RGBDR_ERR_HIP);
   }
+  // The events that order this context's own streams against each other (kernels of one device on both sides) need no
+  // system-scope fence: with it a record writes the caches back for the host's and other devices' benefit and costs the
+  // stream ~20 us (profiles/r06_notes/display_pipeline.md).  RGBDR_DEV_SYSTEM_FENCE=1: the default fence, for A/B runs.
+  const unsigned own = hipEventDisableTiming | (std::getenv("RGBDR_DEV_SYSTEM_FENCE") ? 0u : hipEventDisableSystemFence);
   for (int b = 0; b < 2; ++b)
-    if (hipEventCreateWithFlags(&ctx->ev_pre[b], hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&ctx->ev_pre[b], own) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_in_read[b], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_int[b], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_int[b], own) != hipSuccess) {
       ctx->err = "hipEventCreate failed";
       return cleanup(RGBDR_ERR_HIP);
     }
   for (int b = 0; b < 2; ++b)
-    if (hipEventCreateWithFlags(&ctx->ev_view_read[b], hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&ctx->ev_view_read[b], own) != hipSuccess) {
       ctx->err = "hipEventCreate failed";
       return cleanup(RGBDR_ERR_HIP);
     }
