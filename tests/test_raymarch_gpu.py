@@ -366,7 +366,8 @@ def test_an_upload_ahead_of_the_draw_on_a_pipelined_context(pkg, orc):
     pipe.close()
 
 
-def test_a_host_far_ahead_of_a_pipelined_context(pkg, orc):
+@pytest.mark.parametrize("compress_rgb", [0, 1])
+def test_a_host_far_ahead_of_a_pipelined_context(pkg, orc, compress_rgb):
     """sixteen frames of two alternating scenes enqueued without the host ever waiting (frames uploaded from device memory, every
     ray-marched frame copied aside by a device-to-device copy on the context's stream): the chain of frame k + 2 refills the
     buffers frame k lives in, and must not do so before the view pass of frame k has read them -- every frame equals the
@@ -378,14 +379,15 @@ def test_a_host_far_ahead_of_a_pipelined_context(pkg, orc):
     hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
     scenes = [synth.Scene(2, 128, 106, lut_res=(32, 27, 32), color_wh=(128, 106)),
               synth.Scene(2, 128, 106, lut_res=(32, 27, 32), seed=4321, sphere_r=0.7, color_wh=(128, 106))]
-    dev = [(torch.from_numpy(sc.depth).cuda(), torch.from_numpy(np.ascontiguousarray(sc.color)).cuda()) for sc in scenes]
+    colours = [np.stack([synth.encode_dxt(sc.color[i], 1) for i in range(2)]) if compress_rgb else sc.color for sc in scenes]
+    dev = [(torch.from_numpy(sc.depth).cuda(), torch.from_numpy(np.ascontiguousarray(c)).cuda()) for sc, c in zip(scenes, colours)]
     inv = scenes[0].inverse((64, 64, 64))
     view = capi.make_view((2.2, 1.6, 1.9), (0.0, 0.9, 0.0), (0.0, 1.0, 0.0), 50.0, 640, 360, BMIN, BMAX)
     view.skip_space = 1
     K, npix = 16, 640 * 360
     frames = []
     for pipelined in (False, True):
-        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64), 0)
+        ctx = capi.Context(capi.make_config(2, (128, 106), voxel_size=2.0 / 64, brick_size=8 * 2.0 / 64, compress_rgb=compress_rgb), 0)
         for i in range(2):
             ctx.set_calibration(i, scenes[0].xyz[i], scenes[0].lut_res, scenes[0].uv[i], scenes[0].lut_res, (0.5, 4.5))
             ctx.set_inverse_calibration(i, inv[i], (64, 64, 64))
