@@ -386,7 +386,8 @@ try {
   // The events that order this context's own streams against each other (kernels of one device on both sides) need no
   // system-scope fence: with it a record writes the caches back for the host's and other devices' benefit and costs the
   // stream ~20 us (profiles/r06_notes/display_pipeline.md).  RGBDR_DEV_SYSTEM_FENCE=1: the default fence, for A/B runs.
-  const unsigned own = hipEventDisableTiming | (std::getenv("RGBDR_DEV_SYSTEM_FENCE") ? 0u : hipEventDisableSystemFence);
+  ctx->fenceless_events = cfg->slab_count <= 1 && !std::getenv("RGBDR_DEV_SYSTEM_FENCE");  // (a slab's halos come from other devices)
+  const unsigned own = hipEventDisableTiming | (ctx->fenceless_events ? hipEventDisableSystemFence : 0u);
   for (int b = 0; b < 2; ++b)
     if (hipEventCreateWithFlags(&ctx->ev_pre[b], own) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_h2d[b], hipEventDisableTiming) != hipSuccess ||
@@ -680,6 +681,24 @@ RGBDR_CONTAIN(ctx)
 }  // extern "C"
 // clearOccupiedBricks is deferred; anything that reads the counters before process_textures ran flushes it
 // the RGB8 colour frame for consumers other than pre_depth (which reads DXT blocks directly)
+int rgbdr::system_fence_events(rgbdr_ctx* ctx)
+{
+  if (!ctx->fenceless_events) return RGBDR_OK;
+  { int rc_ = sync_all(ctx); if (rc_ != RGBDR_OK) return rc_; }  // nothing is in flight: the old events have nothing left to say
+  for (int b = 0; b < 2; ++b) {
+    hipEvent_t* evs[3] = {&ctx->ev_pre[b], &ctx->ev_int[b], &ctx->ev_view_read[b]};
+    for (hipEvent_t* e : evs) {
+      hipEvent_t fresh = nullptr;
+      HIPCHK(hipEventCreateWithFlags(&fresh, hipEventDisableTiming));
+      if (*e) (void)hipEventDestroy(*e);
+      *e = fresh;
+    }
+    ctx->ev_pre_rec[b] = ctx->ev_int_rec[b] = ctx->ev_view_rec[b] = ctx->int_unrecorded[b] = false;
+  }
+  ctx->draw_expected = false;
+  ctx->fenceless_events = false;
+  return RGBDR_OK;
+}
 // the sweep and the view pass of the frame that lives in half w of the frame buffers (images, mask, counts) read it on the
 // first stream: the chain's stream waits for them before it writes there
 int rgbdr::wait_last_readers(rgbdr_ctx* ctx, int w, hipStream_t ps)

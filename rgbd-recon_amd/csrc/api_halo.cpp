@@ -240,6 +240,7 @@ try {
     ctx->shard_first = ctx->shard_count = 0;
   } else {
     if (first < 0 || first + count > N) return ctx->fail(RGBDR_ERR_OUT_OF_RANGE, "sensor shard outside [0, num_sensors)");
+    { int rc_ = system_fence_events(ctx); if (rc_ != RGBDR_OK) return rc_; }  // (the other sensors' frames come from other devices)
     ctx->shard_first = first;
     ctx->shard_count = count;
   }
@@ -258,6 +259,7 @@ int rgbdr_shard_view(rgbdr_ctx* ctx, rgbdr_shard_device_view* out)
 try {
   if (!ctx || !out) return RGBDR_ERR_INVALID_ARGUMENT;
   if (!ctx->textures_processed) return ctx->fail(RGBDR_ERR_STATE, "rgbdr_shard_view before process_textures");
+  { int rc_ = system_fence_events(ctx); if (rc_ != RGBDR_OK) return rc_; }  // (the host's own collective writes into these buffers)
   const int N = nsens(ctx);
   out->frames = ctx->frame_buf(ctx->rbuf);
   out->sensor_bytes = (size_t)ctx->cfg.depth_w * ctx->cfg.depth_h * sizeof(uint2);
@@ -287,6 +289,7 @@ RGBDR_CONTAIN(ctx)
 // (rgbd-recon_amd/dist.py LaggedChain).
 static int import_pointers(rgbdr_ctx* ctx, const void* packed_frames, const void* brick_counters, hipEvent_t wait_a, hipEvent_t wait_b)
 {
+  { int rc_ = system_fence_events(ctx); if (rc_ != RGBDR_OK) return rc_; }  // (the frames may come from another device's collective)
   if (ctx->occ_lazy && ctx->occ_lazy_cbuf == ctx->cbuf) {  // the counters a pending filter reads are about to change
     int rc_ = materialise_mask(ctx);
     if (rc_ != RGBDR_OK) return rc_;

@@ -68,6 +68,10 @@ struct rgbdr_ctx {
   // has followed a sweep the next sweep leaves its record out (int_unrecorded), and the chain that refills that half of the
   // frame buffers records late -- behind whatever the first stream holds by then -- should no draw have come after all.
   bool draw_expected = false, int_unrecorded[2] = {false, false};
+  // ev_pre / ev_int / ev_view_read are created without the system-scope fence (kernels of this device on both sides).  What
+  // another device or a host library writes into the frame buffers (a sensor shard's all-gather, rgbdr_shard_view,
+  // rgbdr_import_frame) needs the fence on the way to the sweep: those entry points switch the events back (system_fence_events).
+  bool fenceless_events = false;
   bool pipelined() const { return (cfg.flags & RGBDR_FLAG_PIPELINE) != 0; }
   hipStream_t pstream() const { return pipelined() ? pre_stream : stream; }
   uint2* frame_buf(int b) const { return d_frame + (size_t)b * cfg.num_sensors * cfg.depth_w * cfg.depth_h; }
@@ -298,6 +302,7 @@ int ensure_window_background(rgbdr_ctx* c);
 int skip_sweep(rgbdr_ctx* c, IntegrateParams& p);  // the RGBDR_FLAG_SKIP_BACKGROUND sweep (p: filled by rgbdr_integrate)
 int flush_clear(rgbdr_ctx* ctx);        // perform a pending clearOccupiedBricks
 int materialise_mask(rgbdr_ctx* ctx);
+int system_fence_events(rgbdr_ctx* ctx);  // the events between the context's streams with the default fence from now on
 int wait_last_readers(rgbdr_ctx* ctx, int w, hipStream_t ps);  // before the chain's stream refills half w of the frame buffers
 int ensure_color_decoded(rgbdr_ctx* ctx, int half = -1);  // RGB8 frame of a DXT upload, decoded on demand   // perform a pending (lazy) updateOccupiedBricks filter
 // api_timers.cpp
